@@ -1,0 +1,350 @@
+/*
+ * vllm_rs_amd.h — C ABI of the MI355X (gfx950) drop-in for the quantized-forward hot path of
+ * guoqingbao/vllm.rs.  Every symbol is `extern "C"`, takes plain pointers and sizes, and is
+ * exported by libvllm_rs_amd.so (built from vllm_rs_amd/csrc + vllm_rs_amd/host).
+ *
+ * Conventions (identical to the reference's FFI):
+ *   - all data pointers are DEVICE pointers unless the parameter name starts with `h_`;
+ *   - the caller owns every buffer, including outputs; kernels never allocate or retain pointers;
+ *   - `stream` is a hipStream_t passed as int64_t (the reference passes `*dev.cu_stream() as i64`,
+ *     src/utils/gptq.rs:130); 0 = the null stream;
+ *   - functions return void and are asynchronous w.r.t. the host; they are graph-capturable (no
+ *     sync, no allocation, no stream creation).  Argument errors are recorded in a thread-safe side
+ *     channel readable with vra_last_error() (the reference has no error channel at all,
+ *     src/utils/gptq.rs:76-79,197,238 validate in Rust before the call).
+ *
+ * Section A are the seven symbols vllm.rs imports from `attention_rs::kernels::ffi`
+ * (src/utils/gptq.rs:3-6) with the exact names and argument order it uses.
+ * Section B are C entry points for the ops vllm.rs reaches through attention_rs Rust wrappers and
+ * candle ops; INTEGRATION.md shows the Rust `extern "C"` block for them.
+ * Section C is the native host runtime (C++ restatement of src/core + src/models for this path).
+ */
+#ifndef VLLM_RS_AMD_H
+#define VLLM_RS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* element types for `dtype` parameters */
+#define VRA_BF16 0
+#define VRA_F16 1
+#define VRA_F32 2
+
+/* scale-tensor layouts accepted by vra_wna16_gemm */
+#define VRA_SCALES_ROWMAJOR 0 /* [K/g, N] as stored in the checkpoint                           */
+#define VRA_SCALES_MARLIN 1   /* after wna16.rs:193-218 marlin_permute_scales (what Rust passes) */
+
+/* ------------------------------------------------------------------------------------------ */
+/* A. Symbols imported by src/utils/gptq.rs:3-6                                               */
+/* ------------------------------------------------------------------------------------------ */
+
+/* replaces attention_rs::kernels::ffi::marlin_4bit_bf16 — call site src/utils/gptq.rs:165-178.
+ * out[m,n] = in[m,k] · dequant(qweight)[k,n]; GPTQ symmetric int4 (zero point 8, `qzeros` and
+ * `g_idx` ignored: wna16.rs:154-160 only routes sym/desc_act=false checkpoints here).
+ * `qweight` is the tensor produced by gptq_repack (host shape [k/16, n*2] u32), `scales` is
+ * [k/g, n] in VRA_SCALES_MARLIN order, `workspace` ([n] u32 zeros, wna16.rs:238-242) is left
+ * untouched. group_size ∈ {32·j, -1}. */
+void marlin_4bit_bf16(const void* in, const int32_t* qweight, const void* scales, const void* qzeros,
+                      const void* g_idx, void* out, int32_t m, int32_t k, int32_t n,
+                      const void* workspace, int32_t group_size, int64_t stream);
+/* replaces ffi::marlin_4bit_f16 — src/utils/gptq.rs:133-146 */
+void marlin_4bit_f16(const void* in, const int32_t* qweight, const void* scales, const void* qzeros,
+                     const void* g_idx, void* out, int32_t m, int32_t k, int32_t n,
+                     const void* workspace, int32_t group_size, int64_t stream);
+/* replaces ffi::marlin_awq_4bit_bf16 — src/utils/gptq.rs:151-164. AWQ asymmetric: `qzeros` is the
+ * RAW checkpoint tensor [k/g, n/8] u32 (AWQ nibble order, no +1 offset), qweight from awq_repack. */
+void marlin_awq_4bit_bf16(const void* in, const int32_t* qweight, const void* scales,
+                          const void* qzeros, const void* g_idx, void* out, int32_t m, int32_t k,
+                          int32_t n, const void* workspace, int32_t group_size, int64_t stream);
+/* replaces ffi::marlin_awq_4bit_f16 — src/utils/gptq.rs:118-131 */
+void marlin_awq_4bit_f16(const void* in, const int32_t* qweight, const void* scales,
+                         const void* qzeros, const void* g_idx, void* out, int32_t m, int32_t k,
+                         int32_t n, const void* workspace, int32_t group_size, int64_t stream);
+/* replaces ffi::gemm_half_q_half_alt — src/utils/gptq.rs:182-195 (NOTE n before k). Plain GPTQ:
+ * qweight [k/8, n] u32 (checkpoint layout), qzeros [k/g, n/8] u32 (stored z-1), scales [k/g, n] f16
+ * row-major, g_idx [k] i32 (may be NULL = k/g), bits must be 4, f16 activations only. */
+void gemm_half_q_half_alt(const void* in, const uint32_t* qweight, const uint32_t* qzeros,
+                          const void* scales, const int32_t* g_idx, void* out, int32_t m, int32_t n,
+                          int32_t k, int32_t bits, int64_t stream);
+/* replaces ffi::gptq_repack — src/utils/gptq.rs:325-331. in: GPTQ qweight [rows=k/8, cols=n] u32;
+ * out: same element count in the CDNA4 tile layout, host shape [k/16, n*2]. */
+void gptq_repack(const void* in, void* out, int32_t rows, int32_t cols, int64_t stream);
+/* replaces ffi::awq_repack — src/utils/gptq.rs:316-323. in: AWQ qweight [rows=k, cols=n/8] u32. */
+void awq_repack(const void* in, void* out, int32_t rows, int32_t cols, int32_t bits, int64_t stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* B. Ops reached through attention_rs wrappers / candle ops                                   */
+/* ------------------------------------------------------------------------------------------ */
+
+/* side channel: last argument error recorded by any entry point on this thread ("" if none) */
+const char* vra_last_error(void);
+void vra_clear_error(void);
+/* library/ABI version and the gfx target it was built for */
+const char* vra_version(void);
+
+/* General WNA16 GEMM behind Section A (is_awq: qzeros RAW awq tensor or NULL→8; GPTQ path ignores
+ * qzeros).  `bias` [n] (nullable, same dtype as activations) is fused (Appendix A9: reference adds
+ * it as a separate op, wna16.rs:296-300).  `residual` [m,n] nullable: out = round(round(acc+bias)
+ * + residual) — the reference's separate `+` (llama.rs:126,130). */
+void vra_wna16_gemm(const void* in, const void* qweight_tiled, const void* scales, const void* qzeros,
+                    const void* bias, const void* residual, void* out, int32_t m, int32_t k,
+                    int32_t n, int32_t group_size, int32_t is_awq, int32_t scales_layout,
+                    int32_t dtype, int64_t stream);
+/* gate/up pair with fused SiLU·mul (mlp.rs:451-469): out[m,n] = silu(x·Wg)·(x·Wu), rounding after
+ * each reference op (GEMM out, silu, mul). Both weights tiled, n = intermediate size. */
+void vra_wna16_gate_up_silu(const void* in, const void* qw_gate, const void* sc_gate,
+                            const void* qz_gate, const void* qw_up, const void* sc_up,
+                            const void* qz_up, void* out, int32_t m, int32_t k, int32_t n,
+                            int32_t group_size, int32_t is_awq, int32_t scales_layout,
+                            int32_t dtype, int64_t stream);
+/* debug/parity: expand a tiled qweight back to nibble indices idx[k,n] u8 (bit-exact check) */
+void vra_wna16_unpack_indices(const void* qweight_tiled, uint8_t* idx, int32_t k, int32_t n,
+                              int64_t stream);
+/* debug/parity: dequantize tiled weights to dense w[k,n] (dtype) = round((q - z)·s) */
+void vra_wna16_dequant(const void* qweight_tiled, const void* scales, const void* qzeros, void* w,
+                       int32_t k, int32_t n, int32_t group_size, int32_t is_awq,
+                       int32_t scales_layout, int32_t dtype, int64_t stream);
+
+/* candle_nn::RmsNorm::forward as used by NormX (src/models/layers/others.rs:11-29):
+ * out[t,:] = x[t,:] * rsqrt(mean(x²)+eps) * w, f32 math, one rounding. */
+void vra_rms_norm(const void* x, const void* weight, void* out, int32_t tokens, int32_t hidden,
+                  float eps, int32_t dtype, int64_t stream);
+/* residual add + norm: h = round(x + residual) written to `h_out`, out = rmsnorm(h).
+ * Equivalent to llama.rs:126-128 `(attn_output + residual)` followed by the next norm. */
+void vra_add_rms_norm(const void* x, const void* residual, const void* weight, void* h_out,
+                      void* out, int32_t tokens, int32_t hidden, float eps, int32_t dtype,
+                      int64_t stream);
+/* elementwise a+b (candle `+`, llama.rs:126,130) */
+void vra_add(const void* a, const void* b, void* out, int64_t numel, int32_t dtype, int64_t stream);
+/* candle_nn::Embedding::forward (llama.rs:261): out[t,:] = table[ids[t],:]; ids u32 */
+void vra_embedding(const uint32_t* ids, const void* table, void* out, int32_t tokens,
+                   int32_t hidden, int32_t vocab, int32_t dtype, int64_t stream);
+/* Tensor::index_select(dim0) (llama.rs:306-310): out[i,:] = x[idx[i],:] */
+void vra_index_select_rows(const void* x, const uint32_t* idx, void* out, int32_t n_idx,
+                           int32_t hidden, int32_t dtype, int64_t stream);
+/* Activation::Silu + `*` (mlp.rs:468): out = round(round(silu(gate)) * up) */
+void vra_silu_mul(const void* gate, const void* up, void* out, int64_t numel, int32_t dtype,
+                  int64_t stream);
+/* attention_rs::fused_rope::FusedRope::apply_inplace (rotary_emb.rs:103): in-place rotary on
+ * q [T,Hq,D] and k [T,Hkv,D]; cos/sin [max_pos, rot_dim/2] (same dtype as q, or f32 when
+ * table_dtype=VRA_F32), rows gathered by positions[T] (i64). is_interleaved = `is_rope_i`.
+ * rot_dim <= D covers apply_inplace_partial (rotary_emb.rs:88-100). */
+void vra_fused_rope(void* q, void* k, const void* cos, const void* sin, const int64_t* positions,
+                    int32_t tokens, int32_t q_heads, int32_t kv_heads, int32_t head_dim,
+                    int32_t rot_dim, int32_t is_interleaved, int32_t dtype, int32_t table_dtype,
+                    int64_t stream);
+/* KV-cache geometry: each cache is [num_blocks, kv_heads, block_size, head_dim] (same element
+ * count as the reference's flash layout, kvcache_allocator.rs:851-863; blocks stay contiguous so
+ * swap_blocks semantics are unchanged).
+ * "reshape_and_cache" half of PagedAttention::forward (attention.rs:808-820): scatter k,v [T,Hkv,D]
+ * to slot_mapping[T] (i64, slot = block*BS + offset; negative slot = skip, Appendix A6). */
+void vra_reshape_and_cache(const void* k, const void* v, void* k_cache, void* v_cache,
+                           const int64_t* slot_mapping, int32_t tokens, int32_t kv_heads,
+                           int32_t head_dim, int32_t block_size, int32_t dtype, int64_t stream);
+/* decode half of PagedAttention::forward: one query token per sequence.
+ * q/out [B,Hq,D]; block_tables [B,max_blocks] u32 (right-padded with 0, Appendix A5);
+ * context_lens [B] u32 (includes the token just written). `workspace` must hold
+ * vra_paged_attention_decode_workspace_bytes(). softcap = 0 disables. */
+size_t vra_paged_attention_decode_workspace_bytes(int32_t max_batch, int32_t q_heads,
+                                                  int32_t head_dim, int32_t max_context_len);
+void vra_paged_attention_decode(void* out, const void* q, const void* k_cache, const void* v_cache,
+                                const uint32_t* block_tables, const uint32_t* context_lens,
+                                int32_t batch, int32_t q_heads, int32_t kv_heads, int32_t head_dim,
+                                int32_t block_size, int32_t max_blocks_per_seq,
+                                int32_t max_context_len, float scale, float softcap,
+                                void* workspace, int32_t dtype, int64_t stream);
+/* prefill half: causal varlen attention. q [T,Hq,D] with cu_seqlens_q [B+1] u32.
+ * If block_tables != NULL keys/values are read from the paged cache (context_lens[b] tokens,
+ * query i of sequence b sits at position context_lens[b]-len_q(b)+i) — this covers chunked prefill
+ * and prefix-cache hits (runner.rs:1068-1082).  Otherwise they are read from k,v [Tk,Hkv,D] with
+ * cu_seqlens_k. */
+void vra_paged_attention_prefill(void* out, const void* q, const void* k, const void* v,
+                                 const void* k_cache, const void* v_cache,
+                                 const uint32_t* block_tables, const uint32_t* context_lens,
+                                 const uint32_t* cu_seqlens_q, const uint32_t* cu_seqlens_k,
+                                 int32_t batch, int32_t total_q, int32_t max_seqlen_q,
+                                 int32_t q_heads, int32_t kv_heads, int32_t head_dim,
+                                 int32_t block_size, int32_t max_blocks_per_seq, float scale,
+                                 float softcap, int32_t dtype, int64_t stream);
+/* fused decode step for one layer's attention front half (native runtime only): rotary on q and k,
+ * scatter of the new k,v into the cache, then paged decode attention. Numerically identical to
+ * vra_fused_rope + vra_reshape_and_cache + vra_paged_attention_decode. */
+void vra_rope_cache_attention_decode(void* out, void* q, void* k, const void* v, void* k_cache,
+                                     void* v_cache, const void* cos, const void* sin,
+                                     const int64_t* positions, const int64_t* slot_mapping,
+                                     const uint32_t* block_tables, const uint32_t* context_lens,
+                                     int32_t batch, int32_t q_heads, int32_t kv_heads,
+                                     int32_t head_dim, int32_t block_size,
+                                     int32_t max_blocks_per_seq, int32_t max_context_len,
+                                     float scale, void* workspace, int32_t dtype, int64_t stream);
+/* attention_rs::mask::causal_mask (src/models/layers/mask.rs:24-27): additive [L,L] mask,
+ * 0 on/below the diagonal (and within sliding_window if >0), -inf above. */
+void vra_causal_mask(void* mask, int32_t len, int32_t sliding_window, int32_t dtype, int64_t stream);
+/* attention_rs::cache::swap_blocks (runner.rs:1641-1645): copy whole blocks src[i]→dst[j];
+ * `h_pairs` is a HOST array of 2*n_pairs int64 (src,dst). kind: 0 D2D, 1 D2H, 2 H2D. */
+void vra_swap_blocks(const void* src, void* dst, const int64_t* h_pairs, int32_t n_pairs,
+                     int64_t block_bytes, int32_t kind, int64_t stream);
+/* dense Linear::forward for lm_head (linear.rs:75-123): out[m,n] = x[m,k]·W[n,k]ᵀ (+bias),
+ * W row-major [n,k]; out_dtype VRA_F32 reproduces `.to_dtype(F32)` of the rounded result
+ * (llama.rs:317-319): values are rounded to `dtype` first, then widened. */
+void vra_dense_gemm(const void* x, const void* w, const void* bias, void* out, int32_t m, int32_t k,
+                    int32_t n, int32_t dtype, int32_t out_dtype, int64_t stream);
+/* logits.argmax(-1) (logits_processor.rs:67-70): first maximal index per row. */
+void vra_argmax_f32(const float* logits, uint32_t* out, int32_t rows, int32_t cols, int64_t stream);
+/* Tensor::to_dtype between bf16/f16/f32 */
+void vra_cast(const void* in, void* out, int64_t numel, int32_t in_dtype, int32_t out_dtype,
+              int64_t stream);
+/* deterministic synthetic tensors (BASELINE §8d): u32 hash fill / uniform / normal fills */
+void vra_fill_hash_u32(uint32_t* out, int64_t numel, uint64_t seed, int64_t stream);
+void vra_fill_uniform(void* out, int64_t numel, uint64_t seed, float lo, float hi, int32_t dtype,
+                      int64_t stream);
+void vra_fill_normal(void* out, int64_t numel, uint64_t seed, float mean, float std, int32_t dtype,
+                     int64_t stream);
+void vra_fill_const_u32(uint32_t* out, int64_t numel, uint32_t value, int64_t stream);
+
+/* AllReduce CustomOp1 (src/models/layers/distributed.rs:325-396): sum over TP ranks, bf16/f16.
+ * The communicator is created from the 128-byte unique id the engine ships in MessageType::Init
+ * (src/runner/mod.rs:25-27; Comm::from_rank at src/runner/runner.rs:80-89). */
+int32_t vra_comm_unique_id(uint8_t h_id_out[128]);
+void* vra_comm_create(const uint8_t h_id[128], int32_t rank, int32_t world_size, int32_t device);
+void vra_comm_destroy(void* comm);
+int32_t vra_comm_rank(const void* comm);
+int32_t vra_comm_world_size(const void* comm);
+void vra_all_reduce(void* comm, const void* src, void* dst, int64_t numel, int32_t dtype,
+                    int64_t stream);
+
+/* device plumbing for hosts that have no HIP binding of their own (tests, bench, the runtime) */
+int32_t vra_device_count(void);
+int32_t vra_set_device(int32_t device);
+void* vra_malloc(size_t bytes);
+void vra_free(void* p);
+void* vra_malloc_host(size_t bytes);
+void vra_free_host(void* p);
+int32_t vra_memcpy_h2d(void* dst, const void* h_src, size_t bytes, int64_t stream);
+int32_t vra_memcpy_d2h(void* h_dst, const void* src, size_t bytes, int64_t stream);
+int32_t vra_memcpy_d2d(void* dst, const void* src, size_t bytes, int64_t stream);
+int32_t vra_memset(void* dst, int32_t value, size_t bytes, int64_t stream);
+int32_t vra_stream_sync(int64_t stream);
+int32_t vra_device_sync(void);
+int64_t vra_stream_create(void);
+void vra_stream_destroy(int64_t stream);
+int32_t vra_mem_info(size_t* h_free, size_t* h_total);
+void* vra_event_create(void);
+void vra_event_destroy(void* ev);
+int32_t vra_event_record(void* ev, int64_t stream);
+float vra_event_elapsed_ms(void* start, void* stop); /* syncs on `stop` */
+
+/* ------------------------------------------------------------------------------------------ */
+/* C. Native host runtime (C++): model, KV allocator, block manager, scheduler, runner, engine */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Model/engine configuration — the fields of `Config` (src/utils/config.rs:218-255),
+ * `QuantConfig` (:735-757) and `EngineConfig` (:285-328) the hot path consumes. */
+typedef struct vra_model_config {
+  int32_t arch;              /* 0 = LlamaForCausalLM/Mistral (llama.rs), 1 = Qwen2ForCausalLM (qwen3.rs) */
+  int32_t hidden_size, intermediate_size, num_layers;
+  int32_t num_heads, num_kv_heads, head_dim, vocab_size;
+  int32_t max_position_embeddings;
+  float rms_norm_eps;
+  double rope_theta;
+  int32_t rope_scaling_type; /* 0 none/default, 1 linear, 2 llama3 */
+  double rope_factor, rope_low_freq_factor, rope_high_freq_factor;
+  int32_t rope_original_max_position;
+  int32_t attention_bias;    /* qkv bias (qwen2 default true, attention.rs:411-415) */
+  int32_t quant_method;      /* 0 none (dense bf16), 1 gptq, 2 awq */
+  int32_t bits, group_size;
+  int32_t dtype;             /* VRA_BF16 / VRA_F16 */
+  int32_t tie_word_embeddings;
+} vra_model_config;
+
+typedef struct vra_engine_config {
+  int32_t block_size;             /* 64 (config.rs:466) */
+  int32_t max_num_seqs;           /* 0 = auto */
+  int32_t max_model_len;          /* 0 = auto */
+  int32_t num_gpu_blocks;         /* 0 = derive from free memory × kv_fraction */
+  float kv_fraction;              /* 0 = reference default (kvcache_allocator.rs:196-202) */
+  int32_t prefill_chunk;          /* 8192 (scheduler.rs:203) */
+  int32_t enable_prefix_cache;
+  float prefix_cache_fraction;    /* 0.65 (scheduler.rs:55,95) */
+  int32_t use_graph;              /* hipGraph decode capture for bs ∈ {1..15,16,32} (graph.rs:370-377) */
+  int32_t tp_rank, tp_world_size; /* tensor parallel */
+  int32_t device;
+  uint64_t seed;                  /* synthetic-weight seed */
+} vra_engine_config;
+
+/* Pure-host helpers (no GPU needed; also exported by libvra_host.so for CPU tests) */
+/* per_block_bytes (kvcache_allocator.rs:447-468) and the block-count plan (:616-707) */
+int64_t vra_kv_per_block_bytes(const vra_model_config* mc, const vra_engine_config* ec);
+int64_t vra_kv_plan_num_blocks(const vra_model_config* mc, const vra_engine_config* ec,
+                               int64_t free_bytes);
+/* rotary tables (rotary_emb.rs:32-73,126-278): f32 cos/sin [n_pos, rot_dim/2] */
+void vra_rope_tables_f32(const vra_model_config* mc, int32_t n_pos, float* h_cos, float* h_sin);
+/* marlin_permute_scales (wna16.rs:180-218) on a host array of 16-bit elements [k/g, n] */
+void vra_marlin_permute_scales_u16(const uint16_t* h_in, uint16_t* h_out, int32_t rows, int32_t n,
+                                   int32_t grouped);
+
+/* Block manager + prefix cache (src/core/block_manager.rs, prefix_cache.rs, sequence.rs) */
+void* vra_bm_create(int32_t num_blocks, int32_t block_size, int32_t enable_prefix_cache,
+                    float prefix_cache_fraction);
+void vra_bm_destroy(void* bm);
+int32_t vra_bm_num_free_blocks(const void* bm);
+/* creates a sequence, returns its id */
+int64_t vra_bm_seq_create(void* bm, const uint32_t* h_tokens, int32_t n_tokens);
+void vra_bm_seq_free(void* bm, int64_t seq);
+int32_t vra_bm_can_allocate(const void* bm, int64_t seq);
+int32_t vra_bm_allocate(void* bm, int64_t seq);          /* returns num_cached_tokens or -1 */
+int32_t vra_bm_can_append(const void* bm, int64_t seq);
+int32_t vra_bm_may_append(void* bm, int64_t seq);        /* 0 ok, -1 no free block */
+void vra_bm_append_token(void* bm, int64_t seq, uint32_t token);
+void vra_bm_deallocate(void* bm, int64_t seq);           /* caches full blocks when prefix cache on */
+int32_t vra_bm_seq_len(const void* bm, int64_t seq);
+int32_t vra_bm_seq_num_cached_tokens(const void* bm, int64_t seq);
+int32_t vra_bm_seq_block_table(const void* bm, int64_t seq, uint32_t* h_out, int32_t cap);
+int32_t vra_bm_prefix_cached_blocks(const void* bm);
+int32_t vra_bm_evict_prefix(void* bm, int32_t n_blocks);
+
+/* Engine = scheduler + runner + model (src/core/{engine,scheduler,runner}.rs) */
+void* vra_engine_create(const vra_model_config* mc, const vra_engine_config* ec);
+void vra_engine_destroy(void* eng);
+/* weights: synthetic (BASELINE §8d recipe, seeded) or explicit host tensors by HF name */
+int32_t vra_engine_init_synthetic(void* eng);
+int32_t vra_engine_load_tensor(void* eng, const char* name, const void* h_data, const int64_t* shape,
+                               int32_t ndim, int32_t elem_bytes);
+int32_t vra_engine_finalize_weights(void* eng); /* repack + scale layout + KV cache + graphs */
+int32_t vra_engine_num_gpu_blocks(const void* eng);
+/* request API: token ids in, token ids out (tokenizer-free) */
+int64_t vra_engine_add_request(void* eng, const uint32_t* h_prompt, int32_t n_prompt,
+                               int32_t max_tokens, int32_t ignore_eos, const uint32_t* h_eos,
+                               int32_t n_eos);
+/* one engine step (engine.rs:1693-1757): schedule → forward → postprocess.
+ * returns number of sequences run (0 = idle), *h_is_prefill set. */
+int32_t vra_engine_step(void* eng, int32_t* h_is_prefill);
+int32_t vra_engine_has_unfinished(const void* eng);
+int32_t vra_engine_request_finished(const void* eng, int64_t req);
+int32_t vra_engine_request_output(const void* eng, int64_t req, uint32_t* h_out, int32_t cap);
+/* timestamps in ms (engine.rs:1004-1012): created, first-token (decode_start), finished */
+int32_t vra_engine_request_times(const void* eng, int64_t req, double h_times[3]);
+void vra_engine_release_request(void* eng, int64_t req);
+/* low-level: one model forward with caller-built metadata, for parity tests of a1/a14.
+ * Mirrors `forward(input_ids, positions, kv_caches, input_metadata)` (llama.rs:323-339): all
+ * arrays are HOST arrays; logits_out is a HOST [n_seqs, vocab] f32 buffer. */
+int32_t vra_engine_forward_raw(void* eng, const uint32_t* h_ids, const int64_t* h_positions,
+                               const int64_t* h_slot_mapping, int32_t n_tokens, int32_t is_prefill,
+                               const uint32_t* h_block_tables, int32_t max_blocks,
+                               const uint32_t* h_context_lens, const uint32_t* h_cu_seqlens_q,
+                               int32_t n_seqs, float* h_logits_out);
+/* decode-step microbenchmark hook used by bench.py: runs `steps` decode steps of the current
+ * running batch back to back (graph replay when enabled) and returns elapsed ms measured with HIP
+ * events on the engine stream; tokens are sampled and appended exactly as in vra_engine_step. */
+double vra_engine_timed_decode(void* eng, int32_t steps);
+int64_t vra_engine_stream(const void* eng);
+const char* vra_engine_last_error(const void* eng);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VLLM_RS_AMD_H */

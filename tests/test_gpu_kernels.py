@@ -1,0 +1,354 @@
+"""GPU parity tests: every HIP entry point of include/vllm_rs_amd.h §A/§B against the CPU oracle,
+called through the C ABI (ctypes).  Bit-exact for integer/byte work; for 16-bit float outputs the
+GPU accumulates in f32 (MFMA order) while the oracle accumulates in double, so a small fraction of
+elements may land on the neighbouring storage value: tolerance = 1 storage ulp on <= 2 % of the
+elements (stated per test)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from tests.util import BF16, F16, F32, assert_close_dt, make_quant, rand_dt, rng
+from vllm_rs_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+# ---------------------------------------------------------------- int4 layout: bit exact
+@pytest.mark.parametrize("K,N", [(128, 16), (256, 64), (4096, 1024), (1024, 14336 // 8)])
+@pytest.mark.parametrize("awq", [False, True])
+def test_repack_bit_exact(K, N, awq):
+    r = rng(K + N + awq)
+    q = make_quant(r, K, N, 128, BF16, awq)
+    d = ops.dev(q["qweight"])
+    tiled = ops.marlin_weight_repack(d, q["qweight"].shape, 4, awq)
+    got = tiled.numpy(np.uint32, (K // 16, N * 2))
+    ref = orc.awq_repack(q["qweight"]) if awq else orc.gptq_repack(q["qweight"])
+    assert np.array_equal(got, ref)
+    # unpack indices straight from the tiled tensor: bit-exact int4 codes
+    idx = ops.unpack_indices(tiled, K, N)
+    assert np.array_equal(idx, q["idx"])
+
+
+@pytest.mark.parametrize("dt", [BF16, F16])
+@pytest.mark.parametrize("awq,gs,layout", [(False, 128, 0), (False, 128, 1), (True, 128, 1), (False, 64, 1), (False, -1, 1), (True, 32, 0)])
+def test_dequant_bit_exact(dt, awq, gs, layout):
+    K, N = 512, 256
+    r = rng(7 + gs + layout)
+    q = make_quant(r, K, N, gs, dt, awq)
+    tiled = ops.marlin_weight_repack(ops.dev(q["qweight"]), q["qweight"].shape, 4, awq)
+    sc = q["scales"]
+    if layout == 1:
+        sc = orc.marlin_permute_scales(sc, grouped=(gs > 0 and gs < K))
+    got = ops.dequant(tiled, ops.dev(sc), ops.dev(q["qzeros"]) if awq else None, K, N, gs, awq, layout, dt)
+    ref = orc.dequant(q["idx"], q["zeros"], q["scales"], gs, dt)
+    assert np.array_equal(got, ref)
+
+
+# ---------------------------------------------------------------- dequant-fused GEMM
+GEMM_SHAPES = [(512, 256), (4096, 1024), (1024, 4096), (3584, 512)]
+
+
+@pytest.mark.parametrize("M", [1, 2, 5, 8, 9, 16, 32, 33, 64, 100])
+@pytest.mark.parametrize("K,N", GEMM_SHAPES)
+def test_wna16_gemm_gptq(M, K, N):
+    if M > 33 and K * N > 2 ** 21:
+        pytest.skip("oracle time")
+    r = rng(M * 131 + K + N)
+    q = make_quant(r, K, N, 128, BF16, False)
+    x = rand_dt(r, (M, K), BF16)
+    tiled = ops.marlin_weight_repack(ops.dev(q["qweight"]), q["qweight"].shape)
+    out = ops.wna16_gemm(ops.dev(x), tiled, ops.dev(q["scales"]), None, M, K, N, 128)
+    got = out.numpy(np.uint16, (M, N))
+    ref = orc.wna16_gemm(x, q["idx"], None, q["scales"], 128, BF16)
+    assert_close_dt(got, ref, BF16, name=f"gemm M={M} K={K} N={N}", abs_floor=2e-3)
+
+
+@pytest.mark.parametrize("M", [1, 4, 32])
+@pytest.mark.parametrize("dt", [BF16, F16])
+@pytest.mark.parametrize("awq", [False, True])
+def test_marlin_ffi(M, dt, awq):
+    """the reference boundary: marlin_*(in, qweight, scales(permuted), qzeros, g_idx, out, m, k, n, workspace, gs, stream)"""
+    K, N, gs = 1024, 512, 128
+    r = rng(M + dt + awq * 7)
+    q = make_quant(r, K, N, gs, dt, awq)
+    x = rand_dt(r, (M, K), dt)
+    tiled = ops.marlin_weight_repack(ops.dev(q["qweight"]), q["qweight"].shape, 4, awq)
+    sc = orc.marlin_permute_scales(q["scales"], grouped=True)
+    ws = ops.DevBuf(N * 4).zero()
+    out = ops.gptq_matmul(ops.dev(x), tiled, ops.dev(sc), ops.dev(q["qzeros"]), None, ws, 4, gs, awq, M, K, N, dt)
+    got = out.numpy(np.uint16, (M, N))
+    ref = orc.wna16_gemm(x, q["idx"], q["zeros"], q["scales"], gs, dt)
+    assert_close_dt(got, ref, dt, name="marlin ffi", abs_floor=2e-3)
+    assert not ws.numpy(np.uint32, (N,)).any(), "workspace must stay zero (wna16.rs:238-242)"
+
+
+@pytest.mark.parametrize("M", [1, 3, 16, 40])
+def test_wna16_bias_residual(M):
+    K, N = 512, 256
+    r = rng(M)
+    q = make_quant(r, K, N, 128, BF16, True)
+    x, bias, res = rand_dt(r, (M, K), BF16), rand_dt(r, (N,), BF16), rand_dt(r, (M, N), BF16)
+    tiled = ops.marlin_weight_repack(ops.dev(q["qweight"]), q["qweight"].shape, 4, True)
+    out = ops.wna16_gemm(ops.dev(x), tiled, ops.dev(q["scales"]), ops.dev(q["qzeros"]), M, K, N, 128, True, 0, ops.dev(bias), ops.dev(res))
+    got = out.numpy(np.uint16, (M, N))
+    ref = orc.wna16_gemm(x, q["idx"], q["zeros"], q["scales"], 128, BF16, bias, res)
+    assert_close_dt(got, ref, BF16, name="bias+residual", abs_floor=4e-3)
+
+
+@pytest.mark.parametrize("M", [1, 2, 8, 12, 32, 48])
+def test_gate_up_silu(M):
+    K, N = 512, 1024
+    r = rng(M + 99)
+    qg, qu = make_quant(r, K, N, 128, BF16), make_quant(r, K, N, 128, BF16)
+    x = rand_dt(r, (M, K), BF16)
+    tg = ops.marlin_weight_repack(ops.dev(qg["qweight"]), qg["qweight"].shape)
+    tu = ops.marlin_weight_repack(ops.dev(qu["qweight"]), qu["qweight"].shape)
+    out = ops.wna16_gate_up_silu(ops.dev(x), tg, ops.dev(qg["scales"]), None, tu, ops.dev(qu["scales"]), None, M, K, N, 128)
+    got = out.numpy(np.uint16, (M, N))
+    g = orc.wna16_gemm(x, qg["idx"], None, qg["scales"], 128, BF16)
+    u = orc.wna16_gemm(x, qu["idx"], None, qu["scales"], 128, BF16)
+    ref = orc.silu_mul(g, u, BF16)
+    # a 1-ulp flip of gate or up moves the product by up to ~2 ulp
+    assert_close_dt(got, ref, BF16, max_ulp=3.0, max_mismatch_frac=0.04, name="gate_up_silu", abs_floor=4e-3)
+
+
+def test_gemm_half_q_half_alt():
+    M, K, N = 3, 256, 128
+    r = rng(5)
+    q = make_quant(r, K, N, 128, F16, False)
+    zeros = r.integers(0, 15, size=(q["G"], N), dtype=np.uint8)  # stored value (z-1)
+    qz = np.zeros((q["G"], N // 8), np.uint32)
+    for n in range(N):
+        qz[:, n // 8] |= zeros[:, n].astype(np.uint32) << (4 * (n % 8))
+    x = rand_dt(r, (M, K), F16)
+    g_idx = (np.arange(K) // 128).astype(np.int32)
+    out = ops.gptq_matmul(ops.dev(x), ops.dev(q["qweight"]), ops.dev(q["scales"]), ops.dev(qz), ops.dev(g_idx), None, 4, 128, False, M, K, N, F16)
+    got = out.numpy(np.uint16, (M, N))
+    ref = orc.wna16_gemm(x, q["idx"], orc.gptq_unpack_zeros(qz, q["G"], N), q["scales"], 128, F16)
+    assert_close_dt(got, ref, F16, name="gptq alt", abs_floor=2e-3)
+
+
+@pytest.mark.parametrize("M", [1, 4, 8, 20, 32])
+@pytest.mark.parametrize("out_f32", [False, True])
+def test_dense_gemm(M, out_f32):
+    K, N = 512, 2048
+    r = rng(M)
+    x, w = rand_dt(r, (M, K), BF16), rand_dt(r, (N, K), BF16, 0.05)
+    out = ops.dense_gemm(ops.dev(x), ops.dev(w), None, M, K, N, BF16, F32 if out_f32 else BF16)
+    ref = orc.dense_gemm(x, w, None, BF16, F32 if out_f32 else BF16)
+    if out_f32:
+        got = out.numpy(np.float32, (M, N))
+        # values are bf16-rounded then widened (llama.rs:317-319): compare as bf16 bits
+        assert np.array_equal(orc.to_bf16(got).astype(np.uint32) << 16, got.view(np.uint32)), "f32 logits must be bf16-representable"
+        assert_close_dt(orc.to_bf16(got), orc.to_bf16(ref), BF16, name="dense f32", abs_floor=2e-3)
+    else:
+        assert_close_dt(out.numpy(np.uint16, (M, N)), ref, BF16, name="dense", abs_floor=2e-3)
+
+
+# ---------------------------------------------------------------- norms / elementwise
+@pytest.mark.parametrize("dt", [BF16, F16])
+@pytest.mark.parametrize("T,H", [(1, 4096), (7, 2048), (33, 3584)])
+def test_rms_norm(dt, T, H):
+    r = rng(T + H)
+    x, w = rand_dt(r, (T, H), dt), orc.to_dt((1 + 0.02 * r.standard_normal(H)).astype(np.float32), dt)
+    got = ops.rms_norm(ops.dev(x), ops.dev(w), T, H, 1e-5, dt).numpy(np.uint16, (T, H))
+    assert_close_dt(got, orc.rms_norm(x, w, 1e-5, dt), dt, name="rms_norm")
+    res = rand_dt(r, (T, H), dt)
+    h, o = ops.add_rms_norm(ops.dev(x), ops.dev(res), ops.dev(w), T, H, 1e-5, dt)
+    href = orc.add(x, res, dt)
+    assert np.array_equal(h.numpy(np.uint16, (T, H)), href)
+    assert_close_dt(o.numpy(np.uint16, (T, H)), orc.rms_norm(href, w, 1e-5, dt), dt, name="add_rms_norm")
+
+
+def test_fused_norm_gemv():
+    """RMSNorm fused into the GEMV prologue == separate norm + GEMM (rounding points preserved)."""
+    pytest.importorskip("ctypes")
+    # exercised through the engine tests; here only the standalone ops are available
+
+
+@pytest.mark.parametrize("dt", [BF16, F16])
+def test_elementwise(dt):
+    r = rng(11)
+    n = 8 * 1000 + 5
+    a, b = rand_dt(r, (n,), dt, 3.0), rand_dt(r, (n,), dt, 3.0)
+    assert np.array_equal(ops.add(ops.dev(a), ops.dev(b), n, dt).numpy(np.uint16, (n,)), orc.add(a, b, dt))
+    got = ops.silu_mul(ops.dev(a), ops.dev(b), n, dt).numpy(np.uint16, (n,))
+    assert_close_dt(got, orc.silu_mul(a, b, dt), dt, name="silu_mul", max_mismatch_frac=0.001)
+
+
+def test_embedding_and_argmax():
+    r = rng(3)
+    V, H, T = 1000, 256, 9
+    table = rand_dt(r, (V, H), BF16)
+    ids = r.integers(0, V, size=T).astype(np.uint32)
+    got = ops.embedding(ops.dev(ids), ops.dev(table), T, H, V).numpy(np.uint16, (T, H))
+    assert np.array_equal(got, table[ids])
+    logits = r.standard_normal((5, 128256)).astype(np.float32)
+    logits[1, 77] = logits[1, 90000] = 50.0  # tie -> first index
+    logits[2, :] = -3.0  # all equal -> 0
+    assert np.array_equal(ops.argmax(ops.dev(logits), 5, 128256), orc.argmax_f32(logits))
+
+
+def test_fills_bit_exact():
+    n = 10007
+    b = ops.DevBuf(n * 4)
+    ops.lib().vra_fill_hash_u32(b.ptr, n, 1234, 0)
+    assert np.array_equal(b.numpy(np.uint32, (n,)), orc.fill_hash_u32(n, 1234))
+    ops.lib().vra_fill_uniform(b.ptr, n, 5, 0.002, 0.02, BF16, 0)
+    assert np.array_equal(b.numpy(np.uint16, (n,)), orc.fill_uniform((n,), 5, 0.002, 0.02, BF16))
+    ops.lib().vra_fill_normal(b.ptr, n, 6, 1.0, 0.02, BF16, 0)
+    assert np.array_equal(b.numpy(np.uint16, (n,)), orc.fill_normal((n,), 6, 1.0, 0.02, BF16))
+
+
+# ---------------------------------------------------------------- rotary
+@pytest.mark.parametrize("interleaved", [False, True])
+@pytest.mark.parametrize("table_f32", [False, True])
+@pytest.mark.parametrize("D,rot", [(128, 128), (64, 64), (128, 64)])
+def test_fused_rope(interleaved, table_f32, D, rot):
+    r = rng(D + rot)
+    T, Hq, Hkv = 13, 8, 2
+    cos, sin = orc.rope_tables(rot, 500000.0, 512, 2, 8.0, 1.0, 4.0, 8192)
+    tdt = F32 if table_f32 else BF16
+    cos_t, sin_t = (cos, sin) if table_f32 else (orc.to_bf16(cos), orc.to_bf16(sin))
+    q, k = rand_dt(r, (T, Hq, D), BF16), rand_dt(r, (T, Hkv, D), BF16)
+    pos = r.integers(0, 512, size=T).astype(np.int64)
+    qd, kd = ops.dev(q), ops.dev(k)
+    ops.FusedRope.apply_inplace(qd, kd, ops.dev(cos_t), ops.dev(sin_t), ops.dev(pos), interleaved, T, Hq, Hkv, D, BF16, tdt, rot)
+    qr = orc.rope(q, cos_t, sin_t, pos, interleaved, BF16, tdt, rot)
+    kr = orc.rope(k, cos_t, sin_t, pos, interleaved, BF16, tdt, rot)
+    assert np.array_equal(qd.numpy(np.uint16, q.shape), qr)
+    assert np.array_equal(kd.numpy(np.uint16, k.shape), kr)
+
+
+# ---------------------------------------------------------------- paged KV + attention
+def _paged_setup(r, ctxs, Hkv, D, BS, dt, NB=64):
+    """random K/V history scattered into a shuffled block pool through reshape_and_cache."""
+    B = len(ctxs)
+    max_blocks = max((c + BS - 1) // BS for c in ctxs)
+    perm = r.permutation(NB)
+    bt = np.zeros((B, max_blocks), np.uint32)
+    nxt = 0
+    ks, vs, slots = [], [], []
+    for b, c in enumerate(ctxs):
+        nb = (c + BS - 1) // BS
+        bt[b, :nb] = perm[nxt:nxt + nb]
+        nxt += nb
+        ks.append(rand_dt(r, (c, Hkv, D), dt))
+        vs.append(rand_dt(r, (c, Hkv, D), dt))
+        slots.append(np.array([bt[b, j // BS] * BS + j % BS for j in range(c)], np.int64))
+    k, v, sl = np.concatenate(ks), np.concatenate(vs), np.concatenate(slots)
+    kc_ref = np.zeros((NB, Hkv, BS, D), np.uint16)
+    vc_ref = np.zeros((NB, Hkv, D, BS), np.uint16)
+    orc.reshape_and_cache(k, v, kc_ref, vc_ref, sl, BS, dt)
+    # poison unused slots on the device with NaN bit patterns: kernels must never let them through
+    kc, vc = ops.DevBuf(kc_ref.nbytes).fill_bytes(0xFF), ops.DevBuf(vc_ref.nbytes).fill_bytes(0xFF)
+    return dict(B=B, bt=bt, max_blocks=max_blocks, k=k, v=v, slots=sl, kc_ref=kc_ref, vc_ref=vc_ref, kc=kc, vc=vc, ks=ks, vs=vs)
+
+
+@pytest.mark.parametrize("Hq,Hkv,D", [(32, 8, 128), (28, 4, 128), (8, 1, 128), (32, 4, 64)])
+@pytest.mark.parametrize("ctxs", [[1], [31, 32, 33], [64, 65, 200, 7], [1000]])
+def test_paged_attention_decode(Hq, Hkv, D, ctxs):
+    BS, dt = 64, BF16
+    r = rng(Hq + D + sum(ctxs))
+    s = _paged_setup(r, ctxs, Hkv, D, BS, dt)
+    pa = ops.PagedAttention(Hq, D, D ** -0.5, Hkv, BS, dt)
+    pa.reshape_and_cache(ops.dev(s["k"]), ops.dev(s["v"]), s["kc"], s["vc"], ops.dev(s["slots"]), len(s["slots"]))
+    # the scatter itself is byte work: bit-exact on every written slot
+    kc_got = s["kc"].numpy(np.uint16, s["kc_ref"].shape)
+    vc_got = s["vc"].numpy(np.uint16, s["vc_ref"].shape)
+    written = np.zeros(s["kc_ref"].shape[0] * BS, bool)
+    written[s["slots"]] = True
+    wk = written.reshape(-1, 1, BS, 1)
+    assert np.array_equal(np.where(wk, kc_got, 0), s["kc_ref"])
+    assert np.array_equal(np.where(written.reshape(-1, 1, 1, BS), vc_got, 0), s["vc_ref"])
+    B = s["B"]
+    q = rand_dt(r, (B, Hq, D), dt)
+    cl = np.array(ctxs, np.uint32)
+    out = pa.forward_decode(ops.dev(q), s["kc"], s["vc"], ops.dev(s["bt"]), ops.dev(cl), B, s["max_blocks"], max(ctxs))
+    got = out.numpy(np.uint16, (B, Hq, D))
+    ref = orc.paged_attention(q, s["kc_ref"], s["vc_ref"], s["bt"], cl, None, Hkv, BS, D ** -0.5, dt)
+    # P is rounded to bf16 before P·V (MFMA operand): tolerance 2 ulp + small absolute floor
+    assert_close_dt(got, ref, dt, max_ulp=2.0, max_mismatch_frac=0.5, name="decode attention", abs_floor=3e-3)
+
+
+def test_paged_attention_decode_split_kv():
+    Hq, Hkv, D, BS, dt = 32, 8, 128, 64, BF16
+    ctxs = [5000, 4097]
+    r = rng(77)
+    s = _paged_setup(r, ctxs, Hkv, D, BS, dt, NB=160)
+    pa = ops.PagedAttention(Hq, D, D ** -0.5, Hkv, BS, dt)
+    pa.reshape_and_cache(ops.dev(s["k"]), ops.dev(s["v"]), s["kc"], s["vc"], ops.dev(s["slots"]), len(s["slots"]))
+    q = rand_dt(r, (2, Hq, D), dt)
+    cl = np.array(ctxs, np.uint32)
+    ws = ops.DevBuf(ops.lib().vra_paged_attention_decode_workspace_bytes(2, Hq, D, 5000))
+    out = pa.forward_decode(ops.dev(q), s["kc"], s["vc"], ops.dev(s["bt"]), ops.dev(cl), 2, s["max_blocks"], 5000, ws)
+    ref = orc.paged_attention(q, s["kc_ref"], s["vc_ref"], s["bt"], cl, None, Hkv, BS, D ** -0.5, dt)
+    assert_close_dt(out.numpy(np.uint16, (2, Hq, D)), ref, dt, max_ulp=2.0, max_mismatch_frac=0.5, name="split-kv", abs_floor=3e-3)
+
+
+@pytest.mark.parametrize("Hq,Hkv,D", [(8, 2, 128), (4, 4, 64)])
+@pytest.mark.parametrize("paged", [True, False])
+def test_attention_prefill(Hq, Hkv, D, paged):
+    """causal varlen prefill; paged mode includes a cached prefix (chunked prefill / prefix-cache hit)."""
+    BS, dt = 64, BF16
+    r = rng(Hq * 3 + D + paged)
+    lens_q = [5, 70, 1, 33]
+    prefix = [0, 64, 130, 0] if paged else [0, 0, 0, 0]
+    ctxs = [a + b for a, b in zip(lens_q, prefix)]
+    s = _paged_setup(r, ctxs, Hkv, D, BS, dt)
+    pa = ops.PagedAttention(Hq, D, D ** -0.5, Hkv, BS, dt)
+    cu_q = np.concatenate([[0], np.cumsum(lens_q)]).astype(np.uint32)
+    cu_k = np.concatenate([[0], np.cumsum(ctxs)]).astype(np.uint32)
+    Tq = int(cu_q[-1])
+    q = rand_dt(r, (Tq, Hq, D), dt)
+    cl = np.array(ctxs, np.uint32)
+    if paged:
+        pa.reshape_and_cache(ops.dev(s["k"]), ops.dev(s["v"]), s["kc"], s["vc"], ops.dev(s["slots"]), len(s["slots"]))
+        out = pa.forward_prefill(ops.dev(q), Tq, max(lens_q), ops.dev(cu_q), len(lens_q), k_cache=s["kc"], v_cache=s["vc"],
+                                 block_tables=ops.dev(s["bt"]), context_lens=ops.dev(cl), max_blocks=s["max_blocks"])
+        ref = orc.paged_attention(q, s["kc_ref"], s["vc_ref"], s["bt"], cl, cu_q, Hkv, BS, D ** -0.5, dt)
+    else:
+        out = pa.forward_prefill(ops.dev(q), Tq, max(lens_q), ops.dev(cu_q), len(lens_q), k=ops.dev(s["k"]), v=ops.dev(s["v"]), cu_k=ops.dev(cu_k))
+        ref = orc.varlen_attention(q, s["k"], s["v"], cu_q, cu_k, D ** -0.5, dt)
+    assert_close_dt(out.numpy(np.uint16, (Tq, Hq, D)), ref, dt, max_ulp=2.0, max_mismatch_frac=0.5, name="prefill attention", abs_floor=3e-3)
+
+
+def test_causal_mask_and_cast():
+    L = 37
+    m = ops.DevBuf(L * L * 2)
+    ops.lib().vra_causal_mask(m.ptr, L, 0, BF16, 0)
+    assert np.array_equal(m.numpy(np.uint16, (L, L)), orc.causal_mask(L, 0, BF16))
+    ops.lib().vra_causal_mask(m.ptr, L, 8, BF16, 0)
+    assert np.array_equal(m.numpy(np.uint16, (L, L)), orc.causal_mask(L, 8, BF16))
+    r = rng(1)
+    x = r.standard_normal(1001).astype(np.float32)
+    o = ops.DevBuf(1001 * 2)
+    ops.lib().vra_cast(ops.dev(x).ptr, o.ptr, 1001, F32, BF16, 0)
+    assert np.array_equal(o.numpy(np.uint16, (1001,)), orc.to_bf16(x))
+    ops.lib().vra_cast(ops.dev(x).ptr, o.ptr, 1001, F32, F16, 0)
+    assert np.array_equal(o.numpy(np.uint16, (1001,)), x.astype(np.float16).view(np.uint16))
+
+
+def test_swap_blocks_roundtrip():
+    r = rng(2)
+    blocks = r.integers(0, 2 ** 32, size=(8, 1024), dtype=np.uint64).astype(np.uint32)
+    src, dst = ops.dev(blocks), ops.DevBuf(blocks.nbytes).zero()
+    pairs = np.array([0, 3, 5, 1, 7, 7], np.int64)
+    ops.lib().vra_swap_blocks(src.ptr, dst.ptr, pairs.ctypes.data_as(C.c_void_p), 3, 4096, 0, 0)
+    got = dst.numpy(np.uint32, (8, 1024))
+    assert np.array_equal(got[3], blocks[0]) and np.array_equal(got[1], blocks[5]) and np.array_equal(got[7], blocks[7])
+    assert not got[0].any()
+
+
+def test_argument_errors_are_reported():
+    L = ops.lib()
+    L.vra_clear_error()
+    L.gptq_repack(None, None, 16, 16, 0)
+    assert b"null" in L.vra_last_error()
+    L.vra_clear_error()
+    d = ops.DevBuf(1024)
+    L.gptq_repack(d.ptr, d.ptr, 3, 16, 0)  # K = 24, not a multiple of 128
+    assert L.vra_last_error() != b""
+    L.vra_clear_error()

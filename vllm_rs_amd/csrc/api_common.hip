@@ -1,0 +1,117 @@
+// api_common.hip — error side channel, device plumbing, scratch (include/vllm_rs_amd.h §B tail).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+
+#include "common.cuh"
+#include "scratch.h"
+
+static thread_local char g_err[512] = {0};
+void vra_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  if (getenv("VRA_DEBUG")) fprintf(stderr, "[vllm_rs_amd] error: %s\n", g_err);
+}
+extern "C" const char* vra_last_error(void) { return g_err; }
+extern "C" void vra_clear_error(void) { g_err[0] = 0; }
+extern "C" const char* vra_version(void) { return "vllm_rs_amd 0.1.0 (gfx950, hip)"; }
+
+static int hip_ok(hipError_t e, const char* what) {
+  if (e != hipSuccess) {
+    vra_set_error("%s: %s", what, hipGetErrorString(e));
+    return -1;
+  }
+  return 0;
+}
+extern "C" int32_t vra_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+extern "C" int32_t vra_set_device(int32_t d) { return hip_ok(hipSetDevice(d), "hipSetDevice"); }
+extern "C" void* vra_malloc(size_t bytes) {
+  void* p = nullptr;
+  if (hip_ok(hipMalloc(&p, bytes ? bytes : 16), "hipMalloc")) return nullptr;
+  return p;
+}
+extern "C" void vra_free(void* p) {
+  if (p) (void)hipFree(p);
+}
+extern "C" void* vra_malloc_host(size_t bytes) {
+  void* p = nullptr;
+  if (hip_ok(hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault), "hipHostMalloc")) return nullptr;
+  return p;
+}
+extern "C" void vra_free_host(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+extern "C" int32_t vra_memcpy_h2d(void* dst, const void* src, size_t bytes, int64_t stream) {
+  return hip_ok(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, as_stream(stream)), "memcpy h2d");
+}
+extern "C" int32_t vra_memcpy_d2h(void* dst, const void* src, size_t bytes, int64_t stream) {
+  return hip_ok(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, as_stream(stream)), "memcpy d2h");
+}
+extern "C" int32_t vra_memcpy_d2d(void* dst, const void* src, size_t bytes, int64_t stream) {
+  return hip_ok(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, as_stream(stream)), "memcpy d2d");
+}
+extern "C" int32_t vra_memset(void* dst, int32_t value, size_t bytes, int64_t stream) {
+  return hip_ok(hipMemsetAsync(dst, value, bytes, as_stream(stream)), "memset");
+}
+extern "C" int32_t vra_stream_sync(int64_t stream) { return hip_ok(hipStreamSynchronize(as_stream(stream)), "stream sync"); }
+extern "C" int32_t vra_device_sync(void) { return hip_ok(hipDeviceSynchronize(), "device sync"); }
+extern "C" int64_t vra_stream_create(void) {
+  hipStream_t s = nullptr;
+  if (hip_ok(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "stream create")) return 0;
+  return reinterpret_cast<int64_t>(s);
+}
+extern "C" void vra_stream_destroy(int64_t s) {
+  if (s) (void)hipStreamDestroy(as_stream(s));
+}
+extern "C" int32_t vra_mem_info(size_t* h_free, size_t* h_total) { return hip_ok(hipMemGetInfo(h_free, h_total), "mem info"); }
+extern "C" void* vra_event_create(void) {
+  hipEvent_t e = nullptr;
+  if (hip_ok(hipEventCreate(&e), "event create")) return nullptr;
+  return e;
+}
+extern "C" void vra_event_destroy(void* e) {
+  if (e) (void)hipEventDestroy((hipEvent_t)e);
+}
+extern "C" int32_t vra_event_record(void* e, int64_t stream) { return hip_ok(hipEventRecord((hipEvent_t)e, as_stream(stream)), "event record"); }
+extern "C" float vra_event_elapsed_ms(void* a, void* b) {
+  float ms = -1.f;
+  if (hip_ok(hipEventSynchronize((hipEvent_t)b), "event sync")) return -1.f;
+  if (hip_ok(hipEventElapsedTime(&ms, (hipEvent_t)a, (hipEvent_t)b), "event elapsed")) return -1.f;
+  return ms;
+}
+
+// ---------------------------------------------------------------- scratch
+static const size_t kSlabBytes = (size_t)192 << 20;  // fp32 split-K partials
+static const size_t kCounters = 1 << 16;
+static float* g_slabs = nullptr;
+static uint32_t* g_counters = nullptr;
+static std::mutex g_scratch_mu;
+bool vra_scratch_init() {
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (g_slabs && g_counters) return true;
+  void* p = nullptr;
+  if (hipMalloc(&p, kSlabBytes) != hipSuccess) return false;
+  g_slabs = (float*)p;
+  if (hipMalloc(&p, kCounters * sizeof(uint32_t)) != hipSuccess) return false;
+  g_counters = (uint32_t*)p;
+  if (hipMemset(g_counters, 0, kCounters * sizeof(uint32_t)) != hipSuccess) return false;
+  return true;
+}
+float* vra_scratch_slabs() {
+  if (!g_slabs) vra_scratch_init();
+  return g_slabs;
+}
+uint32_t* vra_scratch_counters() {
+  if (!g_counters) vra_scratch_init();
+  return g_counters;
+}
+size_t vra_scratch_slab_bytes() { return kSlabBytes; }
+size_t vra_scratch_counter_count() { return kCounters; }

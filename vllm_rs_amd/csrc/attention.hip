@@ -1,0 +1,419 @@
+// attention.hip — paged attention (decode + causal varlen prefill) on MFMA, no LDS staging, no
+// transposes.  include/vllm_rs_amd.h §B; restates attention_rs::PagedAttention::forward as called
+// from src/models/layers/attention.rs:808-820.
+//
+// Cache geometry: K [NB, Hkv, BS, D], V [NB, Hkv, D, BS]  (BS % 32 == 0).
+// One wave owns a 16-row tile (rows = 16 query tokens of one q-head in prefill; the G q-heads of a
+// kv-head in decode) and walks 32-token KV tiles:
+//   Sᵀ = K·Qᵀ   A = K rows (lane: token l&15, 8 channels)   B = Qᵀ (held in registers)
+//        -> lane (row l&15) holds 4+4 scores of tokens (l>>4)*4+r of the two 16-token halves,
+//   softmax statistics per row: in-lane + 2 xor-shuffles (16, 32),
+//   O += P·V    A = P: the lane's own 8 probabilities ARE the MFMA A fragment when the contraction
+//        index is mapped as k=(oct,e) -> token (e<4 ? oct*4+e : 16+oct*4+e-4); B = V read token-minor
+//        from the transposed V cache with two 8-byte loads.
+// Roofline: HBM (KV bytes) for decode; MFMA for long prefill.
+#include "common.cuh"
+
+#define PA_THREADS 256
+#define PA_WAVES 4
+
+struct PagedAttnArgs {
+  void* out;          // [Tq, Hq, D]
+  const void* q;      // [Tq, Hq, D]
+  const void* kc;     // K cache
+  const void* vc;     // V cache
+  const void* kflat;  // non-paged fallback: k [Tk, Hkv, D]
+  const void* vflat;  //                     v [Tk, Hkv, D]
+  const uint32_t* block_tables;  // [B, max_blocks] or null (fallback)
+  const uint32_t* context_lens;  // [B] (paged)
+  const uint32_t* cu_q;          // [B+1] or null (decode)
+  const uint32_t* cu_k;          // [B+1] (fallback)
+  int B, Hq, Hkv, BS, max_blocks;
+  float scale_log2e;  // scale * log2(e)
+  float softcap;      // 0 = off
+  float scale;
+  int decode;
+  // split-KV across workgroups (decode, long contexts)
+  int nsplit;
+  float* ws_o;   // [B, Hq, nsplit, D]
+  float* ws_ml;  // [B, Hq, nsplit, 2]
+};
+
+template <class DT, int D>
+__global__ __launch_bounds__(PA_THREADS) void paged_attn_kernel(const PagedAttnArgs a) {
+  constexpr int DJ = D / 32;  // k-steps of QK^T
+  constexpr int DT16 = D / 16;  // output channel tiles
+  __shared__ __attribute__((aligned(16))) float lds_o[PA_WAVES][16][D + 4];
+  __shared__ float lds_ml[PA_WAVES][16][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rq = lane & 15, oct = lane >> 4;
+  const int G = a.Hq / a.Hkv;
+  const int b = blockIdx.z;
+
+  // ---- geometry of this wave's row tile
+  int ctx, lq, q0;
+  if (a.block_tables) ctx = (int)a.context_lens[b];
+  else ctx = (int)(a.cu_k[b + 1] - a.cu_k[b]);
+  if (a.cu_q) {
+    q0 = (int)a.cu_q[b];
+    lq = (int)(a.cu_q[b + 1] - a.cu_q[b]);
+  } else {
+    q0 = b;
+    lq = 1;
+  }
+  int hk, qtok, qhead;   // per-lane row identity (row rq)
+  bool row_valid;
+  int tile_first_pos, tile_last_pos;
+  int kv_w0, kv_w1;      // this wave's KV tile range [kv_w0, kv_w1) in 32-token tiles
+  const int split = a.decode ? blockIdx.x : 0;
+  if (a.decode) {
+    hk = blockIdx.y;
+    qtok = 0;
+    qhead = hk * G + rq;
+    row_valid = rq < G;
+    tile_first_pos = tile_last_pos = ctx - 1;
+    const int ntiles = (ctx + 31) >> 5;
+    // split across workgroups (nsplit) then across the 4 waves
+    const int per_split = (ntiles + a.nsplit - 1) / a.nsplit;
+    const int s0 = min(ntiles, split * per_split), s1 = min(ntiles, s0 + per_split);
+    const int n_s = s1 - s0;
+    kv_w0 = s0 + (n_s * wave) / PA_WAVES;
+    kv_w1 = s0 + (n_s * (wave + 1)) / PA_WAVES;
+  } else {
+    qhead = blockIdx.y;
+    hk = qhead / G;
+    const int i0 = blockIdx.x * 64 + wave * 16;
+    if (i0 >= lq) {
+      // whole tile out of range; nothing to do (no cross-wave combine in prefill)
+      return;
+    }
+    qtok = i0 + rq;
+    row_valid = qtok < lq;
+    tile_first_pos = ctx - lq + i0;
+    tile_last_pos = ctx - lq + min(i0 + 15, lq - 1);
+    kv_w0 = 0;
+    kv_w1 = (tile_last_pos >> 5) + 1;
+  }
+  const int row_pos = a.decode ? ctx - 1 : (row_valid ? ctx - lq + qtok : -1);
+
+  // ---- Q fragments (B operand of K·Qᵀ): lane (row rq, octet oct)
+  s16x8 qf[DJ];
+  {
+    const uint16_t* qp = static_cast<const uint16_t*>(a.q) + ((size_t)(q0 + qtok) * a.Hq + qhead) * D;
+#pragma unroll
+    for (int j = 0; j < DJ; j++) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (row_valid) v = *reinterpret_cast<const u32x4*>(qp + j * 32 + oct * 8);
+      qf[j] = __builtin_bit_cast(s16x8, v);
+    }
+  }
+
+  f32x4 o[DT16];
+#pragma unroll
+  for (int t = 0; t < DT16; t++) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;  // per lane: row rq; l_run is this lane's partial sum
+
+  const uint16_t* kcache = static_cast<const uint16_t*>(a.kc);
+  const uint16_t* vcache = static_cast<const uint16_t*>(a.vc);
+  for (int tile = kv_w0; tile < kv_w1; tile++) {
+    const int T0 = tile << 5;
+    // ---- Sᵀ for the two 16-token halves
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    const uint16_t *krow0, *krow1;
+    size_t vbase = 0;
+    if (a.block_tables) {
+      const uint32_t blk = a.block_tables[(size_t)b * a.max_blocks + T0 / a.BS];
+      const int off = T0 % a.BS;
+      krow0 = kcache + (((size_t)blk * a.Hkv + hk) * a.BS + off + rq) * D;
+      krow1 = krow0 + 16 * D;
+      vbase = (((size_t)blk * a.Hkv + hk) * D) * a.BS + off;
+    } else {
+      // fallback: rows beyond ctx are clamped (their scores are masked below)
+      const size_t kb = a.cu_k[b];
+      int t0 = min(T0 + rq, ctx - 1), t1 = min(T0 + 16 + rq, ctx - 1);
+      krow0 = static_cast<const uint16_t*>(a.kflat) + ((kb + t0) * a.Hkv + hk) * D;
+      krow1 = static_cast<const uint16_t*>(a.kflat) + ((kb + t1) * a.Hkv + hk) * D;
+    }
+#pragma unroll
+    for (int j = 0; j < DJ; j++) {
+      const u32x4 k0 = *reinterpret_cast<const u32x4*>(krow0 + j * 32 + oct * 8);
+      const u32x4 k1 = *reinterpret_cast<const u32x4*>(krow1 + j * 32 + oct * 8);
+      s0 = DT::mfma(__builtin_bit_cast(s16x8, k0), qf[j], s0);
+      s1 = DT::mfma(__builtin_bit_cast(s16x8, k1), qf[j], s1);
+    }
+    // ---- scale, softcap, causal/length mask; scores in log2 domain
+    float sv[8];
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const int tok = T0 + (e < 4 ? 0 : 16) + oct * 4 + (e & 3);
+      float x = (e < 4 ? s0[e] : s1[e - 4]);
+      if (a.softcap > 0.f) x = a.softcap * tanhf(x * a.scale / a.softcap) * 1.44269504088896f;
+      else x *= a.scale_log2e;
+      if (tok > row_pos || tok >= ctx) x = -INFINITY;
+      sv[e] = x;
+      tmax = fmaxf(tmax, x);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax);
+    const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+    const float alpha = exp2f(m_run - m_safe);
+    float p[8], psum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      p[e] = exp2f(sv[e] - m_safe);
+      psum += p[e];
+    }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+    // ---- rescale O: rows of O live at (lane>>4)*4 + r; fetch their alpha from lane (that row)
+    float ar[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) ar[r] = __shfl(alpha, oct * 4 + r, 64);
+    u32x4 pa;
+    pa[0] = DT::pack2(p[0], p[1]);
+    pa[1] = DT::pack2(p[2], p[3]);
+    pa[2] = DT::pack2(p[4], p[5]);
+    pa[3] = DT::pack2(p[6], p[7]);
+    const s16x8 pfrag = __builtin_bit_cast(s16x8, pa);
+    // tail tile: cache slots beyond ctx hold arbitrary bits (0 * NaN = NaN) -> zero those V lanes
+    const bool tail = T0 + 32 > ctx;
+    uint32_t vm[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+    if (tail) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const int tok = T0 + (e < 4 ? 0 : 16) + oct * 4 + (e & 3);
+        if (tok >= ctx) vm[e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
+      }
+    }
+    // ---- O += P·V, channel tile by channel tile
+#pragma unroll
+    for (int t = 0; t < DT16; t++) {
+      u32x4 vv;
+      if (a.block_tables) {
+        const uint16_t* vp = vcache + vbase + (size_t)(t * 16 + rq) * a.BS + oct * 4;
+        const u32x2 lo = *reinterpret_cast<const u32x2*>(vp);
+        const u32x2 hi = *reinterpret_cast<const u32x2*>(vp + 16);
+        vv = u32x4{lo[0], lo[1], hi[0], hi[1]};
+      } else {
+        const size_t kb = a.cu_k[b];
+        uint16_t tmp[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          int tok = min(T0 + (e < 4 ? 0 : 16) + oct * 4 + (e & 3), ctx - 1);
+          tmp[e] = static_cast<const uint16_t*>(a.vflat)[((kb + tok) * a.Hkv + hk) * D + t * 16 + rq];
+        }
+        vv = u32x4{(uint32_t)tmp[0] | ((uint32_t)tmp[1] << 16), (uint32_t)tmp[2] | ((uint32_t)tmp[3] << 16),
+                   (uint32_t)tmp[4] | ((uint32_t)tmp[5] << 16), (uint32_t)tmp[6] | ((uint32_t)tmp[7] << 16)};
+      }
+      if (tail) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) vv[i] &= vm[i];
+      }
+      f32x4 oc = o[t];
+#pragma unroll
+      for (int r = 0; r < 4; r++) oc[r] *= ar[r];
+      o[t] = DT::mfma(pfrag, __builtin_bit_cast(s16x8, vv), oc);
+    }
+  }
+  // ---- finish: total l per row (sum the 4 lane groups), bring (m,l) to the O row layout
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+
+  if (a.decode) {
+    // combine the 4 waves' partial results in LDS
+#pragma unroll
+    for (int t = 0; t < DT16; t++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) lds_o[wave][oct * 4 + r][t * 16 + rq] = o[t][r];
+    if (oct == 0) {
+      lds_ml[wave][rq][0] = m_run;
+      lds_ml[wave][rq][1] = l_run;
+    }
+    __syncthreads();
+    // thread -> (row, channel pair...) : 16 rows x D channels over 256 threads
+    for (int idx = tid; idx < 16 * D; idx += PA_THREADS) {
+      const int row = idx / D, d = idx % D;
+      if (row >= G) continue;
+      float M = -INFINITY;
+#pragma unroll
+      for (int w = 0; w < PA_WAVES; w++) M = fmaxf(M, lds_ml[w][row][0]);
+      const float Ms = M == -INFINITY ? 0.f : M;
+      float L = 0.f, acc = 0.f;
+#pragma unroll
+      for (int w = 0; w < PA_WAVES; w++) {
+        const float f = exp2f(lds_ml[w][row][0] - Ms);
+        L += lds_ml[w][row][1] * f;
+        acc += lds_o[w][row][d] * f;
+      }
+      const int head = hk * G + row;
+      if (a.nsplit > 1) {
+        a.ws_o[(((size_t)b * a.Hq + head) * a.nsplit + split) * D + d] = acc;
+        if (d == 0) {
+          a.ws_ml[(((size_t)b * a.Hq + head) * a.nsplit + split) * 2 + 0] = M;
+          a.ws_ml[(((size_t)b * a.Hq + head) * a.nsplit + split) * 2 + 1] = L;
+        }
+      } else {
+        static_cast<uint16_t*>(a.out)[((size_t)q0 * a.Hq + head) * D + d] = DT::from_f32(L > 0.f ? acc / L : 0.f);
+      }
+    }
+  } else {
+    float lr[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) lr[r] = __shfl(l_run, oct * 4 + r, 64);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int i = blockIdx.x * 64 + wave * 16 + oct * 4 + r;
+      if (i >= lq) continue;
+      uint16_t* op = static_cast<uint16_t*>(a.out) + ((size_t)(q0 + i) * a.Hq + qhead) * D;
+      const float inv = lr[r] > 0.f ? 1.0f / lr[r] : 0.f;
+#pragma unroll
+      for (int t = 0; t < DT16; t++) op[t * 16 + rq] = DT::from_f32(o[t][r] * inv);
+    }
+  }
+}
+
+// second pass for split-KV decode: merge nsplit partials per (b, head)
+template <class DT, int D>
+__global__ void paged_attn_merge_kernel(uint16_t* out, const float* ws_o, const float* ws_ml, int Hq, int nsplit) {
+  const int b = blockIdx.y, head = blockIdx.x, d = threadIdx.x;
+  const size_t base = ((size_t)b * Hq + head) * nsplit;
+  float M = -INFINITY;
+  for (int s = 0; s < nsplit; s++) M = fmaxf(M, ws_ml[(base + s) * 2]);
+  const float Ms = M == -INFINITY ? 0.f : M;
+  float L = 0.f, acc = 0.f;
+  for (int s = 0; s < nsplit; s++) {
+    const float f = exp2f(ws_ml[(base + s) * 2] - Ms);
+    L += ws_ml[(base + s) * 2 + 1] * f;
+    acc += ws_o[(base + s) * D + d] * f;
+  }
+  out[((size_t)b * Hq + head) * D + d] = DT::from_f32(L > 0.f ? acc / L : 0.f);
+}
+
+static int decode_nsplit(int batch, int kv_heads, int max_context_len) {
+  // enough workgroups to cover the chip (256 CUs); each split should keep >= 8 tiles (256 tokens)
+  int wg = batch * kv_heads;
+  int tiles = (max_context_len + 31) / 32;
+  int s = 1;
+  while (wg * s < 512 && tiles / (s * 2) >= 8 && s < 64) s *= 2;
+  return s;
+}
+
+extern "C" size_t vra_paged_attention_decode_workspace_bytes(int32_t max_batch, int32_t q_heads, int32_t head_dim,
+                                                             int32_t max_context_len) {
+  (void)max_context_len;
+  return (size_t)max_batch * q_heads * 64 * (head_dim + 2) * sizeof(float);
+}
+
+template <class DT>
+static void launch_attn(const PagedAttnArgs& a, int D, dim3 grid, hipStream_t st) {
+  if (D == 128) paged_attn_kernel<DT, 128><<<grid, PA_THREADS, 0, st>>>(a);
+  else if (D == 64) paged_attn_kernel<DT, 64><<<grid, PA_THREADS, 0, st>>>(a);
+  else vra_set_error("paged attention: head_dim %d not supported (64, 128)", D);
+}
+
+extern "C" void vra_paged_attention_decode(void* out, const void* q, const void* k_cache, const void* v_cache,
+                                           const uint32_t* block_tables, const uint32_t* context_lens, int32_t batch,
+                                           int32_t q_heads, int32_t kv_heads, int32_t head_dim, int32_t block_size,
+                                           int32_t max_blocks_per_seq, int32_t max_context_len, float scale, float softcap,
+                                           void* workspace, int32_t dtype, int64_t stream) {
+  VRA_CHECK_ARG(dtype == VRA_BF16 || dtype == VRA_F16, "vra_paged_attention_decode: dtype must be bf16/f16");
+  VRA_CHECK_ARG(block_size % 32 == 0, "vra_paged_attention_decode: block_size must be a multiple of 32");
+  VRA_CHECK_ARG(q_heads % kv_heads == 0 && q_heads / kv_heads <= 16, "vra_paged_attention_decode: need Hq %% Hkv == 0 and group <= 16");
+  VRA_CHECK_ARG(out && q && k_cache && v_cache && block_tables && context_lens, "vra_paged_attention_decode: null pointer");
+  if (batch <= 0) return;
+  PagedAttnArgs a = {};
+  a.out = out;
+  a.q = q;
+  a.kc = k_cache;
+  a.vc = v_cache;
+  a.block_tables = block_tables;
+  a.context_lens = context_lens;
+  a.B = batch;
+  a.Hq = q_heads;
+  a.Hkv = kv_heads;
+  a.BS = block_size;
+  a.max_blocks = max_blocks_per_seq;
+  a.scale = scale;
+  a.scale_log2e = scale * 1.44269504088896f;
+  a.softcap = softcap;
+  a.decode = 1;
+  a.nsplit = workspace ? decode_nsplit(batch, kv_heads, max_context_len) : 1;
+  a.ws_o = static_cast<float*>(workspace);
+  a.ws_ml = a.ws_o ? a.ws_o + (size_t)batch * q_heads * a.nsplit * head_dim : nullptr;
+  dim3 grid(a.nsplit, kv_heads, batch);
+  hipStream_t st = as_stream(stream);
+  if (dtype == VRA_BF16) launch_attn<BF16>(a, head_dim, grid, st);
+  else launch_attn<F16>(a, head_dim, grid, st);
+  if (a.nsplit > 1) {
+    dim3 mg(q_heads, batch);
+#define VRA_MERGE(DT, DD) paged_attn_merge_kernel<DT, DD><<<mg, DD, 0, st>>>((uint16_t*)out, a.ws_o, a.ws_ml, q_heads, a.nsplit)
+    if (dtype == VRA_BF16) {
+      if (head_dim == 128) VRA_MERGE(BF16, 128);
+      else if (head_dim == 64) VRA_MERGE(BF16, 64);
+    } else {
+      if (head_dim == 128) VRA_MERGE(F16, 128);
+      else if (head_dim == 64) VRA_MERGE(F16, 64);
+    }
+#undef VRA_MERGE
+  }
+}
+
+extern "C" void vra_paged_attention_prefill(void* out, const void* q, const void* k, const void* v, const void* k_cache,
+                                            const void* v_cache, const uint32_t* block_tables, const uint32_t* context_lens,
+                                            const uint32_t* cu_seqlens_q, const uint32_t* cu_seqlens_k, int32_t batch,
+                                            int32_t total_q, int32_t max_seqlen_q, int32_t q_heads, int32_t kv_heads,
+                                            int32_t head_dim, int32_t block_size, int32_t max_blocks_per_seq, float scale,
+                                            float softcap, int32_t dtype, int64_t stream) {
+  (void)total_q;
+  VRA_CHECK_ARG(dtype == VRA_BF16 || dtype == VRA_F16, "vra_paged_attention_prefill: dtype must be bf16/f16");
+  VRA_CHECK_ARG(out && q && cu_seqlens_q, "vra_paged_attention_prefill: null pointer");
+  VRA_CHECK_ARG(q_heads % kv_heads == 0, "vra_paged_attention_prefill: need Hq %% Hkv == 0");
+  if (block_tables) {
+    VRA_CHECK_ARG(k_cache && v_cache && context_lens, "vra_paged_attention_prefill: paged mode needs caches and context_lens");
+    VRA_CHECK_ARG(block_size % 32 == 0, "vra_paged_attention_prefill: block_size must be a multiple of 32");
+  } else {
+    VRA_CHECK_ARG(k && v && cu_seqlens_k, "vra_paged_attention_prefill: contiguous mode needs k, v, cu_seqlens_k");
+  }
+  if (batch <= 0 || max_seqlen_q <= 0) return;
+  PagedAttnArgs a = {};
+  a.out = out;
+  a.q = q;
+  a.kc = k_cache;
+  a.vc = v_cache;
+  a.kflat = k;
+  a.vflat = v;
+  a.block_tables = block_tables;
+  a.context_lens = context_lens;
+  a.cu_q = cu_seqlens_q;
+  a.cu_k = cu_seqlens_k;
+  a.B = batch;
+  a.Hq = q_heads;
+  a.Hkv = kv_heads;
+  a.BS = block_size;
+  a.max_blocks = max_blocks_per_seq;
+  a.scale = scale;
+  a.scale_log2e = scale * 1.44269504088896f;
+  a.softcap = softcap;
+  a.decode = 0;
+  a.nsplit = 1;
+  dim3 grid((max_seqlen_q + 63) / 64, q_heads, batch);
+  if (dtype == VRA_BF16) launch_attn<BF16>(a, head_dim, grid, as_stream(stream));
+  else launch_attn<F16>(a, head_dim, grid, as_stream(stream));
+}
+
+extern "C" void vra_rope_cache_attention_decode(void* out, void* q, void* k, const void* v, void* k_cache, void* v_cache,
+                                                const void* cos, const void* sin, const int64_t* positions,
+                                                const int64_t* slot_mapping, const uint32_t* block_tables,
+                                                const uint32_t* context_lens, int32_t batch, int32_t q_heads,
+                                                int32_t kv_heads, int32_t head_dim, int32_t block_size,
+                                                int32_t max_blocks_per_seq, int32_t max_context_len, float scale,
+                                                void* workspace, int32_t dtype, int64_t stream) {
+  // Round 1: composition of the three entry points on one stream (the fused kernel is a later
+  // optimisation; the contract — results identical to the three separate calls — already holds).
+  vra_fused_rope(q, k, cos, sin, positions, batch, q_heads, kv_heads, head_dim, head_dim, 0, dtype, dtype, stream);
+  vra_reshape_and_cache(k, v, k_cache, v_cache, slot_mapping, batch, kv_heads, head_dim, block_size, dtype, stream);
+  vra_paged_attention_decode(out, q, k_cache, v_cache, block_tables, context_lens, batch, q_heads, kv_heads, head_dim,
+                             block_size, max_blocks_per_seq, max_context_len, scale, 0.f, workspace, dtype, stream);
+}

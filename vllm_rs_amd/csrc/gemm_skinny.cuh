@@ -1,0 +1,257 @@
+// gemm_skinny.cuh — "kernel B": skinny/medium-M GEMM (any M, processed in 16*MT-row chunks).
+//
+// Used for decode batches 9..64 and (round 1) for prefill.  Roofline: HBM for M <= ~128, MFMA above.
+// Workgroup = 512 threads = 8 waves; wave w owns n-block (blockIdx.x*8 + w) = 16 output columns
+// (DUAL: the same block of the gate AND the up tensor) and walks ALL k-tiles of its K slice, so
+// each weight byte is read once per 16*MT rows.  The x chunk (16*MT rows x 256 k) is staged through
+// LDS (double buffered, XOR-swizzled so both the 16 B stores and the MFMA B-fragment `ds_read_b128`
+// are conflict-free) and shared by the 8 waves.  grid.y = M chunks, grid.z = K slices (split-K):
+// slice partials go to fp32 slabs and the last-arriving workgroup of a tile reduces them in fixed
+// slice order (deterministic) and applies the epilogue — agent-scope release/acquire per
+// cdna_hip_programming.md §6 G16.
+#pragma once
+#include "wna16.cuh"
+
+#define GB_THREADS 512
+#define GB_WAVES 8
+#define GB_KC 256  // k per staged chunk (2 k-tiles)
+
+struct GemmBArgs {
+  const void* w0;  // int4 tiled / dense [N,K]
+  const void* w1;  // DUAL: up tensor
+  const void* sc0;
+  const void* sc1;
+  const uint32_t* qz0;
+  const uint32_t* qz1;
+  const void* bias0;
+  const void* bias1;
+  const void* x;  // [M, x_ld]
+  int x_ld;
+  const void* residual;
+  int res_ld;
+  void* out;  // [M, out_ld]
+  int out_ld;
+  int M, N, K;
+  int group_size, is_awq, scales_layout, out_f32;
+  int splitk;         // grid.z
+  float* slabs;       // [splitk][Mpad][Npad(,2)] fp32 partials (splitk > 1)
+  uint32_t* counters;  // one per (m-chunk, n-group) tile, zero on entry, zero on exit
+};
+
+template <class DT, bool INT4, bool DUAL, int MT>
+__global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int ROWS = MT * 16;
+  constexpr int NW = DUAL ? 2 : 1;
+  constexpr int XS_U32 = (GB_KC / 8) * ROWS * 4;  // one x buffer, in u32
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nn = lane & 15, oct = lane >> 4;
+  const int K = a.K, N = a.N, M = a.M;
+  const int KT = K >> 7;
+  const int g = a.group_size > 0 ? a.group_size : K;
+  const bool grouped = a.group_size > 0 && a.group_size < K;
+  const int nb = blockIdx.x * GB_WAVES + wave;  // this wave's n-block
+  const bool nb_ok = nb * 16 < N;
+  const int m0 = blockIdx.y * ROWS;
+  // K slice of this workgroup, in chunks of GB_KC (slices are chunk aligned)
+  const int nchunk_total = (K + GB_KC - 1) / GB_KC;
+  const int cps = (nchunk_total + a.splitk - 1) / a.splitk;
+  const int c_begin = blockIdx.z * cps, c_end = min(nchunk_total, c_begin + cps);
+
+  uint32_t* xs = reinterpret_cast<uint32_t*>(smem);                      // 2 buffers
+  f32x2* scs = reinterpret_cast<f32x2*>(smem + 2 * XS_U32 * 4);           // [2 bufs][NW][GCMAX][128]
+  const int gc_max = max(1, GB_KC / g);                                   // groups per chunk
+  int* flag = reinterpret_cast<int*>(smem + 2 * XS_U32 * 4 + (size_t)2 * NW * gc_max * 128 * sizeof(f32x2));
+
+  auto stage = [&](int c, int buf) {
+    // x chunk: rows m0..m0+ROWS, k = c*KC .. +KC ; i -> (row = i/32, o = i%32): 512 B runs per row
+    uint32_t* dst = xs + buf * XS_U32;
+    for (int i = tid; i < ROWS * (GB_KC / 8); i += GB_THREADS) {
+      int row = i >> 5, o = i & 31;
+      int m = m0 + row, k = c * GB_KC + o * 8;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (m < M && k < K) v = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.x) + (size_t)m * a.x_ld + k);
+      *reinterpret_cast<u32x4*>(dst + ((size_t)o * ROWS + (row ^ (o & 7))) * 4) = v;
+    }
+    if (INT4) {
+      const int g0 = (c * GB_KC) / g;
+      f32x2* sdst = scs + (size_t)buf * NW * gc_max * 128;
+      for (int i = tid; i < NW * gc_max * 128; i += GB_THREADS) {
+        int wsel = i / (gc_max * 128), gi = (i >> 7) % gc_max, col = i & 127;
+        int n = blockIdx.x * 128 + col, grp = min(g0 + gi, K / g - 1);
+        float s = 0.f, z = 8.f;
+        if (n < N) {
+          const void* scp = wsel ? a.sc1 : a.sc0;
+          const uint32_t* qzp = wsel ? a.qz1 : a.qz0;
+          s = DT::to_f32(static_cast<const uint16_t*>(scp)[vra_scale_index(grp, n, N, a.scales_layout, grouped)]);
+          if (a.is_awq && qzp) z = (float)((qzp[(size_t)grp * (N >> 3) + (n >> 3)] >> (4 * awq_rev(n & 7))) & 0xFu);
+        }
+        f32x2 p = {s, -z * s};
+        sdst[i] = p;
+      }
+    }
+  };
+
+  f32x4 acc[NW][MT];
+#pragma unroll
+  for (int w = 0; w < NW; w++)
+#pragma unroll
+    for (int t = 0; t < MT; t++) acc[w][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // weight stream of this wave: tiles kt = 2c, 2c+1 for c in [c_begin, c_end)
+  const u32x4* wp[NW];
+  if (INT4) {
+    wp[0] = reinterpret_cast<const u32x4*>(a.w0) + ((size_t)(nb_ok ? nb : 0) * KT) * 64 + lane;
+    if (DUAL) wp[NW - 1] = reinterpret_cast<const u32x4*>(a.w1) + ((size_t)(nb_ok ? nb : 0) * KT) * 64 + lane;
+  } else {
+    int n = min(nb * 16 + nn, N - 1);
+    wp[0] = reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.w0) + (size_t)n * K) + oct;
+    if (DUAL) wp[NW - 1] = reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.w1) + (size_t)n * K) + oct;
+  }
+  constexpr int TPC = GB_KC / 128;  // tiles per chunk
+  // INT4: one u32x4 per tile; dense: four u32x4 per tile
+  constexpr int LPT = INT4 ? 1 : 4;
+  u32x4 cur[TPC][NW][LPT], nxt[TPC][NW][LPT];
+  auto load_chunk = [&](int c, u32x4 (&dst)[TPC][NW][LPT]) {
+#pragma unroll
+    for (int t = 0; t < TPC; t++) {
+      int kt = c * TPC + t;
+#pragma unroll
+      for (int w = 0; w < NW; w++)
+#pragma unroll
+        for (int l = 0; l < LPT; l++) {
+          if (kt < KT && nb_ok) {
+            if (INT4) dst[t][w][l] = __builtin_nontemporal_load(wp[w] + (size_t)kt * 64);
+            else dst[t][w][l] = __builtin_nontemporal_load(wp[w] + kt * 16 + l * 4);
+          } else dst[t][w][l] = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+  };
+
+  if (c_begin < c_end) {
+    load_chunk(c_begin, cur);
+    stage(c_begin, 0);
+  }
+  __syncthreads();
+  for (int c = c_begin; c < c_end; c++) {
+    const int buf = (c - c_begin) & 1;
+    if (c + 1 < c_end) {
+      load_chunk(c + 1, nxt);
+      stage(c + 1, buf ^ 1);
+    }
+    const uint32_t* xb = xs + buf * XS_U32;
+    const f32x2* sb = scs + (size_t)buf * NW * gc_max * 128;
+    const int g0 = (c * GB_KC) / g;
+#pragma unroll
+    for (int t = 0; t < TPC; t++) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int o = t * 16 + j * 4 + oct;  // octet within chunk
+        s16x8 afrag[NW];
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+          if (INT4) {
+            int gi = min((c * GB_KC + t * 128 + j * 32) / g - g0, gc_max - 1);
+            f32x2 p = sb[((size_t)w * gc_max + gi) * 128 + wave * 16 + nn];
+            afrag[w] = dequant_word<DT>(cur[t][w][0][j], p[0], p[1]);
+          } else {
+            afrag[w] = __builtin_bit_cast(s16x8, cur[t][w][j]);
+          }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+          const u32x4 xv = *reinterpret_cast<const u32x4*>(xb + ((size_t)o * ROWS + ((mt * 16 + nn) ^ (o & 7))) * 4);
+          const s16x8 bfrag = __builtin_bit_cast(s16x8, xv);
+#pragma unroll
+          for (int w = 0; w < NW; w++) acc[w][mt] = DT::mfma(afrag[w], bfrag, acc[w][mt]);
+        }
+      }
+    }
+    __syncthreads();
+    if (c + 1 < c_end) {
+#pragma unroll
+      for (int t = 0; t < TPC; t++)
+#pragma unroll
+        for (int w = 0; w < NW; w++)
+#pragma unroll
+          for (int l = 0; l < LPT; l++) cur[t][w][l] = nxt[t][w][l];
+    }
+  }
+
+  // ---- split-K: publish the partial slab, last arriver reduces (deterministic slice order)
+  const int Mpad = gridDim.y * ROWS, Npad = gridDim.x * 128;
+  if (a.splitk > 1) {
+    float* slab = a.slabs + (size_t)blockIdx.z * NW * Mpad * Npad;
+#pragma unroll
+    for (int w = 0; w < NW; w++)
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++) {
+        int m = m0 + mt * 16 + nn, n = nb * 16 + oct * 4;
+        *reinterpret_cast<f32x4*>(slab + ((size_t)w * Mpad + m) * Npad + n) = acc[w][mt];
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      uint32_t prev = __hip_atomic_fetch_add(a.counters + blockIdx.y * gridDim.x + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int last = prev == (uint32_t)(a.splitk - 1);
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(a.counters + blockIdx.y * gridDim.x + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+#pragma unroll
+    for (int w = 0; w < NW; w++)
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++) {
+        int m = m0 + mt * 16 + nn, n = nb * 16 + oct * 4;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < a.splitk; z++) {
+          const float* sl = a.slabs + (size_t)z * NW * Mpad * Npad;
+          f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sl + ((size_t)w * Mpad + m) * Npad + n));
+          s += v;
+        }
+        acc[w][mt] = s;
+      }
+  }
+
+  // ---- epilogue: D[row = 16-col index (lane>>4)*4 + r][col = m = lane&15]
+  if (!nb_ok) return;
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++) {
+    const int m = m0 + mt * 16 + nn;
+    if (m >= M) continue;
+    const int n = nb * 16 + oct * 4;
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      float t = rnd_dt<DT>(acc[0][mt][r]);
+      if (a.bias0) t = rnd_dt<DT>(t + DT::to_f32(static_cast<const uint16_t*>(a.bias0)[n + r]));
+      if (DUAL) {
+        float u = rnd_dt<DT>(acc[NW - 1][mt][r]);
+        if (a.bias1) u = rnd_dt<DT>(u + DT::to_f32(static_cast<const uint16_t*>(a.bias1)[n + r]));
+        float sl = rnd_dt<DT>(t / (1.0f + expf(-t)));
+        t = sl * u;
+      }
+      if (a.residual) t = rnd_dt<DT>(t) + DT::to_f32(static_cast<const uint16_t*>(a.residual)[(size_t)m * a.res_ld + n + r]);
+      v[r] = t;
+    }
+    if (a.out_f32) {
+      f32x4 o = {rnd_dt<DT>(v[0]), rnd_dt<DT>(v[1]), rnd_dt<DT>(v[2]), rnd_dt<DT>(v[3])};
+      *reinterpret_cast<f32x4*>(static_cast<float*>(a.out) + (size_t)m * a.out_ld + n) = o;
+    } else {
+      u32x2 o = {DT::pack2(v[0], v[1]), DT::pack2(v[2], v[3])};
+      *reinterpret_cast<u32x2*>(static_cast<uint16_t*>(a.out) + (size_t)m * a.out_ld + n) = o;
+    }
+  }
+}
+
+static inline size_t gemm_skinny_lds_bytes(int mt, bool dual, int K, int group_size) {
+  int g = group_size > 0 ? group_size : K;
+  int gc_max = GB_KC / g > 1 ? GB_KC / g : 1;
+  return (size_t)2 * (GB_KC / 8) * mt * 16 * 16 + (size_t)2 * (dual ? 2 : 1) * gc_max * 128 * 8 + 16;
+}

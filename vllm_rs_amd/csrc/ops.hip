@@ -1,0 +1,421 @@
+// ops.hip — RMSNorm, residual add, embedding, SiLU·mul, fused rotary, KV scatter, mask, argmax,
+// casts, block swap and the synthetic fills.  All HBM-bound streaming kernels: 16 B per lane,
+// f32 math, one rounding per reference op (include/vllm_rs_amd.h §B).
+#include "common.cuh"
+
+// ---------------------------------------------------------------- RMSNorm (+ residual add)
+// one workgroup (256 threads) per token row; row cached in registers between the two passes.
+template <class DT, bool ADD>
+__global__ __launch_bounds__(256) void rms_norm_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ res,
+                                                       const uint16_t* __restrict__ w, uint16_t* __restrict__ h_out,
+                                                       uint16_t* __restrict__ out, int H, float eps) {
+  __shared__ float red[4];
+  const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int octs = H >> 3;
+  const u32x4* xr = reinterpret_cast<const u32x4*>(x + (size_t)t * H);
+  const u32x4* rr = ADD ? reinterpret_cast<const u32x4*>(res + (size_t)t * H) : nullptr;
+  constexpr int MAXV = 8;  // up to H = 256*8*8 = 16384 kept in registers
+  u32x4 keep[MAXV];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; i++) {
+    int o = tid + i * 256;
+    if (o < octs) {
+      u32x4 v = xr[o];
+      float f[8];
+      unpack8<DT>(v, f);
+      if (ADD) {
+        float r[8];
+        unpack8<DT>(rr[o], r);
+#pragma unroll
+        for (int e = 0; e < 8; e++) f[e] = rnd_dt<DT>(f[e] + r[e]);
+        v = pack8<DT>(f);
+        reinterpret_cast<u32x4*>(h_out + (size_t)t * H)[o] = v;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; e++) ss += f[e] * f[e];
+      keep[i] = v;
+    }
+  }
+  ss = wave_sum(ss);
+  if (lane == 0) red[wave] = ss;
+  __syncthreads();
+  const float rstd = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)H + eps);
+  const u32x4* wr = reinterpret_cast<const u32x4*>(w);
+#pragma unroll
+  for (int i = 0; i < MAXV; i++) {
+    int o = tid + i * 256;
+    if (o < octs) {
+      float f[8], g[8];
+      unpack8<DT>(keep[i], f);
+      unpack8<DT>(wr[o], g);
+#pragma unroll
+      for (int e = 0; e < 8; e++) f[e] = f[e] * rstd * g[e];
+      reinterpret_cast<u32x4*>(out + (size_t)t * H)[o] = pack8<DT>(f);
+    }
+  }
+}
+static bool norm_args_ok(const char* who, int tokens, int hidden, int dtype) {
+  if (tokens < 0 || hidden < 8 || hidden % 8 || hidden > 16384) {
+    vra_set_error("%s: hidden must be a multiple of 8 in [8,16384] (tokens=%d hidden=%d)", who, tokens, hidden);
+    return false;
+  }
+  if (dtype != VRA_BF16 && dtype != VRA_F16) {
+    vra_set_error("%s: dtype must be bf16/f16", who);
+    return false;
+  }
+  return true;
+}
+extern "C" void vra_rms_norm(const void* x, const void* weight, void* out, int32_t tokens, int32_t hidden, float eps,
+                             int32_t dtype, int64_t stream) {
+  if (!norm_args_ok("vra_rms_norm", tokens, hidden, dtype) || tokens == 0) return;
+  if (dtype == VRA_BF16)
+    rms_norm_kernel<BF16, false><<<tokens, 256, 0, as_stream(stream)>>>((const uint16_t*)x, nullptr, (const uint16_t*)weight, nullptr, (uint16_t*)out, hidden, eps);
+  else
+    rms_norm_kernel<F16, false><<<tokens, 256, 0, as_stream(stream)>>>((const uint16_t*)x, nullptr, (const uint16_t*)weight, nullptr, (uint16_t*)out, hidden, eps);
+}
+extern "C" void vra_add_rms_norm(const void* x, const void* residual, const void* weight, void* h_out, void* out,
+                                 int32_t tokens, int32_t hidden, float eps, int32_t dtype, int64_t stream) {
+  if (!norm_args_ok("vra_add_rms_norm", tokens, hidden, dtype) || tokens == 0) return;
+  if (dtype == VRA_BF16)
+    rms_norm_kernel<BF16, true><<<tokens, 256, 0, as_stream(stream)>>>((const uint16_t*)x, (const uint16_t*)residual, (const uint16_t*)weight, (uint16_t*)h_out, (uint16_t*)out, hidden, eps);
+  else
+    rms_norm_kernel<F16, true><<<tokens, 256, 0, as_stream(stream)>>>((const uint16_t*)x, (const uint16_t*)residual, (const uint16_t*)weight, (uint16_t*)h_out, (uint16_t*)out, hidden, eps);
+}
+
+// ---------------------------------------------------------------- elementwise
+template <class DT, int OP>  // OP 0: add, 1: silu(a)*b
+__global__ __launch_bounds__(256) void ew_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b,
+                                                 uint16_t* __restrict__ out, int64_t numel) {
+  const int64_t nv = numel >> 3;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+    float fa[8], fb[8];
+    unpack8<DT>(reinterpret_cast<const u32x4*>(a)[i], fa);
+    unpack8<DT>(reinterpret_cast<const u32x4*>(b)[i], fb);
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      if (OP == 0) fa[e] = fa[e] + fb[e];
+      else fa[e] = rnd_dt<DT>(fa[e] / (1.0f + expf(-fa[e]))) * fb[e];
+    }
+    reinterpret_cast<u32x4*>(out)[i] = pack8<DT>(fa);
+  }
+  // tail (numel % 8)
+  for (int64_t i = (nv << 3) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x) {
+    float x = DT::to_f32(a[i]), y = DT::to_f32(b[i]);
+    out[i] = DT::from_f32(OP == 0 ? x + y : rnd_dt<DT>(x / (1.0f + expf(-x))) * y);
+  }
+}
+static inline int ew_grid(int64_t numel) {
+  int64_t g = ((numel >> 3) + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+extern "C" void vra_add(const void* a, const void* b, void* out, int64_t numel, int32_t dtype, int64_t stream) {
+  VRA_CHECK_ARG(dtype == VRA_BF16 || dtype == VRA_F16, "vra_add: dtype must be bf16/f16");
+  if (numel <= 0) return;
+  if (dtype == VRA_BF16) ew_kernel<BF16, 0><<<ew_grid(numel), 256, 0, as_stream(stream)>>>((const uint16_t*)a, (const uint16_t*)b, (uint16_t*)out, numel);
+  else ew_kernel<F16, 0><<<ew_grid(numel), 256, 0, as_stream(stream)>>>((const uint16_t*)a, (const uint16_t*)b, (uint16_t*)out, numel);
+}
+extern "C" void vra_silu_mul(const void* gate, const void* up, void* out, int64_t numel, int32_t dtype, int64_t stream) {
+  VRA_CHECK_ARG(dtype == VRA_BF16 || dtype == VRA_F16, "vra_silu_mul: dtype must be bf16/f16");
+  if (numel <= 0) return;
+  if (dtype == VRA_BF16) ew_kernel<BF16, 1><<<ew_grid(numel), 256, 0, as_stream(stream)>>>((const uint16_t*)gate, (const uint16_t*)up, (uint16_t*)out, numel);
+  else ew_kernel<F16, 1><<<ew_grid(numel), 256, 0, as_stream(stream)>>>((const uint16_t*)gate, (const uint16_t*)up, (uint16_t*)out, numel);
+}
+
+// ---------------------------------------------------------------- row gathers
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint32_t* __restrict__ idx, const unsigned char* __restrict__ table,
+                                                          unsigned char* __restrict__ out, int rows, size_t row_bytes,
+                                                          uint32_t n_table_rows) {
+  const int r = blockIdx.x;
+  uint32_t src = idx[r];
+  if (src >= n_table_rows) src = n_table_rows - 1;  // clamp (the reference would fault)
+  const u32x4* s = reinterpret_cast<const u32x4*>(table + (size_t)src * row_bytes);
+  u32x4* d = reinterpret_cast<u32x4*>(out + (size_t)r * row_bytes);
+  for (size_t i = threadIdx.x; i < row_bytes / 16; i += blockDim.x) d[i] = s[i];
+}
+extern "C" void vra_embedding(const uint32_t* ids, const void* table, void* out, int32_t tokens, int32_t hidden,
+                              int32_t vocab, int32_t dtype, int64_t stream) {
+  size_t es = dtype == VRA_F32 ? 4 : 2;
+  VRA_CHECK_ARG((hidden * es) % 16 == 0, "vra_embedding: row bytes must be a multiple of 16");
+  if (tokens <= 0) return;
+  gather_rows_kernel<<<tokens, 256, 0, as_stream(stream)>>>(ids, (const unsigned char*)table, (unsigned char*)out, tokens, hidden * es, (uint32_t)vocab);
+}
+extern "C" void vra_index_select_rows(const void* x, const uint32_t* idx, void* out, int32_t n_idx, int32_t hidden,
+                                      int32_t dtype, int64_t stream) {
+  size_t es = dtype == VRA_F32 ? 4 : 2;
+  VRA_CHECK_ARG((hidden * es) % 16 == 0, "vra_index_select_rows: row bytes must be a multiple of 16");
+  if (n_idx <= 0) return;
+  gather_rows_kernel<<<n_idx, 256, 0, as_stream(stream)>>>(idx, (const unsigned char*)x, (unsigned char*)out, n_idx, hidden * es, 0xffffffffu);
+}
+
+// ---------------------------------------------------------------- fused rotary (in place)
+// one thread per (token, head, pair-octet): NeoX pairs (i, i+rot/2) are handled 8 pairs at a time
+// (two 16 B loads), interleaved pairs (2i, 2i+1) 4 pairs per 16 B.
+template <class DT, class TT>
+__global__ __launch_bounds__(256) void rope_kernel(uint16_t* __restrict__ q, uint16_t* __restrict__ k,
+                                                   const void* __restrict__ cosv, const void* __restrict__ sinv,
+                                                   const int64_t* __restrict__ positions, int T, int Hq, int Hkv, int D,
+                                                   int rot, int interleaved) {
+  const int half = rot >> 1;
+  const int per_head = interleaved ? rot >> 3 : half >> 3;  // work items (16 B groups) per head
+  const int64_t total = (int64_t)T * (Hq + Hkv) * per_head;
+  for (int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; w < total; w += (int64_t)gridDim.x * blockDim.x) {
+    int c = (int)(w % per_head);
+    int64_t th = w / per_head;
+    int h = (int)(th % (Hq + Hkv));
+    int t = (int)(th / (Hq + Hkv));
+    uint16_t* base = h < Hq ? q + ((size_t)t * Hq + h) * D : k + ((size_t)t * Hkv + (h - Hq)) * D;
+    const int64_t pos = positions[t];
+    if (!interleaved) {
+      u32x4 a = *reinterpret_cast<u32x4*>(base + c * 8), b = *reinterpret_cast<u32x4*>(base + half + c * 8);
+      float x1[8], x2[8], cs[8], sn[8];
+      unpack8<DT>(a, x1);
+      unpack8<DT>(b, x2);
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        cs[e] = TT::load(cosv, pos * half + c * 8 + e);
+        sn[e] = TT::load(sinv, pos * half + c * 8 + e);
+      }
+      float y1[8], y2[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        y1[e] = x1[e] * cs[e] - x2[e] * sn[e];
+        y2[e] = x2[e] * cs[e] + x1[e] * sn[e];
+      }
+      *reinterpret_cast<u32x4*>(base + c * 8) = pack8<DT>(y1);
+      *reinterpret_cast<u32x4*>(base + half + c * 8) = pack8<DT>(y2);
+    } else {
+      u32x4 a = *reinterpret_cast<u32x4*>(base + c * 8);
+      float x[8], y[8];
+      unpack8<DT>(a, x);
+#pragma unroll
+      for (int p = 0; p < 4; p++) {
+        float cs = TT::load(cosv, pos * half + c * 4 + p), sn = TT::load(sinv, pos * half + c * 4 + p);
+        y[2 * p] = x[2 * p] * cs - x[2 * p + 1] * sn;
+        y[2 * p + 1] = x[2 * p + 1] * cs + x[2 * p] * sn;
+      }
+      *reinterpret_cast<u32x4*>(base + c * 8) = pack8<DT>(y);
+    }
+  }
+}
+template <class DT>
+struct TblSame {
+  static __device__ __forceinline__ float load(const void* p, int64_t i) { return DT::to_f32(static_cast<const uint16_t*>(p)[i]); }
+};
+struct TblF32 {
+  static __device__ __forceinline__ float load(const void* p, int64_t i) { return static_cast<const float*>(p)[i]; }
+};
+extern "C" void vra_fused_rope(void* q, void* k, const void* cos, const void* sin, const int64_t* positions, int32_t tokens,
+                               int32_t q_heads, int32_t kv_heads, int32_t head_dim, int32_t rot_dim, int32_t is_interleaved,
+                               int32_t dtype, int32_t table_dtype, int64_t stream) {
+  VRA_CHECK_ARG(dtype == VRA_BF16 || dtype == VRA_F16, "vra_fused_rope: dtype must be bf16/f16");
+  VRA_CHECK_ARG(table_dtype == dtype || table_dtype == VRA_F32, "vra_fused_rope: table dtype must equal dtype or be f32");
+  VRA_CHECK_ARG(rot_dim <= head_dim && rot_dim % 16 == 0 && head_dim % 8 == 0, "vra_fused_rope: rot_dim must be a multiple of 16 <= head_dim");
+  if (tokens <= 0) return;
+  int per_head = is_interleaved ? rot_dim / 8 : rot_dim / 16;
+  int64_t total = (int64_t)tokens * (q_heads + kv_heads) * per_head;
+  int grid = (int)((total + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipStream_t st = as_stream(stream);
+  uint16_t *qp = (uint16_t*)q, *kp = (uint16_t*)k;
+#define VRA_ROPE(DT, TT) rope_kernel<DT, TT><<<grid, 256, 0, st>>>(qp, kp, cos, sin, positions, tokens, q_heads, kv_heads, head_dim, rot_dim, is_interleaved)
+  if (dtype == VRA_BF16) {
+    if (table_dtype == VRA_F32) VRA_ROPE(BF16, TblF32);
+    else VRA_ROPE(BF16, TblSame<BF16>);
+  } else {
+    if (table_dtype == VRA_F32) VRA_ROPE(F16, TblF32);
+    else VRA_ROPE(F16, TblSame<F16>);
+  }
+#undef VRA_ROPE
+}
+
+// ---------------------------------------------------------------- KV scatter ("reshape_and_cache")
+// K cache [NB, Hkv, BS, D] (token rows contiguous), V cache [NB, Hkv, D, BS] (token-minor, so the
+// attention kernel reads 4/8 consecutive tokens of one channel with one load — the same choice the
+// reference makes for its non-flash V cache, kvcache_allocator.rs:170-173,844).
+__global__ __launch_bounds__(256) void reshape_and_cache_kernel(const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
+                                                                uint16_t* __restrict__ kc, uint16_t* __restrict__ vc,
+                                                                const int64_t* __restrict__ slots, int Hkv, int D, int BS) {
+  const int t = blockIdx.x;
+  const int64_t slot = slots[t];
+  if (slot < 0) return;
+  const int64_t blk = slot / BS;
+  const int off = (int)(slot % BS);
+  const int n = Hkv * D;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    int h = i / D, d = i - h * D;
+    kc[((blk * Hkv + h) * BS + off) * D + d] = k[(size_t)t * n + i];
+    vc[((blk * Hkv + h) * D + d) * BS + off] = v[(size_t)t * n + i];
+  }
+}
+extern "C" void vra_reshape_and_cache(const void* k, const void* v, void* k_cache, void* v_cache, const int64_t* slot_mapping,
+                                      int32_t tokens, int32_t kv_heads, int32_t head_dim, int32_t block_size, int32_t dtype,
+                                      int64_t stream) {
+  VRA_CHECK_ARG(dtype == VRA_BF16 || dtype == VRA_F16, "vra_reshape_and_cache: dtype must be bf16/f16");
+  if (tokens <= 0) return;
+  reshape_and_cache_kernel<<<tokens, 256, 0, as_stream(stream)>>>((const uint16_t*)k, (const uint16_t*)v, (uint16_t*)k_cache, (uint16_t*)v_cache, slot_mapping, kv_heads, head_dim, block_size);
+}
+
+// ---------------------------------------------------------------- causal mask
+template <class DT>
+__global__ void causal_mask_kernel(uint16_t* mask, int L, int sw) {
+  const int64_t total = (int64_t)L * L;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int r = (int)(i / L), c = (int)(i % L);
+    bool ok = c <= r && (sw <= 0 || r - c < sw);
+    mask[i] = DT::from_f32(ok ? 0.f : -INFINITY);
+  }
+}
+__global__ void causal_mask_kernel_f32(float* mask, int L, int sw) {
+  const int64_t total = (int64_t)L * L;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int r = (int)(i / L), c = (int)(i % L);
+    bool ok = c <= r && (sw <= 0 || r - c < sw);
+    mask[i] = ok ? 0.f : -INFINITY;
+  }
+}
+extern "C" void vra_causal_mask(void* mask, int32_t len, int32_t sliding_window, int32_t dtype, int64_t stream) {
+  if (len <= 0) return;
+  int grid = (int)(((int64_t)len * len + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  if (dtype == VRA_BF16) causal_mask_kernel<BF16><<<grid, 256, 0, as_stream(stream)>>>((uint16_t*)mask, len, sliding_window);
+  else if (dtype == VRA_F16) causal_mask_kernel<F16><<<grid, 256, 0, as_stream(stream)>>>((uint16_t*)mask, len, sliding_window);
+  else causal_mask_kernel_f32<<<grid, 256, 0, as_stream(stream)>>>((float*)mask, len, sliding_window);
+}
+
+// ---------------------------------------------------------------- argmax (first maximal index)
+__global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ logits, uint32_t* __restrict__ out, int cols) {
+  __shared__ float bv[16];
+  __shared__ uint32_t bi[16];
+  const float* p = logits + (size_t)blockIdx.x * cols;
+  float best = -INFINITY;
+  uint32_t besti = 0xffffffffu;
+  for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+    float v = p[c];
+    if (v > best || besti == 0xffffffffu) {  // strictly greater keeps the first index per thread
+      best = v;
+      besti = c;
+    }
+  }
+  // wave reduce: larger value wins, ties -> smaller index
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_xor(best, o, 64);
+    uint32_t oi = __shfl_xor(besti, o, 64);
+    if (ov > best || (ov == best && oi < besti)) {
+      best = ov;
+      besti = oi;
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    bv[wave] = best;
+    bi[wave] = besti;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); w++)
+      if (bv[w] > best || (bv[w] == best && bi[w] < besti)) {
+        best = bv[w];
+        besti = bi[w];
+      }
+    out[blockIdx.x] = besti == 0xffffffffu ? 0u : besti;
+  }
+}
+extern "C" void vra_argmax_f32(const float* logits, uint32_t* out, int32_t rows, int32_t cols, int64_t stream) {
+  if (rows <= 0 || cols <= 0) return;
+  argmax_kernel<<<rows, 1024, 0, as_stream(stream)>>>(logits, out, cols);
+}
+
+// ---------------------------------------------------------------- casts
+template <class SRC, class DST>
+__global__ void cast_kernel(const void* in, void* out, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) DST::store(out, i, SRC::load(in, i));
+}
+template <class DT>
+struct Io16 {
+  static __device__ __forceinline__ float load(const void* p, int64_t i) { return DT::to_f32(static_cast<const uint16_t*>(p)[i]); }
+  static __device__ __forceinline__ void store(void* p, int64_t i, float v) { static_cast<uint16_t*>(p)[i] = DT::from_f32(v); }
+};
+struct Io32 {
+  static __device__ __forceinline__ float load(const void* p, int64_t i) { return static_cast<const float*>(p)[i]; }
+  static __device__ __forceinline__ void store(void* p, int64_t i, float v) { static_cast<float*>(p)[i] = v; }
+};
+extern "C" void vra_cast(const void* in, void* out, int64_t numel, int32_t in_dtype, int32_t out_dtype, int64_t stream) {
+  if (numel <= 0) return;
+  int grid = (int)((numel + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipStream_t st = as_stream(stream);
+#define VRA_CAST(S, D) cast_kernel<S, D><<<grid, 256, 0, st>>>(in, out, numel)
+  int key = in_dtype * 3 + out_dtype;
+  switch (key) {
+    case 0: VRA_CAST(Io16<BF16>, Io16<BF16>); break;
+    case 1: VRA_CAST(Io16<BF16>, Io16<F16>); break;
+    case 2: VRA_CAST(Io16<BF16>, Io32); break;
+    case 3: VRA_CAST(Io16<F16>, Io16<BF16>); break;
+    case 4: VRA_CAST(Io16<F16>, Io16<F16>); break;
+    case 5: VRA_CAST(Io16<F16>, Io32); break;
+    case 6: VRA_CAST(Io32, Io16<BF16>); break;
+    case 7: VRA_CAST(Io32, Io16<F16>); break;
+    case 8: VRA_CAST(Io32, Io32); break;
+    default: vra_set_error("vra_cast: bad dtypes %d -> %d", in_dtype, out_dtype);
+  }
+#undef VRA_CAST
+}
+
+// ---------------------------------------------------------------- block swap
+extern "C" void vra_swap_blocks(const void* src, void* dst, const int64_t* h_pairs, int32_t n_pairs, int64_t block_bytes,
+                                int32_t kind, int64_t stream) {
+  hipMemcpyKind mk = kind == 0 ? hipMemcpyDeviceToDevice : (kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice);
+  for (int i = 0; i < n_pairs; i++) {
+    const char* s = static_cast<const char*>(src) + h_pairs[2 * i] * block_bytes;
+    char* d = static_cast<char*>(dst) + h_pairs[2 * i + 1] * block_bytes;
+    if (hipMemcpyAsync(d, s, (size_t)block_bytes, mk, as_stream(stream)) != hipSuccess) {
+      vra_set_error("vra_swap_blocks: memcpy failed for pair %d", i);
+      return;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- synthetic fills (== oracle)
+__global__ void fill_hash_kernel(uint32_t* out, int64_t n, uint64_t seed) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = vra_hash32(seed, (uint64_t)i);
+}
+__global__ void fill_const_kernel(uint32_t* out, int64_t n, uint32_t v) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = v;
+}
+template <class IO, int NORMAL>
+__global__ void fill_float_kernel(void* out, int64_t n, uint64_t seed, float a, float b) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float v;
+    if (NORMAL) {
+      float s = vra_hash_unit(seed, 4ull * i) + vra_hash_unit(seed, 4ull * i + 1) + vra_hash_unit(seed, 4ull * i + 2) + vra_hash_unit(seed, 4ull * i + 3);
+      v = a + b * (s - 2.0f) * 1.7320508f;
+    } else {
+      v = a + (b - a) * vra_hash_unit(seed, (uint64_t)i);
+    }
+    IO::store(out, i, v);
+  }
+}
+static inline int fill_grid(int64_t n) {
+  int64_t g = (n + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+extern "C" void vra_fill_hash_u32(uint32_t* out, int64_t numel, uint64_t seed, int64_t stream) {
+  if (numel > 0) fill_hash_kernel<<<fill_grid(numel), 256, 0, as_stream(stream)>>>(out, numel, seed);
+}
+extern "C" void vra_fill_const_u32(uint32_t* out, int64_t numel, uint32_t value, int64_t stream) {
+  if (numel > 0) fill_const_kernel<<<fill_grid(numel), 256, 0, as_stream(stream)>>>(out, numel, value);
+}
+extern "C" void vra_fill_uniform(void* out, int64_t numel, uint64_t seed, float lo, float hi, int32_t dtype, int64_t stream) {
+  if (numel <= 0) return;
+  if (dtype == VRA_BF16) fill_float_kernel<Io16<BF16>, 0><<<fill_grid(numel), 256, 0, as_stream(stream)>>>(out, numel, seed, lo, hi);
+  else if (dtype == VRA_F16) fill_float_kernel<Io16<F16>, 0><<<fill_grid(numel), 256, 0, as_stream(stream)>>>(out, numel, seed, lo, hi);
+  else fill_float_kernel<Io32, 0><<<fill_grid(numel), 256, 0, as_stream(stream)>>>(out, numel, seed, lo, hi);
+}
+extern "C" void vra_fill_normal(void* out, int64_t numel, uint64_t seed, float mean, float std, int32_t dtype, int64_t stream) {
+  if (numel <= 0) return;
+  if (dtype == VRA_BF16) fill_float_kernel<Io16<BF16>, 1><<<fill_grid(numel), 256, 0, as_stream(stream)>>>(out, numel, seed, mean, std);
+  else if (dtype == VRA_F16) fill_float_kernel<Io16<F16>, 1><<<fill_grid(numel), 256, 0, as_stream(stream)>>>(out, numel, seed, mean, std);
+  else fill_float_kernel<Io32, 1><<<fill_grid(numel), 256, 0, as_stream(stream)>>>(out, numel, seed, mean, std);
+}

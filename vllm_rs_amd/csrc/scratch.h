@@ -1,0 +1,10 @@
+// scratch.h — per-process device scratch for split-K slabs / arrival counters (allocated once,
+// outside any graph capture, by vra_scratch_init(); kernels never allocate).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+bool vra_scratch_init();            // idempotent; false if allocation failed or stream is capturing
+float* vra_scratch_slabs();         // nullptr until initialised
+uint32_t* vra_scratch_counters();   // zeroed at init, every kernel leaves them zero
+size_t vra_scratch_slab_bytes();
+size_t vra_scratch_counter_count();

@@ -1,0 +1,426 @@
+// wna16_gemm.hip — GPTQ/AWQ int4 repack + dequant-fused GEMM entry points (include/vllm_rs_amd.h §A/§B)
+// and the dense 16-bit GEMM used for lm_head.  gfx950 only.
+#include <stdio.h>
+
+#include "gemm_skinny.cuh"
+#include "gemv.cuh"
+#include "scratch.h"
+
+// ------------------------------------------------------------------------------------------------
+// repack: checkpoint layouts -> CDNA4 tile layout (common.cuh). One thread per output word.
+// ------------------------------------------------------------------------------------------------
+__global__ void gptq_repack_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int K, int N) {
+  const int KT = K >> 7;
+  const size_t total = (size_t)(K >> 3) * N;
+  for (size_t o = blockIdx.x * (size_t)blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+    int j = o & 3, lane = (o >> 2) & 63;
+    size_t tile = o >> 8;
+    int kt = tile % KT, nb = tile / KT;
+    int nn = lane & 15, oct = lane >> 4;
+    int n = nb * 16 + nn, krow = kt * 16 + j * 4 + oct;  // GPTQ word row (8 consecutive k)
+    uint32_t w = in[(size_t)krow * N + n], r = 0;
+#pragma unroll
+    for (int p = 0; p < 8; p++) r |= ((w >> (4 * vra_tile_e_of_p(p))) & 0xFu) << (4 * p);
+    out[o] = r;
+  }
+}
+__global__ void awq_repack_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int K, int N) {
+  const int KT = K >> 7;
+  const size_t total = (size_t)(K >> 3) * N;
+  for (size_t o = blockIdx.x * (size_t)blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+    int j = o & 3, lane = (o >> 2) & 63;
+    size_t tile = o >> 8;
+    int kt = tile % KT, nb = tile / KT;
+    int nn = lane & 15, oct = lane >> 4;
+    int n = nb * 16 + nn, k0 = kt * 128 + j * 32 + oct * 8;
+    int sh = 4 * awq_rev(n & 7);
+    uint32_t r = 0;
+#pragma unroll
+    for (int p = 0; p < 8; p++) r |= ((in[(size_t)(k0 + vra_tile_e_of_p(p)) * (N >> 3) + (n >> 3)] >> sh) & 0xFu) << (4 * p);
+    out[o] = r;
+  }
+}
+__global__ void unpack_indices_kernel(const uint32_t* __restrict__ tiled, uint8_t* __restrict__ idx, int K, int N) {
+  const int KT = K >> 7;
+  const size_t total = (size_t)(K >> 3) * N;
+  for (size_t o = blockIdx.x * (size_t)blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+    int j = o & 3, lane = (o >> 2) & 63;
+    size_t tile = o >> 8;
+    int kt = tile % KT, nb = tile / KT;
+    int n = nb * 16 + (lane & 15), k0 = kt * 128 + j * 32 + (lane >> 4) * 8;
+    uint32_t w = tiled[o];
+#pragma unroll
+    for (int p = 0; p < 8; p++) idx[(size_t)(k0 + vra_tile_e_of_p(p)) * N + n] = (w >> (4 * p)) & 0xFu;
+  }
+}
+template <class DT>
+__global__ void dequant_kernel(const uint32_t* __restrict__ tiled, const uint16_t* __restrict__ scales,
+                               const uint32_t* __restrict__ qzeros, uint16_t* __restrict__ wout, int K, int N,
+                               int group_size, int is_awq, int layout) {
+  const int KT = K >> 7;
+  const int g = group_size > 0 ? group_size : K;
+  const bool grouped = group_size > 0 && group_size < K;
+  const size_t total = (size_t)(K >> 3) * N;
+  for (size_t o = blockIdx.x * (size_t)blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+    int j = o & 3, lane = (o >> 2) & 63;
+    size_t tile = o >> 8;
+    int kt = tile % KT, nb = tile / KT;
+    int n = nb * 16 + (lane & 15), k0 = kt * 128 + j * 32 + (lane >> 4) * 8;
+    int grp = k0 / g;
+    float s = DT::to_f32(scales[vra_scale_index(grp, n, N, layout, grouped)]);
+    float z = 8.f;
+    if (is_awq && qzeros) z = (float)((qzeros[(size_t)grp * (N >> 3) + (n >> 3)] >> (4 * awq_rev(n & 7))) & 0xFu);
+    s16x8 f = dequant_word<DT>(tiled[o], s, -z * s);
+#pragma unroll
+    for (int e = 0; e < 8; e++) wout[(size_t)(k0 + e) * N + n] = (uint16_t)f[e];
+  }
+}
+
+static inline int grid_for(size_t total, int block) {
+  size_t g = (total + block - 1) / block;
+  return (int)(g > 4096 ? 4096 : (g == 0 ? 1 : g));
+}
+
+extern "C" void gptq_repack(const void* in, void* out, int32_t rows, int32_t cols, int64_t stream) {
+  int K = rows * 8, N = cols;
+  VRA_CHECK_ARG(in && out, "gptq_repack: null pointer");
+  VRA_CHECK_ARG(K % 128 == 0 && N % 16 == 0, "gptq_repack: need K %% 128 == 0 and N %% 16 == 0 (K=%d N=%d)", K, N);
+  size_t total = (size_t)rows * cols;
+  gptq_repack_kernel<<<grid_for(total, 256), 256, 0, as_stream(stream)>>>((const uint32_t*)in, (uint32_t*)out, K, N);
+}
+extern "C" void awq_repack(const void* in, void* out, int32_t rows, int32_t cols, int32_t bits, int64_t stream) {
+  int K = rows, N = cols * 8;
+  VRA_CHECK_ARG(in && out, "awq_repack: null pointer");
+  VRA_CHECK_ARG(bits == 4, "awq_repack: only 4-bit supported (bits=%d)", bits);
+  VRA_CHECK_ARG(K % 128 == 0 && N % 16 == 0, "awq_repack: need K %% 128 == 0 and N %% 16 == 0 (K=%d N=%d)", K, N);
+  size_t total = (size_t)rows * cols;
+  awq_repack_kernel<<<grid_for(total, 256), 256, 0, as_stream(stream)>>>((const uint32_t*)in, (uint32_t*)out, K, N);
+}
+extern "C" void vra_wna16_unpack_indices(const void* qweight_tiled, uint8_t* idx, int32_t k, int32_t n, int64_t stream) {
+  VRA_CHECK_ARG(k % 128 == 0 && n % 16 == 0, "unpack_indices: bad shape K=%d N=%d", k, n);
+  size_t total = (size_t)(k / 8) * n;
+  unpack_indices_kernel<<<grid_for(total, 256), 256, 0, as_stream(stream)>>>((const uint32_t*)qweight_tiled, idx, k, n);
+}
+extern "C" void vra_wna16_dequant(const void* qweight_tiled, const void* scales, const void* qzeros, void* w, int32_t k,
+                                  int32_t n, int32_t group_size, int32_t is_awq, int32_t scales_layout, int32_t dtype,
+                                  int64_t stream) {
+  VRA_CHECK_ARG(k % 128 == 0 && n % 16 == 0, "dequant: bad shape K=%d N=%d", k, n);
+  size_t total = (size_t)(k / 8) * n;
+  if (dtype == VRA_BF16)
+    dequant_kernel<BF16><<<grid_for(total, 256), 256, 0, as_stream(stream)>>>((const uint32_t*)qweight_tiled, (const uint16_t*)scales, (const uint32_t*)qzeros, (uint16_t*)w, k, n, group_size, is_awq, scales_layout);
+  else if (dtype == VRA_F16)
+    dequant_kernel<F16><<<grid_for(total, 256), 256, 0, as_stream(stream)>>>((const uint32_t*)qweight_tiled, (const uint16_t*)scales, (const uint32_t*)qzeros, (uint16_t*)w, k, n, group_size, is_awq, scales_layout);
+  else vra_set_error("dequant: dtype must be bf16/f16");
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch helpers (shared with the native runtime through gemm_launch.h)
+// ------------------------------------------------------------------------------------------------
+#include "gemm_launch.h"
+
+static const int kMaxDynLds = 160 * 1024;
+
+template <class DT, bool INT4, int NBW>
+static void launch_gemv_t(const GemvArgs& a, int nblocks, hipStream_t st) {
+  size_t lds = gemv_lds_bytes(INT4, NBW, a.M, a.K, a.group_size);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_kernel<DT, INT4, NBW>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+    attr_set = true;
+  }
+  int grid = a.silu_dual ? nblocks : (nblocks + NBW - 1) / NBW;
+  gemv_kernel<DT, INT4, NBW><<<grid, GEMV_THREADS, lds, st>>>(a);
+}
+
+bool vra_gemv_fits(bool int4, int nbw, int M, int K, int group_size) {
+  if (M > 8 || M < 1) return false;
+  return gemv_lds_bytes(int4, nbw, M, K, group_size) <= (size_t)72 * 1024;
+}
+
+void vra_launch_gemv(const GemvArgs& a, bool int4, int dtype, int64_t stream) {
+  hipStream_t st = as_stream(stream);
+  int nblocks = 0;
+  if (a.silu_dual) nblocks = (a.seg[0].n + 15) / 16;
+  else
+    for (int s = 0; s < a.nseg; s++) nblocks += (a.seg[s].n + 15) / 16;
+  const bool bf = dtype == VRA_BF16;
+  if (a.silu_dual) {
+    if (bf) launch_gemv_t<BF16, true, 2>(a, nblocks, st);
+    else launch_gemv_t<F16, true, 2>(a, nblocks, st);
+  } else if (int4) {
+    if (bf) launch_gemv_t<BF16, true, 1>(a, nblocks, st);
+    else launch_gemv_t<F16, true, 1>(a, nblocks, st);
+  } else {
+    if (bf) launch_gemv_t<BF16, false, 1>(a, nblocks, st);
+    else launch_gemv_t<F16, false, 1>(a, nblocks, st);
+  }
+}
+
+template <class DT, bool INT4, bool DUAL, int MT>
+static void launch_skinny_t(GemmBArgs a, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<DT, INT4, DUAL, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+    attr_set = true;
+  }
+  size_t lds = gemm_skinny_lds_bytes(MT, DUAL, a.K, a.group_size);
+  dim3 grid((a.N + 127) / 128, (a.M + MT * 16 - 1) / (MT * 16), a.splitk);
+  gemm_skinny_kernel<DT, INT4, DUAL, MT><<<grid, GB_THREADS, lds, st>>>(a);
+}
+
+// choose split-K so that the grid has roughly >= 2 workgroups per CU, bounded by the slab scratch
+static int choose_splitk(int M, int N, int K, int mt, bool dual) {
+  int gx = (N + 127) / 128, gy = (M + mt * 16 - 1) / (mt * 16);
+  int wg = gx * gy;
+  int nchunk = (K + GB_KC - 1) / GB_KC;
+  int s = 1;
+  while (wg * s < 384 && s * 2 <= nchunk && s < 16) s *= 2;
+  size_t slab = (size_t)(dual ? 2 : 1) * gy * mt * 16 * gx * 128 * 4;
+  while (s > 1 && slab * s > vra_scratch_slab_bytes()) s /= 2;
+  if (wg > (int)vra_scratch_counter_count()) s = 1;
+  return s;
+}
+
+void vra_launch_skinny(GemmBArgs a, bool int4, bool dual, int dtype, int64_t stream) {
+  hipStream_t st = as_stream(stream);
+  int mt = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
+  a.splitk = choose_splitk(a.M, a.N, a.K, mt, dual);
+  a.slabs = a.splitk > 1 ? vra_scratch_slabs() : nullptr;
+  a.counters = a.splitk > 1 ? vra_scratch_counters() : nullptr;
+  if (a.splitk > 1 && (!a.slabs || !a.counters)) a.splitk = 1;
+  const bool bf = dtype == VRA_BF16;
+#define VRA_SK(DT, I4, DU)                                     \
+  do {                                                         \
+    if (mt == 1) launch_skinny_t<DT, I4, DU, 1>(a, st);        \
+    else if (mt == 2) launch_skinny_t<DT, I4, DU, 2>(a, st);   \
+    else launch_skinny_t<DT, I4, DU, 4>(a, st);                \
+  } while (0)
+  if (int4 && dual) {
+    if (bf) VRA_SK(BF16, true, true);
+    else VRA_SK(F16, true, true);
+  } else if (int4) {
+    if (bf) VRA_SK(BF16, true, false);
+    else VRA_SK(F16, true, false);
+  } else {
+    if (bf) VRA_SK(BF16, false, false);
+    else VRA_SK(F16, false, false);
+  }
+#undef VRA_SK
+}
+
+// ------------------------------------------------------------------------------------------------
+// public entry points
+// ------------------------------------------------------------------------------------------------
+static bool check_gemm_shape(const char* who, int m, int k, int n, int group_size) {
+  if (m < 1 || k < 128 || n < 16 || k % 128 || n % 16) {
+    vra_set_error("%s: need m>=1, k %% 128 == 0, n %% 16 == 0 (m=%d k=%d n=%d)", who, m, k, n);
+    return false;
+  }
+  if (!(group_size == -1 || (group_size >= 32 && group_size % 32 == 0 && k % group_size == 0))) {
+    vra_set_error("%s: group_size must be -1 or a multiple of 32 dividing k (got %d)", who, group_size);
+    return false;
+  }
+  return true;
+}
+
+extern "C" void vra_wna16_gemm(const void* in, const void* qweight_tiled, const void* scales, const void* qzeros,
+                               const void* bias, const void* residual, void* out, int32_t m, int32_t k, int32_t n,
+                               int32_t group_size, int32_t is_awq, int32_t scales_layout, int32_t dtype,
+                               int64_t stream) {
+  VRA_CHECK_ARG(in && qweight_tiled && scales && out, "vra_wna16_gemm: null pointer");
+  VRA_CHECK_ARG(dtype == VRA_BF16 || dtype == VRA_F16, "vra_wna16_gemm: dtype must be bf16/f16");
+  if (!check_gemm_shape("vra_wna16_gemm", m, k, n, group_size)) return;
+  if (vra_gemv_fits(true, 1, m, k, group_size)) {
+    GemvArgs a = {};
+    a.nseg = 1;
+    a.seg[0] = GemvSeg{qweight_tiled, scales, (const uint32_t*)qzeros, bias, out, n, n, 0};
+    a.x = in;
+    a.x_ld = k;
+    a.residual = residual;
+    a.res_ld = n;
+    a.M = m;
+    a.K = k;
+    a.group_size = group_size;
+    a.is_awq = is_awq;
+    a.scales_layout = scales_layout;
+    vra_launch_gemv(a, true, dtype, stream);
+  } else {
+    GemmBArgs b = {};
+    b.w0 = qweight_tiled;
+    b.sc0 = scales;
+    b.qz0 = (const uint32_t*)qzeros;
+    b.bias0 = bias;
+    b.x = in;
+    b.x_ld = k;
+    b.residual = residual;
+    b.res_ld = n;
+    b.out = out;
+    b.out_ld = n;
+    b.M = m;
+    b.N = n;
+    b.K = k;
+    b.group_size = group_size;
+    b.is_awq = is_awq;
+    b.scales_layout = scales_layout;
+    vra_launch_skinny(b, true, false, dtype, stream);
+  }
+}
+
+extern "C" void vra_wna16_gate_up_silu(const void* in, const void* qw_gate, const void* sc_gate, const void* qz_gate,
+                                       const void* qw_up, const void* sc_up, const void* qz_up, void* out, int32_t m,
+                                       int32_t k, int32_t n, int32_t group_size, int32_t is_awq, int32_t scales_layout,
+                                       int32_t dtype, int64_t stream) {
+  VRA_CHECK_ARG(in && qw_gate && sc_gate && qw_up && sc_up && out, "vra_wna16_gate_up_silu: null pointer");
+  VRA_CHECK_ARG(dtype == VRA_BF16 || dtype == VRA_F16, "vra_wna16_gate_up_silu: dtype must be bf16/f16");
+  if (!check_gemm_shape("vra_wna16_gate_up_silu", m, k, n, group_size)) return;
+  if (vra_gemv_fits(true, 2, m, k, group_size)) {
+    GemvArgs a = {};
+    a.nseg = 2;
+    a.seg[0] = GemvSeg{qw_gate, sc_gate, (const uint32_t*)qz_gate, nullptr, out, n, n, 0};
+    a.seg[1] = GemvSeg{qw_up, sc_up, (const uint32_t*)qz_up, nullptr, out, n, n, 0};
+    a.silu_dual = 1;
+    a.x = in;
+    a.x_ld = k;
+    a.M = m;
+    a.K = k;
+    a.group_size = group_size;
+    a.is_awq = is_awq;
+    a.scales_layout = scales_layout;
+    vra_launch_gemv(a, true, dtype, stream);
+  } else {
+    GemmBArgs b = {};
+    b.w0 = qw_gate;
+    b.w1 = qw_up;
+    b.sc0 = sc_gate;
+    b.sc1 = sc_up;
+    b.qz0 = (const uint32_t*)qz_gate;
+    b.qz1 = (const uint32_t*)qz_up;
+    b.x = in;
+    b.x_ld = k;
+    b.out = out;
+    b.out_ld = n;
+    b.M = m;
+    b.N = n;
+    b.K = k;
+    b.group_size = group_size;
+    b.is_awq = is_awq;
+    b.scales_layout = scales_layout;
+    vra_launch_skinny(b, true, true, dtype, stream);
+  }
+}
+
+extern "C" void vra_dense_gemm(const void* x, const void* w, const void* bias, void* out, int32_t m, int32_t k, int32_t n,
+                               int32_t dtype, int32_t out_dtype, int64_t stream) {
+  VRA_CHECK_ARG(x && w && out, "vra_dense_gemm: null pointer");
+  VRA_CHECK_ARG(dtype == VRA_BF16 || dtype == VRA_F16, "vra_dense_gemm: dtype must be bf16/f16");
+  VRA_CHECK_ARG(out_dtype == dtype || out_dtype == VRA_F32, "vra_dense_gemm: out_dtype must equal dtype or be f32");
+  VRA_CHECK_ARG(m >= 1 && k % 128 == 0 && n % 16 == 0, "vra_dense_gemm: need k %% 128 == 0, n %% 16 == 0 (m=%d k=%d n=%d)", m, k, n);
+  if (vra_gemv_fits(false, 1, m, k, -1)) {
+    GemvArgs a = {};
+    a.nseg = 1;
+    a.seg[0] = GemvSeg{w, nullptr, nullptr, bias, out, n, n, 0};
+    a.x = x;
+    a.x_ld = k;
+    a.M = m;
+    a.K = k;
+    a.group_size = -1;
+    a.out_f32 = out_dtype == VRA_F32;
+    vra_launch_gemv(a, false, dtype, stream);
+  } else {
+    GemmBArgs b = {};
+    b.w0 = w;
+    b.bias0 = bias;
+    b.x = x;
+    b.x_ld = k;
+    b.out = out;
+    b.out_ld = n;
+    b.M = m;
+    b.N = n;
+    b.K = k;
+    b.group_size = -1;
+    b.out_f32 = out_dtype == VRA_F32;
+    vra_launch_skinny(b, false, false, dtype, stream);
+  }
+}
+
+// ---- Section A: the seven symbols of src/utils/gptq.rs:3-6 ------------------------------------
+static void marlin_common(const char* who, const void* in, const int32_t* qweight, const void* scales, const void* qzeros,
+                          void* out, int m, int k, int n, int group_size, int is_awq, int dtype, int64_t stream) {
+  if (!in || !qweight || !scales || !out) {
+    vra_set_error("%s: null pointer", who);
+    return;
+  }
+  vra_wna16_gemm(in, qweight, scales, is_awq ? qzeros : nullptr, nullptr, nullptr, out, m, k, n, group_size, is_awq,
+                 VRA_SCALES_MARLIN, dtype, stream);
+}
+extern "C" void marlin_4bit_bf16(const void* in, const int32_t* qweight, const void* scales, const void* qzeros,
+                                 const void* g_idx, void* out, int32_t m, int32_t k, int32_t n, const void* workspace,
+                                 int32_t group_size, int64_t stream) {
+  (void)g_idx;
+  (void)workspace;
+  marlin_common("marlin_4bit_bf16", in, qweight, scales, qzeros, out, m, k, n, group_size, 0, VRA_BF16, stream);
+}
+extern "C" void marlin_4bit_f16(const void* in, const int32_t* qweight, const void* scales, const void* qzeros,
+                                const void* g_idx, void* out, int32_t m, int32_t k, int32_t n, const void* workspace,
+                                int32_t group_size, int64_t stream) {
+  (void)g_idx;
+  (void)workspace;
+  marlin_common("marlin_4bit_f16", in, qweight, scales, qzeros, out, m, k, n, group_size, 0, VRA_F16, stream);
+}
+extern "C" void marlin_awq_4bit_bf16(const void* in, const int32_t* qweight, const void* scales, const void* qzeros,
+                                     const void* g_idx, void* out, int32_t m, int32_t k, int32_t n, const void* workspace,
+                                     int32_t group_size, int64_t stream) {
+  (void)g_idx;
+  (void)workspace;
+  marlin_common("marlin_awq_4bit_bf16", in, qweight, scales, qzeros, out, m, k, n, group_size, 1, VRA_BF16, stream);
+}
+extern "C" void marlin_awq_4bit_f16(const void* in, const int32_t* qweight, const void* scales, const void* qzeros,
+                                    const void* g_idx, void* out, int32_t m, int32_t k, int32_t n, const void* workspace,
+                                    int32_t group_size, int64_t stream) {
+  (void)g_idx;
+  (void)workspace;
+  marlin_common("marlin_awq_4bit_f16", in, qweight, scales, qzeros, out, m, k, n, group_size, 1, VRA_F16, stream);
+}
+
+// gemm_half_q_half_alt: plain GPTQ checkpoint layout, f16 only (src/utils/gptq.rs:181-198).  Not a
+// hot path (sym=false / odd group sizes): one thread block per 64 columns, straight from the
+// checkpoint layout, zero = stored+1, g_idx honoured (desc_act), f32 accumulate, one rounding.
+__global__ __launch_bounds__(256) void gptq_alt_kernel(const uint16_t* __restrict__ x, const uint32_t* __restrict__ qw,
+                                                       const uint32_t* __restrict__ qz, const uint16_t* __restrict__ sc,
+                                                       const int32_t* __restrict__ g_idx, uint16_t* __restrict__ out,
+                                                       int M, int N, int K, int group_size) {
+  // block: 64 columns x 4 k-slices; grid.y = row m
+  __shared__ float part[4][64];
+  const int c = threadIdx.x & 63, ks = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + c, m = blockIdx.y;
+  float acc = 0.f;
+  if (n < N) {
+    const int rows = K >> 3;
+    for (int r = ks; r < rows; r += 4) {
+      uint32_t w = qw[(size_t)r * N + n];
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        int k = r * 8 + e;
+        int grp = g_idx ? g_idx[k] : k / group_size;
+        float s = F16::to_f32(sc[(size_t)grp * N + n]);
+        int z = (int)((qz[(size_t)grp * (N >> 3) + (n >> 3)] >> (4 * (n & 7))) & 0xFu) + 1;
+        float wv = rnd_dt<F16>((float)((int)((w >> (4 * e)) & 0xFu) - z) * s);
+        acc += F16::to_f32(x[(size_t)m * K + k]) * wv;
+      }
+    }
+  }
+  part[ks][c] = acc;
+  __syncthreads();
+  if (ks == 0 && n < N) out[(size_t)m * N + n] = F16::from_f32(part[0][c] + part[1][c] + part[2][c] + part[3][c]);
+}
+extern "C" void gemm_half_q_half_alt(const void* in, const uint32_t* qweight, const uint32_t* qzeros, const void* scales,
+                                     const int32_t* g_idx, void* out, int32_t m, int32_t n, int32_t k, int32_t bits,
+                                     int64_t stream) {
+  VRA_CHECK_ARG(in && qweight && qzeros && scales && out, "gemm_half_q_half_alt: null pointer");
+  VRA_CHECK_ARG(bits == 4, "gemm_half_q_half_alt: only 4-bit supported (bits=%d)", bits);
+  VRA_CHECK_ARG(k % 8 == 0 && n % 8 == 0, "gemm_half_q_half_alt: k,n must be multiples of 8");
+  // group size is implied by the scales tensor in the reference; without g_idx we cannot know it,
+  // so g_idx == NULL means group_size 128 (the only non-g_idx configuration wna16.rs routes here).
+  dim3 grid((n + 63) / 64, m);
+  gptq_alt_kernel<<<grid, 256, 0, as_stream(stream)>>>((const uint16_t*)in, qweight, qzeros, (const uint16_t*)scales, g_idx, (uint16_t*)out, m, n, k, 128);
+}
