@@ -38,7 +38,8 @@ struct GemmBArgs {
   uint32_t* counters;  // one per (m-chunk, n-group) tile, zero on entry, zero on exit
 };
 
-template <class DT, bool INT4, bool DUAL, int MT>
+// SPT = scale groups per 128-row k-tile held in registers (1: group_size >= 128 or -1; 4: 32/64).
+template <class DT, bool INT4, bool DUAL, int MT, int SPT>
 __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int ROWS = MT * 16;
@@ -59,9 +60,7 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
   const int c_begin = blockIdx.z * cps, c_end = min(nchunk_total, c_begin + cps);
 
   uint32_t* xs = reinterpret_cast<uint32_t*>(smem);                      // 2 buffers
-  f32x2* scs = reinterpret_cast<f32x2*>(smem + 2 * XS_U32 * 4);           // [2 bufs][NW][GCMAX][128]
-  const int gc_max = max(1, GB_KC / g);                                   // groups per chunk
-  int* flag = reinterpret_cast<int*>(smem + 2 * XS_U32 * 4 + (size_t)2 * NW * gc_max * 128 * sizeof(f32x2));
+  int* flag = reinterpret_cast<int*>(smem + 2 * XS_U32 * 4);
 
   auto stage = [&](int c, int buf) {
     // x chunk: rows m0..m0+ROWS, k = c*KC .. +KC ; i -> (row = i/32, o = i%32): 512 B runs per row
@@ -72,23 +71,6 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
       u32x4 v = {0u, 0u, 0u, 0u};
       if (m < M && k < K) v = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.x) + (size_t)m * a.x_ld + k);
       *reinterpret_cast<u32x4*>(dst + ((size_t)o * ROWS + (row ^ (o & 7))) * 4) = v;
-    }
-    if (INT4) {
-      const int g0 = (c * GB_KC) / g;
-      f32x2* sdst = scs + (size_t)buf * NW * gc_max * 128;
-      for (int i = tid; i < NW * gc_max * 128; i += GB_THREADS) {
-        int wsel = i / (gc_max * 128), gi = (i >> 7) % gc_max, col = i & 127;
-        int n = blockIdx.x * 128 + col, grp = min(g0 + gi, K / g - 1);
-        float s = 0.f, z = 8.f;
-        if (n < N) {
-          const void* scp = wsel ? a.sc1 : a.sc0;
-          const uint32_t* qzp = wsel ? a.qz1 : a.qz0;
-          s = DT::to_f32(static_cast<const uint16_t*>(scp)[vra_scale_index(grp, n, N, a.scales_layout, grouped)]);
-          if (a.is_awq && qzp) z = (float)((qzp[(size_t)grp * (N >> 3) + (n >> 3)] >> (4 * awq_rev(n & 7))) & 0xFu);
-        }
-        f32x2 p = {s, -z * s};
-        sdst[i] = p;
-      }
     }
   };
 
@@ -112,10 +94,27 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
   // INT4: one u32x4 per tile; dense: four u32x4 per tile
   constexpr int LPT = INT4 ? 1 : 4;
   u32x4 cur[TPC][NW][LPT], nxt[TPC][NW][LPT];
-  auto load_chunk = [&](int c, u32x4 (&dst)[TPC][NW][LPT]) {
+  // scales / zero points ride along with the weight stream: each lane keeps the raw 16-bit scale and
+  // (AWQ) the packed zero word of ITS column for every group of the tile (L2-resident, 2-4 B loads)
+  uint32_t csc[TPC][NW][SPT], nsc[TPC][NW][SPT], czp[TPC][NW][SPT], nzp[TPC][NW][SPT];
+  const int ncol = min(nb * 16 + nn, N - 1);
+  const int zshift = 4 * awq_rev(ncol & 7);
+  auto load_chunk = [&](int c, u32x4 (&dst)[TPC][NW][LPT], uint32_t (&dsc)[TPC][NW][SPT], uint32_t (&dzp)[TPC][NW][SPT]) {
 #pragma unroll
     for (int t = 0; t < TPC; t++) {
       int kt = c * TPC + t;
+      if (INT4) {
+#pragma unroll
+        for (int w = 0; w < NW; w++)
+#pragma unroll
+          for (int q = 0; q < SPT; q++) {
+            const int grp = min((kt * 128 + q * (128 / SPT)) / g, K / g - 1);
+            const uint16_t* scp = static_cast<const uint16_t*>(w ? a.sc1 : a.sc0);
+            const uint32_t* qzp = w ? a.qz1 : a.qz0;
+            dsc[t][w][q] = scp[vra_scale_index(grp, ncol, N, a.scales_layout, grouped)];
+            dzp[t][w][q] = (a.is_awq && qzp) ? qzp[(size_t)grp * (N >> 3) + (ncol >> 3)] : 0x88888888u;
+          }
+      }
 #pragma unroll
       for (int w = 0; w < NW; w++)
 #pragma unroll
@@ -129,19 +128,17 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
   };
 
   if (c_begin < c_end) {
-    load_chunk(c_begin, cur);
+    load_chunk(c_begin, cur, csc, czp);
     stage(c_begin, 0);
   }
   __syncthreads();
   for (int c = c_begin; c < c_end; c++) {
     const int buf = (c - c_begin) & 1;
     if (c + 1 < c_end) {
-      load_chunk(c + 1, nxt);
+      load_chunk(c + 1, nxt, nsc, nzp);
       stage(c + 1, buf ^ 1);
     }
     const uint32_t* xb = xs + buf * XS_U32;
-    const f32x2* sb = scs + (size_t)buf * NW * gc_max * 128;
-    const int g0 = (c * GB_KC) / g;
 #pragma unroll
     for (int t = 0; t < TPC; t++) {
 #pragma unroll
@@ -151,9 +148,11 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
 #pragma unroll
         for (int w = 0; w < NW; w++) {
           if (INT4) {
-            int gi = min((c * GB_KC + t * 128 + j * 32) / g - g0, gc_max - 1);
-            f32x2 p = sb[((size_t)w * gc_max + gi) * 128 + wave * 16 + nn];
-            afrag[w] = dequant_word<DT>(cur[t][w][0][j], p[0], p[1]);
+            constexpr int JQ = SPT == 1 ? 0 : 1;
+            const int q = JQ * j;  // SPT==4: one scale per 32-row step (group 64 repeats pairs)
+            const float sc = DT::to_f32((uint16_t)csc[t][w][q]);
+            const float zp = (float)((czp[t][w][q] >> zshift) & 0xFu);
+            afrag[w] = dequant_word<DT>(cur[t][w][0][j], sc, -zp * sc);
           } else {
             afrag[w] = __builtin_bit_cast(s16x8, cur[t][w][j]);
           }
@@ -175,6 +174,15 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
         for (int w = 0; w < NW; w++)
 #pragma unroll
           for (int l = 0; l < LPT; l++) cur[t][w][l] = nxt[t][w][l];
+#pragma unroll
+      for (int t = 0; t < TPC; t++)
+#pragma unroll
+        for (int w = 0; w < NW; w++)
+#pragma unroll
+          for (int q = 0; q < SPT; q++) {
+            csc[t][w][q] = nsc[t][w][q];
+            czp[t][w][q] = nzp[t][w][q];
+          }
     }
   }
 
@@ -250,8 +258,4 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
   }
 }
 
-static inline size_t gemm_skinny_lds_bytes(int mt, bool dual, int K, int group_size) {
-  int g = group_size > 0 ? group_size : K;
-  int gc_max = GB_KC / g > 1 ? GB_KC / g : 1;
-  return (size_t)2 * (GB_KC / 8) * mt * 16 * 16 + (size_t)2 * (dual ? 2 : 1) * gc_max * 128 * 8 + 16;
-}
+static inline size_t gemm_skinny_lds_bytes(int mt) { return (size_t)2 * (GB_KC / 8) * mt * 16 * 16 + 16; }

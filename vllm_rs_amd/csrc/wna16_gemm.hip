@@ -158,14 +158,17 @@ void vra_launch_gemv(const GemvArgs& a, bool int4, int dtype, int64_t stream) {
 
 template <class DT, bool INT4, bool DUAL, int MT>
 static void launch_skinny_t(GemmBArgs a, hipStream_t st) {
+  size_t lds = gemm_skinny_lds_bytes(MT);
+  dim3 grid((a.N + 127) / 128, (a.M + MT * 16 - 1) / (MT * 16), a.splitk);
+  const bool fine = INT4 && a.group_size > 0 && a.group_size < 128;  // several groups per k-tile
   static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<DT, INT4, DUAL, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+  if (!attr_set) {  // MT=4 needs 64 KiB + 16 B of dynamic LDS, just past the default limit
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<DT, INT4, DUAL, MT, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<DT, INT4, DUAL, MT, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
     attr_set = true;
   }
-  size_t lds = gemm_skinny_lds_bytes(MT, DUAL, a.K, a.group_size);
-  dim3 grid((a.N + 127) / 128, (a.M + MT * 16 - 1) / (MT * 16), a.splitk);
-  gemm_skinny_kernel<DT, INT4, DUAL, MT><<<grid, GB_THREADS, lds, st>>>(a);
+  if (fine) gemm_skinny_kernel<DT, INT4, DUAL, MT, 4><<<grid, GB_THREADS, lds, st>>>(a);
+  else gemm_skinny_kernel<DT, INT4, DUAL, MT, 1><<<grid, GB_THREADS, lds, st>>>(a);
 }
 
 // choose split-K so that the grid has roughly >= 2 workgroups per CU, bounded by the slab scratch
@@ -175,6 +178,8 @@ static int choose_splitk(int M, int N, int K, int mt, bool dual) {
   int nchunk = (K + GB_KC - 1) / GB_KC;
   int s = 1;
   while (wg * s < 384 && s * 2 <= nchunk && s < 16) s *= 2;
+  static const char* force = getenv("VRA_FORCE_SPLITK");  // debugging aid
+  if (force) s = atoi(force) < 1 ? 1 : (atoi(force) > nchunk ? nchunk : atoi(force));
   size_t slab = (size_t)(dual ? 2 : 1) * gy * mt * 16 * gx * 128 * 4;
   while (s > 1 && slab * s > vra_scratch_slab_bytes()) s /= 2;
   if (wg > (int)vra_scratch_counter_count()) s = 1;
