@@ -341,6 +341,16 @@ int32_t vra_engine_forward_raw(void* eng, const uint32_t* h_ids, const int64_t* 
  * running batch back to back (graph replay when enabled) and returns elapsed ms measured with HIP
  * events on the engine stream; tokens are sampled and appended exactly as in vra_engine_step. */
 double vra_engine_timed_decode(void* eng, int32_t steps);
+/* tensor parallel: attach a communicator created with vra_comm_create before finalize */
+int32_t vra_engine_set_comm(void* eng, void* comm);
+/* roofline leg of bench.py: average duration (ms) of ONE launch of a decode-shaped GEMM kernel
+ * family at m rows, rotating over all layers' weights so nothing is cache resident, measured with
+ * HIP events on the engine stream. which: 0 = norm+q/k/v, 1 = o_proj(+residual),
+ * 2 = norm+gate/up+SiLU·mul, 3 = down(+residual).  vra_engine_gemm_bytes = SURVEY §8(d)
+ * algorithmic bytes of that launch. */
+double vra_engine_bench_gemm(void* eng, int32_t which, int32_t m, int32_t iters);
+int64_t vra_engine_gemm_bytes(const void* eng, int32_t which, int32_t m);
+int64_t vra_engine_weight_bytes(const void* eng);
 int64_t vra_engine_stream(const void* eng);
 const char* vra_engine_last_error(const void* eng);
 

@@ -1,0 +1,150 @@
+"""CPU ORACLE for the whole forward (TEST INFRASTRUCTURE ONLY — see oracle/vra_oracle.c header).
+
+Restates, op by op and rounding by rounding, the reference's
+  LLaMaForCausalLM::forward_inner      src/models/llama.rs:269-321
+  LLaMaDecoderLayer::forward           src/models/llama.rs:107-131
+  Qwen3ForCausalLM (Qwen2 checkpoints) src/models/qwen3.rs:308-371 (qkv bias attention.rs:411-415)
+  Attention::forward_ext               src/models/layers/attention.rs:648-839
+  MLP::forward                         src/models/layers/mlp.rs:451-469
+  WNA16::forward                       src/models/layers/wna16.rs:263-306
+on top of the C primitives in vra_oracle.c.  Weights are given in CHECKPOINT format under their
+HuggingFace names (qweight/qzeros/scales for gptq|awq, weight for dense).
+"""
+import numpy as np
+
+from . import oracle as orc
+
+BF16, F16, F32 = 0, 1, 2
+
+
+class Linear:
+    def __init__(self, w, prefix, cfg):
+        self.dt = cfg["dtype"]
+        self.bias = w.get(prefix + ".bias")
+        if prefix + ".qweight" in w:
+            self.quant = True
+            self.gs = cfg["group_size"]
+            self.scales = w[prefix + ".scales"]
+            G, N = self.scales.shape
+            if cfg["quant_method"] == "awq":
+                K = w[prefix + ".qweight"].shape[0]
+                self.idx = orc.awq_unpack(w[prefix + ".qweight"], K, N)
+                self.zeros = orc.awq_unpack_zeros(w[prefix + ".qzeros"], G, N)
+            else:  # gptq, symmetric (marlin path, wna16.rs:154-160): zero point 8
+                K = w[prefix + ".qweight"].shape[0] * 8
+                self.idx = orc.gptq_unpack(w[prefix + ".qweight"], K, N)
+                self.zeros = None
+        else:
+            self.quant = False
+            self.w = w[prefix + ".weight"]  # [N, K]
+
+    def __call__(self, x, residual=None):
+        if self.quant:
+            return orc.wna16_gemm(x, self.idx, self.zeros, self.scales, self.gs, self.dt, self.bias, residual)
+        out = orc.dense_gemm(x, self.w, self.bias, self.dt, self.dt)
+        return orc.add(out, residual, self.dt) if residual is not None else out
+
+
+class OracleModel:
+    def __init__(self, cfg, weights, num_blocks, block_size=64):
+        self.cfg, self.w, self.BS = cfg, weights, block_size
+        dt = cfg["dtype"]
+        self.dt = dt
+        L, Hkv, D = cfg["num_layers"], cfg["num_kv_heads"], cfg["head_dim"]
+        self.kc = [np.zeros((num_blocks, Hkv, block_size, D), np.uint16) for _ in range(L)]
+        self.vc = [np.zeros((num_blocks, Hkv, D, block_size), np.uint16) for _ in range(L)]
+        rs = cfg.get("rope_scaling") or {}
+        st = {"": 0, "default": 0, "linear": 1, "llama3": 2}[rs.get("rope_type", "")]
+        cos, sin = orc.rope_tables(D, cfg["rope_theta"], cfg["max_position_embeddings"], st, rs.get("factor", 1.0),
+                                   rs.get("low_freq_factor", 1.0), rs.get("high_freq_factor", 4.0),
+                                   rs.get("original_max_position_embeddings", cfg["max_position_embeddings"]))
+        self.cos, self.sin = orc.to_dt(cos, dt), orc.to_dt(sin, dt)  # tables cast to the model dtype (llama.rs:179-189)
+        self.layers = []
+        for i in range(L):
+            p = f"model.layers.{i}."
+            self.layers.append(dict(
+                attn_norm=weights[p + "input_layernorm.weight"], ffn_norm=weights[p + "post_attention_layernorm.weight"],
+                q=Linear(weights, p + "self_attn.q_proj", cfg), k=Linear(weights, p + "self_attn.k_proj", cfg),
+                v=Linear(weights, p + "self_attn.v_proj", cfg), o=Linear(weights, p + "self_attn.o_proj", cfg),
+                gate=Linear(weights, p + "mlp.gate_proj", cfg), up=Linear(weights, p + "mlp.up_proj", cfg),
+                down=Linear(weights, p + "mlp.down_proj", cfg)))
+        self.embed = weights["model.embed_tokens.weight"]
+        self.final_norm = weights["model.norm.weight"]
+        self.lm_head = weights.get("lm_head.weight", self.embed)
+
+    def forward(self, ids, positions, slot_mapping, block_tables, context_lens, cu_q=None):
+        """returns f32 logits [n_seqs, vocab]; cu_q None => decode (one token per sequence)."""
+        cfg, dt = self.cfg, self.dt
+        Hq, Hkv, D, eps = cfg["num_heads"], cfg["num_kv_heads"], cfg["head_dim"], cfg["rms_norm_eps"]
+        ids = np.asarray(ids, np.uint32)
+        T = len(ids)
+        h = orc.embedding(ids, self.embed, dt)
+        for li, L in enumerate(self.layers):
+            x = orc.rms_norm(h, L["attn_norm"], eps, dt)
+            q = L["q"](x).reshape(T, Hq, D)
+            k = L["k"](x).reshape(T, Hkv, D)
+            v = L["v"](x).reshape(T, Hkv, D)
+            q = orc.rope(q, self.cos, self.sin, positions, False, dt, dt)
+            k = orc.rope(k, self.cos, self.sin, positions, False, dt, dt)
+            orc.reshape_and_cache(k, v, self.kc[li], self.vc[li], slot_mapping, self.BS, dt)
+            a = orc.paged_attention(q, self.kc[li], self.vc[li], block_tables, context_lens, cu_q, Hkv, self.BS, D ** -0.5, dt)
+            h = L["o"](a.reshape(T, Hq * D), residual=h)                      # attn_output + residual
+            x = orc.rms_norm(h, L["ffn_norm"], eps, dt)
+            act = orc.silu_mul(L["gate"](x), L["up"](x), dt)
+            h = L["down"](act, residual=h)                                    # residual + mlp_output
+        if cu_q is not None:  # last token of each sequence (llama.rs:306-310)
+            rows = np.asarray(cu_q[1:], np.int64) - 1
+            h = np.ascontiguousarray(h[rows])
+        x = orc.rms_norm(h, self.final_norm, eps, dt)
+        return orc.dense_gemm(x, self.lm_head, None, dt, F32)
+
+
+def make_random_checkpoint(cfg, seed=0):
+    """small random model in checkpoint format (HF names); returns dict name -> numpy array."""
+    r = np.random.default_rng(seed)
+    dt = cfg["dtype"]
+    H, I, V, L = cfg["hidden_size"], cfg["intermediate_size"], cfg["vocab_size"], cfg["num_layers"]
+    Hq, Hkv, D = cfg["num_heads"], cfg["num_kv_heads"], cfg["head_dim"]
+    qm, gs = cfg.get("quant_method"), cfg.get("group_size", 128)
+    w = {}
+
+    def f(shape, std=0.02, mean=0.0):
+        return orc.to_dt((mean + std * r.standard_normal(shape)).astype(np.float32), dt)
+
+    def lin(prefix, K, N, bias=False, std=None):
+        if qm in ("gptq", "awq"):
+            g = gs if gs > 0 else K
+            idx = r.integers(0, 16, size=(K, N), dtype=np.uint8)
+            # scale so that dequantised weights have std ~ 1/sqrt(K) (keeps activations O(1))
+            s = (1.0 / np.sqrt(K) / 4.6) * (0.5 + r.random((K // g, N)))
+            w[prefix + ".scales"] = orc.to_dt(s.astype(np.float32), dt)
+            if qm == "awq":
+                zeros = r.integers(0, 16, size=(K // g, N), dtype=np.uint8)
+                w[prefix + ".qweight"] = orc.awq_pack(idx)
+                w[prefix + ".qzeros"] = orc.awq_pack(zeros)
+            else:
+                w[prefix + ".qweight"] = orc.gptq_pack(idx)
+                w[prefix + ".qzeros"] = np.full((K // g, N // 8), 0x77777777, np.uint32)
+                w[prefix + ".g_idx"] = (np.arange(K) // g).astype(np.uint32)
+        else:
+            w[prefix + ".weight"] = f((N, K), std or 1.0 / np.sqrt(K))
+        if bias:
+            w[prefix + ".bias"] = f((N,), 0.1)
+
+    w["model.embed_tokens.weight"] = f((V, H), 1.0)
+    w["model.norm.weight"] = f((H,), 0.05, 1.0)
+    if not cfg.get("tie_word_embeddings"):
+        w["lm_head.weight"] = f((V, H), 1.0 / np.sqrt(H))
+    for i in range(L):
+        p = f"model.layers.{i}."
+        w[p + "input_layernorm.weight"] = f((H,), 0.05, 1.0)
+        w[p + "post_attention_layernorm.weight"] = f((H,), 0.05, 1.0)
+        b = bool(cfg.get("attention_bias"))
+        lin(p + "self_attn.q_proj", H, Hq * D, b)
+        lin(p + "self_attn.k_proj", H, Hkv * D, b)
+        lin(p + "self_attn.v_proj", H, Hkv * D, b)
+        lin(p + "self_attn.o_proj", Hq * D, H)
+        lin(p + "mlp.gate_proj", H, I)
+        lin(p + "mlp.up_proj", H, I)
+        lin(p + "mlp.down_proj", I, H)
+    return w

@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# the oracle is OpenMP code; on a 256-core GPU host the default team size makes tiny problems crawl
+os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

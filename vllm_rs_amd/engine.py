@@ -1,0 +1,164 @@
+"""Python mirror of the reference's `EngineBuilder`/`LLMEngine` surface for this path
+(src/api.rs:25-114, src/core/engine.rs:108,1291,1457): token ids in, token ids out.  All work is
+done by the native runtime in libvllm_rs_amd.so (host/*.cpp + csrc/*.hip); no CPU fallback."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import EngineConfig, ModelConfig
+
+BF16, F16, F32 = 0, 1, 2
+QUANT = {None: 0, "": 0, "none": 0, "gptq": 1, "awq": 2}
+ROPE = {None: 0, "": 0, "default": 0, "linear": 1, "llama3": 2}
+
+
+def model_config(cfg):
+    """dict with HF config.json-style keys -> ModelConfig (config.rs:218-255)."""
+    rs = cfg.get("rope_scaling") or {}
+    head_dim = cfg.get("head_dim") or cfg["hidden_size"] // cfg["num_heads"]
+    return ModelConfig(
+        arch=1 if cfg.get("arch", "llama") in ("qwen2", 1) else 0,
+        hidden_size=cfg["hidden_size"], intermediate_size=cfg["intermediate_size"], num_layers=cfg["num_layers"],
+        num_heads=cfg["num_heads"], num_kv_heads=cfg["num_kv_heads"], head_dim=head_dim, vocab_size=cfg["vocab_size"],
+        max_position_embeddings=cfg["max_position_embeddings"], rms_norm_eps=cfg["rms_norm_eps"],
+        rope_theta=cfg["rope_theta"], rope_scaling_type=ROPE[rs.get("rope_type", rs.get("type", ""))],
+        rope_factor=rs.get("factor", 1.0), rope_low_freq_factor=rs.get("low_freq_factor", 1.0),
+        rope_high_freq_factor=rs.get("high_freq_factor", 4.0),
+        rope_original_max_position=rs.get("original_max_position_embeddings", cfg["max_position_embeddings"]),
+        attention_bias=int(bool(cfg.get("attention_bias"))), quant_method=QUANT[cfg.get("quant_method")],
+        bits=4, group_size=cfg.get("group_size", 128), dtype=cfg.get("dtype", BF16),
+        tie_word_embeddings=int(bool(cfg.get("tie_word_embeddings"))))
+
+
+LLAMA3_8B = dict(arch="llama", hidden_size=4096, intermediate_size=14336, num_layers=32, num_heads=32, num_kv_heads=8,
+                 head_dim=128, vocab_size=128256, max_position_embeddings=8192, rms_norm_eps=1e-5, rope_theta=500000.0,
+                 quant_method="gptq", group_size=128, dtype=BF16)
+QWEN2_7B = dict(arch="qwen2", hidden_size=3584, intermediate_size=18944, num_layers=28, num_heads=28, num_kv_heads=4,
+                head_dim=128, vocab_size=152064, max_position_embeddings=32768, rms_norm_eps=1e-6, rope_theta=1000000.0,
+                attention_bias=True, quant_method="awq", group_size=128, dtype=BF16)
+LLAMA3_70B = dict(arch="llama", hidden_size=8192, intermediate_size=28672, num_layers=80, num_heads=64, num_kv_heads=8,
+                  head_dim=128, vocab_size=128256, max_position_embeddings=8192, rms_norm_eps=1e-5, rope_theta=500000.0,
+                  quant_method="gptq", group_size=128, dtype=BF16)
+TINYLLAMA = dict(arch="llama", hidden_size=2048, intermediate_size=5632, num_layers=22, num_heads=32, num_kv_heads=4,
+                 head_dim=64, vocab_size=32000, max_position_embeddings=2048, rms_norm_eps=1e-5, rope_theta=10000.0,
+                 quant_method=None, dtype=BF16)
+
+
+class Engine:
+    def __init__(self, cfg, *, block_size=64, max_num_seqs=32, max_model_len=0, num_gpu_blocks=0, kv_fraction=0.0,
+                 prefill_chunk=8192, enable_prefix_cache=False, use_graph=True, tp_rank=0, tp_world_size=1, device=0,
+                 seed=1234, comm=None):
+        self.L = _lib.load()
+        if self.L.vra_device_count() <= 0:
+            raise RuntimeError("vllm_rs_amd.Engine needs a GPU: no HIP device visible (there is no CPU fallback)")
+        self.cfg = cfg
+        self.mc = model_config(cfg)
+        self.ec = EngineConfig(block_size=block_size, max_num_seqs=max_num_seqs, max_model_len=max_model_len,
+                               num_gpu_blocks=num_gpu_blocks, kv_fraction=kv_fraction, prefill_chunk=prefill_chunk,
+                               enable_prefix_cache=int(enable_prefix_cache), prefix_cache_fraction=0.65,
+                               use_graph=int(use_graph), tp_rank=tp_rank, tp_world_size=tp_world_size, device=device,
+                               seed=seed)
+        self.h = self.L.vra_engine_create(C.byref(self.mc), C.byref(self.ec))
+        if not self.h:
+            raise RuntimeError("vra_engine_create failed")
+        if comm is not None:
+            self.L.vra_engine_set_comm(self.h, comm)
+
+    def _check(self, rc, what):
+        if rc is None or rc < 0:
+            raise RuntimeError(f"{what}: {self.L.vra_engine_last_error(self.h).decode()}")
+        return rc
+
+    def init_synthetic(self):
+        self._check(self.L.vra_engine_init_synthetic(self.h), "init_synthetic")
+        self._check(self.L.vra_engine_finalize_weights(self.h), "finalize")
+        return self
+
+    def load_weights(self, tensors):
+        """tensors: name -> numpy array in checkpoint format (16-bit floats as uint16 bit patterns in model dtype)."""
+        for name, a in tensors.items():
+            a = np.ascontiguousarray(a)
+            shape = (C.c_int64 * a.ndim)(*a.shape)
+            self._check(self.L.vra_engine_load_tensor(self.h, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim, a.itemsize),
+                        f"load_tensor({name})")
+        self._check(self.L.vra_engine_finalize_weights(self.h), "finalize")
+        return self
+
+    @property
+    def num_gpu_blocks(self):
+        return self.L.vra_engine_num_gpu_blocks(self.h)
+
+    def add_request(self, prompt, max_tokens=16, ignore_eos=False, eos=()):
+        p = np.ascontiguousarray(prompt, np.uint32)
+        e = np.ascontiguousarray(list(eos), np.uint32)
+        rid = self.L.vra_engine_add_request(self.h, p.ctypes.data_as(C.c_void_p), len(p), max_tokens, int(ignore_eos),
+                                            e.ctypes.data_as(C.c_void_p) if len(e) else None, len(e))
+        return self._check(rid, "add_request")
+
+    def step(self):
+        pf = C.c_int32(0)
+        n = self.L.vra_engine_step(self.h, C.byref(pf))
+        self._check(n, "step")
+        return n, bool(pf.value)
+
+    def has_unfinished(self):
+        return bool(self.L.vra_engine_has_unfinished(self.h))
+
+    def finished(self, rid):
+        return bool(self.L.vra_engine_request_finished(self.h, rid))
+
+    def output(self, rid, cap=1 << 16):
+        buf = np.empty(cap, np.uint32)
+        n = self.L.vra_engine_request_output(self.h, rid, buf.ctypes.data_as(C.c_void_p), cap)
+        return buf[:max(n, 0)].copy()
+
+    def times(self, rid):
+        t = (C.c_double * 3)()
+        self.L.vra_engine_request_times(self.h, rid, t)
+        return dict(created_ms=t[0], first_token_ms=t[1], finished_ms=t[2])
+
+    def generate(self, prompts, max_tokens=16, ignore_eos=False, eos=()):
+        """LLMEngine::generate_sync (engine.rs:1291): run to completion, return outputs in request order."""
+        rids = [self.add_request(p, max_tokens, ignore_eos, eos) for p in prompts]
+        while self.has_unfinished():
+            self.step()
+        return [self.output(r) for r in rids]
+
+    def forward_raw(self, ids, positions, slot_mapping, block_tables, context_lens, cu_q=None):
+        """`forward(input_ids, positions, kv_caches, input_metadata)` (llama.rs:323-339) → f32 logits [n_seqs, V]."""
+        ids = np.ascontiguousarray(ids, np.uint32)
+        positions = np.ascontiguousarray(positions, np.int64)
+        slot_mapping = np.ascontiguousarray(slot_mapping, np.int64)
+        block_tables = np.ascontiguousarray(block_tables, np.uint32)
+        context_lens = np.ascontiguousarray(context_lens, np.uint32)
+        B, mb = block_tables.shape
+        cu = None if cu_q is None else np.ascontiguousarray(cu_q, np.uint32)
+        out = np.empty((B, self.mc.vocab_size), np.float32)
+        rc = self.L.vra_engine_forward_raw(self.h, ids.ctypes.data_as(C.c_void_p), positions.ctypes.data_as(C.c_void_p),
+                                           slot_mapping.ctypes.data_as(C.c_void_p), len(ids), int(cu is not None),
+                                           block_tables.ctypes.data_as(C.c_void_p), mb, context_lens.ctypes.data_as(C.c_void_p),
+                                           cu.ctypes.data_as(C.c_void_p) if cu is not None else None, B,
+                                           out.ctypes.data_as(C.c_void_p))
+        self._check(rc, "forward_raw")
+        return out
+
+    def timed_decode(self, steps):
+        return self.L.vra_engine_timed_decode(self.h, steps)
+
+    def bench_gemm(self, which, m, iters):
+        return self.L.vra_engine_bench_gemm(self.h, which, m, iters)
+
+    def gemm_bytes(self, which, m):
+        return self.L.vra_engine_gemm_bytes(self.h, which, m)
+
+    def close(self):
+        if self.h:
+            self.L.vra_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,570 @@
+// model.cpp — see model.h.
+#include "model.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+
+#include "../csrc/gemm_launch.h"
+#include "../csrc/scratch.h"
+#include "host_utils.h"
+
+namespace vra {
+
+Model::Model(const vra_model_config& mc, const vra_engine_config& ec) : mc_(mc), ec_(ec) {
+  rank_ = ec.tp_world_size > 1 ? ec.tp_rank : 0;
+  world_ = ec.tp_world_size > 1 ? ec.tp_world_size : 1;
+  hq_ = mc.num_heads / world_;
+  hkv_ = mc.num_kv_heads >= world_ ? mc.num_kv_heads / world_ : 1;  // kv_head_shard (distributed.rs:498-538)
+  inter_ = mc.intermediate_size / world_;
+  dt_ = mc.dtype;
+  es_ = 2;
+  layers_.resize(mc.num_layers);
+}
+Model::~Model() {
+  for (void* p : allocs_) (void)hipFree(p);
+}
+void* Model::dalloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) {
+    error = "hipMalloc failed for " + std::to_string(bytes) + " bytes";
+    return nullptr;
+  }
+  allocs_.push_back(p);
+  return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weights
+// ---------------------------------------------------------------------------------------------
+bool Model::qlinear_synth(QLinear& l, int K, int N, bool bias, uint64_t seed) {
+  // BASELINE.md / SURVEY §8d synthetic recipe: qweight uniform u32, GPTQ zeros 8 (stored 0x77777777),
+  // AWQ zeros uniform nibbles, scales ~ U(0.002, 0.02), dense weights ~ N(0, 0.02).
+  l.K = K;
+  l.N = N;
+  l.quant = mc_.quant_method != 0;
+  l.awq = mc_.quant_method == 2;
+  if (l.quant) {
+    const int g = mc_.group_size > 0 ? mc_.group_size : K;
+    const size_t words = (size_t)(K / 8) * N;
+    if (!(l.w = dalloc(words * 4))) return false;
+    vra_fill_hash_u32((uint32_t*)l.w, (int64_t)words, seed, 0);  // tiled layout directly (codes are iid)
+    const size_t ns = (size_t)(K / g) * N;
+    if (!(l.scales = dalloc(ns * es_))) return false;
+    vra_fill_uniform(l.scales, (int64_t)ns, seed + 1, 0.002f, 0.02f, dt_, 0);
+    weight_bytes_ += words * 4 + ns * es_;
+    if (l.awq) {
+      if (!(l.qzeros = (uint32_t*)dalloc(ns / 8 * 4))) return false;
+      vra_fill_hash_u32(l.qzeros, (int64_t)(ns / 8), seed + 2, 0);
+      weight_bytes_ += ns / 8 * 4;
+    }
+  } else {
+    if (!(l.w = dalloc((size_t)K * N * es_))) return false;
+    vra_fill_normal(l.w, (int64_t)K * N, seed, 0.f, 0.02f, dt_, 0);
+    weight_bytes_ += (size_t)K * N * es_;
+  }
+  if (bias) {
+    if (!(l.bias = dalloc((size_t)N * es_))) return false;
+    vra_fill_normal(l.bias, N, seed + 3, 0.f, 0.02f, dt_, 0);
+  }
+  return true;
+}
+
+static void* upload(Model* m, std::vector<void*>& allocs, const void* host, size_t bytes, std::string& err) {
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) {
+    err = "hipMalloc failed";
+    return nullptr;
+  }
+  allocs.push_back(p);
+  if (hipMemcpy(p, host, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+    err = "hipMemcpy failed";
+    return nullptr;
+  }
+  (void)m;
+  return p;
+}
+
+bool Model::init_synthetic(uint64_t seed) {
+  const int H = mc_.hidden_size, D = mc_.head_dim, V = mc_.vocab_size;
+  // TP: every rank draws its own shard (seed offset by rank) — good for throughput runs; parity runs
+  // load explicit tensors through load_tensor(), which shards exactly like the reference.
+  const uint64_t base = seed + (uint64_t)rank_ * 1000003ull;
+  if (!(embed_ = dalloc((size_t)V * H * es_))) return false;
+  vra_fill_normal(embed_, (int64_t)V * H, seed + 7, 0.f, 0.02f, dt_, 0);
+  if (!(final_norm_ = dalloc((size_t)H * es_))) return false;
+  vra_fill_normal(final_norm_, H, seed + 8, 1.f, 0.02f, dt_, 0);
+  if (mc_.tie_word_embeddings) {
+    lm_head_.K = H;
+    lm_head_.N = V;
+    lm_head_.w = embed_;
+  } else {
+    lm_head_.K = H;
+    lm_head_.N = V;
+    if (!(lm_head_.w = dalloc((size_t)V * H * es_))) return false;
+    vra_fill_normal(lm_head_.w, (int64_t)V * H, seed + 9, 0.f, 0.02f, dt_, 0);
+  }
+  weight_bytes_ += (size_t)V * H * es_;
+  for (int l = 0; l < mc_.num_layers; l++) {
+    LayerWeights& L = layers_[l];
+    const uint64_t s = base + 1234 + (uint64_t)l * 64;
+    if (!(L.attn_norm = dalloc((size_t)H * es_)) || !(L.ffn_norm = dalloc((size_t)H * es_))) return false;
+    vra_fill_normal(L.attn_norm, H, seed + 100 + l * 2, 1.f, 0.02f, dt_, 0);
+    vra_fill_normal(L.ffn_norm, H, seed + 101 + l * 2, 1.f, 0.02f, dt_, 0);
+    const bool qb = mc_.attention_bias != 0;
+    if (!qlinear_synth(L.q, H, hq_ * D, qb, s + 0) || !qlinear_synth(L.k, H, hkv_ * D, qb, s + 4) ||
+        !qlinear_synth(L.v, H, hkv_ * D, qb, s + 8) || !qlinear_synth(L.o, hq_ * D, H, false, s + 12) ||
+        !qlinear_synth(L.gate, H, inter_, false, s + 16) || !qlinear_synth(L.up, H, inter_, false, s + 20) ||
+        !qlinear_synth(L.down, inter_, H, false, s + 24))
+      return false;
+  }
+  if (hipDeviceSynchronize() != hipSuccess) {
+    error = "synthetic init: device error";
+    return false;
+  }
+  return finalize_weights();
+}
+
+// 2-D host slice: rows [r0,r1) x cols [c0,c1) of a row-major [rows, cols] array
+static std::vector<uint8_t> slice2d(const void* src, int64_t cols, size_t es, int64_t r0, int64_t r1, int64_t c0, int64_t c1) {
+  std::vector<uint8_t> out((size_t)(r1 - r0) * (c1 - c0) * es);
+  for (int64_t r = r0; r < r1; r++)
+    memcpy(out.data() + (size_t)(r - r0) * (c1 - c0) * es, (const uint8_t*)src + ((size_t)r * cols + c0) * es, (size_t)(c1 - c0) * es);
+  return out;
+}
+
+bool Model::load_tensor(const std::string& name, const void* host, const int64_t* shape, int ndim, int elem_bytes) {
+  const int H = mc_.hidden_size;
+  auto up1 = [&](void*& dst, size_t n_elems) {
+    dst = upload(this, allocs_, host, n_elems * (size_t)elem_bytes, error);
+    return dst != nullptr;
+  };
+  if (name == "model.embed_tokens.weight") {
+    if (!up1(embed_, (size_t)shape[0] * shape[1])) return false;
+    if (mc_.tie_word_embeddings) {
+      lm_head_.K = H;
+      lm_head_.N = mc_.vocab_size;
+      lm_head_.w = embed_;
+    }
+    return true;
+  }
+  if (name == "model.norm.weight") return up1(final_norm_, (size_t)shape[0]);
+  if (name == "lm_head.weight") {
+    lm_head_.K = H;
+    lm_head_.N = mc_.vocab_size;
+    return up1(lm_head_.w, (size_t)shape[0] * shape[1]);
+  }
+  // model.layers.{i}.<sub>
+  int li = -1;
+  char sub[160] = {0};
+  if (sscanf(name.c_str(), "model.layers.%d.%150s", &li, sub) != 2 || li < 0 || li >= mc_.num_layers) {
+    error = "unknown tensor name: " + name;
+    return false;
+  }
+  LayerWeights& L = layers_[li];
+  std::string s(sub);
+  if (s == "input_layernorm.weight") return up1(L.attn_norm, (size_t)shape[0]);
+  if (s == "post_attention_layernorm.weight") return up1(L.ffn_norm, (size_t)shape[0]);
+  struct Target {
+    const char* prefix;
+    QLinear* l;
+    bool row_parallel;  // shard K (o_proj, down_proj) vs shard N
+    bool is_kv;
+  } targets[] = {{"self_attn.q_proj.", &L.q, false, false},    {"self_attn.k_proj.", &L.k, false, true},
+                 {"self_attn.v_proj.", &L.v, false, true},     {"self_attn.o_proj.", &L.o, true, false},
+                 {"mlp.gate_proj.", &L.gate, false, false},    {"mlp.up_proj.", &L.up, false, false},
+                 {"mlp.down_proj.", &L.down, true, false}};
+  for (auto& t : targets) {
+    const size_t pl = strlen(t.prefix);
+    if (s.compare(0, pl, t.prefix) != 0) continue;
+    const std::string leaf = s.substr(pl);
+    QLinear& l = *t.l;
+    // shard index/count: kv projections replicate heads when num_kv_heads < world (distributed.rs:526-537)
+    int nshard = world_, ishard = rank_;
+    if (t.is_kv && mc_.num_kv_heads < world_) {
+      nshard = mc_.num_kv_heads;
+      ishard = rank_ / (world_ / mc_.num_kv_heads);
+    }
+    const int64_t R = shape[0], Ccols = ndim > 1 ? shape[1] : 1;
+    auto shard_upload = [&](bool shard_rows, bool shard_cols, int64_t row_unit, void*& dst, int* out_r, int* out_c) {
+      int64_t r0 = 0, r1 = R, c0 = 0, c1 = Ccols;
+      if (shard_rows) {
+        r0 = R / nshard * ishard;
+        r1 = r0 + R / nshard;
+      }
+      if (shard_cols) {
+        c0 = Ccols / nshard * ishard;
+        c1 = c0 + Ccols / nshard;
+      }
+      (void)row_unit;
+      auto buf = slice2d(host, Ccols, (size_t)elem_bytes, r0, r1, c0, c1);
+      dst = upload(this, allocs_, buf.data(), buf.size(), error);
+      if (out_r) *out_r = (int)(r1 - r0);
+      if (out_c) *out_c = (int)(c1 - c0);
+      return dst != nullptr;
+    };
+    const bool sharded = world_ > 1;
+    if (leaf == "weight") {  // dense [N, K]: column-parallel shards dim 0, row-parallel dim 1
+      l.quant = false;
+      int r, c;
+      if (!shard_upload(sharded && !t.row_parallel, sharded && t.row_parallel, 1, l.w, &r, &c)) return false;
+      l.N = r;
+      l.K = c;
+      return true;
+    }
+    if (leaf == "qweight") {  // gptq [K/8, N] / awq [K, N/8]: packed tensors are stored [in, out] (wna16.rs:35-40)
+      l.quant = true;
+      l.awq = mc_.quant_method == 2;
+      if (!shard_upload(sharded && t.row_parallel, sharded && !t.row_parallel, 1, l.raw_qweight, &l.raw_rows, &l.raw_cols)) return false;
+      if (l.awq) {
+        l.K = l.raw_rows;
+        l.N = l.raw_cols * 8;
+      } else {
+        l.K = l.raw_rows * 8;
+        l.N = l.raw_cols;
+      }
+      return true;
+    }
+    if (leaf == "scales") {
+      int r, c;
+      return shard_upload(sharded && t.row_parallel, sharded && !t.row_parallel, 1, l.scales, &r, &c);
+    }
+    if (leaf == "qzeros") {
+      int r, c;
+      void* p = nullptr;
+      if (!shard_upload(sharded && t.row_parallel, sharded && !t.row_parallel, 1, p, &r, &c)) return false;
+      l.qzeros = (uint32_t*)p;
+      return true;
+    }
+    if (leaf == "g_idx") return true;  // desc_act=false only: trivial map, ignored (Appendix A7)
+    if (leaf == "bias") {
+      int r, c;
+      // bias [N]: sharded with the output dim for column-parallel layers
+      int64_t n0 = 0, n1 = R;
+      if (sharded && !t.row_parallel) {
+        n0 = R / nshard * ishard;
+        n1 = n0 + R / nshard;
+      }
+      (void)r;
+      (void)c;
+      l.bias = upload(this, allocs_, (const uint8_t*)host + (size_t)n0 * elem_bytes, (size_t)(n1 - n0) * elem_bytes, error);
+      return l.bias != nullptr;
+    }
+    error = "unknown tensor leaf: " + name;
+    return false;
+  }
+  error = "unknown tensor name: " + name;
+  return false;
+}
+
+bool Model::finalize_weights() {
+  // one-time repack of checkpoint-format qweights into the CDNA4 tile layout (MarlinRepack,
+  // src/utils/gptq.rs:266-360, invoked from wna16.rs:220-224 at load time)
+  auto fin = [&](QLinear& l, const char* what) {
+    if (l.raw_qweight) {
+      const size_t words = (size_t)l.raw_rows * l.raw_cols;
+      if (!(l.w = dalloc(words * 4))) return false;
+      if (l.awq) awq_repack(l.raw_qweight, l.w, l.raw_rows, l.raw_cols, 4, 0);
+      else gptq_repack(l.raw_qweight, l.w, l.raw_rows, l.raw_cols, 0);
+      const char* e = vra_last_error();
+      if (e && e[0]) {
+        error = std::string("repack ") + what + ": " + e;
+        return false;
+      }
+      weight_bytes_ += words * 4;
+      l.raw_qweight = nullptr;
+    }
+    if (!l.w) {
+      error = std::string("missing weight: ") + what;
+      return false;
+    }
+    if (l.quant && !l.scales) {
+      error = std::string("missing scales: ") + what;
+      return false;
+    }
+    if (l.quant && l.awq && !l.qzeros) {
+      error = std::string("missing qzeros (awq): ") + what;
+      return false;
+    }
+    return true;
+  };
+  for (auto& L : layers_) {
+    if (!L.attn_norm || !L.ffn_norm) {
+      error = "missing layer norm weights";
+      return false;
+    }
+    if (!fin(L.q, "q_proj") || !fin(L.k, "k_proj") || !fin(L.v, "v_proj") || !fin(L.o, "o_proj") || !fin(L.gate, "gate_proj") ||
+        !fin(L.up, "up_proj") || !fin(L.down, "down_proj"))
+      return false;
+  }
+  if (!embed_ || !final_norm_ || !lm_head_.w) {
+    error = "missing embed/norm/lm_head";
+    return false;
+  }
+  // rotary tables in the model dtype (llama.rs:179-189; rotary_emb.rs:32-73,208-278)
+  const int half = mc_.head_dim / 2;
+  rope_rows_ = mc_.max_position_embeddings;
+  std::vector<float> c((size_t)rope_rows_ * half), s((size_t)rope_rows_ * half);
+  vra_rope_tables_f32(&mc_, rope_rows_, c.data(), s.data());
+  std::vector<uint16_t> cb(c.size()), sb(s.size());
+  for (size_t i = 0; i < c.size(); i++) {
+    cb[i] = dt_ == VRA_BF16 ? host_f32_to_bf16(c[i]) : host_f32_to_f16(c[i]);
+    sb[i] = dt_ == VRA_BF16 ? host_f32_to_bf16(s[i]) : host_f32_to_f16(s[i]);
+  }
+  cos_ = upload(this, allocs_, cb.data(), cb.size() * 2, error);
+  sin_ = upload(this, allocs_, sb.data(), sb.size() * 2, error);
+  if (!cos_ || !sin_) return false;
+  if (!vra_scratch_init()) {
+    error = "scratch allocation failed";
+    return false;
+  }
+  return hipDeviceSynchronize() == hipSuccess;
+}
+
+bool Model::init_kv_cache(int num_blocks) {
+  // per layer: K [NB, Hkv, BS, D], V [NB, Hkv, D, BS] (kvcache_allocator.rs:737-932 shapes, re-laid)
+  num_blocks_ = num_blocks;
+  const size_t per = (size_t)num_blocks * hkv_ * ec_.block_size * mc_.head_dim * es_;
+  kc_.resize(mc_.num_layers);
+  vc_.resize(mc_.num_layers);
+  for (int l = 0; l < mc_.num_layers; l++) {
+    if (!(kc_[l] = dalloc(per)) || !(vc_[l] = dalloc(per))) return false;
+    (void)hipMemset(kc_[l], 0, per);
+    (void)hipMemset(vc_[l], 0, per);
+  }
+  return hipDeviceSynchronize() == hipSuccess;
+}
+
+bool Model::init_buffers(int max_tokens, int max_seqs) {
+  max_tokens_ = max_tokens;
+  max_seqs_ = max_seqs;
+  const size_t T = max_tokens, H = mc_.hidden_size, D = mc_.head_dim;
+  if (!(h_ = dalloc(T * H * es_)) || !(xn_ = dalloc(T * H * es_)) || !(q_ = dalloc(T * hq_ * D * es_)) ||
+      !(k_ = dalloc(T * hkv_ * D * es_)) || !(v_ = dalloc(T * hkv_ * D * es_)) || !(attn_ = dalloc(T * hq_ * D * es_)) ||
+      !(act_ = dalloc(T * inter_ * es_)) || !(tmp_ = dalloc(T * H * es_)) || !(last_ = dalloc((size_t)max_seqs * H * es_)) ||
+      !(logits_ = (float*)dalloc((size_t)max_seqs * mc_.vocab_size * 4)))
+    return false;
+  if (mc_.quant_method == 0) {
+    if (!(gate_ = dalloc(T * inter_ * es_)) || !(up_ = dalloc(T * inter_ * es_))) return false;
+  }
+  const size_t ws = vra_paged_attention_decode_workspace_bytes(max_seqs, hq_, mc_.head_dim, mc_.max_position_embeddings);
+  if (!(attn_ws_ = dalloc(ws))) return false;
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// linear layers
+// ---------------------------------------------------------------------------------------------
+static bool take_err(std::string& error, const char* where) {
+  const char* e = vra_last_error();
+  if (e && e[0]) {
+    error = std::string(where) + ": " + e;
+    vra_clear_error();
+    return true;
+  }
+  return false;
+}
+
+bool Model::linear(const QLinear& l, const void* x, void* out, int M, const void* residual, int64_t stream) {
+  if (l.quant) {
+    vra_wna16_gemm(x, l.w, l.scales, l.qzeros, l.bias, residual, out, M, l.K, l.N, mc_.group_size, l.awq ? 1 : 0,
+                   VRA_SCALES_ROWMAJOR, dt_, stream);
+  } else if (!residual) {
+    vra_dense_gemm(x, l.w, l.bias, out, M, l.K, l.N, dt_, dt_, stream);
+  } else {
+    // dense + residual: kernel A handles it directly for small M, otherwise GEMM then add
+    if (vra_gemv_fits(false, 1, M, l.K, -1)) {
+      GemvArgs a = {};
+      a.nseg = 1;
+      a.seg[0] = GemvSeg{l.w, nullptr, nullptr, l.bias, out, l.N, l.N, 0};
+      a.x = x;
+      a.x_ld = l.K;
+      a.residual = residual;
+      a.res_ld = l.N;
+      a.M = M;
+      a.K = l.K;
+      a.group_size = -1;
+      vra_launch_gemv(a, false, dt_, stream);
+    } else {
+      vra_dense_gemm(x, l.w, l.bias, tmp_, M, l.K, l.N, dt_, dt_, stream);
+      vra_add(tmp_, residual, out, (int64_t)M * l.N, dt_, stream);
+    }
+  }
+  return !take_err(error, "linear");
+}
+
+bool Model::linear_fused_norm(const QLinear* ls, int nl, void* const* outs, const void* x, const void* norm_w, int M, int64_t stream) {
+  // RMSNorm (NormX::forward, others.rs:11-29) folded into the GEMV prologue when the whole x fits LDS;
+  // q/k/v (Separate projections, attention.rs:224-228,660-669) go out in ONE launch.
+  const int K = ls[0].K;
+  bool fusable = nl <= GEMV_MAX_SEG && vra_gemv_fits(ls[0].quant, 1, M, K, ls[0].quant ? mc_.group_size : -1);
+  for (int i = 1; i < nl; i++) fusable = fusable && ls[i].quant == ls[0].quant && ls[i].K == K;
+  if (fusable) {
+    GemvArgs a = {};
+    a.nseg = nl;
+    int blk = 0;
+    for (int i = 0; i < nl; i++) {
+      a.seg[i] = GemvSeg{ls[i].w, ls[i].scales, ls[i].qzeros, ls[i].bias, outs[i], ls[i].N, ls[i].N, blk};
+      blk += (ls[i].N + 15) / 16;
+    }
+    a.x = x;
+    a.x_ld = K;
+    a.norm_w = norm_w;
+    a.eps = mc_.rms_norm_eps;
+    a.M = M;
+    a.K = K;
+    a.group_size = ls[0].quant ? mc_.group_size : -1;
+    a.is_awq = ls[0].awq ? 1 : 0;
+    a.scales_layout = VRA_SCALES_ROWMAJOR;
+    vra_launch_gemv(a, ls[0].quant, dt_, stream);
+    return !take_err(error, "fused norm gemv");
+  }
+  vra_rms_norm(x, norm_w, xn_, M, K, mc_.rms_norm_eps, dt_, stream);
+  for (int i = 0; i < nl; i++)
+    if (!linear(ls[i], xn_, outs[i], M, nullptr, stream)) return false;
+  return !take_err(error, "norm + linear");
+}
+
+bool Model::gate_up(const LayerWeights& L, const void* x, const void* norm_w, void* act, int M, int64_t stream) {
+  // MLP::forward (mlp.rs:451-469): down(act(gate(x)) * up(x)); gate/up Separate for GPTQ/AWQ (mlp.rs:142-146)
+  const int K = L.gate.K, N = L.gate.N;
+  if (L.gate.quant) {
+    if (vra_gemv_fits(true, 2, M, K, mc_.group_size)) {
+      GemvArgs a = {};
+      a.nseg = 2;
+      a.seg[0] = GemvSeg{L.gate.w, L.gate.scales, L.gate.qzeros, nullptr, act, N, N, 0};
+      a.seg[1] = GemvSeg{L.up.w, L.up.scales, L.up.qzeros, nullptr, act, N, N, 0};
+      a.silu_dual = 1;
+      a.x = x;
+      a.x_ld = K;
+      a.norm_w = norm_w;
+      a.eps = mc_.rms_norm_eps;
+      a.M = M;
+      a.K = K;
+      a.group_size = mc_.group_size;
+      a.is_awq = L.gate.awq ? 1 : 0;
+      vra_launch_gemv(a, true, dt_, stream);
+    } else {
+      vra_rms_norm(x, norm_w, xn_, M, K, mc_.rms_norm_eps, dt_, stream);
+      vra_wna16_gate_up_silu(xn_, L.gate.w, L.gate.scales, L.gate.qzeros, L.up.w, L.up.scales, L.up.qzeros, act, M, K, N,
+                             mc_.group_size, L.gate.awq ? 1 : 0, VRA_SCALES_ROWMAJOR, dt_, stream);
+    }
+    return !take_err(error, "gate_up");
+  }
+  const QLinear ls[2] = {L.gate, L.up};
+  void* outs[2] = {gate_, up_};
+  if (!linear_fused_norm(ls, 2, outs, x, norm_w, M, stream)) return false;
+  vra_silu_mul(gate_, up_, act, (int64_t)M * N, dt_, stream);
+  return !take_err(error, "gate_up dense");
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+bool Model::forward(const InputMetadata& md, int64_t stream) {
+  const int T = md.n_tokens, B = md.n_seqs, H = mc_.hidden_size, D = mc_.head_dim;
+  if (T <= 0 || T > max_tokens_ || B <= 0 || B > max_seqs_) {
+    error = "forward: batch out of range (tokens " + std::to_string(T) + ", seqs " + std::to_string(B) + ")";
+    return false;
+  }
+  const float scale = 1.0f / sqrtf((float)D);
+  // embed_forward (llama.rs:260-267)
+  vra_embedding(md.input_ids, embed_, h_, T, H, mc_.vocab_size, dt_, stream);
+  for (int l = 0; l < mc_.num_layers; l++) {
+    const LayerWeights& L = layers_[l];
+    // ---- attention block (llama.rs:115-126): norm -> q,k,v -> rope -> cache + attention -> o_proj (+ residual)
+    const QLinear qkv[3] = {L.q, L.k, L.v};
+    void* outs[3] = {q_, k_, v_};
+    if (!linear_fused_norm(qkv, 3, outs, h_, L.attn_norm, T, stream)) return false;
+    vra_fused_rope(q_, k_, cos_, sin_, md.positions, T, hq_, hkv_, D, D, 0, dt_, dt_, stream);
+    vra_reshape_and_cache(k_, v_, kc_[l], vc_[l], md.slot_mapping, T, hkv_, D, ec_.block_size, dt_, stream);
+    if (md.is_prefill) {
+      vra_paged_attention_prefill(attn_, q_, nullptr, nullptr, kc_[l], vc_[l], md.block_tables, md.context_lens, md.cu_seqlens_q,
+                                  nullptr, B, T, md.max_seqlen_q, hq_, hkv_, D, ec_.block_size, md.max_blocks, scale, 0.f, dt_, stream);
+    } else {
+      vra_paged_attention_decode(attn_, q_, kc_[l], vc_[l], md.block_tables, md.context_lens, B, hq_, hkv_, D, ec_.block_size,
+                                 md.max_blocks, md.max_context_len, scale, 0.f, attn_ws_, dt_, stream);
+    }
+    if (take_err(error, "attention")) return false;
+    if (world_ > 1) {  // TensorParallelRowLinear: partial GEMM -> all_reduce -> + residual (distributed.rs:438-455)
+      if (!linear(L.o, attn_, tmp_, T, nullptr, stream)) return false;
+      vra_all_reduce(comm_, tmp_, tmp_, (int64_t)T * H, dt_, stream);
+      vra_add(tmp_, h_, h_, (int64_t)T * H, dt_, stream);
+    } else if (!linear(L.o, attn_, h_, T, h_, stream)) {
+      return false;
+    }
+    // ---- MLP block (llama.rs:127-130)
+    if (!gate_up(L, h_, L.ffn_norm, act_, T, stream)) return false;
+    if (world_ > 1) {
+      if (!linear(L.down, act_, tmp_, T, nullptr, stream)) return false;
+      vra_all_reduce(comm_, tmp_, tmp_, (int64_t)T * H, dt_, stream);
+      vra_add(tmp_, h_, h_, (int64_t)T * H, dt_, stream);
+    } else if (!linear(L.down, act_, h_, T, h_, stream)) {
+      return false;
+    }
+  }
+  // last token of every sequence (llama.rs:306-310), final norm, lm_head -> f32 (llama.rs:311-320)
+  const void* xin = h_;
+  int rows = T;
+  if (md.is_prefill) {
+    vra_index_select_rows(h_, md.last_token_rows, last_, B, H, dt_, stream);
+    xin = last_;
+    rows = B;
+  }
+  if (vra_gemv_fits(false, 1, rows, H, -1)) {
+    GemvArgs a = {};
+    a.nseg = 1;
+    a.seg[0] = GemvSeg{lm_head_.w, nullptr, nullptr, nullptr, logits_, lm_head_.N, lm_head_.N, 0};
+    a.x = xin;
+    a.x_ld = H;
+    a.norm_w = final_norm_;
+    a.eps = mc_.rms_norm_eps;
+    a.M = rows;
+    a.K = H;
+    a.group_size = -1;
+    a.out_f32 = 1;
+    vra_launch_gemv(a, false, dt_, stream);
+  } else {
+    vra_rms_norm(xin, final_norm_, xn_, rows, H, mc_.rms_norm_eps, dt_, stream);
+    vra_dense_gemm(xn_, lm_head_.w, nullptr, logits_, rows, H, lm_head_.N, dt_, VRA_F32, stream);
+  }
+  return !take_err(error, "lm_head");
+}
+
+// ---------------------------------------------------------------------------------------------
+// roofline microbench hooks
+// ---------------------------------------------------------------------------------------------
+bool Model::launch_gemm(int which, int layer, int M, int64_t stream) {
+  if (layer < 0 || layer >= mc_.num_layers || M < 1 || M > max_tokens_) return false;
+  const LayerWeights& L = layers_[layer];
+  switch (which) {
+    case 0: {
+      const QLinear qkv[3] = {L.q, L.k, L.v};
+      void* outs[3] = {q_, k_, v_};
+      return linear_fused_norm(qkv, 3, outs, h_, L.attn_norm, M, stream);
+    }
+    case 1: return linear(L.o, attn_, tmp_, M, h_, stream);
+    case 2: return gate_up(L, h_, L.ffn_norm, act_, M, stream);
+    case 3: return linear(L.down, act_, tmp_, M, h_, stream);
+    default: return false;
+  }
+}
+int64_t Model::gemm_algorithmic_bytes(int which, int M) const {
+  // K*N/2 (packed) + (K/g)*N*2 (scales) + (K/g)*N/2 (zeros) + M*K*2 (act) + M*N*2 (out)
+  auto one = [&](const QLinear& l) -> int64_t {
+    const int64_t K = l.K, N = l.N;
+    if (!l.quant) return K * N * 2 + (int64_t)M * K * 2 + (int64_t)M * N * 2;
+    const int64_t g = mc_.group_size > 0 ? mc_.group_size : K;
+    return K * N / 2 + (K / g) * N * 2 + (K / g) * N / 2 + (int64_t)M * K * 2 + (int64_t)M * N * 2;
+  };
+  const LayerWeights& L = layers_[0];
+  switch (which) {
+    case 0: return one(L.q) + one(L.k) + one(L.v);
+    case 1: return one(L.o);
+    case 2: return one(L.gate) + one(L.up);
+    case 3: return one(L.down);
+    default: return 0;
+  }
+}
+
+}  // namespace vra

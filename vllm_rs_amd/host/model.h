@@ -1,0 +1,115 @@
+// model.h — native restatement of the reference's model contract for this path:
+//   LLaMaForCausalLM (src/models/llama.rs:107-131,269-321) and Qwen2 via Qwen3ForCausalLM
+//   (src/models/qwen3.rs:75-97,308-371; qkv bias per attention.rs:411-415),
+//   Attention::forward_ext (attention.rs:648-839), MLP::forward (mlp.rs:451-469),
+//   WNA16 (wna16.rs:25-307), TensorParallel{Column,Row}Linear + kv_head_shard (distributed.rs).
+// forward(input_ids, positions, kv_caches, input_metadata) -> f32 logits [n_seqs, vocab].
+#pragma once
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/vllm_rs_amd.h"
+
+namespace vra {
+
+struct QLinear {
+  int K = 0, N = 0;  // local (per-rank) shape
+  bool quant = false, awq = false;
+  void* w = nullptr;             // quant: tiled words; dense: [N, K] 16-bit
+  void* scales = nullptr;        // [K/g, N] model dtype, row-major
+  uint32_t* qzeros = nullptr;    // awq raw [K/g, N/8]
+  void* bias = nullptr;          // [N] or null
+  // staging of checkpoint-format pieces until finalize()
+  void* raw_qweight = nullptr;
+  int raw_rows = 0, raw_cols = 0;
+};
+
+struct LayerWeights {
+  void* attn_norm = nullptr;
+  void* ffn_norm = nullptr;
+  QLinear q, k, v, o, gate, up, down;
+};
+
+// The data contract between runner and kernels (InputMetadata, runner.rs:1222-1238,1369-1385);
+// all pointers are device buffers owned by the runner.
+struct InputMetadata {
+  bool is_prefill = false;
+  int n_tokens = 0;
+  int n_seqs = 0;
+  const uint32_t* input_ids = nullptr;      // [T]
+  const int64_t* positions = nullptr;       // [T]
+  const int64_t* slot_mapping = nullptr;    // [T]
+  const uint32_t* block_tables = nullptr;   // [B, max_blocks]
+  const uint32_t* context_lens = nullptr;   // [B]
+  const uint32_t* cu_seqlens_q = nullptr;   // [B+1] (prefill)
+  const uint32_t* last_token_rows = nullptr;  // [B] = seqlens[i]-1 (llama.rs:306-310)
+  int max_blocks = 0;
+  int max_seqlen_q = 0;
+  int max_context_len = 0;
+};
+
+class Model {
+ public:
+  Model(const vra_model_config& mc, const vra_engine_config& ec);
+  ~Model();
+  std::string error;
+
+  // weights
+  bool init_synthetic(uint64_t seed);
+  bool load_tensor(const std::string& name, const void* host, const int64_t* shape, int ndim, int elem_bytes);
+  bool finalize_weights();   // repack staged checkpoint tensors, check completeness
+  // kv cache
+  bool init_kv_cache(int num_blocks);
+  int num_blocks() const { return num_blocks_; }
+  // activations are sized for max_tokens rows
+  bool init_buffers(int max_tokens, int max_seqs);
+  void set_comm(void* comm) { comm_ = comm; }
+  // forward → logits (device, f32 [n_seqs, vocab]) ; returns false on argument error
+  bool forward(const InputMetadata& md, int64_t stream);
+  float* logits() const { return logits_; }
+  const vra_model_config& config() const { return mc_; }
+  int local_heads() const { return hq_; }
+  int local_kv_heads() const { return hkv_; }
+  size_t weight_bytes() const { return weight_bytes_; }
+  // microbenchmark hooks (bench.py roofline leg): launch one decode-shaped GEMM of layer `layer`
+  // which: 0 qkv(fused norm) 1 o_proj 2 gate_up 3 down 4 lm_head ; M rows
+  bool launch_gemm(int which, int layer, int M, int64_t stream);
+  int64_t gemm_algorithmic_bytes(int which, int M) const;
+
+ private:
+  void* dalloc(size_t bytes);
+  bool qlinear_synth(QLinear& l, int K, int N, bool bias, uint64_t seed);
+  bool linear(const QLinear& l, const void* x, void* out, int M, const void* residual, int64_t stream);
+  bool linear_fused_norm(const QLinear* ls, int nl, void* const* outs, const void* x, const void* norm_w, int M, int64_t stream);
+  bool gate_up(const LayerWeights& L, const void* x, const void* norm_w, void* act, int M, int64_t stream);
+  vra_model_config mc_;
+  vra_engine_config ec_;
+  int rank_, world_;
+  int hq_, hkv_, inter_;  // local sizes
+  int dt_;
+  size_t es_;
+  void* comm_ = nullptr;
+  std::vector<void*> allocs_;
+  size_t weight_bytes_ = 0;
+  // weights
+  void* embed_ = nullptr;
+  void* final_norm_ = nullptr;
+  QLinear lm_head_;
+  std::vector<LayerWeights> layers_;
+  void* cos_ = nullptr;
+  void* sin_ = nullptr;
+  int rope_rows_ = 0;
+  // kv cache
+  std::vector<void*> kc_, vc_;
+  int num_blocks_ = 0;
+  // activations
+  int max_tokens_ = 0, max_seqs_ = 0;
+  void *h_ = nullptr, *xn_ = nullptr, *q_ = nullptr, *k_ = nullptr, *v_ = nullptr, *attn_ = nullptr, *act_ = nullptr,
+       *tmp_ = nullptr, *gate_ = nullptr, *up_ = nullptr, *last_ = nullptr, *attn_ws_ = nullptr;
+  float* logits_ = nullptr;
+};
+
+}  // namespace vra
