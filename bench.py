@@ -33,6 +33,7 @@ def parse():
     ap.add_argument("--model", default="llama3-8b-gptq")
     ap.add_argument("--no-extras", action="store_true", help="skip bs=32 / TTFT / roofline / cpu legs")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches (rocprofv3 kernel tracing crashes on hipGraph replay)")
     ap.add_argument("--blocks", type=int, default=8192, help="KV blocks (64 tokens each); 0 = kv_fraction of free HBM")
     return ap.parse_args()
 
@@ -144,7 +145,7 @@ def main():
 
     cfg = dict(E.LLAMA3_8B) if a.model == "llama3-8b-gptq" else dict(E.QWEN2_7B)
     max_bs = max(32, a.batch)
-    eng = E.Engine(cfg, max_num_seqs=max_bs, max_model_len=8192, num_gpu_blocks=a.blocks, use_graph=True, device=local_rank,
+    eng = E.Engine(cfg, max_num_seqs=max_bs, max_model_len=8192, num_gpu_blocks=a.blocks, use_graph=not a.no_graph, device=local_rank,
                    seed=1234 + rank).init_synthetic()
     V = cfg["vocab_size"]
 

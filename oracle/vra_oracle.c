@@ -279,7 +279,12 @@ void orc_gemm_wdense(const void* x, const void* w, const void* bias, const void*
     }
   }
 }
-/* Same result without materialising w (used for big shapes / the timed CPU baseline).
+/* The fused W4A16 GEMM of the build: the mathematically exact product with the true
+ * GPTQ/AWQ weights W = s·(q − z) and ONE rounding at the output,
+ *     out = rnd( Σ_k x_k · s_g(k) · (q_k − z_g(k)) )   [+ bias, + residual, each rounded as the reference's ops].
+ * (The Marlin kernels behind src/utils/gptq.rs:116-178 additionally round every dequantised weight
+ * to 16 bits before the MMA — orc_dequant/orc_gemm_wdense above restate that variant; the two differ
+ * by < 1 output ulp and the reference's kernel sources are not in the tree to arbitrate.)
  * x [M,K] dt; idx [K,N]; scales [G,N]; zeros [G,N] or NULL. */
 void orc_wna16_gemm(const void* x, const uint8_t* idx, const uint8_t* zeros, const void* scales,
                     const void* bias, const void* residual, int M, int K, int N, int group_size,
@@ -296,8 +301,8 @@ void orc_wna16_gemm(const void* x, const uint8_t* idx, const uint8_t* zeros, con
       for (int k = 0; k < K; k++) {
         int grp = k / g;
         int z = zeros ? zeros[(int64_t)grp * N + n] : 8;
-        float wv = rnd((float)((int)idx[(int64_t)k * N + n] - z) * ld(scales, (int64_t)grp * N + n, dt), dt);
-        for (int m = 0; m < M; m++) acc[m] += (double)xf[(int64_t)m * K + k] * (double)wv;
+        double wv = (double)((int)idx[(int64_t)k * N + n] - z) * (double)ld(scales, (int64_t)grp * N + n, dt);
+        for (int m = 0; m < M; m++) acc[m] += (double)xf[(int64_t)m * K + k] * wv;
       }
       for (int m = 0; m < M; m++) {
         float v = rnd((float)acc[m], dt);
@@ -330,7 +335,7 @@ void orc_gptq_gemv_fast(const void* x, const uint32_t* qw, const void* scales, i
           uint32_t w = qw[(int64_t)kw * N + n];
           float s = ld(scales, (int64_t)grp * N + n, dt);
           for (int e = 0; e < 8; e++) {
-            float wv = rnd((float)((int)((w >> (4 * e)) & 0xF) - 8) * s, dt);
+            float wv = (float)((int)((w >> (4 * e)) & 0xF) - 8) * s;
             for (int m = 0; m < M; m++) acc[m * 64 + c] += xf[(int64_t)m * K + kw * 8 + e] * wv;
           }
         }

@@ -21,15 +21,16 @@ def ulp_of(ref_f32, dt):
     return 2.0 ** (np.floor(np.log2(mag)) - (bits - 1))
 
 
-def assert_close_dt(got_bits, ref_bits, dt, max_ulp=1.0, max_mismatch_frac=0.02, name="", abs_floor=0.0):
+def assert_close_dt(got_bits, ref_bits, dt, max_ulp=1.0, max_mismatch_frac=0.02, name="", abs_floor=0.0, mag=None):
     """bit patterns equal except for a small fraction of <= max_ulp differences (f32-vs-f64
     accumulation order flipping a rounding).  abs_floor: absolute slack for values near zero where
-    cancellation makes ulp-relative comparison meaningless."""
+    cancellation makes ulp-relative comparison meaningless.  mag: magnitude at which the ulp is taken
+    when the result went through larger, separately rounded intermediates (default: |ref|)."""
     got, ref = orc.from_dt(got_bits, dt), orc.from_dt(ref_bits, dt)
     assert got.shape == ref.shape, (got.shape, ref.shape)
     assert np.isfinite(got).all(), f"{name}: non-finite output"
     diff = np.abs(got - ref)
-    tol = np.maximum(max_ulp * ulp_of(ref, dt) * 1.0001, abs_floor)
+    tol = np.maximum(max_ulp * ulp_of(ref if mag is None else np.maximum(np.abs(ref), mag), dt) * 1.0001, abs_floor)
     bad = diff > tol
     frac = float((got_bits != ref_bits).mean())
     assert not bad.any(), f"{name}: {int(bad.sum())} elements beyond {max_ulp} ulp; worst diff {diff.max()} at ref {ref.flat[int(diff.argmax())]}"

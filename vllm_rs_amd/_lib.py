@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libvllm_rs_amd.so")
+LIB_PATH = os.environ.get("VRA_LIB", os.path.join(_PKG, "libvllm_rs_amd.so"))  # VRA_LIB: A/B kernel experiments
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "vllm_rs_amd.h")
 
 _lib = None

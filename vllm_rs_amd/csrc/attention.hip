@@ -45,7 +45,8 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_kernel(const PagedAttnA
   constexpr int DT16 = D / 16;  // output channel tiles
   __shared__ __attribute__((aligned(16))) float lds_o[PA_WAVES][16][D + 4];
   __shared__ float lds_ml[PA_WAVES][16][2];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches, no exec masking
   const int rq = lane & 15, oct = lane >> 4;
   const int G = a.Hq / a.Hkv;
   const int b = blockIdx.z;
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_kernel(const PagedAttnA
 
   f32x4 o[DT16];
 #pragma unroll
-  for (int t = 0; t < DT16; t++) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < DT16; t++) o[t] = vra_zero_acc();
   float m_run = -INFINITY, l_run = 0.f;  // per lane: row rq; l_run is this lane's partial sum
 
   const uint16_t* kcache = static_cast<const uint16_t*>(a.kc);
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_kernel(const PagedAttnA
   for (int tile = kv_w0; tile < kv_w1; tile++) {
     const int T0 = tile << 5;
     // ---- Sᵀ for the two 16-token halves
-    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 s0 = vra_zero_acc(), s1 = vra_zero_acc();
     const uint16_t *krow0, *krow1;
     size_t vbase = 0;
     if (a.block_tables) {
@@ -138,9 +139,10 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_kernel(const PagedAttnA
     for (int j = 0; j < DJ; j++) {
       const u32x4 k0 = *reinterpret_cast<const u32x4*>(krow0 + j * 32 + oct * 8);
       const u32x4 k1 = *reinterpret_cast<const u32x4*>(krow1 + j * 32 + oct * 8);
-      s0 = DT::mfma(__builtin_bit_cast(s16x8, k0), qf[j], s0);
-      s1 = DT::mfma(__builtin_bit_cast(s16x8, k1), qf[j], s1);
+      DT::mfma(s0, __builtin_bit_cast(s16x8, k0), qf[j]);
+      DT::mfma(s1, __builtin_bit_cast(s16x8, k1), qf[j]);
     }
+    VRA_MFMA_DRAIN();  // s0/s1 (and the previous tile's O updates) are complete past this point
     // ---- scale, softcap, causal/length mask; scores in log2 domain
     float sv[8];
     float tmax = -INFINITY;
@@ -211,12 +213,12 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_kernel(const PagedAttnA
 #pragma unroll
         for (int i = 0; i < 4; i++) vv[i] &= vm[i];
       }
-      f32x4 oc = o[t];
 #pragma unroll
-      for (int r = 0; r < 4; r++) oc[r] *= ar[r];
-      o[t] = DT::mfma(pfrag, __builtin_bit_cast(s16x8, vv), oc);
+      for (int r = 0; r < 4; r++) o[t][r] *= ar[r];
+      DT::mfma(o[t], pfrag, __builtin_bit_cast(s16x8, vv));
     }
   }
+  VRA_MFMA_DRAIN();  // O is read by the VALU below
   // ---- finish: total l per row (sum the 4 lane groups), bring (m,l) to the O row layout
   l_run += __shfl_xor(l_run, 16, 64);
   l_run += __shfl_xor(l_run, 32, 64);

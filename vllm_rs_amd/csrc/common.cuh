@@ -29,6 +29,33 @@ void vra_set_error(const char* fmt, ...);
 
 static inline hipStream_t as_stream(int64_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// ---------------------------------------------------------------- MFMA (gfx950 v_mfma_f32_16x16x32_*)
+// Two hazards of the double-rate 16x16x32 instruction were found on MI355X with hipcc / ROCm 7.2
+// (both show up as result registers 2,3 of the 4-register destination being wrong):
+//  (1) builtin form: when SrcA/SrcB die at the instruction the register allocator may place the
+//      destination ON TOP of them (legal for the 4-pass 16x16x16 form).  The hardware still reads the
+//      upper half of A/B after it has started writing D.  It happens when C is the literal 0 or when
+//      control flow makes the compiler move accumulators between registers (D != C).
+//  (2) inline-asm form with a tied accumulator: the compiler does not know the statement is an MFMA and
+//      may copy the accumulator one wait state later, reading it half written.
+// The builtin cannot be told to keep D off A/B (the allocator does it even in straight-line code), so the
+// instruction is issued through inline asm with the accumulator TIED ("+v": D = C, never A or B), every
+// MFMA region is kept branch free (no accumulator copies at control-flow merges), every chain starts from
+// vra_zero_acc(), VRA_MFMA_DRAIN() (12 wait states + scheduling barrier) stands between the last MFMA of
+// a chain and the first non-MFMA use of its accumulator, `s_nop 1` in front of each MFMA covers VALU-written
+// operands — and `make` runs tools/check_mfma_overlap.py over the generated ISA: the build FAILS if any
+// v_mfma has D overlapping A/B or if anything but an accumulating MFMA touches D within 12 wait states.
+#define VRA_MFMA_DRAIN()                \
+  do {                                  \
+    asm volatile("s_nop 7\n\ts_nop 4"); \
+    __builtin_amdgcn_sched_barrier(0);  \
+  } while (0)
+__device__ __forceinline__ f32x4 vra_zero_acc() {
+  f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  asm volatile("" : "+v"(z));
+  return z;
+}
+
 // ---------------------------------------------------------------- 16-bit storage types
 struct BF16 {
   static constexpr int id = VRA_BF16;
@@ -47,8 +74,8 @@ struct BF16 {
     bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
     return __builtin_bit_cast(uint32_t, r);
   }
-  static __device__ __forceinline__ f32x4 mfma(s16x8 a, s16x8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  static __device__ __forceinline__ void mfma(f32x4& acc, s16x8 a, s16x8 b) {  // acc += A·B
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
   }
 };
 struct F16 {
@@ -60,8 +87,8 @@ struct F16 {
     f16x2_t r = {(_Float16)a, (_Float16)b};
     return __builtin_bit_cast(uint32_t, r);
   }
-  static __device__ __forceinline__ f32x4 mfma(s16x8 a, s16x8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  static __device__ __forceinline__ void mfma(f32x4& acc, s16x8 a, s16x8 b) {  // acc += A·B
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
   }
 };
 template <class DT>

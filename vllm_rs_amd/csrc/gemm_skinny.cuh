@@ -45,7 +45,8 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
   constexpr int ROWS = MT * 16;
   constexpr int NW = DUAL ? 2 : 1;
   constexpr int XS_U32 = (GB_KC / 8) * ROWS * 4;  // one x buffer, in u32
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches, no exec masking
   const int nn = lane & 15, oct = lane >> 4;
   const int K = a.K, N = a.N, M = a.M;
   const int KT = K >> 7;
@@ -59,8 +60,12 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
   const int cps = (nchunk_total + a.splitk - 1) / a.splitk;
   const int c_begin = blockIdx.z * cps, c_end = min(nchunk_total, c_begin + cps);
 
+  constexpr int TPC = GB_KC / 128;   // tiles per chunk
+  constexpr int FPC = TPC * SPT;     // zero-point fix-up steps per chunk
+  constexpr int OPG = 16 / SPT;      // octets per fix-up step
   uint32_t* xs = reinterpret_cast<uint32_t*>(smem);                      // 2 buffers
-  int* flag = reinterpret_cast<int*>(smem + 2 * XS_U32 * 4);
+  float* xsum = reinterpret_cast<float*>(smem + 2 * XS_U32 * 4);          // [2][ROWS][FPC]: Σx per row and fix-up step
+  int* flag = reinterpret_cast<int*>(smem + 2 * XS_U32 * 4 + 2 * ROWS * FPC * 4);
 
   auto stage = [&](int c, int buf) {
     // x chunk: rows m0..m0+ROWS, k = c*KC .. +KC ; i -> (row = i/32, o = i%32): 512 B runs per row
@@ -71,6 +76,14 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
       u32x4 v = {0u, 0u, 0u, 0u};
       if (m < M && k < K) v = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.x) + (size_t)m * a.x_ld + k);
       *reinterpret_cast<u32x4*>(dst + ((size_t)o * ROWS + (row ^ (o & 7))) * 4) = v;
+      if (INT4) {  // ROWS*32 is a multiple of 512: every lane takes part in the shuffles
+        float f[8];
+        unpack8<DT>(v, f);
+        float s8 = ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+#pragma unroll
+        for (int d = 1; d < OPG; d <<= 1) s8 += __shfl_xor(s8, d, 64);
+        if ((o % OPG) == 0) xsum[((size_t)buf * ROWS + row) * FPC + o / OPG] = s8;
+      }
     }
   };
 
@@ -78,7 +91,7 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
 #pragma unroll
   for (int w = 0; w < NW; w++)
 #pragma unroll
-    for (int t = 0; t < MT; t++) acc[w][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < MT; t++) acc[w][t] = vra_zero_acc();
 
   // weight stream of this wave: tiles kt = 2c, 2c+1 for c in [c_begin, c_end)
   const u32x4* wp[NW];
@@ -90,16 +103,15 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
     wp[0] = reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.w0) + (size_t)n * K) + oct;
     if (DUAL) wp[NW - 1] = reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.w1) + (size_t)n * K) + oct;
   }
-  constexpr int TPC = GB_KC / 128;  // tiles per chunk
   // INT4: one u32x4 per tile; dense: four u32x4 per tile
   constexpr int LPT = INT4 ? 1 : 4;
   u32x4 cur[TPC][NW][LPT], nxt[TPC][NW][LPT];
-  // scales / zero points ride along with the weight stream: each lane keeps the raw 16-bit scale and
-  // (AWQ) the packed zero word of ITS column for every group of the tile (L2-resident, 2-4 B loads)
-  uint32_t csc[TPC][NW][SPT], nsc[TPC][NW][SPT], czp[TPC][NW][SPT], nzp[TPC][NW][SPT];
-  const int ncol = min(nb * 16 + nn, N - 1);
-  const int zshift = 4 * awq_rev(ncol & 7);
-  auto load_chunk = [&](int c, u32x4 (&dst)[TPC][NW][LPT], uint32_t (&dsc)[TPC][NW][SPT], uint32_t (&dzp)[TPC][NW][SPT]) {
+  // scales / zero points ride along with the weight stream in the MFMA OUTPUT layout: each lane keeps
+  // the 4 scales (8 B) and the AWQ zero word of its 4 output columns per group (L2-resident loads)
+  u32x2 csc[TPC][NW][SPT], nsc[TPC][NW][SPT];
+  uint32_t czp[TPC][NW][SPT], nzp[TPC][NW][SPT];
+  const int n4 = min(nb * 16 + oct * 4, N - 4);
+  auto load_chunk = [&](int c, u32x4 (&dst)[TPC][NW][LPT], u32x2 (&dsc)[TPC][NW][SPT], uint32_t (&dzp)[TPC][NW][SPT]) {
 #pragma unroll
     for (int t = 0; t < TPC; t++) {
       int kt = c * TPC + t;
@@ -109,10 +121,7 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
 #pragma unroll
           for (int q = 0; q < SPT; q++) {
             const int grp = min((kt * 128 + q * (128 / SPT)) / g, K / g - 1);
-            const uint16_t* scp = static_cast<const uint16_t*>(w ? a.sc1 : a.sc0);
-            const uint32_t* qzp = w ? a.qz1 : a.qz0;
-            dsc[t][w][q] = scp[vra_scale_index(grp, ncol, N, a.scales_layout, grouped)];
-            dzp[t][w][q] = (a.is_awq && qzp) ? qzp[(size_t)grp * (N >> 3) + (ncol >> 3)] : 0x88888888u;
+            load_scale4_raw<DT>(w ? a.sc1 : a.sc0, w ? a.qz1 : a.qz0, grp, n4, N, a.scales_layout, grouped, a.is_awq != 0, dsc[t][w][q], dzp[t][w][q]);
           }
       }
 #pragma unroll
@@ -139,30 +148,47 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
       stage(c + 1, buf ^ 1);
     }
     const uint32_t* xb = xs + buf * XS_U32;
+    const float* sxb = xsum + (size_t)buf * ROWS * FPC;
 #pragma unroll
     for (int t = 0; t < TPC; t++) {
+      f32x4 ag[NW][MT];
+#pragma unroll
+      for (int w = 0; w < NW; w++)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) ag[w][mt] = vra_zero_acc();
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const int o = t * 16 + j * 4 + oct;  // octet within chunk
         s16x8 afrag[NW];
 #pragma unroll
-        for (int w = 0; w < NW; w++) {
-          if (INT4) {
-            constexpr int JQ = SPT == 1 ? 0 : 1;
-            const int q = JQ * j;  // SPT==4: one scale per 32-row step (group 64 repeats pairs)
-            const float sc = DT::to_f32((uint16_t)csc[t][w][q]);
-            const float zp = (float)((czp[t][w][q] >> zshift) & 0xFu);
-            afrag[w] = dequant_word<DT>(cur[t][w][0][j], sc, -zp * sc);
-          } else {
-            afrag[w] = __builtin_bit_cast(s16x8, cur[t][w][j]);
-          }
-        }
+        for (int w = 0; w < NW; w++) afrag[w] = INT4 ? magic_word<DT>(cur[t][w][0][j]) : __builtin_bit_cast(s16x8, cur[t][w][INT4 ? 0 : j]);
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
           const u32x4 xv = *reinterpret_cast<const u32x4*>(xb + ((size_t)o * ROWS + ((mt * 16 + nn) ^ (o & 7))) * 4);
           const s16x8 bfrag = __builtin_bit_cast(s16x8, xv);
 #pragma unroll
-          for (int w = 0; w < NW; w++) acc[w][mt] = DT::mfma(afrag[w], bfrag, acc[w][mt]);
+          for (int w = 0; w < NW; w++) {
+            if (INT4) DT::mfma(ag[w][mt], afrag[w], bfrag);
+            else DT::mfma(acc[w][mt], afrag[w], bfrag);
+          }
+        }
+        if (INT4 && (SPT == 4 || j == 3)) {  // end of a scale group: acc += s * (acc_g - (C+z) * Σx_g)
+          VRA_MFMA_DRAIN();
+          const int q = SPT == 4 ? j : 0;
+#pragma unroll
+          for (int w = 0; w < NW; w++) {
+            float sc4[4], zc4[4];
+            unpack_scale4<DT>(csc[t][w][q], czp[t][w][q], n4, sc4, zc4);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+              const float sx = sxb[(size_t)(mt * 16 + nn) * FPC + t * SPT + q];
+#pragma unroll
+              for (int r = 0; r < 4; r++) {
+                acc[w][mt][r] = fmaf(sc4[r], fmaf(-zc4[r], sx, ag[w][mt][r]), acc[w][mt][r]);
+              }
+              if (SPT == 4 && j < 3) ag[w][mt] = vra_zero_acc();
+            }
+          }
         }
       }
     }
@@ -186,6 +212,7 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
     }
   }
 
+  if (!INT4) VRA_MFMA_DRAIN();  // the dense path accumulates straight into acc
   // ---- split-K: publish the partial slab, last arriver reduces (deterministic slice order)
   const int Mpad = gridDim.y * ROWS, Npad = gridDim.x * 128;
   if (a.splitk > 1) {
@@ -258,4 +285,6 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
   }
 }
 
-static inline size_t gemm_skinny_lds_bytes(int mt) { return (size_t)2 * (GB_KC / 8) * mt * 16 * 16 + 16; }
+static inline size_t gemm_skinny_lds_bytes(int mt, int spt) {
+  return (size_t)2 * (GB_KC / 8) * mt * 16 * 16 + (size_t)2 * mt * 16 * (GB_KC / 128) * spt * 4 + 16;
+}

@@ -1,19 +1,22 @@
-// gemv.cuh — "kernel A": skinny GEMM (M <= 8 rows) streaming each weight byte exactly once.
+// gemv.cuh — "kernel A": skinny GEMM (M <= 8 rows) that streams every weight byte exactly once.
 //
 // Roofline: HBM.  Algorithmic bytes per call: K*N/2 (packed int4) + (K/g)*N*2 (scales)
 // [+ (K/g)*N/2 zeros] + M*K*2 + M*N*2   (dense variant: N*K*2 + ...).
 //
 // Shape of the launch:
-//   workgroup = 512 threads = 8 waves; it owns NBW adjacent-in-role 16-column n-blocks and the
-//   FULL K range.  Wave w takes k-tiles w, w+8, ... (128 rows each, one 1 KiB coalesced
-//   `global_load_dwordx4` per tile: 64 lanes x 16 B) so the eight waves of a workgroup walk one
-//   contiguous K/128 KiB run of the tiled weight tensor.  Partial sums meet in LDS — no inter-
-//   workgroup traffic, no atomics, no second launch.
-//   x (optionally RMS-normalised on the fly: the reference's separate NormX launch,
-//   others.rs:11-29) and the scales/zeros of the owned columns are staged in LDS once.
-//   The multiply is `v_mfma_f32_16x16x32` with A = dequantised weights (16 columns x 32 k),
-//   B = xT (32 k x 16 rows, rows >= M are zero): MFMA does the cross-lane k reduction for free
-//   and the VALU only dequantises.
+//   PERSISTENT workgroups (grid = resident capacity), 512 threads = 8 waves.  A work item is one
+//   16-column n-block (NBW=2: the same block of the gate AND the up tensor) over the FULL K range; the 8
+//   waves of a workgroup split its k-tiles (wave w takes tiles w, w+8, ...: 1 KiB coalesced per tile,
+//   the whole workgroup walks one contiguous K/128 KiB run) and meet in LDS — no inter-workgroup
+//   traffic, no atomics, no second launch.  Work items are streamed: the loads of sub-step s+1 (4 tiles
+//   per wave, possibly of the NEXT n-block) are issued before sub-step s is consumed, and the very first
+//   loads go out BEFORE the prologue, so HBM latency hides under the x staging / RMSNorm.
+//   x (optionally RMS-normalised on the fly: the reference's separate NormX launch, others.rs:11-29)
+//   is staged in LDS ONCE per workgroup together with its per-group sums Σx (needed by the zero-point
+//   fix-up, wna16.cuh), and reused for all work items.
+//   The multiply is `v_mfma_f32_16x16x32` with A = (C + q) "magic" 16-bit floats (16 columns x 32 k,
+//   one VALU op per two weights), B = xT (32 k x 16 rows; rows >= M read an all-zero LDS slot).  Per
+//   scale group the partial result is folded as acc += s·(acc_g − (C+z)·Σx): 2 VALU ops per output.
 #pragma once
 #include "wna16.cuh"
 
@@ -45,13 +48,31 @@ struct GemvArgs {
   int is_awq, scales_layout;
   int silu_dual;  // 1: seg0 = gate, seg1 = up, out = silu(gate)*up into seg0.out
   int out_f32;    // 1: store (float)round_dt(v)
+  int n_items;    // work items (n-blocks, or gate/up pairs)
+  int dbg;        // experiment switches (VRA_EXP): 1 = prologue only, 2 = skip the x staging
+  unsigned long long* ts;  // VRA_GEMV_TS builds: [grid][32] wall-clock stamps of wave 0
 };
+#ifdef VRA_GEMV_TS
+#define GEMV_STAMP(i)                                                     \
+  do {                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                    \
+    if (a.ts && tid == 0) a.ts[(size_t)blockIdx.x * 32 + (i)] = wall_clock64(); \
+    __builtin_amdgcn_sched_barrier(0);                                    \
+  } while (0)
+#elif defined(VRA_GEMV_SB)
+#define GEMV_STAMP(i) __builtin_amdgcn_sched_barrier(0)
+#else
+#define GEMV_STAMP(i) do {} while (0)
+#endif
 
+// Stage x[M,K] into LDS (image xs[(oct*M + m)*4 .. +4] = x[m][oct*8 .. +8]), optionally RMS-normalised,
+// and the sums of the staged (rounded) values over every run of OPG consecutive octets: xsum[m*NF + f].
 template <class DT>
-__device__ __forceinline__ void gemv_stage_x(const GemvArgs& a, uint32_t* xs, float* red8) {
-  // LDS image: xs[(oct * M + m) * 4 .. +4] (u32) = x[m][oct*8 .. +8]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__device__ __forceinline__ void gemv_stage_x(const GemvArgs& a, uint32_t* xs, float* xsum, int opg, float* red8) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches, no exec masking
   const int octs = a.K >> 3;
+  const int nf = octs / opg;
   for (int m = 0; m < a.M; m++) {
     const u32x4* xr = reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.x) + (size_t)m * a.x_ld);
     float rstd = 1.0f;
@@ -73,198 +94,272 @@ __device__ __forceinline__ void gemv_stage_x(const GemvArgs& a, uint32_t* xs, fl
       rstd = 1.0f / sqrtf(tot / (float)a.K + a.eps);
     }
     const u32x4* nw = reinterpret_cast<const u32x4*>(a.norm_w);
-    for (int o = tid; o < octs; o += GEMV_THREADS) {
-      u32x4 v = xr[o];
-      if (a.norm_w) {
-        float f[8], g[8];
+    for (int o0 = 0; o0 < octs; o0 += GEMV_THREADS) {  // uniform trip count: the shuffles below need all lanes
+      const int o = o0 + tid;
+      float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (o < octs) {
+        u32x4 v = xr[o];
         unpack8<DT>(v, f);
-        unpack8<DT>(nw[o], g);
+        if (a.norm_w) {
+          float g[8];
+          unpack8<DT>(nw[o], g);
 #pragma unroll
-        for (int i = 0; i < 8; i++) f[i] = f[i] * rstd * g[i];
-        v = pack8<DT>(f);
+          for (int i = 0; i < 8; i++) f[i] = f[i] * rstd * g[i];
+          v = pack8<DT>(f);
+          unpack8<DT>(v, f);  // sums are taken over the ROUNDED values the MFMA will see
+        }
+        *reinterpret_cast<u32x4*>(xs + ((size_t)o * a.M + m) * 4) = v;
       }
-      *reinterpret_cast<u32x4*>(xs + ((size_t)o * a.M + m) * 4) = v;
+      if (xsum) {
+        float s8 = ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+        for (int d = 1; d < opg; d <<= 1) s8 += __shfl_xor(s8, d, 64);
+        if (o < octs && (o % opg) == 0) xsum[(size_t)m * nf + o / opg] = s8;
+      }
     }
   }
 }
 
 // INT4 = true: tiled int4 weights; false: dense row-major 16-bit weights.
-template <class DT, bool INT4, int NBW>
-__global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(const GemvArgs a) {
+// NBW = tensors per work item (2 = gate/up pair).  SPT = scale groups per k-tile (1: g >= 128, 4: 32/64).
+// AWQ = per-group zero points (otherwise the zero point is the constant 8 and no zero words are loaded).
+template <class DT, bool INT4, int NBW, int SPT, bool AWQ>
+__global__ __launch_bounds__(GEMV_THREADS, 4) void gemv_kernel(const GemvArgs a) {  // 4 waves/SIMD = 2 workgroups per CU (<= 128 VGPRs)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int LPT = INT4 ? 1 : 4;  // 16 B loads per lane and tile
+  constexpr int UK = INT4 ? 4 / NBW : 1;  // k-tiles per wave per sub-step (two sub-steps = 8 x 16 B loads in flight)
+  constexpr int NSC = INT4 ? SPT : 1;
+  constexpr int NZP = AWQ ? NSC : 1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches, no exec masking
   const int nn = lane & 15, oct = lane >> 4;
   const int K = a.K, M = a.M, KT = K >> 7;
   const int g = a.group_size > 0 ? a.group_size : K;
-  const int G = K / g;
+  const bool grouped = a.group_size > 0 && a.group_size < K;
+  const int NF = KT * SPT;  // fix-up steps along K
+  GEMV_STAMP(0);
 
-  // ---- which n-blocks does this workgroup own?
-  int segi[NBW], nb[NBW];
-  if (a.silu_dual) {  // NBW == 2: block b of gate and block b of up
-    segi[0] = 0;
-    nb[0] = blockIdx.x;
-    if (NBW > 1) {
-      segi[NBW - 1] = 1;
-      nb[NBW - 1] = blockIdx.x;
-    }
-  } else {
-#pragma unroll
-    for (int b = 0; b < NBW; b++) {
-      int fb = blockIdx.x * NBW + b;
+  // ---- LDS carve-up
+  uint32_t* xs = reinterpret_cast<uint32_t*>(smem);  // M*K*2 bytes + zero slot (16 B of zeros, also the Σx of missing rows)
+  const uint32_t zero_slot = (uint32_t)((((size_t)M * K * 2 + 15) & ~(size_t)15) >> 2);
+  size_t off = ((size_t)zero_slot << 2) + 16;
+  float* xsum = reinterpret_cast<float*>(smem + off);  // [M][NF]
+  off += INT4 ? (((size_t)M * NF * 4 + 15) & ~(size_t)15) : 0;
+  f32x4* red = reinterpret_cast<f32x4*>(smem + off);  // [2][8][NBW][64] f32x4
+  off += (size_t)2 * GEMV_WAVES * NBW * 64 * sizeof(f32x4);
+  float* red8 = reinterpret_cast<float*>(smem + off);  // 8 floats
+
+  // ---- this workgroup's stream of sub-steps
+  const int nsub = ((KT + GEMV_WAVES - 1) / GEMV_WAVES + UK - 1) / UK;  // sub-steps per work item
+  const int my_items = (a.n_items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int total_sub = (a.dbg & 1) ? 0 : my_items * nsub;
+
+  // register ring of NBUF sub-steps: a buffer is refilled (for the sub-step NBUF ahead) right after it
+  // has been consumed, so NBUF*UK*NBW KiB per wave are in flight all the time and nothing is copied
+  constexpr int NBUF = 3;
+  u32x4 wbuf[NBUF][UK][NBW][LPT];
+  u32x2 sbuf[NBUF][UK][NBW][NSC];
+  uint32_t zbuf[NBUF][UK][NBW][NZP];
+
+  auto resolve = [&](int item, int b, int& segi, int& nb) {
+    const int fb = (int)blockIdx.x + item * (int)gridDim.x;
+    if (a.silu_dual) {
+      segi = b;
+      nb = fb;
+    } else {
       int s = 0;
       if (a.nseg > 1 && fb >= a.seg[1].blk_start) s = 1;
       if (a.nseg > 2 && fb >= a.seg[2].blk_start) s = 2;
-      segi[b] = s;
-      nb[b] = fb - a.seg[s].blk_start;
+      segi = s;
+      nb = fb - a.seg[s].blk_start;
     }
-  }
-
-  // ---- LDS carve-up
-  uint32_t* xs = reinterpret_cast<uint32_t*>(smem);                           // M*K*2 bytes
-  size_t off = (((size_t)M * K * 2 + 15) & ~(size_t)15) + 16;  // + one 16 B all-zero slot
-  f32x2* sc = reinterpret_cast<f32x2*>(smem + off);                           // NBW*G*16 pairs
-  off += INT4 ? (size_t)NBW * G * 16 * sizeof(f32x2) : 0;
-  f32x4* red = reinterpret_cast<f32x4*>(smem + off);                          // 8*NBW*64 f32x4
-  off += (size_t)GEMV_WAVES * NBW * 64 * sizeof(f32x4);
-  float* red8 = reinterpret_cast<float*>(smem + off);                         // 8 floats
-
-  // ---- stage scales / zero points of the owned columns as (s, -z*s) in f32
-  if (INT4) {
-    for (int idx = tid; idx < NBW * G * 16; idx += GEMV_THREADS) {
-      int b = idx / (G * 16), grp = (idx >> 4) % G, c = idx & 15;
-      const GemvSeg& sg = a.seg[segi[b]];
-      int n = nb[b] * 16 + c;
-      float s = 0.f, z = 8.f;
-      if (n < sg.n) {
-        s = DT::to_f32(static_cast<const uint16_t*>(sg.scales)[vra_scale_index(grp, n, sg.n, a.scales_layout, a.group_size > 0 && a.group_size < K)]);
-        if (a.is_awq && sg.qzeros) z = (float)((sg.qzeros[(size_t)grp * (sg.n >> 3) + (n >> 3)] >> (4 * awq_rev(n & 7))) & 0xFu);
-      }
-      f32x2 p = {s, -z * s};
-      sc[idx] = p;
-    }
-  }
-  const uint32_t zero_slot = (uint32_t)((((size_t)M * K * 2 + 15) & ~(size_t)15) >> 2);
-  if (tid < 4) xs[zero_slot + tid] = 0u;
-  gemv_stage_x<DT>(a, xs, red8);
-  __syncthreads();
-
-  // ---- main loop: wave `wave` owns k-tiles wave, wave+8, ...
-  f32x4 acc[NBW];
+  };
+  auto issue = [&](int item, int sub, u32x4 (&w)[UK][NBW][LPT], u32x2 (&sc)[UK][NBW][NSC], uint32_t (&zp)[UK][NBW][NZP]) {
 #pragma unroll
-  for (int b = 0; b < NBW; b++) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int nt = (KT - wave + GEMV_WAVES - 1) / GEMV_WAVES;  // tiles of this wave (may be <= 0)
+    for (int b = 0; b < NBW; b++) {
+      int segi, nb;
+      resolve(item, b, segi, nb);
+      const GemvSeg& sg = a.seg[segi];
+#pragma unroll
+      for (int u = 0; u < UK; u++) {
+        const int kt = wave + GEMV_WAVES * (sub * UK + u);
+        if (kt < KT) {
+          if (INT4) {
+            w[u][b][0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(sg.w) + ((size_t)nb * KT + kt) * 64 + lane);
+            const int n4 = min(nb * 16 + oct * 4, sg.n - 4);
+#pragma unroll
+            for (int q = 0; q < NSC; q++) {
+              const int grp = min((kt * 128 + q * (128 / NSC)) / g, K / g - 1);
+              uint32_t zdummy;
+              load_scale4_raw<DT>(sg.scales, sg.qzeros, grp, n4, sg.n, a.scales_layout, grouped, AWQ, sc[u][b][q], AWQ ? zp[u][b][AWQ ? q : 0] : zdummy);
+            }
+          } else {
+            const int n = min(nb * 16 + nn, sg.n - 1);
+            const u32x4* wp = reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(sg.w) + (size_t)n * K) + oct;
+#pragma unroll
+            for (int l = 0; l < 4; l++) w[u][b][INT4 ? 0 : l] = __builtin_nontemporal_load(wp + kt * 16 + l * 4);
+          }
+        } else {
+          // no such k-tile for this wave: zero weights / zero scales contribute exactly 0 and keep the
+          // consume loop below free of branches (see common.cuh on MFMA register hazards)
+#pragma unroll
+          for (int l = 0; l < LPT; l++) w[u][b][l] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+          for (int q = 0; q < NSC; q++) sc[u][b][q] = u32x2{0u, 0u};
+          if (AWQ) {
+#pragma unroll
+            for (int q = 0; q < NZP; q++) zp[u][b][q] = 0u;
+          }
+        }
+      }
+    }
+  };
+
+  // the first NBUF sub-steps go out BEFORE the prologue: HBM latency hides under the x staging
+  int iitem = 0, isub = 0, issued = 0;  // issue cursor
+  auto advance = [&](int& it, int& sb) {
+    if (++sb == nsub) {
+      sb = 0;
+      ++it;
+    }
+  };
+#pragma unroll
+  for (int r = 0; r < NBUF; r++) {
+    if (issued < total_sub) {
+      issue(iitem, isub, wbuf[r], sbuf[r], zbuf[r]);
+      advance(iitem, isub);
+      ++issued;
+    }
+  }
+
+  GEMV_STAMP(1);
+  if (tid < 4) xs[zero_slot + tid] = 0u;
+  if (!(a.dbg & 2)) gemv_stage_x<DT>(a, xs, INT4 ? xsum : nullptr, 16 / SPT, red8);
+  __syncthreads();
+  GEMV_STAMP(2);
+
   // B fragment addressing: lanes whose batch row does not exist read the zero slot (stride 0)
   const bool row_ok = nn < M;
   const uint32_t xbase = row_ok ? (uint32_t)(oct * M + nn) * 4u : zero_slot;
   const uint32_t xstride = row_ok ? (uint32_t)M * 4u : 0u;  // u32 per octet step
+  const float* sxp = row_ok ? xsum + (size_t)nn * NF : reinterpret_cast<const float*>(xs + zero_slot);
+  const int sxstride = row_ok ? 1 : 0;
 
-  if (INT4) {
-    const u32x4* wp[NBW];
+  f32x4 acc[NBW];
 #pragma unroll
-    for (int b = 0; b < NBW; b++)
-      wp[b] = reinterpret_cast<const u32x4*>(a.seg[segi[b]].w) + ((size_t)nb[b] * KT) * 64 + lane;
-    constexpr int UK = 4 / NBW;  // k-tiles per batch (4 loads in flight per batch, 2 batches deep)
-    u32x4 cur[UK][NBW], nxt[UK][NBW];
+  for (int b = 0; b < NBW; b++) acc[b] = vra_zero_acc();
+  int item = 0, sub = 0, parity = 0;
+  for (int s0 = 0; s0 < total_sub; s0 += NBUF) {
+#pragma unroll
+   for (int rb = 0; rb < NBUF; rb++) {
+    if (s0 + rb >= total_sub) break;
+    u32x4 (&cur)[UK][NBW][LPT] = wbuf[rb];
+    u32x2 (&csc)[UK][NBW][NSC] = sbuf[rb];
+    uint32_t (&czp)[UK][NBW][NZP] = zbuf[rb];
+    // ---- consume sub-step (item, sub)
+    int n4b[NBW];
+#pragma unroll
+    for (int b = 0; b < NBW; b++) {
+      int segi, nb;
+      resolve(item, b, segi, nb);
+      n4b[b] = min(nb * 16 + oct * 4, a.seg[segi].n - 4);
+    }
+    // all MFMAs of a 32-row step (every tile u, every tensor b) are issued back to back into group
+    // accumulators; ONE drain per scale group, then the fix-ups (VALU) of all of them
+    // (tiles past the end of K carry zero weights and zero scales, so this region has no branches)
+    f32x4 ag[UK][NBW];
 #pragma unroll
     for (int u = 0; u < UK; u++)
 #pragma unroll
-      for (int b = 0; b < NBW; b++)
-        if (u < nt) cur[u][b] = __builtin_nontemporal_load(wp[b] + (size_t)(wave + GEMV_WAVES * u) * 64);
-    for (int t0 = 0; t0 < nt; t0 += UK) {
+      for (int b = 0; b < NBW; b++) ag[u][b] = vra_zero_acc();
 #pragma unroll
-      for (int u = 0; u < UK; u++)
-#pragma unroll
-        for (int b = 0; b < NBW; b++)
-          if (t0 + UK + u < nt) nxt[u][b] = __builtin_nontemporal_load(wp[b] + (size_t)(wave + GEMV_WAVES * (t0 + UK + u)) * 64);
+    for (int j = 0; j < 4; j++) {
 #pragma unroll
       for (int u = 0; u < UK; u++) {
-        if (t0 + u < nt) {
-          const int kt = wave + GEMV_WAVES * (t0 + u);
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            const u32x4 xb = *reinterpret_cast<const u32x4*>(xs + xbase + (uint32_t)(kt * 16 + j * 4) * xstride);
-            const s16x8 bfrag = __builtin_bit_cast(s16x8, xb);
-            const int grp = (kt * 128 + j * 32) / g;
-#pragma unroll
-            for (int b = 0; b < NBW; b++) {
-              f32x2 p = sc[(b * G + grp) * 16 + nn];
-              s16x8 afrag = dequant_word<DT>(cur[u][b][j], p[0], p[1]);
-              acc[b] = DT::mfma(afrag, bfrag, acc[b]);
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < UK; u++)
-#pragma unroll
-        for (int b = 0; b < NBW; b++) cur[u][b] = nxt[u][b];
-    }
-  } else {
-    // dense: lane (nn, oct) streams row n = nb*16+nn; per k-tile 4 x 16 B at k = kt*128 + j*32 + oct*8
-    const u32x4* wp[NBW];
-    bool col_ok[NBW];
-#pragma unroll
-    for (int b = 0; b < NBW; b++) {
-      int n = nb[b] * 16 + nn;
-      col_ok[b] = n < a.seg[segi[b]].n;
-      wp[b] = reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.seg[segi[b]].w) + (size_t)(col_ok[b] ? n : 0) * K) + oct;
-    }
-    for (int t = 0; t < nt; t++) {
-      const int kt = wave + GEMV_WAVES * t;
-      u32x4 q[NBW][4];
-#pragma unroll
-      for (int b = 0; b < NBW; b++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) q[b][j] = __builtin_nontemporal_load(wp[b] + kt * 16 + j * 4);
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
+        const int kt = min(wave + GEMV_WAVES * (sub * UK + u), KT - 1);
         const u32x4 xb = *reinterpret_cast<const u32x4*>(xs + xbase + (uint32_t)(kt * 16 + j * 4) * xstride);
         const s16x8 bfrag = __builtin_bit_cast(s16x8, xb);
 #pragma unroll
         for (int b = 0; b < NBW; b++) {
-          u32x4 qa = col_ok[b] ? q[b][j] : u32x4{0u, 0u, 0u, 0u};
-          acc[b] = DT::mfma(__builtin_bit_cast(s16x8, qa), bfrag, acc[b]);
+          if (INT4) DT::mfma(ag[u][b], magic_word<DT>(cur[u][b][0][j]), bfrag);
+          else DT::mfma(acc[b], __builtin_bit_cast(s16x8, cur[u][b][INT4 ? 0 : j]), bfrag);
+        }
+      }
+      if (INT4 && (SPT == 4 || j == 3)) {  // end of a scale group: acc += s * (acc_g - (C+z) * Σx_g)
+        VRA_MFMA_DRAIN();
+        const int q = SPT == 4 ? j : 0;
+#pragma unroll
+        for (int u = 0; u < UK; u++) {
+          const int kt = min(wave + GEMV_WAVES * (sub * UK + u), KT - 1);
+          const float sx = sxp[(kt * SPT + q) * sxstride];
+#pragma unroll
+          for (int b = 0; b < NBW; b++) {
+            float sc4[4], zc4[4];
+            unpack_scale4<DT>(csc[u][b][q], AWQ ? czp[u][b][AWQ ? q : 0] : 0x88888888u, n4b[b], sc4, zc4);
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[b][r] = fmaf(sc4[r], fmaf(-zc4[r], sx, ag[u][b][r]), acc[b][r]);
+            if (SPT == 4 && j < 3) ag[u][b] = vra_zero_acc();
+          }
         }
       }
     }
-  }
-
-  // ---- cross-wave reduction in LDS, then the fused epilogue
+    GEMV_STAMP(3 + 2 * (s0 + rb < 5 ? s0 + rb : 5));
+    // ---- end of a work item: cross-wave reduction in LDS, then the fused epilogue
+    if (sub == nsub - 1) {
+      f32x4* rbuf = red + (size_t)parity * GEMV_WAVES * NBW * 64;
+      if (!INT4) VRA_MFMA_DRAIN();  // dense path accumulates straight into acc
 #pragma unroll
-  for (int b = 0; b < NBW; b++) red[(wave * NBW + b) * 64 + lane] = acc[b];
-  __syncthreads();
-  const int nout = a.silu_dual ? 16 * M : NBW * 16 * M;
-  for (int idx = tid; idx < nout; idx += GEMV_THREADS) {
-    const int nl = idx & 15, m = (idx >> 4) % M, b = idx / (16 * M);
-    const int rl = (nl >> 2) * 16 + m, rr = nl & 3;  // D layout: row = (lane>>4)*4 + reg, col = lane&15
-    float v = 0.f, v2 = 0.f;
+      for (int b = 0; b < NBW; b++) {
+        rbuf[(wave * NBW + b) * 64 + lane] = acc[b];
+        acc[b] = vra_zero_acc();
+      }
+      __syncthreads();
+      const int nout = a.silu_dual ? 16 * M : NBW * 16 * M;
+      for (int idx = tid; idx < nout; idx += GEMV_THREADS) {
+        const int nl = idx & 15, m = (idx >> 4) % M, b = idx / (16 * M);
+        const int rl = (nl >> 2) * 16 + m, rr = nl & 3;  // D layout: row = (lane>>4)*4 + reg, col = lane&15
+        float v = 0.f, v2 = 0.f;
 #pragma unroll
-    for (int w = 0; w < GEMV_WAVES; w++) {
-      v += red[(w * NBW + b) * 64 + rl][rr];
-      if (NBW > 1) v2 += red[(w * NBW + (NBW - 1)) * 64 + rl][rr];
+        for (int w = 0; w < GEMV_WAVES; w++) {
+          v += rbuf[(w * NBW + b) * 64 + rl][rr];
+          if (NBW > 1) v2 += rbuf[(w * NBW + (NBW - 1)) * 64 + rl][rr];
+        }
+        int segi, nb;
+        resolve(item, b, segi, nb);
+        const GemvSeg& sg = a.seg[segi];
+        const int n = nb * 16 + nl;
+        if (n >= sg.n) continue;
+        v = rnd_dt<DT>(v);
+        if (sg.bias) v = rnd_dt<DT>(v + DT::to_f32(static_cast<const uint16_t*>(sg.bias)[n]));
+        if (a.silu_dual) {
+          const GemvSeg& su = a.seg[1];
+          v2 = rnd_dt<DT>(v2);
+          if (su.bias) v2 = rnd_dt<DT>(v2 + DT::to_f32(static_cast<const uint16_t*>(su.bias)[n]));
+          float sl = rnd_dt<DT>(v / (1.0f + expf(-v)));
+          v = sl * v2;
+        }
+        if (a.residual) v = rnd_dt<DT>(v) + DT::to_f32(static_cast<const uint16_t*>(a.residual)[(size_t)m * a.res_ld + n]);
+        if (a.out_f32) static_cast<float*>(sg.out)[(size_t)m * sg.out_ld + n] = rnd_dt<DT>(v);
+        else static_cast<uint16_t*>(sg.out)[(size_t)m * sg.out_ld + n] = DT::from_f32(v);
+      }
+      parity ^= 1;  // the other buffer is only rewritten after the next barrier: no second barrier needed
     }
-    const GemvSeg& sg = a.seg[segi[b]];
-    const int n = nb[b] * 16 + nl;
-    if (n >= sg.n) continue;
-    v = rnd_dt<DT>(v);
-    if (sg.bias) v = rnd_dt<DT>(v + DT::to_f32(static_cast<const uint16_t*>(sg.bias)[n]));
-    if (a.silu_dual) {
-      const GemvSeg& su = a.seg[1];
-      v2 = rnd_dt<DT>(v2);
-      if (su.bias) v2 = rnd_dt<DT>(v2 + DT::to_f32(static_cast<const uint16_t*>(su.bias)[n]));
-      float sl = rnd_dt<DT>(v / (1.0f + expf(-v)));
-      v = sl * v2;
+    GEMV_STAMP(4 + 2 * (s0 + rb < 5 ? s0 + rb : 5));
+    advance(item, sub);
+    // ---- refill this ring slot with the sub-step NBUF ahead
+    if (issued < total_sub) {
+      issue(iitem, isub, wbuf[rb], sbuf[rb], zbuf[rb]);
+      advance(iitem, isub);
+      ++issued;
     }
-    if (a.residual) v = rnd_dt<DT>(v) + DT::to_f32(static_cast<const uint16_t*>(a.residual)[(size_t)m * a.res_ld + n]);
-    if (a.out_f32) static_cast<float*>(sg.out)[(size_t)m * sg.out_ld + n] = rnd_dt<DT>(v);
-    else static_cast<uint16_t*>(sg.out)[(size_t)m * sg.out_ld + n] = DT::from_f32(v);
+   }
   }
+  GEMV_STAMP(15);
 }
 
 static inline size_t gemv_lds_bytes(bool int4, int nbw, int M, int K, int group_size) {
-  int g = group_size > 0 ? group_size : K;
+  const int spt = (int4 && group_size > 0 && group_size < 128) ? 4 : 1;
   size_t b = (((size_t)M * K * 2 + 15) & ~(size_t)15) + 16;
-  if (int4) b += (size_t)nbw * (K / g) * 16 * 8;
-  b += (size_t)GEMV_WAVES * nbw * 64 * 16 + 64;
+  if (int4) b += (((size_t)M * (K / 128) * spt * 4) + 15) & ~(size_t)15;
+  b += (size_t)2 * GEMV_WAVES * nbw * 64 * 16 + 64;
   return b;
 }

@@ -1,0 +1,420 @@
+// gemv_q4.cuh — "kernel A" for int4 weights: skinny GEMM (M <= 8 rows) that streams every packed
+// weight byte exactly once.  (The dense 16-bit variant used for lm_head lives in gemv.cuh.)
+//
+// Roofline: HBM.  Algorithmic bytes per call: K*N/2 (packed int4) + (K/g)*N*2 (scales)
+// [+ (K/g)*N/2 AWQ zeros] + M*K*2 + M*N*2.
+//
+// Shape of the launch:
+//   PERSISTENT workgroups of NW = 8 or 15 compute waves + ONE epilogue wave.  A work item is one
+//   16-column n-block (NBW = 2: the same block of the gate AND the up tensor) over the FULL K range; the
+//   NW compute waves split its k-tiles
+//   (wave w takes tiles w, w+NW, ...: 1 KiB coalesced per tile, the workgroup walks one contiguous
+//   K/128 KiB run) and meet in LDS — no inter-workgroup traffic, no atomics, no second launch.
+//   Every wave keeps a register ring of D tile-steps (8 KiB) in flight; the ring is filled BEFORE the
+//   prologue computes anything, but AFTER the prologue's own loads have been issued: vector memory
+//   returns in order per wave, so x / norm-weight loads queued behind 8 KiB of weights would wait for
+//   HBM instead of L2.
+//   x (optionally RMS-normalised on the fly: the reference's separate NormX launch, others.rs:11-29)
+//   is staged in LDS once per workgroup together with its per-group sums Σx (zero-point fix-up, see
+//   wna16.cuh) and reused for all work items.
+//   MFMA operands: A = x (16 batch rows x 32 k, rows >= M alias row M-1 and are never stored),
+//   B = (C + q) "magic" 16-bit floats (32 k x 16 columns).  D[m][n]: lane holds column n = lane&15 and
+//   rows m = (lane>>4)*4 + r — so a lane needs ONE scale / zero point per tile, and for M <= 4 only
+//   lanes 0..15 carry results into the cross-wave reduction.
+#pragma once
+#include <type_traits>
+
+#include "gemv.cuh"
+
+#define GQ_MAX_WAVES 16
+#define GQ_XR 5  // x octets per compute thread kept in registers by the prologue
+#ifndef GQ_RING_KIB
+#define GQ_RING_KIB 2  // weights in flight per wave (deeper rings measured SLOWER: see DESIGN.md §4.1)
+#endif
+
+template <class DT>
+__device__ __forceinline__ float gq_scale_f32(uint32_t raw16) { return DT::to_f32((uint16_t)raw16); }
+#ifdef VRA_GEMV_TS
+#define GEMV_STAMP_E(i)                                                                \
+  do {                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    if (a.ts && lane == 0) a.ts[(size_t)blockIdx.x * 32 + (i)] = wall_clock64();        \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+  } while (0)
+#else
+#define GEMV_STAMP_E(i) do {} while (0)
+#endif
+
+#ifdef VRA_GEMV_TS
+#define GEMV_STAMP_E(i)                                                                \
+  do {                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    if (a.ts && lane == 0) a.ts[(size_t)blockIdx.x * 32 + (i)] = wall_clock64();        \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+  } while (0)
+#else
+#define GEMV_STAMP_E(i) do {} while (0)
+#endif
+
+// Element `nl` (0..15, per lane) of 16 consecutive 16-bit values at a WAVE-UNIFORM address, fetched with
+// scalar loads (constant address space => s_load_dwordx8, lgkmcnt): the epilogue's bias / residual reads
+// must stay out of the vector-memory queue, or their s_waitcnt vmcnt(0) would drain the weight ring.
+template <class DT>
+__device__ __forceinline__ float gq_row16_elem(const uint16_t* base_uniform, int nl) {
+  typedef const __attribute__((address_space(4))) uint32_t* cptr32;
+  cptr32 p = (cptr32)(uintptr_t)base_uniform;
+  uint32_t v = p[0];
+#pragma unroll
+  for (int i = 1; i < 8; i++) {
+    const uint32_t d = p[i];
+    v = (nl >> 1) == i ? d : v;
+  }
+  return DT::to_f32((uint16_t)((nl & 1) ? (v >> 16) : (v & 0xffffu)));
+}
+
+// LDS: xs | xsum [NF][16] | red [2][NW][NBW][32] f32x4 | part [GQ_XR][16] + rstd[8]
+static inline size_t gemv_q4_lds_bytes(int nbw, int nw, int M, int K, int group_size) {
+  const int spt = (group_size > 0 && group_size < 128) ? 4 : 1;
+  size_t b = (((size_t)M * K * 2 + 15) & ~(size_t)15);
+  b += (size_t)(K / 128) * spt * 16 * 4;
+  b += (size_t)2 * nw * nbw * 32 * 16;
+  b += (GQ_XR * GQ_MAX_WAVES + 8) * 4;
+  return b;
+}
+
+// NBW = tensors per work item (2 = gate/up pair).  SPT = fix-up steps per k-tile (1: g >= 128, 4: g = 32/64).
+// AWQ = per-group zero points (otherwise the zero point is the constant 8 and no zero words are loaded).
+template <class DT, int NBW, int SPT, bool AWQ>
+__global__ __launch_bounds__(1024) void gemv_q4_kernel(const GemvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int DK = (SPT == 4 && AWQ) ? GQ_RING_KIB / 2 : GQ_RING_KIB;  // fine AWQ groups carry 9 registers per tile
+  constexpr int D = DK / NBW < 1 ? 1 : DK / NBW;  // ring depth in tile-steps
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int NW = (int)(blockDim.x >> 6) - 1, nthr = NW << 6;  // NW compute waves + ONE epilogue wave (the last)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches, no exec masking
+  const bool is_epi = wave == NW;
+  const int nn = lane & 15, oct = lane >> 4;
+  const int K = a.K, M = a.M, KT = K >> 7;
+  const bool grouped = a.group_size > 0 && a.group_size < K;
+  const int gsh = grouped ? 31 - __builtin_clz(a.group_size) : 31;  // k >> gsh = scale group (power-of-two groups)
+  const int NF = KT * SPT;
+  GEMV_STAMP(0);
+
+  // ---- LDS carve-up
+  uint32_t* xs = reinterpret_cast<uint32_t*>(smem);  // image: xs[(o*M + m)*4 .. +4] = x[m][o*8 .. +8]
+  size_t off = ((size_t)M * K * 2 + 15) & ~(size_t)15;
+  float* xsum = reinterpret_cast<float*>(smem + off);  // [NF][16]: Σx of row m over fix-up step f
+  off += (size_t)NF * 16 * 4;
+  f32x4* red = reinterpret_cast<f32x4*>(smem + off);  // [2][NW][NBW][32]
+  off += (size_t)2 * NW * NBW * 32 * sizeof(f32x4);
+  float* part = reinterpret_cast<float*>(smem + off);  // [GQ_XR][GQ_MAX_WAVES] partial Σx², then rstd[8]
+  float* rstd_s = part + GQ_XR * GQ_MAX_WAVES;
+
+  // ---- this workgroup's stream of tile-steps
+  const int T = (KT + NW - 1) / NW;  // steps per work item
+  const int my_items = (a.n_items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int S = (a.dbg & 1) ? 0 : my_items * T;
+
+  const bool rowmajor = a.scales_layout == VRA_SCALES_ROWMAJOR;
+  u32x4 wb[D][NBW];
+  uint32_t sb[D][NBW][SPT];
+  uint32_t zb[D][NBW][AWQ ? SPT : 1];
+
+  // Everything on the issue path is BRANCH FREE (selects and clamps only): hipcc's s_waitcnt insertion
+  // takes the minimum outstanding-load count over all control-flow paths, so a single conditional
+  // load anywhere in the ring turns every `vmcnt(N)` of the consume loop into `vmcnt(0)` — a full
+  // HBM round trip per tile-step.  Steps past the end of the stream re-issue the last valid step
+  // (L2 hits, never consumed).
+  const int nseg = a.nseg;
+  const int blk1 = nseg > 1 ? a.seg[1].blk_start : 0x7fffffff, blk2 = nseg > 2 ? a.seg[2].blk_start : 0x7fffffff;
+  auto issue = [&](int item, int i, u32x4 (&w)[NBW], uint32_t (&sc)[NBW][SPT], uint32_t (&zp)[NBW][AWQ ? SPT : 1]) {
+    const int kt = min(wave + NW * i, KT - 1);  // waves without a tile in this step re-read the last one; their scale is zeroed
+    const int fb = (int)blockIdx.x + item * (int)gridDim.x;
+#pragma unroll
+    for (int b = 0; b < NBW; b++) {
+      const void* wp;
+      const void* scp;
+      const uint32_t* qzp;
+      int n, nb;
+      if (NBW == 2) {  // gate/up pair: tensor b of the same n-block
+        wp = a.seg[b].w, scp = a.seg[b].scales, qzp = a.seg[b].qzeros, n = a.seg[b].n, nb = fb;
+      } else {
+        const bool s1 = fb >= blk1, s2 = fb >= blk2;
+        wp = s2 ? a.seg[2].w : (s1 ? a.seg[1].w : a.seg[0].w);
+        scp = s2 ? a.seg[2].scales : (s1 ? a.seg[1].scales : a.seg[0].scales);
+        qzp = s2 ? a.seg[2].qzeros : (s1 ? a.seg[1].qzeros : a.seg[0].qzeros);
+        n = s2 ? a.seg[2].n : (s1 ? a.seg[1].n : a.seg[0].n);
+        nb = fb - (s2 ? blk2 : (s1 ? blk1 : 0));
+      }
+      w[b] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp) + ((size_t)nb * KT + kt) * 64 + lane);
+      const uint16_t* sp = static_cast<const uint16_t*>(scp);
+#pragma unroll
+      for (int q = 0; q < SPT; q++) {
+        const int grp = (kt * 128 + q * 32) >> gsh;
+        // the 32-bit word holding the scale (its half is a per-lane constant, `shalf`): a 16-bit load gets
+        // an immediate v_and (zero extension) from hipcc, i.e. a wait for the load right after its issue
+        const int64_t rm = (int64_t)grp * n + nb * 16 + nn;
+        const int64_t si = rowmajor ? rm : vra_scale_index(grp, nb * 16 + nn, n, VRA_SCALES_MARLIN, grouped);
+        sc[b][q] = reinterpret_cast<const uint32_t*>(sp)[si >> 1];
+        if (AWQ) zp[b][AWQ ? q : 0] = qzp[(size_t)grp * (n >> 3) + nb * 2 + (nn >> 3)];
+      }
+    }
+  };
+  int iitem = 0, ii = 0;  // issue cursor (clamped to the last step of the stream)
+  auto advance_issue = [&]() {
+    const bool last = iitem == my_items - 1 && ii == T - 1;
+    const bool wrap = ii == T - 1;
+    ii = last ? ii : (wrap ? 0 : ii + 1);
+    iitem = last ? iitem : (wrap ? iitem + 1 : iitem);
+  };
+  auto fill_ring = [&]() {
+#pragma unroll
+    for (int r = 0; r < D; r++) {
+      issue(iitem, ii, wb[r], sb[r], zb[r]);
+      advance_issue();
+    }
+  };
+
+  // ---- prologue: stage x (and Σx) in LDS  [compute waves; the epilogue wave only keeps the barriers]
+  const int octs = K >> 3, OC = M * octs;
+  const int opg = 16 / SPT;  // octets per fix-up step
+  const int nch = (OC + nthr - 1) / nthr;  // x chunks in use (<= GQ_XR: launcher)
+  // every compute thread owns <= GQ_XR octets, loaded with their norm weights BEFORE the ring
+  u32x4 xr[GQ_XR], nr[GQ_XR];
+  if (!is_epi) {
+    // straight-line loads only (no conditional load may precede the ring, see `issue`): chunks past the
+    // end re-read the last octet, a missing norm weight reads x instead
+    const uint16_t* np = static_cast<const uint16_t*>(a.norm_w ? a.norm_w : a.x);
+    auto stage_loads = [&](auto nch_c) {
+      constexpr int NCH = decltype(nch_c)::value;
+#pragma unroll
+      for (int c = 0; c < GQ_XR; c++) {
+        xr[c] = u32x4{0u, 0u, 0u, 0u};
+        nr[c] = u32x4{0u, 0u, 0u, 0u};
+        if (c < NCH) {
+          const int m = min((c * nthr + (wave << 6)) / octs, M - 1);  // octs % 64 == 0: a wave never straddles rows
+          const int oo = min(c * nthr + tid - m * octs, octs - 1);
+          xr[c] = reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.x) + (size_t)m * a.x_ld)[oo];
+          nr[c] = reinterpret_cast<const u32x4*>(np)[oo];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the x / norm-weight loads AHEAD of the ring in the (in-order) memory queue
+      GEMV_STAMP(16);
+      // x and the norm weights (L2 hits) are back before the first HBM load is queued: measured on MI355X, an
+      // L2-hit load queued behind streaming HBM loads of OTHER waves of the CU returns microseconds late
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+      fill_ring();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    stage_loads(std::integral_constant<int, GQ_XR>{});  // (two specialisations would be re-merged by the compiler: ring hoisted above x)
+    GEMV_STAMP(1);
+    if (a.norm_w) {
+#pragma unroll
+      for (int c = 0; c < GQ_XR; c++) {
+        if (c < nch) {
+          float f[8];
+          unpack8<DT>(xr[c], f);
+          float ss = 0.f;
+#pragma unroll
+          for (int i = 0; i < 8; i++) ss += f[i] * f[i];
+          ss = wave_sum(ss);
+          if (lane == 0) part[c * GQ_MAX_WAVES + wave] = ss;
+        }
+      }
+    }
+    GEMV_STAMP(17);
+  }
+  if (a.norm_w) {
+    __syncthreads();
+    if (M > 1) {
+      if (wave == 0) {  // lane p (+64) owns partial (c, w) = (p / NW, p % NW); one masked wave reduction per row: fixed order
+        float pv[2];
+        int prow[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int pp = lane + 64 * h, c = pp / NW, w = pp - c * NW;
+          const int o0 = c * nthr + (w << 6);
+          pv[h] = (c < nch && o0 < OC) ? part[c * GQ_MAX_WAVES + w] : 0.f;
+          prow[h] = o0 / octs;
+        }
+        for (int m = 0; m < M; m++) {
+          const float tot = wave_sum((prow[0] == m ? pv[0] : 0.f) + (prow[1] == m ? pv[1] : 0.f));
+          if (lane == 0) rstd_s[m] = 1.0f / sqrtf(tot / (float)K + a.eps);
+        }
+      }
+      __syncthreads();
+    }
+  }
+  GEMV_STAMP(19);
+  if (!is_epi) {
+    float rs1 = 1.0f;
+    if (a.norm_w && M == 1) {  // single row: every thread adds the partials itself (fixed order), no second barrier
+      float tot = 0.f;
+      for (int c = 0; c < nch; c++)
+        for (int w = 0; w < NW; w++)
+          if (c * nthr + (w << 6) < OC) tot += part[c * GQ_MAX_WAVES + w];
+      rs1 = 1.0f / sqrtf(tot / (float)K + a.eps);
+    }
+#pragma unroll
+    for (int c = 0; c < GQ_XR; c++) {
+      if (c < nch) {
+        const int o = c * nthr + tid;
+        const int m = min((c * nthr + (wave << 6)) / octs, M - 1), oo = o - m * octs;
+        float f[8];
+        u32x4 v = xr[c];
+        unpack8<DT>(v, f);
+        if (a.norm_w) {
+          // (wave-uniform; kept in an SGPR: as a VGPR the packed multiply below reads it as a register PAIR
+          // whose second half may be a ring register with a load in flight — a false vmcnt dependency)
+          const float rs = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(M == 1 ? rs1 : rstd_s[m])));
+          float g[8];
+          unpack8<DT>(nr[c], g);
+#pragma unroll
+          for (int i = 0; i < 8; i++) f[i] = f[i] * rs * g[i];
+          v = pack8<DT>(f);
+          unpack8<DT>(v, f);  // sums are taken over the ROUNDED values the MFMA will see
+        }
+        if (o < OC) *reinterpret_cast<u32x4*>(xs + ((size_t)oo * M + m) * 4) = v;
+        float s8 = ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+        for (int d = 1; d < opg; d <<= 1) s8 += __shfl_xor(s8, d, 64);
+        if (o < OC && (oo & (opg - 1)) == 0) xsum[(oo / opg) * 16 + m] = s8;
+      }
+    }
+  }
+  GEMV_STAMP(20);
+  __syncthreads();
+  GEMV_STAMP(2);
+
+  const int n_it = S / T;  // work items of this workgroup
+  if (is_epi) {
+    // ================= epilogue wave: reduce the NW partial tiles of every work item, fused epilogue, store.
+    // It owns ALL global stores (gfx9 counts loads and stores in one vmcnt and they retire out of order
+    // with each other: one possibly-pending store in a compute wave would force its ring waits to
+    // vmcnt(0)) and prefetches bias / residual BEFORE it waits for the item's partials.
+    int parity = 0;
+    const int nout = 16 * M;
+    for (int it = 0; it < n_it; it++) {
+      const int fb = (int)blockIdx.x + it * (int)gridDim.x;
+      const int segi = NBW == 2 ? 0 : (fb >= blk2 ? 2 : (fb >= blk1 ? 1 : 0));
+      const int nb = fb - (NBW == 2 ? 0 : a.seg[segi].blk_start);
+      const GemvSeg& sg = a.seg[segi];
+      float bv[2] = {0.f, 0.f}, bu[2] = {0.f, 0.f}, rv[2] = {0.f, 0.f};
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int idx = lane + 64 * h;
+        if (idx < nout) {
+          const int n = nb * 16 + (idx & 15), m = idx >> 4;
+          if (sg.bias) bv[h] = DT::to_f32(static_cast<const uint16_t*>(sg.bias)[n]);
+          if (NBW == 2 && a.seg[1].bias) bu[h] = DT::to_f32(static_cast<const uint16_t*>(a.seg[1].bias)[n]);
+          if (a.residual) rv[h] = DT::to_f32(static_cast<const uint16_t*>(a.residual)[(size_t)m * a.res_ld + n]);
+        }
+      }
+      __syncthreads();  // the item's partial tiles are in red[parity]
+      GEMV_STAMP_E(21 + 2 * (it < 3 ? it : 3));
+      const float* rf = reinterpret_cast<const float*>(red + (size_t)parity * NW * NBW * 32);
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int idx = lane + 64 * h;
+        if (idx < nout) {
+          const int nl = idx & 15, m = idx >> 4;
+          const int slot = ((m >> 2) * 16 + nl) * 4 + (m & 3);  // D layout: column = lane&15, row = (lane>>4)*4 + reg
+          float v = 0.f, v2 = 0.f;
+          for (int w = 0; w < NW; w++) {
+            v += rf[(w * NBW) * 128 + slot];
+            if (NBW > 1) v2 += rf[(w * NBW + (NBW - 1)) * 128 + slot];
+          }
+          const int n = nb * 16 + nl;
+          v = rnd_dt<DT>(v);
+          if (sg.bias) v = rnd_dt<DT>(v + bv[h]);
+          if (NBW == 2) {
+            v2 = rnd_dt<DT>(v2);
+            if (a.seg[1].bias) v2 = rnd_dt<DT>(v2 + bu[h]);
+            const float sl = rnd_dt<DT>(v / (1.0f + expf(-v)));
+            v = sl * v2;
+          }
+          if (a.residual) v = rnd_dt<DT>(v) + rv[h];
+          if (a.out_f32) static_cast<float*>(sg.out)[(size_t)m * sg.out_ld + n] = rnd_dt<DT>(v);
+          else static_cast<uint16_t*>(sg.out)[(size_t)m * sg.out_ld + n] = DT::from_f32(v);
+        }
+      }
+      GEMV_STAMP_E(22 + 2 * (it < 3 ? it : 3));
+      parity ^= 1;  // red[parity] is rewritten only after the NEXT barrier, which this wave must reach first
+    }
+    return;
+  }
+
+  // ================= compute waves
+  // A-fragment addressing: lanes whose batch row does not exist alias row M-1 (their D rows are never stored)
+  const uint32_t xbase = (uint32_t)(oct * M + min(nn, M - 1)) * 4u;
+  const uint32_t xstep = (uint32_t)M * 16u;  // u32 per 4 octets (one j step)
+  const int zsh = 4 * awq_rev(nn & 7);
+  // which half of the loaded word is this lane's scale: row-major and the channel-wise Marlin permutation keep
+  // the column parity, the grouped permutation (wna16.rs:180-218) moves bit 3 of the column to bit 0
+  const bool shalf = (rowmajor || !grouped) ? (nn & 1) : ((nn >> 3) & 1);
+  constexpr float CB = Magic<DT>::bias;
+
+  f32x4 acc[NBW];
+#pragma unroll
+  for (int b = 0; b < NBW; b++) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int ci = 0, parity = 0;  // consume cursor
+  // The stream is padded to a multiple of D: the only loop exit is the back edge.  (An exit between two
+  // unrolled bodies is routed by the CFG structurizer through a shared "Flow" block from which the loop
+  // header is syntactically reachable with a half-issued refill — a false path that again degrades the
+  // ring waits to vmcnt(0).)  Padding steps skip the arithmetic; their clamped re-loads hit L2.
+  const int S_pad = (S + D - 1) / D * D;
+  for (int s0 = 0; s0 < S_pad; s0 += D) {
+#pragma unroll
+    for (int r = 0; r < D; r++) {
+      if (s0 + r < S) {
+        // ---- consume tile-step ci of the current item: one branch-free MFMA region per fix-up step (common.cuh)
+        const int ktr = wave + NW * ci;
+        const bool valid = ktr < KT;
+        const int kt = min(ktr, KT - 1);
+        const uint32_t* xp = xs + xbase + (uint32_t)(kt * 4) * xstep;
+        const f32x4* sxp = reinterpret_cast<const f32x4*>(xsum + (size_t)kt * SPT * 16) + oct;
+        f32x4 ag[NBW];
+#pragma unroll
+        for (int b = 0; b < NBW; b++) ag[b] = vra_zero_acc();
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const s16x8 xf = __builtin_bit_cast(s16x8, *reinterpret_cast<const u32x4*>(xp + j * xstep));
+#pragma unroll
+          for (int b = 0; b < NBW; b++) DT::mfma(ag[b], xf, magic_word<DT>(wb[r][b][j]));
+          if (SPT == 4 || j == 3) {  // end of a fix-up step: acc += s * (acc_g - (C+z) * Σx_g)
+            VRA_MFMA_DRAIN();
+            const int q = SPT == 4 ? j : 0;
+            const f32x4 sx = sxp[q * 4];
+#pragma unroll
+            for (int b = 0; b < NBW; b++) {
+              float s = gq_scale_f32<DT>(shalf ? sb[r][b][q] >> 16 : sb[r][b][q]);
+              s = valid ? s : 0.f;
+              const float zc = AWQ ? CB + (float)((zb[r][b][AWQ ? q : 0] >> zsh) & 0xFu) : CB + 8.f;
+#pragma unroll
+              for (int e = 0; e < 4; e++) acc[b][e] = fmaf(s, fmaf(-zc, sx[e], ag[b][e]), acc[b][e]);
+              if (SPT == 4 && j < 3) ag[b] = vra_zero_acc();
+            }
+          }
+        }
+        GEMV_STAMP(3 + 2 * (s0 + r < 5 ? s0 + r : 5));
+        // ---- end of a work item: hand the partial tile to the epilogue wave
+        if (++ci == T) {
+          ci = 0;
+          f32x4* rbuf = red + (size_t)parity * NW * NBW * 32;
+          if (oct * 4 < M) {
+#pragma unroll
+            for (int b = 0; b < NBW; b++) rbuf[(wave * NBW + b) * 32 + lane] = acc[b];
+          }
+#pragma unroll
+          for (int b = 0; b < NBW; b++) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+          __syncthreads();
+          parity ^= 1;
+        }
+        GEMV_STAMP(4 + 2 * (s0 + r < 5 ? s0 + r : 5));
+      }
+      // ---- refill this ring slot with the step D ahead (unconditionally: see the note at `issue`)
+      issue(iitem, ii, wb[r], sb[r], zb[r]);
+      advance_issue();
+    }
+  }
+  GEMV_STAMP(15);
+}

@@ -290,9 +290,32 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
   const float* p = logits + (size_t)blockIdx.x * cols;
   float best = -INFINITY;
   uint32_t besti = 0xffffffffu;
-  for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+  // 16 B loads, 4 independent loads in flight per thread (the row is read once: latency bound otherwise)
+  const int nv = ((reinterpret_cast<uintptr_t>(p) & 15) == 0) ? cols >> 2 : 0;
+  const f32x4* p4 = reinterpret_cast<const f32x4*>(p);
+  for (int c0 = threadIdx.x; c0 < nv; c0 += blockDim.x * 4) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int c = c0 + u * blockDim.x;
+      v[u] = c < nv ? p4[c] : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int c = c0 + u * blockDim.x;
+      if (c < nv) {
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+          if (v[u][e] > best || besti == 0xffffffffu) {  // ascending index order per thread: strict > keeps the first
+            best = v[u][e];
+            besti = (uint32_t)(c * 4 + e);
+          }
+      }
+    }
+  }
+  for (int c = nv * 4 + threadIdx.x; c < cols; c += blockDim.x) {
     float v = p[c];
-    if (v > best || besti == 0xffffffffu) {  // strictly greater keeps the first index per thread
+    if (v > best || besti == 0xffffffffu) {
       best = v;
       besti = c;
     }

@@ -4,6 +4,7 @@
 
 #include "gemm_skinny.cuh"
 #include "gemv.cuh"
+#include "gemv_q4.cuh"
 #include "scratch.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -120,21 +121,111 @@ extern "C" void vra_wna16_dequant(const void* qweight_tiled, const void* scales,
 
 static const int kMaxDynLds = 160 * 1024;
 
-template <class DT, bool INT4, int NBW>
-static void launch_gemv_t(const GemvArgs& a, int nblocks, hipStream_t st) {
-  size_t lds = gemv_lds_bytes(INT4, NBW, a.M, a.K, a.group_size);
+static int num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  }
+  return n;
+}
+
+#ifdef VRA_GEMV_TS
+static unsigned long long* g_ts = nullptr;
+static unsigned long long* vra_gemv_ts_buf() {
+  if (!g_ts) {
+    (void)hipMalloc(&g_ts, 4096 * 32 * 8);
+    (void)hipMemset(g_ts, 0, 4096 * 32 * 8);
+  }
+  return g_ts;
+}
+extern "C" void vra_debug_ts(unsigned long long* host, int n) { (void)hipMemcpy(host, vra_gemv_ts_buf(), (size_t)n * 8, hipMemcpyDeviceToHost); }
+#endif
+struct GemvArgs;
+static void gemv_debug_args(GemvArgs& a);
+template <class DT, bool INT4, int NBW, int SPT, bool AWQ>
+static void launch_gemv_v(GemvArgs a, int nblocks, size_t lds, hipStream_t st) {
   static bool attr_set = false;
+  static size_t occ_lds = ~(size_t)0;
+  static int occ_val = 1;
+  auto kern = gemv_kernel<DT, INT4, NBW, SPT, AWQ>;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_kernel<DT, INT4, NBW>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
     attr_set = true;
   }
-  int grid = a.silu_dual ? nblocks : (nblocks + NBW - 1) / NBW;
-  gemv_kernel<DT, INT4, NBW><<<grid, GEMV_THREADS, lds, st>>>(a);
+  // persistent grid = resident capacity (registers/LDS decide how many workgroups fit a CU), work
+  // items split evenly so that there is no ragged last round
+  if (occ_lds != lds) {
+    int occ = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, GEMV_THREADS, lds);
+    occ_val = (e == hipSuccess && occ > 0) ? (occ > 4 ? 4 : occ) : 1;
+    occ_lds = lds;
+  }
+  a.n_items = nblocks;
+  gemv_debug_args(a);
+  const int cap = num_cus() * occ_val;
+  const int per = (nblocks + cap - 1) / cap;
+  const int grid = (nblocks + per - 1) / per;
+  kern<<<grid, GEMV_THREADS, lds, st>>>(a);
+}
+static void gemv_debug_args(GemvArgs& a) {
+  static const char* exp_env = getenv("VRA_EXP");
+  a.dbg = exp_env ? atoi(exp_env) : 0;
+  if (a.dbg & 4) a.norm_w = nullptr;
+#ifdef VRA_GEMV_TS
+  a.ts = vra_gemv_ts_buf();
+#else
+  a.ts = nullptr;
+#endif
+}
+
+// int4: persistent grid of (8 compute + 1 epilogue)-wave workgroups, two per CU, when there are at least
+// two work items per CU; otherwise one (15 + 1)-wave workgroup per CU (about the same number of waves,
+// twice the k-split per item)
+template <class DT, int NBW, int SPT, bool AWQ>
+static void launch_gemv_q4_v(GemvArgs a, int nblocks, hipStream_t st) {
+  static bool attr_set = false;
+  static int occ9 = 0;  // resident 9-wave workgroups per CU (VGPR budget of this variant)
+  auto kern = gemv_q4_kernel<DT, NBW, SPT, AWQ>;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+    int occ = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 9 * 64, 48 * 1024);
+    occ9 = (e == hipSuccess && occ > 0) ? (occ > 2 ? 2 : occ) : 1;
+    attr_set = true;
+  }
+  const int cus = num_cus();
+  const int oc = a.M * (a.K >> 3);
+  static const char* nw_env = getenv("VRA_GEMV_NW");
+  int nw = (nblocks >= 2 * cus && occ9 >= 2) ? 8 : 15;
+  if (nw_env && (atoi(nw_env) == 8 || atoi(nw_env) == 15)) nw = atoi(nw_env);
+  if (oc > GQ_XR * 8 * 64) nw = 15;  // the prologue keeps x in registers: <= GQ_XR octets per compute thread
+  const size_t lds = gemv_q4_lds_bytes(NBW, nw, a.M, a.K, a.group_size);
+  int per_cu = nw == 8 ? occ9 : 1;
+  if (lds * per_cu > (size_t)kMaxDynLds) per_cu = 1;
+  a.n_items = nblocks;
+  gemv_debug_args(a);
+  const int cap = cus * per_cu;
+  const int grid = nblocks < cap ? nblocks : cap;
+  kern<<<grid, (nw + 1) * 64, lds, st>>>(a);
+}
+template <class DT, int NBW>
+static void launch_gemv_q4_t(const GemvArgs& a, int nblocks, hipStream_t st) {
+  const bool fine = a.group_size > 0 && a.group_size < 128;
+  if (fine && a.is_awq) launch_gemv_q4_v<DT, NBW, 4, true>(a, nblocks, st);
+  else if (fine) launch_gemv_q4_v<DT, NBW, 4, false>(a, nblocks, st);
+  else if (a.is_awq) launch_gemv_q4_v<DT, NBW, 1, true>(a, nblocks, st);
+  else launch_gemv_q4_v<DT, NBW, 1, false>(a, nblocks, st);
 }
 
 bool vra_gemv_fits(bool int4, int nbw, int M, int K, int group_size) {
   if (M > 8 || M < 1) return false;
-  return gemv_lds_bytes(int4, nbw, M, K, group_size) <= (size_t)72 * 1024;
+  if (!int4) return gemv_lds_bytes(false, nbw, M, K, group_size) <= (size_t)72 * 1024;
+  if (K % 512) return false;  // a wave of the x staging must not straddle rows
+  if (M * (K >> 3) > GQ_XR * 15 * 64) return false;  // x is staged through registers: <= GQ_XR octets per compute thread
+  if (group_size > 0 && group_size < K && (group_size & (group_size - 1))) return false;  // power-of-two groups only
+  return gemv_q4_lds_bytes(nbw, 15, M, K, group_size) <= (size_t)96 * 1024;
 }
 
 void vra_launch_gemv(const GemvArgs& a, bool int4, int dtype, int64_t stream) {
@@ -145,30 +236,40 @@ void vra_launch_gemv(const GemvArgs& a, bool int4, int dtype, int64_t stream) {
     for (int s = 0; s < a.nseg; s++) nblocks += (a.seg[s].n + 15) / 16;
   const bool bf = dtype == VRA_BF16;
   if (a.silu_dual) {
-    if (bf) launch_gemv_t<BF16, true, 2>(a, nblocks, st);
-    else launch_gemv_t<F16, true, 2>(a, nblocks, st);
+    if (bf) launch_gemv_q4_t<BF16, 2>(a, nblocks, st);
+    else launch_gemv_q4_t<F16, 2>(a, nblocks, st);
   } else if (int4) {
-    if (bf) launch_gemv_t<BF16, true, 1>(a, nblocks, st);
-    else launch_gemv_t<F16, true, 1>(a, nblocks, st);
+    if (bf) launch_gemv_q4_t<BF16, 1>(a, nblocks, st);
+    else launch_gemv_q4_t<F16, 1>(a, nblocks, st);
   } else {
-    if (bf) launch_gemv_t<BF16, false, 1>(a, nblocks, st);
-    else launch_gemv_t<F16, false, 1>(a, nblocks, st);
+    const size_t lds = gemv_lds_bytes(false, 1, a.M, a.K, a.group_size);
+    if (bf) launch_gemv_v<BF16, false, 1, 1, false>(a, nblocks, lds, st);
+    else launch_gemv_v<F16, false, 1, 1, false>(a, nblocks, lds, st);
   }
 }
 
 template <class DT, bool INT4, bool DUAL, int MT>
 static void launch_skinny_t(GemmBArgs a, hipStream_t st) {
-  size_t lds = gemm_skinny_lds_bytes(MT);
-  dim3 grid((a.N + 127) / 128, (a.M + MT * 16 - 1) / (MT * 16), a.splitk);
   const bool fine = INT4 && a.group_size > 0 && a.group_size < 128;  // several groups per k-tile
+  size_t lds = gemm_skinny_lds_bytes(MT, fine ? 4 : 1);
+  dim3 grid((a.N + 127) / 128, (a.M + MT * 16 - 1) / (MT * 16), a.splitk);
+  // (DUAL, MT=4, SPT=4) would need > 256 VGPRs (spills next to MFMAs): that combination is never
+  // instantiated — vra_launch_skinny caps MT at 2 for gate/up pairs with fine groups
+  constexpr bool kHasFine = INT4 && !(DUAL && MT == 4);
   static bool attr_set = false;
   if (!attr_set) {  // MT=4 needs 64 KiB + 16 B of dynamic LDS, just past the default limit
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<DT, INT4, DUAL, MT, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+    if constexpr (kHasFine)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<DT, INT4, DUAL, MT, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<DT, INT4, DUAL, MT, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
     attr_set = true;
   }
-  if (fine) gemm_skinny_kernel<DT, INT4, DUAL, MT, 4><<<grid, GB_THREADS, lds, st>>>(a);
-  else gemm_skinny_kernel<DT, INT4, DUAL, MT, 1><<<grid, GB_THREADS, lds, st>>>(a);
+  if constexpr (kHasFine) {
+    if (fine) {
+      gemm_skinny_kernel<DT, INT4, DUAL, MT, 4><<<grid, GB_THREADS, lds, st>>>(a);
+      return;
+    }
+  }
+  gemm_skinny_kernel<DT, INT4, DUAL, MT, 1><<<grid, GB_THREADS, lds, st>>>(a);
 }
 
 // choose split-K so that the grid has roughly >= 2 workgroups per CU, bounded by the slab scratch
@@ -189,6 +290,7 @@ static int choose_splitk(int M, int N, int K, int mt, bool dual) {
 void vra_launch_skinny(GemmBArgs a, bool int4, bool dual, int dtype, int64_t stream) {
   hipStream_t st = as_stream(stream);
   int mt = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
+  if (dual && int4 && a.group_size > 0 && a.group_size < 128 && mt == 4) mt = 2;  // see launch_skinny_t
   a.splitk = choose_splitk(a.M, a.N, a.K, mt, dual);
   a.slabs = a.splitk > 1 ? vra_scratch_slabs() : nullptr;
   a.counters = a.splitk > 1 ? vra_scratch_counters() : nullptr;
@@ -409,7 +511,7 @@ __global__ __launch_bounds__(256) void gptq_alt_kernel(const uint16_t* __restric
         int grp = g_idx ? g_idx[k] : k / group_size;
         float s = F16::to_f32(sc[(size_t)grp * N + n]);
         int z = (int)((qz[(size_t)grp * (N >> 3) + (n >> 3)] >> (4 * (n & 7))) & 0xFu) + 1;
-        float wv = rnd_dt<F16>((float)((int)((w >> (4 * e)) & 0xFu) - z) * s);
+        float wv = (float)((int)((w >> (4 * e)) & 0xFu) - z) * s;  // exact (q - z)*s, one rounding at the output
         acc += F16::to_f32(x[(size_t)m * K + k]) * wv;
       }
     }
