@@ -113,6 +113,31 @@ def cpu_baseline(cfg):
                        f"orc_gptq_gemv_fast (~{time.perf_counter() - t0:.0f}s), extrapolated to 32 layers + lm_head bytes")
 
 
+def dist_init(world, local_rank, backend="nccl"):
+    """one process per GPU (torchrun env); backend "nccl" is RCCL on ROCm, "gloo" is used by the CPU tests."""
+    if world <= 1:
+        return None
+    import torch
+    import torch.distributed as dist_mod
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist_mod.init_process_group(backend)
+    return dist_mod
+
+
+def max_over_ranks(dist, seconds):
+    """the job's time is the slowest rank's time."""
+    if dist is None:
+        return seconds
+    import torch
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -125,13 +150,7 @@ def main():
     from vllm_rs_amd import _lib
     from vllm_rs_amd import engine as E
     L = _lib.load()
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist_mod
-        torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        dist = dist_mod
+    dist = dist_init(world, local_rank)
     if L.vra_device_count() <= local_rank:
         raise SystemExit("bench.py needs a GPU: no HIP device for this rank (the product has no CPU fallback)")
     L.vra_set_device(local_rank)
@@ -151,17 +170,13 @@ def main():
 
     # ---------------- timed region: K decode steps at the headline batch
     dt, ms_events, outs = run_decode(eng, make_prompts(a.batch, a.prompt_len, V), a.warmup, a.steps, sync)
-    if dist is not None:
-        import torch
-        t = torch.tensor([dt], device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    tokens = a.batch * a.steps * world
+    dt = max_over_ranks(dist, dt)
+    tokens = a.batch * a.steps * world  # weak scaling: every rank decodes its own batch, no data-path collective
     line = {
         "metric": "decode tokens/sec (+ p50 TTFT), Llama-3-8B int4, bs=1/32",
         "value": tokens / dt, "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16 activations x int4 weights (f32 accumulate)", "data": "synthetic",
+        "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"Llama-3-8B GPTQ int4 g128 TP=1 greedy decode, batch {a.batch} per GPU, prompt {a.prompt_len}, "
                                f"{a.steps} generated tokens, KV block 64, hipGraph replay; N>1 = independent replicas",
                    "model_shape": "H4096 L32 Hq32 Hkv8 D128 I14336 V128256", "batch_per_gpu": a.batch},
@@ -180,7 +195,7 @@ def main():
             tot_b += b
             tot_ms += ms
         dom = per["norm+gate_up+silu"]
-        line["roofline"] = {"bound": "hbm", "kernel": "gemv_kernel<BF16,int4,dual> (norm+gate/up+SiLU*mul)", "achieved": dom["GBps"],
+        line["roofline"] = {"bound": "hbm", "kernel": "gemv_q4_kernel<BF16,NBW=2,SPT=1,AWQ=false> (RMSNorm + gate/up int4 GEMV + SiLU*mul)", "achieved": dom["GBps"],
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": None,
                             "algorithmic_bytes_per_launch": dom["bytes"], "avg_launch_ms": dom["ms"],
                             "family": per, "family_GBps": tot_b / tot_ms / 1e6, "family_frac": tot_b / tot_ms / 1e6 / HBM_PEAK_GBS,

@@ -307,6 +307,18 @@ int32_t vra_bm_seq_block_table(const void* bm, int64_t seq, uint32_t* h_out, int
 int32_t vra_bm_prefix_cached_blocks(const void* bm);
 int32_t vra_bm_evict_prefix(void* bm, int32_t n_blocks);
 
+/* PrefixCache on its own (src/core/prefix_cache.rs:72-293): hash-chained full blocks, leaf-LRU eviction.
+ * insert_prefix returns the number of blocks inserted and the block ids evicted to stay within
+ * max_cached_blocks; match_prefix returns the number of leading full blocks found and their ids. */
+void* vra_pc_create(int32_t block_size, int32_t max_cached_blocks);
+void vra_pc_destroy(void* pc);
+int32_t vra_pc_insert_prefix(void* pc, const uint32_t* h_tokens, int32_t n_tokens, const int32_t* h_blocks,
+                             int32_t n_blocks, int32_t* h_evicted, int32_t cap, int32_t* h_n_evicted);
+int32_t vra_pc_match_prefix(void* pc, const uint32_t* h_tokens, int32_t n_tokens, int32_t* h_blocks,
+                            int32_t cap);
+int32_t vra_pc_cached_blocks(const void* pc);
+int32_t vra_pc_evict_blocks(void* pc, int32_t n, int32_t* h_evicted, int32_t cap);
+
 /* Engine = scheduler + runner + model (src/core/{engine,scheduler,runner}.rs) */
 void* vra_engine_create(const vra_model_config* mc, const vra_engine_config* ec);
 void vra_engine_destroy(void* eng);
@@ -323,6 +335,24 @@ int64_t vra_engine_add_request(void* eng, const uint32_t* h_prompt, int32_t n_pr
 /* one engine step (engine.rs:1693-1757): schedule → forward → postprocess.
  * returns number of sequences run (0 = idle), *h_is_prefill set. */
 int32_t vra_engine_step(void* eng, int32_t* h_is_prefill);
+/* Host-only engine (vra_engine_config.device = -1, explicit num_gpu_blocks; no GPU touched): the two
+ * halves of vra_engine_step around the forward pass, for CPU parity tests of the scheduler
+ * (scheduler.rs:200-380,500-629), the block manager and the metadata arithmetic of
+ * ModelRunner::prepare_prefill / prepare_decode (runner.rs:978-1388).  dry_schedule returns the number
+ * of sequences in the step and HOST pointers to the staged InputMetadata (valid until the next call);
+ * dry_commit feeds the tokens a model would have sampled (one per sequence, in step order). */
+typedef struct vra_step_meta {
+  int32_t n_tokens, n_seqs, max_blocks, max_seqlen_q, max_context_len;
+  const uint32_t* input_ids;    /* [n_tokens] */
+  const int64_t* positions;     /* [n_tokens] */
+  const int64_t* slot_mapping;  /* [n_tokens] */
+  const uint32_t* block_tables; /* [n_seqs, max_blocks] right-padded with 0 */
+  const uint32_t* context_lens; /* [n_seqs] */
+  const uint32_t* cu_seqlens_q; /* [n_seqs + 1] (prefill) */
+  int64_t request_ids[64];      /* request id of each sequence of the step (first 64) */
+} vra_step_meta;
+int32_t vra_engine_dry_schedule(void* eng, int32_t* h_is_prefill, vra_step_meta* out);
+int32_t vra_engine_dry_commit(void* eng, const uint32_t* h_tokens, int32_t n);
 int32_t vra_engine_has_unfinished(const void* eng);
 int32_t vra_engine_request_finished(const void* eng, int64_t req);
 int32_t vra_engine_request_output(const void* eng, int64_t req, uint32_t* h_out, int32_t cap);

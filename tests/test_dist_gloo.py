@@ -1,0 +1,119 @@
+"""world_size-2 `gloo` tests on CPU of the N>1 paths (no GPU):
+
+* bench.py's multi-rank contract: independent replicas per rank (weak scaling, no data-path collective), barrier, the
+  job's time = MAX over ranks, value = units of all ranks / that time
+* the tensor-parallel sharding rules of SURVEY.md §8(e) (wna16.rs:35-40,127-152; distributed.rs:325-396,438-455):
+  column-parallel q/k/v/gate/up shard N, row-parallel o/down shard K in units of the quantisation group, ONE
+  all-reduce(sum) in the storage dtype after each row-parallel GEMM — restated with the oracle on two ranks and
+  compared with the unsharded oracle result.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+BF16 = 0
+
+
+def _init(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    os.environ.setdefault("OMP_NUM_THREADS", "2")
+
+
+def _bench_worker(rank, world, port, q):
+    _init(rank, world, port)
+    import bench
+    d = bench.dist_init(world, rank, backend="gloo")
+    d.barrier()
+    local_s = 0.5 + 0.25 * rank            # rank 1 is the slow one
+    t = bench.max_over_ranks(d, local_s)
+    batch, steps = 4, 10
+    value = batch * steps * world / t      # whole-job aggregate, as bench.py's `value`
+    d.barrier()
+    if rank == 0:
+        q.put((t, value))
+    d.destroy_process_group()
+
+
+def test_bench_aggregation_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, 29611, q)) for r in range(2)]
+    [p.start() for p in procs]
+    t, value = q.get(timeout=120)
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert t == pytest.approx(0.75) and value == pytest.approx(4 * 10 * 2 / 0.75)
+
+
+def test_single_rank_needs_no_process_group():
+    import bench
+    assert bench.dist_init(1, 0) is None and bench.max_over_ranks(None, 1.25) == 1.25
+
+
+def _shard_cols(q, rank, world):
+    """column parallel: packed tensors are stored [in, out] so the OUTPUT dim is dim 1 (wna16.rs:35-40);
+    qzeros in units of 8 columns."""
+    N = q["scales"].shape[1]
+    n0, n1 = rank * N // world, (rank + 1) * N // world
+    return dict(idx=q["idx"][:, n0:n1], scales=q["scales"][:, n0:n1], zeros=None if q["zeros"] is None else q["zeros"][:, n0:n1]), (n0, n1)
+
+
+def _shard_rows(q, rank, world, g):
+    """row parallel: shard K (dim 0 of qweight in units of 8 rows, scales/qzeros rows in units of the group)."""
+    K = q["idx"].shape[0]
+    k0, k1 = rank * K // world, (rank + 1) * K // world
+    assert (K // world) % g == 0, "K/world must be a multiple of the group size (SURVEY §8e)"
+    return dict(idx=q["idx"][k0:k1], scales=q["scales"][k0 // g:k1 // g], zeros=None if q["zeros"] is None else q["zeros"][k0 // g:k1 // g]), (k0, k1)
+
+
+def _tp_worker(rank, world, port, q):
+    _init(rank, world, port)
+    from oracle import oracle as orc
+    dist.init_process_group("gloo")
+    r = np.random.default_rng(5)            # same stream on every rank: identical full tensors
+    H, I, M, g = 256, 512, 3, 128
+    mk = lambda K, N: dict(idx=r.integers(0, 16, size=(K, N), dtype=np.uint8), zeros=None,
+                           scales=orc.to_bf16((0.002 + 0.01 * r.random((K // g, N))).astype(np.float32)))
+    gate, up, down = mk(H, I), mk(H, I), mk(I, H)
+    x = orc.to_bf16(r.standard_normal((M, H)).astype(np.float32))
+    res = orc.to_bf16(r.standard_normal((M, H)).astype(np.float32))
+    # ---- unsharded reference (mlp.rs:451-469)
+    act = orc.silu_mul(orc.wna16_gemm(x, gate["idx"], None, gate["scales"], g, BF16), orc.wna16_gemm(x, up["idx"], None, up["scales"], g, BF16), BF16)
+    full = orc.add(orc.wna16_gemm(act, down["idx"], None, down["scales"], g, BF16), res, BF16)
+    # ---- this rank's shard
+    gs, (n0, n1) = _shard_cols(gate, rank, world)
+    us, _ = _shard_cols(up, rank, world)
+    ds, (k0, k1) = _shard_rows(down, rank, world, g)
+    assert (n0, n1) == (k0, k1)             # the column shard of gate/up feeds the row shard of down directly
+    a = orc.silu_mul(orc.wna16_gemm(x, gs["idx"], None, gs["scales"], g, BF16), orc.wna16_gemm(x, us["idx"], None, us["scales"], g, BF16), BF16)
+    assert (a == act[:, n0:n1]).all()        # column-parallel outputs are exactly the slices of the full result
+    part = orc.wna16_gemm(a, ds["idx"], None, ds["scales"], g, BF16)         # partial sum, rounded to bf16 per rank
+    t = torch.from_numpy(orc.from_bf16(part).copy())
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)                                  # AllReduce (distributed.rs:438-455)
+    out = orc.add(orc.to_bf16(t.numpy()), res, BF16)                          # residual after the reduction
+    d = np.abs(orc.from_bf16(out) - orc.from_bf16(full))
+    ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(orc.from_bf16(full)), 1e-30))) - 7)
+    if rank == 0:
+        # bf16 partial sums: the order of roundings differs from the single-GPU result by at most ~2 ulp
+        q.put((float((d / np.maximum(ulp, 2.0 ** -9)).max()), float((d == 0).mean())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tp2_sharding_rules_with_gloo_allreduce():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_tp_worker, args=(r, 2, 29612, q)) for r in range(2)]
+    [p.start() for p in procs]
+    worst, exact = q.get(timeout=180)
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert worst <= 2.0 and exact > 0.5, (worst, exact)

@@ -41,6 +41,15 @@ class EngineConfig(C.Structure):
 MISSING = []
 
 
+class StepMeta(C.Structure):
+    """vra_step_meta (include/vllm_rs_amd.h): host view of one scheduled step of a host-only engine."""
+    _fields_ = [("n_tokens", C.c_int32), ("n_seqs", C.c_int32), ("max_blocks", C.c_int32), ("max_seqlen_q", C.c_int32),
+                ("max_context_len", C.c_int32), ("input_ids", C.POINTER(C.c_uint32)), ("positions", C.POINTER(C.c_int64)),
+                ("slot_mapping", C.POINTER(C.c_int64)), ("block_tables", C.POINTER(C.c_uint32)),
+                ("context_lens", C.POINTER(C.c_uint32)), ("cu_seqlens_q", C.POINTER(C.c_uint32)),
+                ("request_ids", C.c_int64 * 64)]
+
+
 def _sig(lib, name, restype, *argtypes):
     try:
         fn = getattr(lib, name)
@@ -147,6 +156,12 @@ def load():
     _sig(lib, "vra_bm_seq_block_table", c_i32, P, c_i64, P, c_i32)
     _sig(lib, "vra_bm_prefix_cached_blocks", c_i32, P)
     _sig(lib, "vra_bm_evict_prefix", c_i32, P, c_i32)
+    _sig(lib, "vra_pc_create", P, c_i32, c_i32)
+    _sig(lib, "vra_pc_destroy", None, P)
+    _sig(lib, "vra_pc_insert_prefix", c_i32, P, P, c_i32, P, c_i32, P, c_i32, P)
+    _sig(lib, "vra_pc_match_prefix", c_i32, P, P, c_i32, P, c_i32)
+    _sig(lib, "vra_pc_cached_blocks", c_i32, P)
+    _sig(lib, "vra_pc_evict_blocks", c_i32, P, c_i32, P, c_i32)
     _sig(lib, "vra_engine_create", P, MC, EC)
     _sig(lib, "vra_engine_destroy", None, P)
     _sig(lib, "vra_engine_init_synthetic", c_i32, P)
@@ -155,6 +170,8 @@ def load():
     _sig(lib, "vra_engine_num_gpu_blocks", c_i32, P)
     _sig(lib, "vra_engine_add_request", c_i64, P, P, c_i32, c_i32, c_i32, P, c_i32)
     _sig(lib, "vra_engine_step", c_i32, P, P)
+    _sig(lib, "vra_engine_dry_schedule", c_i32, P, P, P)
+    _sig(lib, "vra_engine_dry_commit", c_i32, P, P, c_i32)
     _sig(lib, "vra_engine_has_unfinished", c_i32, P)
     _sig(lib, "vra_engine_request_finished", c_i32, P, c_i64)
     _sig(lib, "vra_engine_request_output", c_i32, P, c_i64, P, c_i32)

@@ -162,3 +162,74 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+
+class HostEngine:
+    """Host-only engine (vra_engine_config.device = -1): the native scheduler, block manager, prefix cache
+    and metadata staging of the real engine with the forward pass replaced by caller-supplied tokens.
+    Needs no GPU; used by the CPU parity tests of scheduler.rs / block_manager.rs / runner.rs behaviour."""
+
+    def __init__(self, cfg, *, num_gpu_blocks, block_size=64, max_num_seqs=32, max_model_len=0, prefill_chunk=8192,
+                 enable_prefix_cache=False):
+        self.L = _lib.load()
+        self.mc = model_config(cfg)
+        self.ec = EngineConfig(block_size=block_size, max_num_seqs=max_num_seqs, max_model_len=max_model_len,
+                               num_gpu_blocks=num_gpu_blocks, kv_fraction=0.0, prefill_chunk=prefill_chunk,
+                               enable_prefix_cache=int(enable_prefix_cache), prefix_cache_fraction=0.65, use_graph=0,
+                               tp_rank=0, tp_world_size=1, device=-1, seed=0)
+        self.h = self.L.vra_engine_create(C.byref(self.mc), C.byref(self.ec))
+        if not self.h or self.L.vra_engine_finalize_weights(self.h) != 0:
+            raise RuntimeError("host engine: " + (self.L.vra_engine_last_error(self.h).decode() if self.h else "create failed"))
+
+    def add_request(self, prompt, max_tokens=16, ignore_eos=False, eos=()):
+        p = np.ascontiguousarray(prompt, dtype=np.uint32)
+        e = np.ascontiguousarray(list(eos), dtype=np.uint32)
+        rid = self.L.vra_engine_add_request(self.h, p.ctypes.data, len(p), max_tokens, int(ignore_eos),
+                                            e.ctypes.data if len(e) else None, len(e))
+        if rid < 0:
+            raise RuntimeError(self.L.vra_engine_last_error(self.h).decode())
+        return rid
+
+    def schedule(self):
+        """-> None when idle, else dict(is_prefill, ids, positions, slots, block_tables, context_lens, cu_q, requests)."""
+        m = _lib.StepMeta()
+        pf = C.c_int32(0)
+        n = self.L.vra_engine_dry_schedule(self.h, C.byref(pf), C.byref(m))
+        if n < 0:
+            raise RuntimeError(self.L.vra_engine_last_error(self.h).decode())
+        if n == 0:
+            return None
+        T, B, MB = m.n_tokens, m.n_seqs, m.max_blocks
+        arr = lambda ptr, k: np.ctypeslib.as_array(ptr, shape=(k,)).copy()
+        return dict(is_prefill=bool(pf.value), n_tokens=T, n_seqs=B, max_blocks=MB, max_seqlen_q=m.max_seqlen_q,
+                    max_context_len=m.max_context_len, ids=arr(m.input_ids, T), positions=arr(m.positions, T),
+                    slots=arr(m.slot_mapping, T), block_tables=arr(m.block_tables, B * MB).reshape(B, MB),
+                    context_lens=arr(m.context_lens, B), cu_q=arr(m.cu_seqlens_q, B + 1) if pf.value else None,
+                    requests=[int(m.request_ids[i]) for i in range(min(B, 64))])
+
+    def commit(self, tokens):
+        t = np.ascontiguousarray(tokens, dtype=np.uint32)
+        if self.L.vra_engine_dry_commit(self.h, t.ctypes.data, len(t)) < 0:
+            raise RuntimeError(self.L.vra_engine_last_error(self.h).decode())
+
+    def has_unfinished(self):
+        return bool(self.L.vra_engine_has_unfinished(self.h))
+
+    def finished(self, rid):
+        return bool(self.L.vra_engine_request_finished(self.h, rid))
+
+    def output(self, rid, cap=65536):
+        buf = np.zeros(cap, np.uint32)
+        n = self.L.vra_engine_request_output(self.h, rid, buf.ctypes.data, cap)
+        return buf[:max(n, 0)].tolist()
+
+    def close(self):
+        if self.h:
+            self.L.vra_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

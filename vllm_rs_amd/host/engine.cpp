@@ -29,6 +29,10 @@ class Engine {
     if (ec_.prefill_chunk <= 0) ec_.prefill_chunk = 8192;
   }
   ~Engine() {
+    if (ec_.device < 0) {  // host-only engine: nothing was allocated through HIP
+      free(h_meta_);
+      return;
+    }
     for (auto& g : graphs_) (void)hipGraphExecDestroy(g.second);
     if (h_meta_) (void)hipHostFree(h_meta_);
     if (d_meta_) (void)hipFree(d_meta_);
@@ -62,24 +66,26 @@ class Engine {
     return false;
   }
 
-  bool finalize() {
-    if (hipSetDevice(ec_.device) != hipSuccess) return fail("hipSetDevice failed");
-    if (!stream_ && hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) != hipSuccess) return fail("stream create failed");
-    // ---- KV cache sizing (KVCacheAllocator, kvcache_allocator.rs:564-707)
-    size_t free_b = 0, total_b = 0;
-    (void)hipMemGetInfo(&free_b, &total_b);
+  // host-only engine (device = -1): scheduler, block manager and metadata staging exactly as in the real
+  // engine, the forward pass replaced by caller-supplied tokens (vra_engine_dry_schedule / _dry_commit)
+  bool dry() const { return ec_.device < 0; }
+  std::vector<int> pend_ids_;
+  bool pend_prefill_ = false, pend_valid_ = false;
+  InputMetadata pend_md_;
+  bool finalize_dry() {
+    if (ec_.num_gpu_blocks < 2) return fail("dry engine needs an explicit num_gpu_blocks");
     max_model_len_ = ec_.max_model_len > 0 ? ec_.max_model_len : mc_.max_position_embeddings;
     if (max_model_len_ > mc_.max_position_embeddings) max_model_len_ = mc_.max_position_embeddings;
     max_seqs_ = ec_.max_num_seqs > 0 ? ec_.max_num_seqs : 32;
     max_step_tokens_ = std::max(ec_.prefill_chunk, 2048);
     max_step_tokens_ = std::min(max_step_tokens_, 16384);
-    // reserve activations first, then give kv_fraction of what is left to the cache
-    if (!model_.init_buffers(std::max(max_step_tokens_, max_seqs_), max_seqs_)) return fail("activation buffers: " + model_.error);
-    (void)hipMemGetInfo(&free_b, &total_b);
-    int64_t nb = vra_kv_plan_num_blocks(&mc_, &ec_, (int64_t)free_b);
-    if (nb < 2) return fail("not enough memory for the KV cache");
-    if (nb > (1 << 24)) nb = 1 << 24;
-    if (!model_.init_kv_cache((int)nb)) return fail("kv cache: " + model_.error);
+    const int64_t nb = ec_.num_gpu_blocks;
+    setup_host(nb);
+    h_meta_ = (unsigned char*)calloc(1, meta_bytes_);
+    d_meta_ = h_meta_;  // bind() hands out pointers into the (host) staging buffer
+    return h_meta_ != nullptr;
+  }
+  void setup_host(int64_t nb) {
     max_blocks_per_seq_ = (max_model_len_ + ec_.block_size - 1) / ec_.block_size;
     bm_.reset(new BlockManager((int)nb, ec_.block_size, ec_.enable_prefix_cache != 0, ec_.prefix_cache_fraction));
     SchedulerConfig sc;
@@ -102,6 +108,29 @@ class Engine {
     off_cuq_ = o, o += al((B + 1) * 4);
     off_last_ = o, o += al(B * 4);
     meta_bytes_ = o;
+  }
+
+  bool finalize() {
+    if (dry()) return finalize_dry();
+    if (hipSetDevice(ec_.device) != hipSuccess) return fail("hipSetDevice failed");
+    if (!stream_ && hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) != hipSuccess) return fail("stream create failed");
+    // ---- KV cache sizing (KVCacheAllocator, kvcache_allocator.rs:564-707)
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    max_model_len_ = ec_.max_model_len > 0 ? ec_.max_model_len : mc_.max_position_embeddings;
+    if (max_model_len_ > mc_.max_position_embeddings) max_model_len_ = mc_.max_position_embeddings;
+    max_seqs_ = ec_.max_num_seqs > 0 ? ec_.max_num_seqs : 32;
+    max_step_tokens_ = std::max(ec_.prefill_chunk, 2048);
+    max_step_tokens_ = std::min(max_step_tokens_, 16384);
+    // reserve activations first, then give kv_fraction of what is left to the cache
+    if (!model_.init_buffers(std::max(max_step_tokens_, max_seqs_), max_seqs_)) return fail("activation buffers: " + model_.error);
+    (void)hipMemGetInfo(&free_b, &total_b);
+    int64_t nb = vra_kv_plan_num_blocks(&mc_, &ec_, (int64_t)free_b);
+    if (nb < 2) return fail("not enough memory for the KV cache");
+    if (nb > (1 << 24)) nb = 1 << 24;
+    if (!model_.init_kv_cache((int)nb)) return fail("kv cache: " + model_.error);
+    setup_host(nb);
+    const size_t B = max_seqs_;
     if (hipHostMalloc((void**)&h_meta_, meta_bytes_, hipHostMallocDefault) != hipSuccess) return fail("pinned alloc failed");
     if (hipMalloc((void**)&d_meta_, meta_bytes_) != hipSuccess) return fail("meta alloc failed");
     if (hipMalloc((void**)&d_tokens_, B * 4) != hipSuccess) return fail("token alloc failed");
@@ -278,8 +307,55 @@ class Engine {
     return true;
   }
 
+  // ---- dry engine: the two halves of step() around the (absent) forward pass
+  int dry_schedule(int* is_prefill_out) {
+    pend_valid_ = false;
+    bool is_prefill = false;
+    pend_ids_ = sched_->schedule(&is_prefill);
+    pend_prefill_ = is_prefill;
+    if (is_prefill_out) *is_prefill_out = is_prefill ? 1 : 0;
+    if (pend_ids_.empty()) {
+      if (sched_->has_unfinished()) {
+        sched_->abort_one(now_ms());
+        collect();
+      }
+      return 0;
+    }
+    int nb = 0;
+    pend_md_ = is_prefill ? prepare_prefill(pend_ids_, &nb) : prepare_decode(pend_ids_, (int)pend_ids_.size());
+    pend_valid_ = true;
+    return (int)pend_ids_.size();
+  }
+  int dry_commit(const uint32_t* toks, int n) {
+    if (!pend_valid_ || n != (int)pend_ids_.size()) {
+      fail("dry_commit: no pending step or wrong token count");
+      return -1;
+    }
+    pend_valid_ = false;
+    std::vector<uint32_t> tokens(toks, toks + n);
+    finish_step(pend_ids_, pend_prefill_, tokens);
+    return n;
+  }
+  void finish_step(const std::vector<int>& ids, bool is_prefill, const std::vector<uint32_t>& tokens) {
+    const double now = now_ms();
+    if (is_prefill) {
+      std::vector<int> keep, ridx;
+      sched_->filter_prefill_finished(ids, &keep, &ridx);  // only fully-prefilled prompts keep their token (engine.rs:906-916)
+      std::vector<uint32_t> kept;
+      for (int p : keep) kept.push_back(tokens[p]);
+      sched_->postprocess(ridx, kept, now);
+    } else {
+      sched_->postprocess(ids, tokens, now);
+    }
+    collect();
+  }
+
   // ---- one engine step (engine.rs:1693-1757)
   int step(int* is_prefill_out) {
+    if (dry()) {
+      fail("step() on a host-only engine: use vra_engine_dry_schedule / vra_engine_dry_commit");
+      return -1;
+    }
     bool is_prefill = false;
     std::vector<int> ids = sched_->schedule(&is_prefill);
     if (is_prefill_out) *is_prefill_out = is_prefill ? 1 : 0;
@@ -292,17 +368,7 @@ class Engine {
     }
     std::vector<uint32_t> tokens;
     if (!run(ids, is_prefill, &tokens)) return -1;
-    const double now = now_ms();
-    if (is_prefill) {
-      std::vector<int> keep, ridx;
-      sched_->filter_prefill_finished(ids, &keep, &ridx);  // only fully-prefilled prompts keep their token (engine.rs:906-916)
-      std::vector<uint32_t> kept;
-      for (int p : keep) kept.push_back(tokens[p]);
-      sched_->postprocess(ridx, kept, now);
-    } else {
-      sched_->postprocess(ids, tokens, now);
-    }
-    collect();
+    finish_step(ids, is_prefill, tokens);
     return (int)ids.size();
   }
   void collect() {
@@ -396,12 +462,39 @@ extern "C" int32_t vra_bm_seq_block_table(const void* bm, int64_t seq, uint32_t*
 extern "C" int32_t vra_bm_prefix_cached_blocks(const void* bm) { return static_cast<const BmHandle*>(bm)->bm.prefix_cache_blocks(); }
 extern "C" int32_t vra_bm_evict_prefix(void* bm, int32_t n) { return static_cast<BmHandle*>(bm)->bm.evict_prefix_cache(n); }
 
+// ---- prefix cache on its own (the reference's unit tests, prefix_cache.rs:362-403, drive it directly)
+extern "C" void* vra_pc_create(int32_t block_size, int32_t max_cached_blocks) { return new vra::PrefixCache(block_size, true, max_cached_blocks); }
+extern "C" void vra_pc_destroy(void* pc) { delete static_cast<vra::PrefixCache*>(pc); }
+extern "C" int32_t vra_pc_insert_prefix(void* pc, const uint32_t* h_tokens, int32_t n_tokens, const int32_t* h_blocks, int32_t n_blocks,
+                                        int32_t* h_evicted, int32_t cap, int32_t* h_n_evicted) {
+  std::vector<int> blocks(h_blocks, h_blocks + n_blocks);
+  auto up = static_cast<vra::PrefixCache*>(pc)->insert_prefix(h_tokens, n_tokens, blocks);
+  for (int i = 0; i < (int)up.evicted.size() && i < cap; i++) h_evicted[i] = up.evicted[i];
+  if (h_n_evicted) *h_n_evicted = (int)up.evicted.size();
+  return (int)up.inserted.size();
+}
+extern "C" int32_t vra_pc_match_prefix(void* pc, const uint32_t* h_tokens, int32_t n_tokens, int32_t* h_blocks, int32_t cap) {
+  auto* c = static_cast<vra::PrefixCache*>(pc);
+  auto m = c->match_prefix(h_tokens, n_tokens);
+  if (m.has_hash && h_blocks) {
+    auto b = c->blocks_for_match(m.last_hash);
+    for (int i = 0; i < (int)b.size() && i < cap; i++) h_blocks[i] = b[i];
+  }
+  return m.matched_blocks;
+}
+extern "C" int32_t vra_pc_cached_blocks(const void* pc) { return static_cast<const vra::PrefixCache*>(pc)->cached_blocks(); }
+extern "C" int32_t vra_pc_evict_blocks(void* pc, int32_t n, int32_t* h_evicted, int32_t cap) {
+  auto ev = static_cast<vra::PrefixCache*>(pc)->evict_blocks(n);
+  for (int i = 0; i < (int)ev.size() && i < cap; i++) h_evicted[i] = ev[i];
+  return (int)ev.size();
+}
+
 // ================================================================================================
 // C API — engine
 // ================================================================================================
 extern "C" void* vra_engine_create(const vra_model_config* mc, const vra_engine_config* ec) {
   if (!mc || !ec) return nullptr;
-  if (hipSetDevice(ec->device) != hipSuccess) return nullptr;
+  if (ec->device >= 0 && hipSetDevice(ec->device) != hipSuccess) return nullptr;
   return new Engine(*mc, *ec);
 }
 extern "C" void vra_engine_destroy(void* e) { delete static_cast<Engine*>(e); }
@@ -430,6 +523,7 @@ extern "C" int32_t vra_engine_set_comm(void* e, void* comm) {
 }
 extern "C" int32_t vra_engine_finalize_weights(void* e) {
   auto* en = static_cast<Engine*>(e);
+  if (en->dry()) return en->finalize() ? 0 : -1;
   if (en->model_.weight_bytes() == 0 || true) {
     // explicit tensors: repack now (synthetic init has already finalised; finalize is idempotent)
     if (!en->model_.finalize_weights()) {
@@ -457,6 +551,34 @@ extern "C" int64_t vra_engine_add_request(void* e, const uint32_t* h_prompt, int
   return id;
 }
 extern "C" int32_t vra_engine_step(void* e, int32_t* h_is_prefill) { return static_cast<Engine*>(e)->step(h_is_prefill); }
+extern "C" int32_t vra_engine_dry_schedule(void* e, int32_t* h_is_prefill, vra_step_meta* out) {
+  auto* en = static_cast<Engine*>(e);
+  if (!en->dry() || !en->sched_) {
+    en->error = "vra_engine_dry_schedule: not a finalised host-only engine (device = -1)";
+    return -1;
+  }
+  const int n = en->dry_schedule(h_is_prefill);
+  if (out) {
+    memset(out, 0, sizeof(*out));
+    if (n > 0) {
+      const vra::InputMetadata& md = en->pend_md_;
+      out->n_tokens = md.n_tokens;
+      out->n_seqs = md.n_seqs;
+      out->max_blocks = md.max_blocks;
+      out->max_seqlen_q = md.max_seqlen_q;
+      out->max_context_len = md.max_context_len;
+      out->input_ids = md.input_ids;
+      out->positions = md.positions;
+      out->slot_mapping = md.slot_mapping;
+      out->block_tables = md.block_tables;
+      out->context_lens = md.context_lens;
+      out->cu_seqlens_q = md.cu_seqlens_q;
+      for (int i = 0; i < n && i < 64; i++) out->request_ids[i] = en->sched_->running()[en->pend_ids_[i]].id;
+    }
+  }
+  return n;
+}
+extern "C" int32_t vra_engine_dry_commit(void* e, const uint32_t* h_tokens, int32_t n) { return static_cast<Engine*>(e)->dry_commit(h_tokens, n); }
 extern "C" int32_t vra_engine_has_unfinished(const void* e) {
   auto* en = static_cast<const Engine*>(e);
   return en->sched_ && en->sched_->has_unfinished() ? 1 : 0;
