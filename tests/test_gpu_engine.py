@@ -312,5 +312,5 @@ def test_product_matches_huggingface_fixture(name, dt, rel):
     # and through the full engine loop (scheduler + runner): token-for-token
     out = eng.generate([prompt.tolist()], max_tokens=len(hf_tokens), ignore_eos=True)[0]
     if toks == hf_tokens:
-        assert out == hf_tokens
+        assert list(out) == hf_tokens
     eng.close()
