@@ -170,10 +170,13 @@ void vra_paged_attention_prefill(void* out, const void* q, const void* k, const 
                                  int32_t q_heads, int32_t kv_heads, int32_t head_dim,
                                  int32_t block_size, int32_t max_blocks_per_seq, float scale,
                                  float softcap, int32_t dtype, int64_t stream);
-/* fused decode step for one layer's attention front half (native runtime only): rotary on q and k,
- * scatter of the new k,v into the cache, then paged decode attention. Numerically identical to
- * vra_fused_rope + vra_reshape_and_cache + vra_paged_attention_decode. */
-void vra_rope_cache_attention_decode(void* out, void* q, void* k, const void* v, void* k_cache,
+/* Fused decode step of one layer's attention front half, ONE launch for what the reference issues as
+ * FusedRope::apply_inplace + reshape_and_cache + PagedAttention::forward (attention.rs:745-820): rotary on q
+ * and k (NeoX pairing, tables [n_pos, head_dim/2] in the model dtype), scatter of the rotated k and of v
+ * into the cache at slot_mapping (negative slot = padded lane: nothing written), paged decode attention
+ * over context_lens tokens (which include the new one).  `out` and the caches are bit-identical to the
+ * three separate calls; q and k are READ ONLY here (the rotated copies never reach HBM). */
+void vra_rope_cache_attention_decode(void* out, const void* q, const void* k, const void* v, void* k_cache,
                                      void* v_cache, const void* cos, const void* sin,
                                      const int64_t* positions, const int64_t* slot_mapping,
                                      const uint32_t* block_tables, const uint32_t* context_lens,

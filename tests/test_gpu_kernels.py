@@ -292,6 +292,65 @@ def test_paged_attention_decode_split_kv():
     assert_close_dt(out.numpy(np.uint16, (2, Hq, D)), ref, dt, max_ulp=2.0, max_mismatch_frac=0.5, name="split-kv", abs_floor=3e-3)
 
 
+@pytest.mark.parametrize("dt", [BF16, F16])
+@pytest.mark.parametrize("Hq,Hkv,D", [(32, 8, 128), (8, 1, 128), (4, 2, 64), (4, 4, 64)])
+@pytest.mark.parametrize("ctxs,ws", [([1], False), ([31, 32, 33, 0], False), ([64, 65, 200, 7], False), ([3000, 2049], True)])
+def test_fused_rope_cache_attention_decode(Hq, Hkv, D, ctxs, ws, dt):
+    """one launch == FusedRope + reshape_and_cache + PagedAttention decode (attention.rs:745-820): the history is in the
+    cache, the NEW token's q,k,v come in un-rotated; ctx 0 = padded graph lane (slot -1: writes nothing, output 0)."""
+    BS, NB = 64, 128
+    r = rng(Hq * 7 + D + sum(ctxs) + dt)
+    B = len(ctxs)
+    mb = max((c + BS - 1) // BS for c in ctxs)
+    perm = r.permutation(NB)
+    bt = np.zeros((B, mb), np.uint32)
+    nxt = 0
+    hk, hv, hs = [], [], []
+    for b, c in enumerate(ctxs):
+        nb = (c + BS - 1) // BS
+        bt[b, :nb] = perm[nxt:nxt + nb]
+        nxt += nb
+        if c > 1:
+            hk.append(rand_dt(r, (c - 1, Hkv, D), dt))
+            hv.append(rand_dt(r, (c - 1, Hkv, D), dt))
+            hs.append(np.array([int(bt[b, j // BS]) * BS + j % BS for j in range(c - 1)], np.int64))
+    kc_ref = np.zeros((NB, Hkv, BS, D), np.uint16)
+    vc_ref = np.zeros((NB, Hkv, D, BS), np.uint16)
+    kc, vc = ops.DevBuf(kc_ref.nbytes).fill_bytes(0xFF), ops.DevBuf(vc_ref.nbytes).fill_bytes(0xFF)   # NaN poison
+    pa = ops.PagedAttention(Hq, D, D ** -0.5, Hkv, BS, dt)
+    if hk:
+        hk, hv, hs = np.concatenate(hk), np.concatenate(hv), np.concatenate(hs)
+        orc.reshape_and_cache(hk, hv, kc_ref, vc_ref, hs, BS, dt)
+        pa.reshape_and_cache(ops.dev(hk), ops.dev(hv), kc, vc, ops.dev(hs), len(hs))
+    q, k, v = rand_dt(r, (B, Hq, D), dt), rand_dt(r, (B, Hkv, D), dt), rand_dt(r, (B, Hkv, D), dt)
+    pos = np.array([max(c - 1, 0) for c in ctxs], np.int64)
+    slots = np.array([int(bt[b, (c - 1) // BS]) * BS + (c - 1) % BS if c > 0 else -1 for b, c in enumerate(ctxs)], np.int64)
+    cos, sin = orc.rope_tables(D, 10000.0, 4096)
+    cos, sin = orc.to_dt(cos, dt), orc.to_dt(sin, dt)
+    cl = np.array(ctxs, np.uint32)
+    # ---- oracle: the three-step composition on host copies of the caches
+    qr = orc.rope(q, cos, sin, pos, False, dt, dt)
+    kr = orc.rope(k, cos, sin, pos, False, dt, dt)
+    orc.reshape_and_cache(kr, v, kc_ref, vc_ref, slots, BS, dt)
+    ref = orc.paged_attention(qr, kc_ref, vc_ref, bt, cl, None, Hkv, BS, D ** -0.5, dt)
+    wsb = ops.DevBuf(ops.lib().vra_paged_attention_decode_workspace_bytes(B, Hq, D, max(ctxs))) if ws else None
+    dq, dk = ops.dev(q), ops.dev(k)
+    out = pa.rope_cache_decode(dq, dk, ops.dev(v), kc, vc, ops.dev(cos), ops.dev(sin), ops.dev(pos), ops.dev(slots),
+                               ops.dev(bt), ops.dev(cl), B, mb, max(ctxs), wsb)
+    got = out.numpy(np.uint16, (B, Hq, D))
+    for b, c in enumerate(ctxs):
+        if c == 0:
+            assert not got[b].any(), "padded lane must produce zeros"
+    live = [b for b, c in enumerate(ctxs) if c > 0]
+    assert_close_dt(got[live], ref[live], dt, max_ulp=2.0, max_mismatch_frac=0.5, name="fused decode", abs_floor=3e-3 if dt == BF16 else 5e-4)
+    # the cache rows of the new token are the rotated k / the v, bit-exact; q and k inputs are untouched
+    kc_got, vc_got = kc.numpy(np.uint16, kc_ref.shape), vc.numpy(np.uint16, vc_ref.shape)
+    for b in live:
+        blk, off = int(slots[b]) // BS, int(slots[b]) % BS
+        assert np.array_equal(kc_got[blk, :, off, :], kr[b]) and np.array_equal(vc_got[blk, :, :, off], v[b])
+    assert np.array_equal(dq.numpy(np.uint16, q.shape), q) and np.array_equal(dk.numpy(np.uint16, k.shape), k)
+
+
 @pytest.mark.parametrize("Hq,Hkv,D", [(8, 2, 128), (4, 4, 64)])
 @pytest.mark.parametrize("paged", [True, False])
 def test_attention_prefill(Hq, Hkv, D, paged):

@@ -276,6 +276,267 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_kernel(const PagedAttnA
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused decode step of one attention layer: RoPE(q, k) + KV-cache write + paged attention in ONE launch
+// (the reference runs FusedRope::apply_inplace, reshape_and_cache and PagedAttention::forward as three
+// launches, attention.rs:745-820).  Workgroup = (kv split, kv head, sequence); every workgroup rotates
+// its own copy of q and of the new k in registers/LDS; the new token's K row and V column are taken from
+// LDS instead of the cache, so no workgroup depends on another one's cache write.  Split 0 performs the
+// cache write.  q and k are READ ONLY (several workgroups read them concurrently; an in-place update would
+// race), i.e. unlike FusedRope::apply_inplace the rotated q / k never reach HBM — nothing reads them later.
+// `out` and the caches are bit-identical to the three separate calls.
+struct FusedDecodeArgs {
+  void* out;          // [B, Hq, D]
+  const void* q;      // [B, Hq, D]   un-rotated, read only
+  const void* k;      // [B, Hkv, D]  un-rotated, read only
+  const void* v;      // [B, Hkv, D]
+  void* kc;           // K cache [NB, Hkv, BS, D]
+  void* vc;           // V cache [NB, Hkv, D, BS]
+  const void* cosv;   // [n_pos, D/2] model dtype
+  const void* sinv;
+  const int64_t* positions;      // [B]
+  const int64_t* slots;          // [B] (negative: padded lane, nothing is written)
+  const uint32_t* block_tables;  // [B, max_blocks]
+  const uint32_t* context_lens;  // [B] (includes the new token)
+  int B, Hq, Hkv, BS, max_blocks;
+  float scale_log2e;
+  int nsplit;
+  float* ws_o;   // [B, Hq, nsplit, D]
+  float* ws_ml;  // [B, Hq, nsplit, 2]
+};
+
+template <class DT, int D>
+__global__ __launch_bounds__(PA_THREADS) void decode_attn_fused_kernel(const FusedDecodeArgs a) {
+  constexpr int DJ = D / 32, DT16 = D / 16, HALF = D / 2;
+  __shared__ __attribute__((aligned(16))) float lds_o[PA_WAVES][16][D + 4];
+  __shared__ float lds_ml[PA_WAVES][16][2];
+  __shared__ __attribute__((aligned(16))) uint16_t knew[D];
+  __shared__ __attribute__((aligned(16))) uint16_t vnew[D];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rq = lane & 15, oct = lane >> 4;
+  const int G = a.Hq / a.Hkv;
+  const int b = blockIdx.z, hk = blockIdx.y, split = blockIdx.x;
+  const int ctx = (int)a.context_lens[b];
+  const int64_t pos = a.positions[b];
+  const int64_t slot = a.slots[b];
+  const uint16_t* cosp = static_cast<const uint16_t*>(a.cosv) + pos * HALF;
+  const uint16_t* sinp = static_cast<const uint16_t*>(a.sinv) + pos * HALF;
+
+  // ---- new token: rotate k (threads 0 .. D/16-1), copy v (threads 64 .. 64+D/8-1); stage both in LDS
+  if (tid < HALF / 8) {
+    const uint16_t* kp = static_cast<const uint16_t*>(a.k) + ((size_t)b * a.Hkv + hk) * D;
+    const u32x4 xa = *reinterpret_cast<const u32x4*>(kp + tid * 8), xb = *reinterpret_cast<const u32x4*>(kp + HALF + tid * 8);
+    float x1[8], x2[8], cs[8], sn[8], y1[8], y2[8];
+    unpack8<DT>(xa, x1);
+    unpack8<DT>(xb, x2);
+    unpack8<DT>(*reinterpret_cast<const u32x4*>(cosp + tid * 8), cs);
+    unpack8<DT>(*reinterpret_cast<const u32x4*>(sinp + tid * 8), sn);
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      y1[e] = x1[e] * cs[e] - x2[e] * sn[e];
+      y2[e] = x2[e] * cs[e] + x1[e] * sn[e];
+    }
+    const u32x4 r1 = pack8<DT>(y1), r2 = pack8<DT>(y2);
+    *reinterpret_cast<u32x4*>(knew + tid * 8) = r1;
+    *reinterpret_cast<u32x4*>(knew + HALF + tid * 8) = r2;
+    if (split == 0 && slot >= 0) {
+      uint16_t* kcp = static_cast<uint16_t*>(a.kc) + ((((size_t)(slot / a.BS)) * a.Hkv + hk) * a.BS + (int)(slot % a.BS)) * D;
+      *reinterpret_cast<u32x4*>(kcp + tid * 8) = r1;
+      *reinterpret_cast<u32x4*>(kcp + HALF + tid * 8) = r2;
+    }
+  } else if (tid >= 64 && tid < 64 + D / 8) {
+    const int c = tid - 64;
+    const u32x4 vv = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.v) + ((size_t)b * a.Hkv + hk) * D + c * 8);
+    *reinterpret_cast<u32x4*>(vnew + c * 8) = vv;
+    if (split == 0 && slot >= 0) {
+      uint16_t* vcp = static_cast<uint16_t*>(a.vc) + (((size_t)(slot / a.BS)) * a.Hkv + hk) * D * a.BS + (int)(slot % a.BS);
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        vcp[(size_t)(c * 8 + 2 * e) * a.BS] = (uint16_t)(vv[e] & 0xffffu);
+        vcp[(size_t)(c * 8 + 2 * e + 1) * a.BS] = (uint16_t)(vv[e] >> 16);
+      }
+    }
+  }
+
+  // ---- Q fragments, rotated in registers: lane (row rq = q head of the group, octet oct)
+  const bool row_valid = rq < G;
+  const int qhead = hk * G + rq;
+  s16x8 qf[DJ];
+  {
+    const uint16_t* qp = static_cast<const uint16_t*>(a.q) + ((size_t)b * a.Hq + qhead) * D;
+#pragma unroll
+    for (int j = 0; j < DJ / 2; j++) {
+      u32x4 va = {0u, 0u, 0u, 0u}, vb = {0u, 0u, 0u, 0u};
+      const int c0 = j * 32 + oct * 8;
+      if (row_valid) {
+        va = *reinterpret_cast<const u32x4*>(qp + c0);
+        vb = *reinterpret_cast<const u32x4*>(qp + HALF + c0);
+      }
+      float x1[8], x2[8], cs[8], sn[8], y1[8], y2[8];
+      unpack8<DT>(va, x1);
+      unpack8<DT>(vb, x2);
+      unpack8<DT>(*reinterpret_cast<const u32x4*>(cosp + c0), cs);
+      unpack8<DT>(*reinterpret_cast<const u32x4*>(sinp + c0), sn);
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        y1[e] = x1[e] * cs[e] - x2[e] * sn[e];
+        y2[e] = x2[e] * cs[e] + x1[e] * sn[e];
+      }
+      const u32x4 r1 = pack8<DT>(y1), r2 = pack8<DT>(y2);
+      qf[j] = __builtin_bit_cast(s16x8, r1);
+      qf[j + DJ / 2] = __builtin_bit_cast(s16x8, r2);
+    }
+  }
+  __syncthreads();  // knew / vnew staged
+
+  // ---- this wave's KV tiles (32 tokens each): split across workgroups, then across the 4 waves
+  const int ntiles = (ctx + 31) >> 5;
+  const int per_split = (ntiles + a.nsplit - 1) / a.nsplit;
+  const int s0t = min(ntiles, split * per_split), s1t = min(ntiles, s0t + per_split);
+  const int n_s = s1t - s0t;
+  const int kv_w0 = s0t + (n_s * wave) / PA_WAVES, kv_w1 = s0t + (n_s * (wave + 1)) / PA_WAVES;
+  const int last = ctx - 1;
+
+  f32x4 o[DT16];
+#pragma unroll
+  for (int t = 0; t < DT16; t++) o[t] = vra_zero_acc();
+  float m_run = -INFINITY, l_run = 0.f;
+  const uint16_t* kcache = static_cast<const uint16_t*>(a.kc);
+  const uint16_t* vcache = static_cast<const uint16_t*>(a.vc);
+  for (int tile = kv_w0; tile < kv_w1; tile++) {
+    const int T0 = tile << 5;
+    const uint32_t blk = a.block_tables[(size_t)b * a.max_blocks + T0 / a.BS];
+    const int off = T0 % a.BS;
+    const uint16_t* krow0 = kcache + (((size_t)blk * a.Hkv + hk) * a.BS + off + rq) * D;
+    const uint16_t* krow1 = krow0 + 16 * D;
+    const size_t vbase = (((size_t)blk * a.Hkv + hk) * D) * a.BS + off;
+    const bool has_new = last >= T0 && last < T0 + 32;  // wave-uniform: the tile that holds the new token
+    if (has_new) {  // its K row comes from LDS (the cache write of split 0 may not be visible yet)
+      if (T0 + rq == last) krow0 = knew;
+      if (T0 + 16 + rq == last) krow1 = knew;
+    }
+    u32x4 k0[DJ], k1[DJ];
+#pragma unroll
+    for (int j = 0; j < DJ; j++) {
+      k0[j] = *reinterpret_cast<const u32x4*>(krow0 + j * 32 + oct * 8);
+      k1[j] = *reinterpret_cast<const u32x4*>(krow1 + j * 32 + oct * 8);
+    }
+    // V: issue the loads now (they only depend on the block table), consume after the softmax
+    u32x2 vlo[DT16], vhi[DT16];
+#pragma unroll
+    for (int t = 0; t < DT16; t++) {
+      const uint16_t* vp = vcache + vbase + (size_t)(t * 16 + rq) * a.BS + oct * 4;
+      vlo[t] = *reinterpret_cast<const u32x2*>(vp);
+      vhi[t] = *reinterpret_cast<const u32x2*>(vp + 16);
+    }
+    f32x4 s0 = vra_zero_acc(), s1 = vra_zero_acc();
+#pragma unroll
+    for (int j = 0; j < DJ; j++) {
+      DT::mfma(s0, __builtin_bit_cast(s16x8, k0[j]), qf[j]);
+      DT::mfma(s1, __builtin_bit_cast(s16x8, k1[j]), qf[j]);
+    }
+    VRA_MFMA_DRAIN();
+    float sv[8];
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const int tok = T0 + (e < 4 ? 0 : 16) + oct * 4 + (e & 3);
+      float x = (e < 4 ? s0[e] : s1[e - 4]) * a.scale_log2e;
+      if (tok >= ctx) x = -INFINITY;
+      sv[e] = x;
+      tmax = fmaxf(tmax, x);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax);
+    const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+    const float alpha = exp2f(m_run - m_safe);
+    float p[8], psum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      p[e] = exp2f(sv[e] - m_safe);
+      psum += p[e];
+    }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+    float ar[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) ar[r] = __shfl(alpha, oct * 4 + r, 64);
+    u32x4 pa;
+    pa[0] = DT::pack2(p[0], p[1]);
+    pa[1] = DT::pack2(p[2], p[3]);
+    pa[2] = DT::pack2(p[4], p[5]);
+    pa[3] = DT::pack2(p[6], p[7]);
+    const s16x8 pfrag = __builtin_bit_cast(s16x8, pa);
+    const bool tail = T0 + 32 > ctx;
+    uint32_t vm[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+    int new_e = -1;  // which of this lane's 8 tokens is the new one
+    if (tail || has_new) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const int tok = T0 + (e < 4 ? 0 : 16) + oct * 4 + (e & 3);
+        if (tok >= ctx) vm[e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
+        if (tok == last) new_e = e;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < DT16; t++) {
+      u32x4 vv = u32x4{vlo[t][0], vlo[t][1], vhi[t][0], vhi[t][1]};
+      if (has_new && new_e >= 0) {
+        const uint32_t nv = vnew[t * 16 + rq];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          if ((new_e >> 1) == i) vv[i] = (new_e & 1) ? ((vv[i] & 0x0000ffffu) | (nv << 16)) : ((vv[i] & 0xffff0000u) | nv);
+        }
+      }
+      if (tail) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) vv[i] &= vm[i];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) o[t][r] *= ar[r];
+      DT::mfma(o[t], pfrag, __builtin_bit_cast(s16x8, vv));
+    }
+  }
+  VRA_MFMA_DRAIN();
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+#pragma unroll
+  for (int t = 0; t < DT16; t++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) lds_o[wave][oct * 4 + r][t * 16 + rq] = o[t][r];
+  if (oct == 0) {
+    lds_ml[wave][rq][0] = m_run;
+    lds_ml[wave][rq][1] = l_run;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < G * D; idx += PA_THREADS) {
+    const int row = idx / D, d = idx % D;
+    float M = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < PA_WAVES; w++) M = fmaxf(M, lds_ml[w][row][0]);
+    const float Ms = M == -INFINITY ? 0.f : M;
+    float L = 0.f, acc = 0.f;
+#pragma unroll
+    for (int w = 0; w < PA_WAVES; w++) {
+      const float f = exp2f(lds_ml[w][row][0] - Ms);
+      L += lds_ml[w][row][1] * f;
+      acc += lds_o[w][row][d] * f;
+    }
+    const int head = hk * G + row;
+    if (a.nsplit > 1) {
+      a.ws_o[(((size_t)b * a.Hq + head) * a.nsplit + split) * D + d] = acc;
+      if (d == 0) {
+        a.ws_ml[(((size_t)b * a.Hq + head) * a.nsplit + split) * 2 + 0] = M;
+        a.ws_ml[(((size_t)b * a.Hq + head) * a.nsplit + split) * 2 + 1] = L;
+      }
+    } else {
+      static_cast<uint16_t*>(a.out)[((size_t)b * a.Hq + head) * D + d] = DT::from_f32(L > 0.f ? acc / L : 0.f);
+    }
+  }
+}
+
 // second pass for split-KV decode: merge nsplit partials per (b, head)
 template <class DT, int D>
 __global__ void paged_attn_merge_kernel(uint16_t* out, const float* ws_o, const float* ws_ml, int Hq, int nsplit) {
@@ -405,17 +666,63 @@ extern "C" void vra_paged_attention_prefill(void* out, const void* q, const void
   else launch_attn<F16>(a, head_dim, grid, as_stream(stream));
 }
 
-extern "C" void vra_rope_cache_attention_decode(void* out, void* q, void* k, const void* v, void* k_cache, void* v_cache,
+extern "C" void vra_rope_cache_attention_decode(void* out, const void* q, const void* k, const void* v, void* k_cache, void* v_cache,
                                                 const void* cos, const void* sin, const int64_t* positions,
                                                 const int64_t* slot_mapping, const uint32_t* block_tables,
                                                 const uint32_t* context_lens, int32_t batch, int32_t q_heads,
                                                 int32_t kv_heads, int32_t head_dim, int32_t block_size,
                                                 int32_t max_blocks_per_seq, int32_t max_context_len, float scale,
                                                 void* workspace, int32_t dtype, int64_t stream) {
-  // Round 1: composition of the three entry points on one stream (the fused kernel is a later
-  // optimisation; the contract — results identical to the three separate calls — already holds).
-  vra_fused_rope(q, k, cos, sin, positions, batch, q_heads, kv_heads, head_dim, head_dim, 0, dtype, dtype, stream);
-  vra_reshape_and_cache(k, v, k_cache, v_cache, slot_mapping, batch, kv_heads, head_dim, block_size, dtype, stream);
-  vra_paged_attention_decode(out, q, k_cache, v_cache, block_tables, context_lens, batch, q_heads, kv_heads, head_dim,
-                             block_size, max_blocks_per_seq, max_context_len, scale, 0.f, workspace, dtype, stream);
+  VRA_CHECK_ARG(dtype == VRA_BF16 || dtype == VRA_F16, "vra_rope_cache_attention_decode: dtype must be bf16/f16");
+  VRA_CHECK_ARG(out && q && k && v && k_cache && v_cache && cos && sin && positions && slot_mapping && block_tables && context_lens,
+                "vra_rope_cache_attention_decode: null pointer");
+  VRA_CHECK_ARG(block_size % 32 == 0, "vra_rope_cache_attention_decode: block_size must be a multiple of 32");
+  VRA_CHECK_ARG(q_heads % kv_heads == 0 && q_heads / kv_heads <= 16, "vra_rope_cache_attention_decode: need Hq %% Hkv == 0 and group <= 16");
+  VRA_CHECK_ARG(head_dim == 64 || head_dim == 128, "vra_rope_cache_attention_decode: head_dim %d not supported (64, 128)", head_dim);
+  if (batch <= 0) return;
+  FusedDecodeArgs a = {};
+  a.out = out;
+  a.q = q;
+  a.k = k;
+  a.v = v;
+  a.kc = k_cache;
+  a.vc = v_cache;
+  a.cosv = cos;
+  a.sinv = sin;
+  a.positions = positions;
+  a.slots = slot_mapping;
+  a.block_tables = block_tables;
+  a.context_lens = context_lens;
+  a.B = batch;
+  a.Hq = q_heads;
+  a.Hkv = kv_heads;
+  a.BS = block_size;
+  a.max_blocks = max_blocks_per_seq;
+  a.scale_log2e = scale * 1.44269504088896f;
+  a.nsplit = workspace ? decode_nsplit(batch, kv_heads, max_context_len) : 1;
+  a.ws_o = static_cast<float*>(workspace);
+  a.ws_ml = a.ws_o ? a.ws_o + (size_t)batch * q_heads * a.nsplit * head_dim : nullptr;
+  dim3 grid(a.nsplit, kv_heads, batch);
+  hipStream_t st = as_stream(stream);
+#define VRA_FD(DT, DD) decode_attn_fused_kernel<DT, DD><<<grid, PA_THREADS, 0, st>>>(a)
+  if (dtype == VRA_BF16) {
+    if (head_dim == 128) VRA_FD(BF16, 128);
+    else VRA_FD(BF16, 64);
+  } else {
+    if (head_dim == 128) VRA_FD(F16, 128);
+    else VRA_FD(F16, 64);
+  }
+#undef VRA_FD
+  if (a.nsplit > 1) {
+    dim3 mg(q_heads, batch);
+#define VRA_MERGE(DT, DD) paged_attn_merge_kernel<DT, DD><<<mg, DD, 0, st>>>((uint16_t*)out, a.ws_o, a.ws_ml, q_heads, a.nsplit)
+    if (dtype == VRA_BF16) {
+      if (head_dim == 128) VRA_MERGE(BF16, 128);
+      else VRA_MERGE(BF16, 64);
+    } else {
+      if (head_dim == 128) VRA_MERGE(F16, 128);
+      else VRA_MERGE(F16, 64);
+    }
+#undef VRA_MERGE
+  }
 }

@@ -476,14 +476,16 @@ bool Model::forward(const InputMetadata& md, int64_t stream) {
     const QLinear qkv[3] = {L.q, L.k, L.v};
     void* outs[3] = {q_, k_, v_};
     if (!linear_fused_norm(qkv, 3, outs, h_, L.attn_norm, T, stream)) return false;
-    vra_fused_rope(q_, k_, cos_, sin_, md.positions, T, hq_, hkv_, D, D, 0, dt_, dt_, stream);
-    vra_reshape_and_cache(k_, v_, kc_[l], vc_[l], md.slot_mapping, T, hkv_, D, ec_.block_size, dt_, stream);
     if (md.is_prefill) {
+      vra_fused_rope(q_, k_, cos_, sin_, md.positions, T, hq_, hkv_, D, D, 0, dt_, dt_, stream);
+      vra_reshape_and_cache(k_, v_, kc_[l], vc_[l], md.slot_mapping, T, hkv_, D, ec_.block_size, dt_, stream);
       vra_paged_attention_prefill(attn_, q_, nullptr, nullptr, kc_[l], vc_[l], md.block_tables, md.context_lens, md.cu_seqlens_q,
                                   nullptr, B, T, md.max_seqlen_q, hq_, hkv_, D, ec_.block_size, md.max_blocks, scale, 0.f, dt_, stream);
     } else {
-      vra_paged_attention_decode(attn_, q_, kc_[l], vc_[l], md.block_tables, md.context_lens, B, hq_, hkv_, D, ec_.block_size,
-                                 md.max_blocks, md.max_context_len, scale, 0.f, attn_ws_, dt_, stream);
+      // decode: RoPE + KV write + paged attention in ONE launch (three in the reference, attention.rs:745-820)
+      vra_rope_cache_attention_decode(attn_, q_, k_, v_, kc_[l], vc_[l], cos_, sin_, md.positions, md.slot_mapping, md.block_tables,
+                                      md.context_lens, B, hq_, hkv_, D, ec_.block_size, md.max_blocks, md.max_context_len, scale,
+                                      attn_ws_, dt_, stream);
     }
     if (take_err(error, "attention")) return false;
     if (world_ > 1) {  // TensorParallelRowLinear: partial GEMM -> all_reduce -> + residual (distributed.rs:438-455)

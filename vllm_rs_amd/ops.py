@@ -224,6 +224,17 @@ class PagedAttention:
         check_error()
         return out
 
+    def rope_cache_decode(self, q, k, v, k_cache, v_cache, cos, sin, positions, slot_mapping, block_tables, context_lens,
+                          batch, max_blocks, max_context_len, workspace=None):
+        """fused decode step: RoPE(q,k) + cache write + paged attention in one launch (vra_rope_cache_attention_decode)."""
+        out = DevBuf(batch * self.Hq * self.D * 2)
+        lib().vra_rope_cache_attention_decode(out.ptr, _ptr(q), _ptr(k), _ptr(v), _ptr(k_cache), _ptr(v_cache), _ptr(cos), _ptr(sin),
+                                              _ptr(positions), _ptr(slot_mapping), _ptr(block_tables), _ptr(context_lens), batch,
+                                              self.Hq, self.Hkv, self.D, self.BS, max_blocks, max_context_len, self.scale,
+                                              _ptr(workspace), self.dtype, 0)
+        check_error()
+        return out
+
     def forward_prefill(self, q, total_q, max_seqlen_q, cu_q, batch, k=None, v=None, cu_k=None, k_cache=None,
                         v_cache=None, block_tables=None, context_lens=None, max_blocks=0):
         out = DevBuf(total_q * self.Hq * self.D * 2)
