@@ -92,16 +92,20 @@ extern "C" float vra_event_elapsed_ms(void* a, void* b) {
 static const size_t kSlabBytes = (size_t)192 << 20;  // fp32 split-K partials
 static const size_t kCounters = 1 << 16;
 static float* g_slabs = nullptr;
+static const size_t kScaleBytes = (size_t)8 << 20;  // per region; two regions (gate/up)
+static unsigned char* g_scales = nullptr;
 static uint32_t* g_counters = nullptr;
 static std::mutex g_scratch_mu;
 bool vra_scratch_init() {
   std::lock_guard<std::mutex> lk(g_scratch_mu);
-  if (g_slabs && g_counters) return true;
+  if (g_slabs && g_counters && g_scales) return true;
   void* p = nullptr;
   if (hipMalloc(&p, kSlabBytes) != hipSuccess) return false;
   g_slabs = (float*)p;
   if (hipMalloc(&p, kCounters * sizeof(uint32_t)) != hipSuccess) return false;
   g_counters = (uint32_t*)p;
+  if (hipMalloc(&p, 2 * kScaleBytes) != hipSuccess) return false;
+  g_scales = (unsigned char*)p;
   if (hipMemset(g_counters, 0, kCounters * sizeof(uint32_t)) != hipSuccess) return false;
   return true;
 }
@@ -113,5 +117,10 @@ uint32_t* vra_scratch_counters() {
   if (!g_counters) vra_scratch_init();
   return g_counters;
 }
+void* vra_scratch_scales(int which) {
+  if (!g_scales) vra_scratch_init();
+  return g_scales ? g_scales + (size_t)(which & 1) * kScaleBytes : nullptr;
+}
+size_t vra_scratch_scale_bytes() { return kScaleBytes; }
 size_t vra_scratch_slab_bytes() { return kSlabBytes; }
 size_t vra_scratch_counter_count() { return kCounters; }

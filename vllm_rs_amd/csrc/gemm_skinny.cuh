@@ -67,18 +67,29 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
   float* xsum = reinterpret_cast<float*>(smem + 2 * XS_U32 * 4);          // [2][ROWS][FPC]: Σx per row and fix-up step
   int* flag = reinterpret_cast<int*>(smem + 2 * XS_U32 * 4 + 2 * ROWS * FPC * 4);
 
-  auto stage = [&](int c, int buf) {
-    // x chunk: rows m0..m0+ROWS, k = c*KC .. +KC ; i -> (row = i/32, o = i%32): 512 B runs per row
+  // ---- x chunk staging, split in two so that the global loads are issued BEFORE the weight loads of the same
+  // iteration and consumed after the MFMAs: everything on the load path is straight-line code with clamped
+  // addresses (a conditional load anywhere makes hipcc wait with vmcnt(0): see gemv_q4.cuh).
+  constexpr int XPT = ROWS * (GB_KC / 8) / GB_THREADS;  // octets per thread per chunk (= MT)
+  auto x_load = [&](int c, u32x4 (&xr)[XPT]) {
+#pragma unroll
+    for (int r = 0; r < XPT; r++) {
+      const int i = tid + r * GB_THREADS;
+      const int row = i >> 5, o = i & 31;
+      const int m = min(m0 + row, M - 1), k = min(c * GB_KC + o * 8, K - 8);  // rows >= M alias row M-1 (never stored)
+      xr[r] = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.x) + (size_t)m * a.x_ld + k);
+    }
+  };
+  auto x_store = [&](int buf, const u32x4 (&xr)[XPT]) {
     uint32_t* dst = xs + buf * XS_U32;
-    for (int i = tid; i < ROWS * (GB_KC / 8); i += GB_THREADS) {
-      int row = i >> 5, o = i & 31;
-      int m = m0 + row, k = c * GB_KC + o * 8;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (m < M && k < K) v = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.x) + (size_t)m * a.x_ld + k);
-      *reinterpret_cast<u32x4*>(dst + ((size_t)o * ROWS + (row ^ (o & 7))) * 4) = v;
-      if (INT4) {  // ROWS*32 is a multiple of 512: every lane takes part in the shuffles
+#pragma unroll
+    for (int r = 0; r < XPT; r++) {
+      const int i = tid + r * GB_THREADS;
+      const int row = i >> 5, o = i & 31;
+      *reinterpret_cast<u32x4*>(dst + ((size_t)o * ROWS + (row ^ (o & 7))) * 4) = xr[r];
+      if (INT4) {  // every lane takes part in the shuffles
         float f[8];
-        unpack8<DT>(v, f);
+        unpack8<DT>(xr[r], f);
         float s8 = ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
 #pragma unroll
         for (int d = 1; d < OPG; d <<= 1) s8 += __shfl_xor(s8, d, 64);
@@ -93,11 +104,13 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
 #pragma unroll
     for (int t = 0; t < MT; t++) acc[w][t] = vra_zero_acc();
 
-  // weight stream of this wave: tiles kt = 2c, 2c+1 for c in [c_begin, c_end)
+  // weight stream of this wave: tiles kt = 2c, 2c+1 for c in [c_begin, c_end); a wave without an n-block streams
+  // block 0 and contributes nothing (its scales / weights are zeroed at the point of use)
+  const int nbc = nb_ok ? nb : 0;
   const u32x4* wp[NW];
   if (INT4) {
-    wp[0] = reinterpret_cast<const u32x4*>(a.w0) + ((size_t)(nb_ok ? nb : 0) * KT) * 64 + lane;
-    if (DUAL) wp[NW - 1] = reinterpret_cast<const u32x4*>(a.w1) + ((size_t)(nb_ok ? nb : 0) * KT) * 64 + lane;
+    wp[0] = reinterpret_cast<const u32x4*>(a.w0) + ((size_t)nbc * KT) * 64 + lane;
+    if (DUAL) wp[NW - 1] = reinterpret_cast<const u32x4*>(a.w1) + ((size_t)nbc * KT) * 64 + lane;
   } else {
     int n = min(nb * 16 + nn, N - 1);
     wp[0] = reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.w0) + (size_t)n * K) + oct;
@@ -107,50 +120,55 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
   constexpr int LPT = INT4 ? 1 : 4;
   u32x4 cur[TPC][NW][LPT], nxt[TPC][NW][LPT];
   // scales / zero points ride along with the weight stream in the MFMA OUTPUT layout: each lane keeps
-  // the 4 scales (8 B) and the AWQ zero word of its 4 output columns per group (L2-resident loads)
+  // the 4 scales (one 8 B load, row-major [K/g, N]) and the AWQ zero word of its 4 output columns per group
   u32x2 csc[TPC][NW][SPT], nsc[TPC][NW][SPT];
   uint32_t czp[TPC][NW][SPT], nzp[TPC][NW][SPT];
-  const int n4 = min(nb * 16 + oct * 4, N - 4);
+  const int n4 = min(nbc * 16 + oct * 4, N - 4);
+  const int G = grouped ? K / g : 1;
+  const bool awq = a.is_awq != 0 && a.qz0 != nullptr;
   auto load_chunk = [&](int c, u32x4 (&dst)[TPC][NW][LPT], u32x2 (&dsc)[TPC][NW][SPT], uint32_t (&dzp)[TPC][NW][SPT]) {
 #pragma unroll
     for (int t = 0; t < TPC; t++) {
-      int kt = c * TPC + t;
-      if (INT4) {
+      const int kt = min(c * TPC + t, KT - 1);
 #pragma unroll
-        for (int w = 0; w < NW; w++)
-#pragma unroll
-          for (int q = 0; q < SPT; q++) {
-            const int grp = min((kt * 128 + q * (128 / SPT)) / g, K / g - 1);
-            load_scale4_raw<DT>(w ? a.sc1 : a.sc0, w ? a.qz1 : a.qz0, grp, n4, N, a.scales_layout, grouped, a.is_awq != 0, dsc[t][w][q], dzp[t][w][q]);
-          }
-      }
-#pragma unroll
-      for (int w = 0; w < NW; w++)
+      for (int w = 0; w < NW; w++) {
 #pragma unroll
         for (int l = 0; l < LPT; l++) {
-          if (kt < KT && nb_ok) {
-            if (INT4) dst[t][w][l] = __builtin_nontemporal_load(wp[w] + (size_t)kt * 64);
-            else dst[t][w][l] = __builtin_nontemporal_load(wp[w] + kt * 16 + l * 4);
-          } else dst[t][w][l] = u32x4{0u, 0u, 0u, 0u};
+          if (INT4) dst[t][w][l] = __builtin_nontemporal_load(wp[w] + (size_t)kt * 64);
+          else dst[t][w][l] = __builtin_nontemporal_load(wp[w] + kt * 16 + l * 4);
         }
+        if (INT4) {
+#pragma unroll
+          for (int q = 0; q < SPT; q++) {
+            const int grp = min(grouped ? (kt * 128 + q * (128 / SPT)) / g : 0, G - 1);
+            const uint16_t* sp = static_cast<const uint16_t*>(w ? a.sc1 : a.sc0);
+            dsc[t][w][q] = *reinterpret_cast<const u32x2*>(sp + (size_t)grp * N + n4);
+            if (SPT > 0 && awq) dzp[t][w][q] = (w ? a.qz1 : a.qz0)[(size_t)grp * (N >> 3) + (n4 >> 3)];
+            else dzp[t][w][q] = 0x88888888u;
+          }
+        }
+      }
     }
   };
 
   if (c_begin < c_end) {
+    u32x4 xr[XPT];
+    x_load(c_begin, xr);
     load_chunk(c_begin, cur, csc, czp);
-    stage(c_begin, 0);
+    x_store(0, xr);
   }
   __syncthreads();
   for (int c = c_begin; c < c_end; c++) {
     const int buf = (c - c_begin) & 1;
-    if (c + 1 < c_end) {
-      load_chunk(c + 1, nxt, nsc, nzp);
-      stage(c + 1, buf ^ 1);
-    }
+    const int cn = min(c + 1, c_end - 1);  // the last iteration re-loads its own chunk (never consumed)
+    u32x4 xr[XPT];
+    x_load(cn, xr);
+    load_chunk(cn, nxt, nsc, nzp);
     const uint32_t* xb = xs + buf * XS_U32;
     const float* sxb = xsum + (size_t)buf * ROWS * FPC;
 #pragma unroll
     for (int t = 0; t < TPC; t++) {
+      const bool valid = nb_ok && (c * TPC + t) < KT;  // wave-uniform
       f32x4 ag[NW][MT];
 #pragma unroll
       for (int w = 0; w < NW; w++)
@@ -161,7 +179,15 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
         const int o = t * 16 + j * 4 + oct;  // octet within chunk
         s16x8 afrag[NW];
 #pragma unroll
-        for (int w = 0; w < NW; w++) afrag[w] = INT4 ? magic_word<DT>(cur[t][w][0][j]) : __builtin_bit_cast(s16x8, cur[t][w][INT4 ? 0 : j]);
+        for (int w = 0; w < NW; w++) {
+          if (INT4) {
+            afrag[w] = magic_word<DT>(cur[t][w][0][j]);
+          } else {
+            u32x4 wv = cur[t][w][INT4 ? 0 : j];
+            if (!valid) wv = u32x4{0u, 0u, 0u, 0u};
+            afrag[w] = __builtin_bit_cast(s16x8, wv);
+          }
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
           const u32x4 xv = *reinterpret_cast<const u32x4*>(xb + ((size_t)o * ROWS + ((mt * 16 + nn) ^ (o & 7))) * 4);
@@ -180,6 +206,8 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
             float sc4[4], zc4[4];
             unpack_scale4<DT>(csc[t][w][q], czp[t][w][q], n4, sc4, zc4);
 #pragma unroll
+            for (int r = 0; r < 4; r++) sc4[r] = valid ? sc4[r] : 0.f;
+#pragma unroll
             for (int mt = 0; mt < MT; mt++) {
               const float sx = sxb[(size_t)(mt * 16 + nn) * FPC + t * SPT + q];
 #pragma unroll
@@ -192,24 +220,20 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
         }
       }
     }
+    x_store(buf ^ 1, xr);  // the other buffer was last read before the previous barrier
     __syncthreads();
-    if (c + 1 < c_end) {
 #pragma unroll
-      for (int t = 0; t < TPC; t++)
+    for (int t = 0; t < TPC; t++)
 #pragma unroll
-        for (int w = 0; w < NW; w++)
+      for (int w = 0; w < NW; w++) {
 #pragma unroll
-          for (int l = 0; l < LPT; l++) cur[t][w][l] = nxt[t][w][l];
+        for (int l = 0; l < LPT; l++) cur[t][w][l] = nxt[t][w][l];
 #pragma unroll
-      for (int t = 0; t < TPC; t++)
-#pragma unroll
-        for (int w = 0; w < NW; w++)
-#pragma unroll
-          for (int q = 0; q < SPT; q++) {
-            csc[t][w][q] = nsc[t][w][q];
-            czp[t][w][q] = nzp[t][w][q];
-          }
-    }
+        for (int q = 0; q < SPT; q++) {
+          csc[t][w][q] = nsc[t][w][q];
+          czp[t][w][q] = nzp[t][w][q];
+        }
+      }
   }
 
   if (!INT4) VRA_MFMA_DRAIN();  // the dense path accumulates straight into acc

@@ -49,6 +49,9 @@ struct GemvArgs {
   int silu_dual;  // 1: seg0 = gate, seg1 = up, out = silu(gate)*up into seg0.out
   int out_f32;    // 1: store (float)round_dt(v)
   int n_items;    // work items (n-blocks, or gate/up pairs)
+  int m_groups;   // int4 kernel: row-group families (1: all M rows in every workgroup)
+  int rows_per_group;
+  int single_red;  // int4 kernel: single-buffered cross-wave reduction (LDS-tight shapes)
   int dbg;        // experiment switches (VRA_EXP): 1 = prologue only, 2 = skip the x staging
   unsigned long long* ts;  // VRA_GEMV_TS builds: [grid][32] wall-clock stamps of wave 0
 };

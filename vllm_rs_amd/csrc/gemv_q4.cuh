@@ -27,7 +27,9 @@
 #include "gemv.cuh"
 
 #define GQ_MAX_WAVES 16
-#define GQ_XR 5  // x octets per compute thread kept in registers by the prologue
+#define GQ_ROWS 16  // max rows of x per workgroup = one MFMA tile (LDS holds rows * K * 2 bytes)
+#define GQ_XR 2  // x octets per compute thread the fast prologue keeps in registers
+#define GQ_MAX_CHUNKS 16  // x octets per compute thread at most (loop-staged prologue)
 #ifndef GQ_RING_KIB
 #define GQ_RING_KIB 2  // weights in flight per wave (deeper rings measured SLOWER: see DESIGN.md §4.1)
 #endif
@@ -72,13 +74,13 @@ __device__ __forceinline__ float gq_row16_elem(const uint16_t* base_uniform, int
   return DT::to_f32((uint16_t)((nl & 1) ? (v >> 16) : (v & 0xffffu)));
 }
 
-// LDS: xs | xsum [NF][16] | red [2][NW][NBW][32] f32x4 | part [GQ_XR][16] + rstd[8]
-static inline size_t gemv_q4_lds_bytes(int nbw, int nw, int M, int K, int group_size) {
+// LDS: xs | xsum [NF][16] | red [1 or 2][NW][NBW][RL] f32x4 (RL = 32 lanes for <= 8 rows, 64 above) | part + rstd
+static inline size_t gemv_q4_lds_bytes(int nbw, int nw, int M, int K, int group_size, bool single_red = false) {
   const int spt = (group_size > 0 && group_size < 128) ? 4 : 1;
   size_t b = (((size_t)M * K * 2 + 15) & ~(size_t)15);
   b += (size_t)(K / 128) * spt * 16 * 4;
-  b += (size_t)2 * nw * nbw * 32 * 16;
-  b += (GQ_XR * GQ_MAX_WAVES + 8) * 4;
+  b += (size_t)(single_red ? 1 : 2) * nw * nbw * (M > 8 ? 64 : 32) * 16;
+  b += (GQ_MAX_CHUNKS * GQ_MAX_WAVES + 16) * 4;
   return b;
 }
 
@@ -94,7 +96,17 @@ __global__ __launch_bounds__(1024) void gemv_q4_kernel(const GemvArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches, no exec masking
   const bool is_epi = wave == NW;
   const int nn = lane & 15, oct = lane >> 4;
-  const int K = a.K, M = a.M, KT = K >> 7;
+  // row groups (decode batches 9..32): MG workgroup families, each running the M <= 8 algorithm on its own
+  // rows_per_group rows of x (8, or fewer when K is long: the rows must fit LDS).  The MG workgroups that stream the same n-blocks get consecutive-by-8 ids, i.e. the
+  // same XCD and the same dispatch moment, so every packed tile is fetched from HBM once and from the
+  // XCD's L2 by the other MG-1.
+  const int MG = a.m_groups > 1 ? a.m_groups : 1;
+  const int wg = (int)blockIdx.x;
+  const int slot = MG > 1 ? (wg / (8 * MG)) * 8 + (wg & 7) : wg;  // persistent slot within its family
+  const int mgrp = MG > 1 ? (wg >> 3) % MG : 0;
+  const int nslots = (int)gridDim.x / MG;
+  const int m_base = mgrp * a.rows_per_group;
+  const int K = a.K, M = min(a.M - m_base, MG > 1 ? a.rows_per_group : a.M), KT = K >> 7;
   const bool grouped = a.group_size > 0 && a.group_size < K;
   const int gsh = grouped ? 31 - __builtin_clz(a.group_size) : 31;  // k >> gsh = scale group (power-of-two groups)
   const int NF = KT * SPT;
@@ -105,17 +117,18 @@ __global__ __launch_bounds__(1024) void gemv_q4_kernel(const GemvArgs a) {
   size_t off = ((size_t)M * K * 2 + 15) & ~(size_t)15;
   float* xsum = reinterpret_cast<float*>(smem + off);  // [NF][16]: Σx of row m over fix-up step f
   off += (size_t)NF * 16 * 4;
-  f32x4* red = reinterpret_cast<f32x4*>(smem + off);  // [2][NW][NBW][32]
-  off += (size_t)2 * NW * NBW * 32 * sizeof(f32x4);
-  float* part = reinterpret_cast<float*>(smem + off);  // [GQ_XR][GQ_MAX_WAVES] partial Σx², then rstd[8]
-  float* rstd_s = part + GQ_XR * GQ_MAX_WAVES;
+  const int RL = M > 8 ? 64 : 32;  // lanes of a partial tile that carry rows < M
+  const bool single_red = a.single_red != 0;  // one reduction buffer + a second barrier per item (LDS-tight shapes)
+  f32x4* red = reinterpret_cast<f32x4*>(smem + off);  // [1 or 2][NW][NBW][RL]
+  off += (size_t)(single_red ? 1 : 2) * NW * NBW * RL * sizeof(f32x4);
+  float* part = reinterpret_cast<float*>(smem + off);  // [GQ_MAX_CHUNKS][GQ_MAX_WAVES] partial Σx², then rstd[8]
+  float* rstd_s = part + GQ_MAX_CHUNKS * GQ_MAX_WAVES;  // [16]
 
   // ---- this workgroup's stream of tile-steps
   const int T = (KT + NW - 1) / NW;  // steps per work item
-  const int my_items = (a.n_items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int my_items = (a.n_items - slot + nslots - 1) / nslots;
   const int S = (a.dbg & 1) ? 0 : my_items * T;
 
-  const bool rowmajor = a.scales_layout == VRA_SCALES_ROWMAJOR;
   u32x4 wb[D][NBW];
   uint32_t sb[D][NBW][SPT];
   uint32_t zb[D][NBW][AWQ ? SPT : 1];
@@ -129,7 +142,7 @@ __global__ __launch_bounds__(1024) void gemv_q4_kernel(const GemvArgs a) {
   const int blk1 = nseg > 1 ? a.seg[1].blk_start : 0x7fffffff, blk2 = nseg > 2 ? a.seg[2].blk_start : 0x7fffffff;
   auto issue = [&](int item, int i, u32x4 (&w)[NBW], uint32_t (&sc)[NBW][SPT], uint32_t (&zp)[NBW][AWQ ? SPT : 1]) {
     const int kt = min(wave + NW * i, KT - 1);  // waves without a tile in this step re-read the last one; their scale is zeroed
-    const int fb = (int)blockIdx.x + item * (int)gridDim.x;
+    const int fb = slot + item * nslots;
 #pragma unroll
     for (int b = 0; b < NBW; b++) {
       const void* wp;
@@ -153,8 +166,7 @@ __global__ __launch_bounds__(1024) void gemv_q4_kernel(const GemvArgs a) {
         const int grp = (kt * 128 + q * 32) >> gsh;
         // the 32-bit word holding the scale (its half is a per-lane constant, `shalf`): a 16-bit load gets
         // an immediate v_and (zero extension) from hipcc, i.e. a wait for the load right after its issue
-        const int64_t rm = (int64_t)grp * n + nb * 16 + nn;
-        const int64_t si = rowmajor ? rm : vra_scale_index(grp, nb * 16 + nn, n, VRA_SCALES_MARLIN, grouped);
+        const int64_t si = (int64_t)grp * n + nb * 16 + nn;  // row-major [K/g, n] (permuted layouts are converted by the caller)
         sc[b][q] = reinterpret_cast<const uint32_t*>(sp)[si >> 1];
         if (AWQ) zp[b][AWQ ? q : 0] = qzp[(size_t)grp * (n >> 3) + nb * 2 + (nn >> 3)];
       }
@@ -176,109 +188,168 @@ __global__ __launch_bounds__(1024) void gemv_q4_kernel(const GemvArgs a) {
   };
 
   // ---- prologue: stage x (and Σx) in LDS  [compute waves; the epilogue wave only keeps the barriers]
+  // The prologue's loads (L2 hits) are complete BEFORE the first HBM load of the ring is queued: measured on
+  // MI355X, an L2-hit load queued behind streaming HBM loads of other waves of the CU returns microseconds late.
+  // Two shapes: <= GQ_XR octets per thread (decode batches 1..4 at K = 4096: the headline) keep x in registers
+  // and overlap the normalisation with the ring's first HBM round trip; larger x is staged by loops (two
+  // passes over L2 when the RMSNorm is fused) and the ring is filled afterwards.
   const int octs = K >> 3, OC = M * octs;
   const int opg = 16 / SPT;  // octets per fix-up step
-  const int nch = (OC + nthr - 1) / nthr;  // x chunks in use (<= GQ_XR: launcher)
-  // every compute thread owns <= GQ_XR octets, loaded with their norm weights BEFORE the ring
-  u32x4 xr[GQ_XR], nr[GQ_XR];
-  if (!is_epi) {
-    // straight-line loads only (no conditional load may precede the ring, see `issue`): chunks past the
-    // end re-read the last octet, a missing norm weight reads x instead
-    const uint16_t* np = static_cast<const uint16_t*>(a.norm_w ? a.norm_w : a.x);
-    auto stage_loads = [&](auto nch_c) {
-      constexpr int NCH = decltype(nch_c)::value;
+  const int nch = (OC + nthr - 1) / nthr;  // x chunks (one octet per compute thread each)
+  const bool fast = nch <= GQ_XR;
+  const bool norm = a.norm_w != nullptr;
+  const uint16_t* np = static_cast<const uint16_t*>(norm ? a.norm_w : a.x);
+  auto row_of = [&](int c) { return min((c * nthr + (wave << 6)) / octs, M - 1); };  // octs % 64 == 0: a wave never straddles rows
+  auto stage_octet = [&](int c, u32x4 v, u32x4 nv, float rs) {  // normalise (optional), write the LDS image and Σx
+    const int m = row_of(c), o = c * nthr + tid, oo = o - m * octs;
+    float f[8];
+    unpack8<DT>(v, f);
+    if (norm) {
+      float g[8];
+      unpack8<DT>(nv, g);
 #pragma unroll
-      for (int c = 0; c < GQ_XR; c++) {
-        xr[c] = u32x4{0u, 0u, 0u, 0u};
-        nr[c] = u32x4{0u, 0u, 0u, 0u};
-        if (c < NCH) {
-          const int m = min((c * nthr + (wave << 6)) / octs, M - 1);  // octs % 64 == 0: a wave never straddles rows
-          const int oo = min(c * nthr + tid - m * octs, octs - 1);
-          xr[c] = reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.x) + (size_t)m * a.x_ld)[oo];
-          nr[c] = reinterpret_cast<const u32x4*>(np)[oo];
+      for (int i = 0; i < 8; i++) f[i] = f[i] * rs * g[i];
+      v = pack8<DT>(f);
+      unpack8<DT>(v, f);  // sums are taken over the ROUNDED values the MFMA will see
+    }
+    if (o < OC) *reinterpret_cast<u32x4*>(xs + ((size_t)oo * M + m) * 4) = v;
+    float s8 = ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+    for (int d = 1; d < opg; d <<= 1) s8 += __shfl_xor(s8, d, 64);
+    if (o < OC && (oo & (opg - 1)) == 0) xsum[(oo / opg) * 16 + m] = s8;
+  };
+  auto octet_ss = [&](u32x4 v) {
+    float f[8];
+    unpack8<DT>(v, f);
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) ss += f[i] * f[i];
+    return wave_sum(ss);
+  };
+  auto load_x = [&](int c) {
+    const int m = row_of(c), oo = min(c * nthr + tid - m * octs, octs - 1);
+    return reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.x) + (size_t)(m_base + m) * a.x_ld)[oo];
+  };
+  auto load_nw = [&](int c) {
+    const int m = row_of(c), oo = min(c * nthr + tid - m * octs, octs - 1);
+    return reinterpret_cast<const u32x4*>(np)[oo];
+  };
+  // rstd of every row from the per-(chunk, wave) partial sums in `part` (fixed summation order)
+  auto reduce_rows = [&]() {
+    if (wave == 0) {
+      for (int m = 0; m < M; m++) {
+        float acc = 0.f;
+        for (int p0 = 0; p0 < nch * NW; p0 += 64) {
+          const int pp = p0 + lane, c = pp / NW, w = pp - c * NW;
+          const int o0 = c * nthr + (w << 6);
+          const bool mine = c < nch && o0 < OC && o0 / octs == m;
+          acc += wave_sum(mine ? part[c * GQ_MAX_WAVES + w] : 0.f);
         }
+        if (lane == 0) rstd_s[m] = 1.0f / sqrtf(acc / (float)K + a.eps);
       }
-      __builtin_amdgcn_sched_barrier(0);  // keep the x / norm-weight loads AHEAD of the ring in the (in-order) memory queue
+    }
+  };
+  u32x4 xr[GQ_XR], nr[GQ_XR];
+  if (fast) {
+    if (!is_epi) {
+#pragma unroll
+      for (int c = 0; c < GQ_XR; c++) {  // straight line, clamped: no conditional load before the ring (see `issue`)
+        xr[c] = load_x(c);
+        nr[c] = load_nw(c);
+      }
+      __builtin_amdgcn_sched_barrier(0);
       GEMV_STAMP(16);
-      // x and the norm weights (L2 hits) are back before the first HBM load is queued: measured on MI355X, an
-      // L2-hit load queued behind streaming HBM loads of OTHER waves of the CU returns microseconds late
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
       fill_ring();
       __builtin_amdgcn_sched_barrier(0);
-    };
-    stage_loads(std::integral_constant<int, GQ_XR>{});  // (two specialisations would be re-merged by the compiler: ring hoisted above x)
-    GEMV_STAMP(1);
-    if (a.norm_w) {
+      GEMV_STAMP(1);
+      if (norm) {
+#pragma unroll
+        for (int c = 0; c < GQ_XR; c++) {
+          if (c < nch) {
+            const float ss = octet_ss(xr[c]);
+            if (lane == 0) part[c * GQ_MAX_WAVES + wave] = ss;
+          }
+        }
+      }
+      GEMV_STAMP(17);
+    }
+    float rs1 = 1.0f;
+    if (norm) {
+      __syncthreads();
+      if (M > 1) {
+        reduce_rows();
+        __syncthreads();
+      } else if (!is_epi) {  // single row: every thread adds the partials itself (fixed order), no second barrier
+        float tot = 0.f;
+        for (int c = 0; c < nch; c++)
+          for (int w = 0; w < NW; w++)
+            if (c * nthr + (w << 6) < OC) tot += part[c * GQ_MAX_WAVES + w];
+        rs1 = 1.0f / sqrtf(tot / (float)K + a.eps);
+      }
+    }
+    GEMV_STAMP(19);
+    if (!is_epi) {
 #pragma unroll
       for (int c = 0; c < GQ_XR; c++) {
         if (c < nch) {
-          float f[8];
-          unpack8<DT>(xr[c], f);
-          float ss = 0.f;
-#pragma unroll
-          for (int i = 0; i < 8; i++) ss += f[i] * f[i];
-          ss = wave_sum(ss);
-          if (lane == 0) part[c * GQ_MAX_WAVES + wave] = ss;
+          // (wave-uniform; kept in an SGPR: as a VGPR the packed multiply reads it as a register PAIR whose
+          // second half may be a ring register with a load in flight — a false vmcnt dependency)
+          const float rs = norm ? __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(M == 1 ? rs1 : rstd_s[row_of(c)]))) : 1.0f;
+          stage_octet(c, xr[c], nr[c], rs);
         }
       }
     }
-    GEMV_STAMP(17);
-  }
-  if (a.norm_w) {
-    __syncthreads();
-    if (M > 1) {
-      if (wave == 0) {  // lane p (+64) owns partial (c, w) = (p / NW, p % NW); one masked wave reduction per row: fixed order
-        float pv[2];
-        int prow[2];
+  } else {
+    // large x (decode batches > 2 at K = 4096, or K = 14336): batches of 4 octets per thread through L2 (4 loads
+    // in flight per iteration), raw values parked in their final LDS slots; with a fused RMSNorm a second pass
+    // rescales them in place (norm weights again 4 loads per iteration).  The ring is filled afterwards.
+    if (!is_epi) {
+      for (int c0 = 0; c0 < nch; c0 += 4) {
+        u32x4 xv[4];
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-          const int pp = lane + 64 * h, c = pp / NW, w = pp - c * NW;
-          const int o0 = c * nthr + (w << 6);
-          pv[h] = (c < nch && o0 < OC) ? part[c * GQ_MAX_WAVES + w] : 0.f;
-          prow[h] = o0 / octs;
-        }
-        for (int m = 0; m < M; m++) {
-          const float tot = wave_sum((prow[0] == m ? pv[0] : 0.f) + (prow[1] == m ? pv[1] : 0.f));
-          if (lane == 0) rstd_s[m] = 1.0f / sqrtf(tot / (float)K + a.eps);
+        for (int i = 0; i < 4; i++) xv[i] = load_x(min(c0 + i, nch - 1));
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int c = c0 + i;
+          if (c < nch) {
+            if (norm) {
+              const float ss = octet_ss(xv[i]);
+              if (lane == 0) part[c * GQ_MAX_WAVES + wave] = ss;
+              const int m = row_of(c), o = c * nthr + tid, oo = o - m * octs;
+              if (o < OC) *reinterpret_cast<u32x4*>(xs + ((size_t)oo * M + m) * 4) = xv[i];  // raw, rescaled in pass 2
+            } else {
+              stage_octet(c, xv[i], xv[i], 1.0f);
+            }
+          }
         }
       }
+    }
+    if (norm) {
       __syncthreads();
-    }
-  }
-  GEMV_STAMP(19);
-  if (!is_epi) {
-    float rs1 = 1.0f;
-    if (a.norm_w && M == 1) {  // single row: every thread adds the partials itself (fixed order), no second barrier
-      float tot = 0.f;
-      for (int c = 0; c < nch; c++)
-        for (int w = 0; w < NW; w++)
-          if (c * nthr + (w << 6) < OC) tot += part[c * GQ_MAX_WAVES + w];
-      rs1 = 1.0f / sqrtf(tot / (float)K + a.eps);
-    }
+      reduce_rows();
+      __syncthreads();
+      if (!is_epi) {
+        for (int c0 = 0; c0 < nch; c0 += 4) {
+          u32x4 nv[4];
 #pragma unroll
-    for (int c = 0; c < GQ_XR; c++) {
-      if (c < nch) {
-        const int o = c * nthr + tid;
-        const int m = min((c * nthr + (wave << 6)) / octs, M - 1), oo = o - m * octs;
-        float f[8];
-        u32x4 v = xr[c];
-        unpack8<DT>(v, f);
-        if (a.norm_w) {
-          // (wave-uniform; kept in an SGPR: as a VGPR the packed multiply below reads it as a register PAIR
-          // whose second half may be a ring register with a load in flight — a false vmcnt dependency)
-          const float rs = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(M == 1 ? rs1 : rstd_s[m])));
-          float g[8];
-          unpack8<DT>(nr[c], g);
+          for (int i = 0; i < 4; i++) nv[i] = load_nw(min(c0 + i, nch - 1));
 #pragma unroll
-          for (int i = 0; i < 8; i++) f[i] = f[i] * rs * g[i];
-          v = pack8<DT>(f);
-          unpack8<DT>(v, f);  // sums are taken over the ROUNDED values the MFMA will see
+          for (int i = 0; i < 4; i++) {
+            const int c = c0 + i;
+            if (c < nch) {
+              const int m = row_of(c), o = c * nthr + tid, oo = min(o - m * octs, octs - 1);
+              const u32x4 raw = *reinterpret_cast<const u32x4*>(xs + ((size_t)oo * M + m) * 4);
+              const float rs = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(rstd_s[m])));
+              stage_octet(c, raw, nv[i], rs);
+            }
+          }
         }
-        if (o < OC) *reinterpret_cast<u32x4*>(xs + ((size_t)oo * M + m) * 4) = v;
-        float s8 = ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
-        for (int d = 1; d < opg; d <<= 1) s8 += __shfl_xor(s8, d, 64);
-        if (o < OC && (oo & (opg - 1)) == 0) xsum[(oo / opg) * 16 + m] = s8;
       }
+    }
+    if (!is_epi) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+      fill_ring();
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   GEMV_STAMP(20);
@@ -294,47 +365,56 @@ __global__ __launch_bounds__(1024) void gemv_q4_kernel(const GemvArgs a) {
     int parity = 0;
     const int nout = 16 * M;
     for (int it = 0; it < n_it; it++) {
-      const int fb = (int)blockIdx.x + it * (int)gridDim.x;
+      const int fb = slot + it * nslots;
       const int segi = NBW == 2 ? 0 : (fb >= blk2 ? 2 : (fb >= blk1 ? 1 : 0));
       const int nb = fb - (NBW == 2 ? 0 : a.seg[segi].blk_start);
       const GemvSeg& sg = a.seg[segi];
-      float bv[2] = {0.f, 0.f}, bu[2] = {0.f, 0.f}, rv[2] = {0.f, 0.f};
+      float bv[4] = {0.f, 0.f, 0.f, 0.f}, bu[4] = {0.f, 0.f, 0.f, 0.f}, rv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int h = 0; h < 2; h++) {
+      for (int h = 0; h < 4; h++) {
         const int idx = lane + 64 * h;
         if (idx < nout) {
           const int n = nb * 16 + (idx & 15), m = idx >> 4;
           if (sg.bias) bv[h] = DT::to_f32(static_cast<const uint16_t*>(sg.bias)[n]);
           if (NBW == 2 && a.seg[1].bias) bu[h] = DT::to_f32(static_cast<const uint16_t*>(a.seg[1].bias)[n]);
-          if (a.residual) rv[h] = DT::to_f32(static_cast<const uint16_t*>(a.residual)[(size_t)m * a.res_ld + n]);
+          if (a.residual) rv[h] = DT::to_f32(static_cast<const uint16_t*>(a.residual)[(size_t)(m_base + m) * a.res_ld + n]);
         }
       }
       __syncthreads();  // the item's partial tiles are in red[parity]
       GEMV_STAMP_E(21 + 2 * (it < 3 ? it : 3));
-      const float* rf = reinterpret_cast<const float*>(red + (size_t)parity * NW * NBW * 32);
+      const float* rf = reinterpret_cast<const float*>(red + (size_t)(single_red ? 0 : parity) * NW * NBW * RL);
+      float vs[4], v2s[4];
 #pragma unroll
-      for (int h = 0; h < 2; h++) {
+      for (int h = 0; h < 4; h++) {
         const int idx = lane + 64 * h;
+        vs[h] = v2s[h] = 0.f;
         if (idx < nout) {
           const int nl = idx & 15, m = idx >> 4;
           const int slot = ((m >> 2) * 16 + nl) * 4 + (m & 3);  // D layout: column = lane&15, row = (lane>>4)*4 + reg
-          float v = 0.f, v2 = 0.f;
           for (int w = 0; w < NW; w++) {
-            v += rf[(w * NBW) * 128 + slot];
-            if (NBW > 1) v2 += rf[(w * NBW + (NBW - 1)) * 128 + slot];
+            vs[h] += rf[(w * NBW) * RL * 4 + slot];
+            if (NBW > 1) v2s[h] += rf[(w * NBW + (NBW - 1)) * RL * 4 + slot];
           }
+        }
+      }
+      if (single_red && it + 1 < n_it) __syncthreads();  // the buffer may be overwritten by the next item
+#pragma unroll
+      for (int h = 0; h < 4; h++) {
+        const int idx = lane + 64 * h;
+        if (idx < nout) {
+          const int nl = idx & 15, m = idx >> 4;
           const int n = nb * 16 + nl;
-          v = rnd_dt<DT>(v);
+          float v = rnd_dt<DT>(vs[h]);
           if (sg.bias) v = rnd_dt<DT>(v + bv[h]);
           if (NBW == 2) {
-            v2 = rnd_dt<DT>(v2);
+            float v2 = rnd_dt<DT>(v2s[h]);
             if (a.seg[1].bias) v2 = rnd_dt<DT>(v2 + bu[h]);
             const float sl = rnd_dt<DT>(v / (1.0f + expf(-v)));
             v = sl * v2;
           }
           if (a.residual) v = rnd_dt<DT>(v) + rv[h];
-          if (a.out_f32) static_cast<float*>(sg.out)[(size_t)m * sg.out_ld + n] = rnd_dt<DT>(v);
-          else static_cast<uint16_t*>(sg.out)[(size_t)m * sg.out_ld + n] = DT::from_f32(v);
+          if (a.out_f32) static_cast<float*>(sg.out)[(size_t)(m_base + m) * sg.out_ld + n] = rnd_dt<DT>(v);
+          else static_cast<uint16_t*>(sg.out)[(size_t)(m_base + m) * sg.out_ld + n] = DT::from_f32(v);
         }
       }
       GEMV_STAMP_E(22 + 2 * (it < 3 ? it : 3));
@@ -348,15 +428,14 @@ __global__ __launch_bounds__(1024) void gemv_q4_kernel(const GemvArgs a) {
   const uint32_t xbase = (uint32_t)(oct * M + min(nn, M - 1)) * 4u;
   const uint32_t xstep = (uint32_t)M * 16u;  // u32 per 4 octets (one j step)
   const int zsh = 4 * awq_rev(nn & 7);
-  // which half of the loaded word is this lane's scale: row-major and the channel-wise Marlin permutation keep
-  // the column parity, the grouped permutation (wna16.rs:180-218) moves bit 3 of the column to bit 0
-  const bool shalf = (rowmajor || !grouped) ? (nn & 1) : ((nn >> 3) & 1);
+  // which half of the loaded word is this lane's scale
+  const bool shalf = nn & 1;
   constexpr float CB = Magic<DT>::bias;
 
   f32x4 acc[NBW];
 #pragma unroll
   for (int b = 0; b < NBW; b++) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  int ci = 0, parity = 0;  // consume cursor
+  int ci = 0, parity = 0, items_done = 0;  // consume cursor
   // The stream is padded to a multiple of D: the only loop exit is the back edge.  (An exit between two
   // unrolled bodies is routed by the CFG structurizer through a shared "Flow" block from which the loop
   // header is syntactically reachable with a half-issued refill — a false path that again degrades the
@@ -399,10 +478,12 @@ __global__ __launch_bounds__(1024) void gemv_q4_kernel(const GemvArgs a) {
         // ---- end of a work item: hand the partial tile to the epilogue wave
         if (++ci == T) {
           ci = 0;
-          f32x4* rbuf = red + (size_t)parity * NW * NBW * 32;
+          if (single_red && items_done > 0) __syncthreads();  // the epilogue wave has read the previous item
+          ++items_done;
+          f32x4* rbuf = red + (size_t)(single_red ? 0 : parity) * NW * NBW * RL;
           if (oct * 4 < M) {
 #pragma unroll
-            for (int b = 0; b < NBW; b++) rbuf[(wave * NBW + b) * 32 + lane] = acc[b];
+            for (int b = 0; b < NBW; b++) rbuf[(wave * NBW + b) * RL + lane] = acc[b];
           }
 #pragma unroll
           for (int b = 0; b < NBW; b++) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};

@@ -8,3 +8,5 @@ float* vra_scratch_slabs();         // nullptr until initialised
 uint32_t* vra_scratch_counters();   // zeroed at init, every kernel leaves them zero
 size_t vra_scratch_slab_bytes();
 size_t vra_scratch_counter_count();
+void* vra_scratch_scales(int which);  // two regions for row-major copies of Marlin-permuted scale tensors
+size_t vra_scratch_scale_bytes();

@@ -180,6 +180,7 @@ static void gemv_debug_args(GemvArgs& a) {
 #endif
 }
 
+static int gemv_q4_rows_per_group(int nbw, int M, int K, int group_size);
 // int4: persistent grid of (8 compute + 1 epilogue)-wave workgroups, two per CU, when there are at least
 // two work items per CU; otherwise one (15 + 1)-wave workgroup per CU (about the same number of waves,
 // twice the k-split per item)
@@ -196,18 +197,45 @@ static void launch_gemv_q4_v(GemvArgs a, int nblocks, hipStream_t st) {
     attr_set = true;
   }
   const int cus = num_cus();
-  const int oc = a.M * (a.K >> 3);
+  const int rpg = gemv_q4_rows_per_group(NBW, a.M, a.K, a.group_size);
+  const int mg = (a.M + rpg - 1) / rpg;  // row-group families (decode batches up to 32, or long K)
+  const int rows = mg > 1 ? rpg : a.M;
+  const int oc = rows * (a.K >> 3);
+  // shape of the workgroup: two (8+1)-wave workgroups per CU when there is enough work and both fit LDS, else one
+  // (15+1)-wave workgroup, shrinking to 14 / 12 compute waves and a single reduction buffer when 16 rows of x
+  // leave too little LDS
   static const char* nw_env = getenv("VRA_GEMV_NW");
-  int nw = (nblocks >= 2 * cus && occ9 >= 2) ? 8 : 15;
+  int nw = (nblocks * mg >= 2 * cus && occ9 >= 2) ? 8 : 15;
   if (nw_env && (atoi(nw_env) == 8 || atoi(nw_env) == 15)) nw = atoi(nw_env);
-  if (oc > GQ_XR * 8 * 64) nw = 15;  // the prologue keeps x in registers: <= GQ_XR octets per compute thread
-  const size_t lds = gemv_q4_lds_bytes(NBW, nw, a.M, a.K, a.group_size);
+  bool single = false;
+  const size_t lim = (size_t)kMaxDynLds;
+  if (nw == 8 && 2 * gemv_q4_lds_bytes(NBW, 8, rows, a.K, a.group_size) > lim) nw = 15;
+  if (nw != 8) {
+    const int cand[4] = {15, 15, 14, 12};
+    for (int i = 0; i < 4; i++) {
+      nw = cand[i];
+      single = i > 0;
+      if (gemv_q4_lds_bytes(NBW, nw, rows, a.K, a.group_size, single) <= lim) break;
+    }
+  }
+  const size_t lds = gemv_q4_lds_bytes(NBW, nw, rows, a.K, a.group_size, single);
+  a.single_red = single ? 1 : 0;
   int per_cu = nw == 8 ? occ9 : 1;
-  if (lds * per_cu > (size_t)kMaxDynLds) per_cu = 1;
   a.n_items = nblocks;
+  a.m_groups = mg;
+  a.rows_per_group = rpg;
   gemv_debug_args(a);
   const int cap = cus * per_cu;
-  const int grid = nblocks < cap ? nblocks : cap;
+  int grid;
+  if (mg > 1) {
+    int slots = cap / mg / 8 * 8;  // the id -> (slot, family) map works on groups of 8 workgroups (one per XCD)
+    if (slots < 8) slots = 8;
+    const int need = (nblocks + 7) / 8 * 8;
+    if (slots > need) slots = need;
+    grid = slots * mg;
+  } else {
+    grid = nblocks < cap ? nblocks : cap;
+  }
   kern<<<grid, (nw + 1) * 64, lds, st>>>(a);
 }
 template <class DT, int NBW>
@@ -219,13 +247,28 @@ static void launch_gemv_q4_t(const GemvArgs& a, int nblocks, hipStream_t st) {
   else launch_gemv_q4_v<DT, NBW, 1, false>(a, nblocks, st);
 }
 
+// rows of x one workgroup of the int4 kernel can hold (register-staged prologue, LDS image): 0 = none
+static int gemv_q4_rows_per_group(int nbw, int M, int K, int group_size) {
+  static const char* rows_env = getenv("VRA_GEMV_ROWS");  // tuning aid: cap on the rows per row-group family
+  const int cap = rows_env ? atoi(rows_env) : 8;  // measured: 4 families x 8 rows beat 2 x 16 at batch 32
+  const int cand[5] = {16, 8, 4, 2, 1};
+  for (int i = 0; i < 5; i++) {
+    if (cand[i] > cap && cand[i] > 1) continue;
+    const int r = M < cand[i] ? M : cand[i];
+    if (r * (K >> 3) <= GQ_MAX_CHUNKS * 12 * 64 && gemv_q4_lds_bytes(nbw, 12, r, K, group_size, true) <= (size_t)kMaxDynLds) return r;
+  }
+  return 0;
+}
 bool vra_gemv_fits(bool int4, int nbw, int M, int K, int group_size) {
-  if (M > 8 || M < 1) return false;
-  if (!int4) return gemv_lds_bytes(false, nbw, M, K, group_size) <= (size_t)72 * 1024;
+  if (M < 1) return false;
+  if (!int4) return M <= 8 && gemv_lds_bytes(false, nbw, M, K, group_size) <= (size_t)72 * 1024;
+  static const char* mm_env = getenv("VRA_GEMV_MAX_M");  // tuning aid: largest M routed to the streaming kernel
+  if (M > (mm_env ? atoi(mm_env) : 32)) return false;
   if (K % 512) return false;  // a wave of the x staging must not straddle rows
-  if (M * (K >> 3) > GQ_XR * 15 * 64) return false;  // x is staged through registers: <= GQ_XR octets per compute thread
   if (group_size > 0 && group_size < K && (group_size & (group_size - 1))) return false;  // power-of-two groups only
-  return gemv_q4_lds_bytes(nbw, 15, M, K, group_size) <= (size_t)96 * 1024;
+  const int rpg = gemv_q4_rows_per_group(nbw, M, K, group_size);
+  static const char* mg_env = getenv("VRA_GEMV_MAX_MG");
+  return rpg > 0 && (M + rpg - 1) / rpg <= (mg_env ? atoi(mg_env) : 4);  // row-group families each re-do the dequantisation (VALU bound beyond a few)
 }
 
 void vra_launch_gemv(const GemvArgs& a, bool int4, int dtype, int64_t stream) {
@@ -253,9 +296,9 @@ static void launch_skinny_t(GemmBArgs a, hipStream_t st) {
   const bool fine = INT4 && a.group_size > 0 && a.group_size < 128;  // several groups per k-tile
   size_t lds = gemm_skinny_lds_bytes(MT, fine ? 4 : 1);
   dim3 grid((a.N + 127) / 128, (a.M + MT * 16 - 1) / (MT * 16), a.splitk);
-  // (DUAL, MT=4, SPT=4) would need > 256 VGPRs (spills next to MFMAs): that combination is never
-  // instantiated — vra_launch_skinny caps MT at 2 for gate/up pairs with fine groups
-  constexpr bool kHasFine = INT4 && !(DUAL && MT == 4);
+  // fine scale groups (SPT=4) carry 4x the scale registers: (DUAL, MT>=2) and (single, MT=4) would need > 256
+  // VGPRs (spills next to MFMAs) and are never instantiated — vra_launch_skinny caps MT accordingly
+  constexpr bool kHasFine = INT4 && !(DUAL && MT >= 2) && !(!DUAL && MT == 4);
   static bool attr_set = false;
   if (!attr_set) {  // MT=4 needs 64 KiB + 16 B of dynamic LDS, just past the default limit
     if constexpr (kHasFine)
@@ -290,7 +333,7 @@ static int choose_splitk(int M, int N, int K, int mt, bool dual) {
 void vra_launch_skinny(GemmBArgs a, bool int4, bool dual, int dtype, int64_t stream) {
   hipStream_t st = as_stream(stream);
   int mt = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
-  if (dual && int4 && a.group_size > 0 && a.group_size < 128 && mt == 4) mt = 2;  // see launch_skinny_t
+  if (int4 && a.group_size > 0 && a.group_size < 128) mt = dual ? 1 : (mt > 2 ? 2 : mt);  // see launch_skinny_t
   a.splitk = choose_splitk(a.M, a.N, a.K, mt, dual);
   a.slabs = a.splitk > 1 ? vra_scratch_slabs() : nullptr;
   a.counters = a.splitk > 1 ? vra_scratch_counters() : nullptr;
@@ -316,6 +359,33 @@ void vra_launch_skinny(GemmBArgs a, bool int4, bool dual, int dtype, int64_t str
 }
 
 // ------------------------------------------------------------------------------------------------
+// Marlin-permuted scales (wna16.rs:180-218, what a reference-format caller passes to marlin_*): the GEMM
+// kernels read scales row-major only (one load per lane and tile, no index arithmetic in the stream), so a
+// permuted tensor is first copied row-major into per-process scratch on the caller's stream.  The native
+// runtime keeps its scales row-major and never takes this path.
+// ------------------------------------------------------------------------------------------------
+__global__ void unpermute_scales_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int G, int N, int grouped) {
+  const int64_t total = (int64_t)G * N;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int grp = (int)(i / N), n = (int)(i - (int64_t)grp * N);
+    out[i] = in[vra_scale_index(grp, n, N, VRA_SCALES_MARLIN, grouped)];
+  }
+}
+static const void* rowmajor_scales(const void* sc, int32_t& layout, int k, int n, int group_size, int which, int64_t stream) {
+  if (layout == VRA_SCALES_ROWMAJOR || !sc) return sc;
+  const bool grouped = group_size > 0 && group_size < k;
+  const int G = grouped ? k / group_size : 1;
+  const size_t bytes = (size_t)G * n * 2;
+  void* dst = vra_scratch_scales(which);
+  if (!dst || bytes > vra_scratch_scale_bytes()) {
+    vra_set_error("marlin-permuted scales: scratch unavailable or too small (%zu bytes)", bytes);
+    return nullptr;
+  }
+  unpermute_scales_kernel<<<grid_for((size_t)G * n, 256), 256, 0, as_stream(stream)>>>((const uint16_t*)sc, (uint16_t*)dst, G, n, grouped ? 1 : 0);
+  return dst;
+}
+
+// ------------------------------------------------------------------------------------------------
 // public entry points
 // ------------------------------------------------------------------------------------------------
 static bool check_gemm_shape(const char* who, int m, int k, int n, int group_size) {
@@ -337,6 +407,12 @@ extern "C" void vra_wna16_gemm(const void* in, const void* qweight_tiled, const 
   VRA_CHECK_ARG(in && qweight_tiled && scales && out, "vra_wna16_gemm: null pointer");
   VRA_CHECK_ARG(dtype == VRA_BF16 || dtype == VRA_F16, "vra_wna16_gemm: dtype must be bf16/f16");
   if (!check_gemm_shape("vra_wna16_gemm", m, k, n, group_size)) return;
+  {
+    const void* rs = rowmajor_scales(scales, scales_layout, k, n, group_size, 0, stream);
+    if (!rs) return;
+    scales = rs;
+    scales_layout = VRA_SCALES_ROWMAJOR;
+  }
   if (vra_gemv_fits(true, 1, m, k, group_size)) {
     GemvArgs a = {};
     a.nseg = 1;
@@ -380,6 +456,15 @@ extern "C" void vra_wna16_gate_up_silu(const void* in, const void* qw_gate, cons
   VRA_CHECK_ARG(in && qw_gate && sc_gate && qw_up && sc_up && out, "vra_wna16_gate_up_silu: null pointer");
   VRA_CHECK_ARG(dtype == VRA_BF16 || dtype == VRA_F16, "vra_wna16_gate_up_silu: dtype must be bf16/f16");
   if (!check_gemm_shape("vra_wna16_gate_up_silu", m, k, n, group_size)) return;
+  {
+    int32_t l0 = scales_layout, l1 = scales_layout;
+    const void* g0 = rowmajor_scales(sc_gate, l0, k, n, group_size, 0, stream);
+    const void* u0 = rowmajor_scales(sc_up, l1, k, n, group_size, 1, stream);
+    if (!g0 || !u0) return;
+    sc_gate = g0;
+    sc_up = u0;
+    scales_layout = VRA_SCALES_ROWMAJOR;
+  }
   if (vra_gemv_fits(true, 2, m, k, group_size)) {
     GemvArgs a = {};
     a.nseg = 2;
