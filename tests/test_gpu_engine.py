@@ -314,3 +314,45 @@ def test_product_matches_huggingface_fixture(name, dt, rel):
     if toks == hf_tokens:
         assert list(out) == hf_tokens
     eng.close()
+
+
+@pytest.mark.parametrize("qm", ["gptq", "awq", None])
+def test_from_pretrained_checkpoint_directory(tmp_path, qm):
+    """HF-style checkpoint directory on disk (config.json + two safetensors shards, f16 scales/bias for a bf16 model as
+    AutoGPTQ/AutoAWQ write them) -> Engine.from_pretrained -> same logits as the oracle fed the same tensors."""
+    import json
+    from tests.test_checkpoint import write_safetensors
+    cfg = small_cfg(quant_method=qm, arch="qwen2" if qm == "awq" else "llama", attention_bias=(qm == "awq"))
+    w = om.make_random_checkpoint(cfg, seed=11)
+    on_disk, w_model = {}, {}
+    for k, a in w.items():
+        if a.dtype == np.uint16 and (k.endswith(".scales") or k.endswith(".bias")) and qm:
+            f16 = orc.from_bf16(a).astype(np.float16)            # checkpoint stores f16 ...
+            on_disk[k] = (f16.view(np.uint16), "f16")
+            w_model[k] = orc.to_bf16(f16.astype(np.float32))     # ... the model sees it cast to bf16 (wna16.rs:97-109)
+        elif a.dtype == np.uint16:
+            on_disk[k], w_model[k] = (a, "bf16"), a
+        else:
+            on_disk[k], w_model[k] = (a.view(np.int32), "i32"), a
+    names = sorted(on_disk)
+    half = len(names) // 2
+    write_safetensors(tmp_path / "model-00001-of-00002.safetensors", {k: on_disk[k] for k in names[:half]})
+    write_safetensors(tmp_path / "model-00002-of-00002.safetensors", {k: on_disk[k] for k in names[half:]})
+    json.dump({"weight_map": {k: ("model-00001-of-00002.safetensors" if i < half else "model-00002-of-00002.safetensors") for i, k in enumerate(names)}},
+              open(tmp_path / "model.safetensors.index.json", "w"))
+    hf = dict(architectures=["Qwen2ForCausalLM" if qm == "awq" else "LlamaForCausalLM"], hidden_size=cfg["hidden_size"],
+              intermediate_size=cfg["intermediate_size"], num_hidden_layers=cfg["num_layers"], num_attention_heads=cfg["num_heads"],
+              num_key_value_heads=cfg["num_kv_heads"], head_dim=cfg["head_dim"], vocab_size=cfg["vocab_size"],
+              max_position_embeddings=cfg["max_position_embeddings"], rms_norm_eps=cfg["rms_norm_eps"], rope_theta=cfg["rope_theta"],
+              torch_dtype="bfloat16", tie_word_embeddings=False)
+    if qm:
+        hf["quantization_config"] = dict(quant_method=qm, bits=4, group_size=128, desc_act=False, sym=True)
+    json.dump(hf, open(tmp_path / "config.json", "w"))
+    eng = Engine.from_pretrained(str(tmp_path), num_gpu_blocks=16, max_num_seqs=4, max_model_len=256, use_graph=False)
+    oracle = om.OracleModel(cfg, w_model, num_blocks=16)
+    prompt = np.arange(5, 45, dtype=np.uint32)
+    n = len(prompt)
+    bt = np.array([[2]], np.uint32)
+    args = (prompt, np.arange(n, dtype=np.int64), 2 * 64 + np.arange(n, dtype=np.int64), bt, np.array([n], np.uint32), np.array([0, n], np.uint32))
+    check_logits(eng.forward_raw(*args), oracle.forward(*args), f"from_pretrained {qm}")
+    eng.close()

@@ -85,6 +85,20 @@ class Engine:
         self._check(self.L.vra_engine_finalize_weights(self.h), "finalize")
         return self
 
+    @classmethod
+    def from_pretrained(cls, model_dir, dtype=None, **kw):
+        """HF checkpoint directory (config.json + *.safetensors, GPTQ / AWQ int4 or dense) -> engine
+        (`EngineBuilder::build` + `WNA16::new`, src/api.rs:25-114, wna16.rs:56-152)."""
+        from . import checkpoint
+        cfg, tensors = checkpoint.load_pretrained(model_dir, dtype)
+        eng = cls(cfg, **kw)
+        for name, a in tensors:
+            shape = (C.c_int64 * a.ndim)(*a.shape)
+            eng._check(eng.L.vra_engine_load_tensor(eng.h, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim, a.itemsize),
+                       f"load_tensor({name})")
+        eng._check(eng.L.vra_engine_finalize_weights(eng.h), "finalize")
+        return eng
+
     @property
     def num_gpu_blocks(self):
         return self.L.vra_engine_num_gpu_blocks(self.h)
