@@ -264,6 +264,7 @@ bool vra_gemv_fits(bool int4, int nbw, int M, int K, int group_size) {
   if (!int4) return M <= 8 && gemv_lds_bytes(false, nbw, M, K, group_size) <= (size_t)72 * 1024;
   static const char* mm_env = getenv("VRA_GEMV_MAX_M");  // tuning aid: largest M routed to the streaming kernel
   if (M > (mm_env ? atoi(mm_env) : 32)) return false;
+  if (vra_gemm_q4_fits(nbw, M, K, group_size)) return false;  // 9..32 rows: kernel C dequantises once for all rows
   if (K % 512) return false;  // a wave of the x staging must not straddle rows
   if (group_size > 0 && group_size < K && (group_size & (group_size - 1))) return false;  // power-of-two groups only
   const int rpg = gemv_q4_rows_per_group(nbw, M, K, group_size);
@@ -358,6 +359,59 @@ void vra_launch_skinny(GemmBArgs a, bool int4, bool dual, int dtype, int64_t str
 #undef VRA_SK
 }
 
+// ---- kernel C launcher
+bool vra_gemm_q4_fits(int nbw, int M, int K, int group_size) {
+  static const char* off = getenv("VRA_NO_KERNEL_C");  // tuning aid
+  if (off && atoi(off)) return false;
+  if (M < 9 || M > 32) return false;
+  // the n-block-major decomposition re-reads all of x (M*K*2 bytes) per work item: it pays for the wide gate/up pair
+  // (N = 14336: x traffic ~ weight traffic) and not for N = 4096..6144 (x traffic 4..8x the weights: measured 26..80 us)
+  if (nbw != 2) return false;
+  if (group_size > 0 && group_size < K && (group_size < 128 || (group_size & (group_size - 1)))) return false;
+  const int kc = (nbw == 1 && K % 1024 == 0) ? 1024 : 512;
+  return K % kc == 0 && (K >> 7) % 8 == 0;
+}
+template <class DT, int NBW, int MT>
+static void launch_gemm_q4_t(const GemmCArgs& a, bool awq, dim3 grid, size_t lds, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_q4_kernel<DT, NBW, MT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_q4_kernel<DT, NBW, MT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+    attr_set = true;
+  }
+  if (awq) gemm_q4_kernel<DT, NBW, MT, true><<<grid, GC_THREADS, lds, st>>>(a);
+  else gemm_q4_kernel<DT, NBW, MT, false><<<grid, GC_THREADS, lds, st>>>(a);
+}
+void vra_launch_gemm_q4(GemmCArgs a, bool awq, int dtype, int64_t stream) {
+  const int nbw = a.silu_dual ? 2 : 1;
+  const int mt = a.M <= 16 ? 1 : 2;
+  a.kc = (nbw == 1 && a.K % 1024 == 0) ? 1024 : 512;
+  const int tpc = a.kc >> 7;
+  // k-split inside the workgroup: the smallest that still yields >= ~3/4 of a workgroup per CU
+  const int cus = num_cus();
+  int ks = 1;
+  while (ks < 8 && ks * 2 <= tpc && (a.n_blocks + (GC_CW / ks) - 1) / (GC_CW / ks) < cus * 3 / 4) ks *= 2;
+  a.ks = ks;
+  const int items = (a.n_blocks + (GC_CW / ks) - 1) / (GC_CW / ks);
+  dim3 grid(items < cus ? items : cus, (a.M + 16 * mt - 1) / (16 * mt));
+  const size_t lds = gemm_q4_lds_bytes(nbw, mt, a.kc);
+  hipStream_t st = as_stream(stream);
+  const bool bf = dtype == VRA_BF16;
+#define VRA_GC(NBWV, MTV)                                                          \
+  do {                                                                             \
+    if (bf) launch_gemm_q4_t<BF16, NBWV, MTV>(a, awq, grid, lds, st);              \
+    else launch_gemm_q4_t<F16, NBWV, MTV>(a, awq, grid, lds, st);                  \
+  } while (0)
+  if (nbw == 2) {
+    if (mt == 1) VRA_GC(2, 1);
+    else VRA_GC(2, 2);
+  } else {
+    if (mt == 1) VRA_GC(1, 1);
+    else VRA_GC(1, 2);
+  }
+#undef VRA_GC
+}
+
 // ------------------------------------------------------------------------------------------------
 // Marlin-permuted scales (wna16.rs:180-218, what a reference-format caller passes to marlin_*): the GEMM
 // kernels read scales row-major only (one load per lane and tile, no index arithmetic in the stream), so a
@@ -427,6 +481,19 @@ extern "C" void vra_wna16_gemm(const void* in, const void* qweight_tiled, const 
     a.is_awq = is_awq;
     a.scales_layout = scales_layout;
     vra_launch_gemv(a, true, dtype, stream);
+  } else if (vra_gemm_q4_fits(1, m, k, group_size)) {
+    GemmCArgs c = {};
+    c.nseg = 1;
+    c.seg[0] = GemvSeg{qweight_tiled, scales, (const uint32_t*)qzeros, bias, out, n, n, 0};
+    c.x = in;
+    c.x_ld = k;
+    c.residual = residual;
+    c.res_ld = n;
+    c.M = m;
+    c.K = k;
+    c.group_size = group_size;
+    c.n_blocks = n / 16;
+    vra_launch_gemm_q4(c, is_awq != 0 && qzeros != nullptr, dtype, stream);
   } else {
     GemmBArgs b = {};
     b.w0 = qweight_tiled;
@@ -479,6 +546,19 @@ extern "C" void vra_wna16_gate_up_silu(const void* in, const void* qw_gate, cons
     a.is_awq = is_awq;
     a.scales_layout = scales_layout;
     vra_launch_gemv(a, true, dtype, stream);
+  } else if (vra_gemm_q4_fits(2, m, k, group_size)) {
+    GemmCArgs c = {};
+    c.nseg = 2;
+    c.seg[0] = GemvSeg{qw_gate, sc_gate, (const uint32_t*)qz_gate, nullptr, out, n, n, 0};
+    c.seg[1] = GemvSeg{qw_up, sc_up, (const uint32_t*)qz_up, nullptr, out, n, n, 0};
+    c.silu_dual = 1;
+    c.x = in;
+    c.x_ld = k;
+    c.M = m;
+    c.K = k;
+    c.group_size = group_size;
+    c.n_blocks = n / 16;
+    vra_launch_gemm_q4(c, is_awq != 0 && qz_gate != nullptr, dtype, stream);
   } else {
     GemmBArgs b = {};
     b.w0 = qw_gate;

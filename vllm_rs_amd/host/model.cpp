@@ -420,6 +420,25 @@ bool Model::linear_fused_norm(const QLinear* ls, int nl, void* const* outs, cons
     return !take_err(error, "fused norm gemv");
   }
   vra_rms_norm(x, norm_w, xn_, M, K, mc_.rms_norm_eps, dt_, stream);
+  bool same = ls[0].quant && nl <= GEMV_MAX_SEG;
+  for (int i = 1; i < nl; i++) same = same && ls[i].quant && ls[i].K == K && ls[i].awq == ls[0].awq;
+  if (same && vra_gemm_q4_fits(1, M, K, mc_.group_size)) {  // decode batches 9..32: q/k/v in ONE launch of kernel C
+    GemmCArgs c = {};
+    c.nseg = nl;
+    int blk = 0;
+    for (int i = 0; i < nl; i++) {
+      c.seg[i] = GemvSeg{ls[i].w, ls[i].scales, ls[i].qzeros, ls[i].bias, outs[i], ls[i].N, ls[i].N, blk};
+      blk += (ls[i].N + 15) / 16;
+    }
+    c.x = xn_;
+    c.x_ld = K;
+    c.M = M;
+    c.K = K;
+    c.group_size = mc_.group_size;
+    c.n_blocks = blk;
+    vra_launch_gemm_q4(c, ls[0].awq, dt_, stream);
+    return !take_err(error, "norm + gemm_q4");
+  }
   for (int i = 0; i < nl; i++)
     if (!linear(ls[i], xn_, outs[i], M, nullptr, stream)) return false;
   return !take_err(error, "norm + linear");
