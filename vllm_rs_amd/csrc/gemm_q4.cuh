@@ -11,7 +11,7 @@
 //   workgroup = 8 COMPUTE waves + 4 PRODUCER waves, persistent over work items.
 //   A work item = CG = 8/KS consecutive n-blocks (16 columns each; NBW = 2: the same blocks of gate AND up) over the full
 //   K.  Compute wave w = (cg, ks) owns n-block cg of the item and the k-tiles kt ≡ ks (mod KS): a flat stream of T =
-//   KT/KS tile-steps with a 2-deep register ring, branch-free, exact vmcnt (see gemv_q4.cuh for why that matters).
+//   KT/KS tile-steps with an 8 KiB register ring, branch-free, exact vmcnt (see gemv_q4.cuh for why that matters).
 //   MT m-tiles (16 rows each) share every dequantised B fragment: 4*MT MFMAs per tile and tensor.
 //   x reaches the MFMAs through LDS in K-chunks of KC = 512 or 1024 (double buffered, XOR-swizzled like kernel B), staged
 //   by the producer waves — which have no weight loads, so their waits never touch the compute waves' ring — together
@@ -37,12 +37,16 @@ struct GemmCArgs {
   int silu_dual, out_f32;
   int n_blocks;  // n-blocks (or gate/up pairs) in total
   int ks;        // k-split inside the workgroup: 1, 2, 4, 8
-  int kc;        // k per staged chunk: 512 or 1024 (K % kc == 0, (kc/128) % ks == 0)
+  int kc;        // k per staged chunk: 512 or 1024 ((K/kz) % kc == 0, (kc/128) % ks == 0)
+  int kz;        // K slices across workgroups (grid.z): 1 = none.  Slice partials go to fp32 slabs and the last-arriving
+                 // workgroup of an (item, m-chunk) reduces them in slice order (deterministic) and runs the epilogue
+  float* slabs;        // [kz][NBW][Mpad][n_blocks*16]
+  uint32_t* counters;  // one per (item, m-chunk): zero on entry, zero on exit
 };
 
 static inline size_t gemm_q4_lds_bytes(int nbw, int mt, int kc) {
   const int rows = 16 * mt;
-  return (size_t)2 * rows * kc * 2 + (size_t)2 * (kc / 128) * rows * 4 + (size_t)GC_CW * nbw * mt * 64 * 16 + 64;
+  return (size_t)2 * rows * kc * 2 + (size_t)2 * (kc / 128) * rows * 4 + (size_t)GC_CW * nbw * mt * 64 * 16 + 64;  // x | Σx | red | flag
 }
 
 template <class DT, int NBW, int MT, bool AWQ>
@@ -54,10 +58,12 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
   const bool is_prod = wave >= GC_CW;
   const int nn = lane & 15, oct = lane >> 4;
   const int K = a.K, M = a.M, KT = K >> 7;
-  const int KC = a.kc, TPC = KC >> 7, NC = K / KC, OPC = KC >> 3;  // tiles, chunks, octets per chunk
+  const int KZ = a.kz > 1 ? a.kz : 1, zi = (int)blockIdx.z;
+  const int KTZ = KT / KZ, kt0 = zi * KTZ;          // this workgroup's K slice, in tiles
+  const int KC = a.kc, TPC = KC >> 7, NC = KTZ / TPC, OPC = KC >> 3;  // tiles, chunks, octets per chunk
   const int KS = a.ks, CGN = GC_CW / KS;
   const int SC = TPC / KS;        // steps of one compute wave per chunk
-  const int T = KT / KS;          // steps per item
+  const int T = KTZ / KS;         // steps per item
   const bool grouped = a.group_size > 0 && a.group_size < K;
   const int gsh = grouped ? 31 - __builtin_clz(a.group_size) : 31;
   const int m0 = (int)blockIdx.y * ROWS;
@@ -68,6 +74,7 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
   uint32_t* xs = reinterpret_cast<uint32_t*>(smem);
   float* xsum = reinterpret_cast<float*>(smem + (size_t)2 * XS_U32 * 4);  // [2][TPC][ROWS]
   f32x4* red = reinterpret_cast<f32x4*>(smem + (size_t)2 * XS_U32 * 4 + (size_t)2 * TPC * ROWS * 4);  // [GC_CW][NBW][MT][64]
+  int* flag = reinterpret_cast<int*>(smem + (size_t)2 * XS_U32 * 4 + (size_t)2 * TPC * ROWS * 4 + (size_t)GC_CW * NBW * MT * 64 * 16);
 
   const int nseg = a.nseg;
   const int blk1 = nseg > 1 ? a.seg[1].blk_start : 0x7fffffff, blk2 = nseg > 2 ? a.seg[2].blk_start : 0x7fffffff;
@@ -89,7 +96,7 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
             const int i = pt + (r0 + r) * PTHREADS;
             const int row = i >> osh, o = i & (OPC - 1);
             const int m = min(m0 + row, M - 1);           // rows >= M alias row M-1 (never stored)
-            v[r] = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.x) + (size_t)m * a.x_ld + (size_t)c * KC + o * 8);
+            v[r] = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.x) + (size_t)m * a.x_ld + (size_t)kt0 * 128 + (size_t)c * KC + o * 8);
           }
         }
 #pragma unroll
@@ -116,38 +123,136 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
         __syncthreads();
       }
       __syncthreads();  // the item's partial tiles are in `red`
-      // ---- fused epilogue: CGN n-blocks x ROWS rows x 16 columns
-      const int nout = CGN * ROWS * 16;
-      for (int idx = pt; idx < nout; idx += PTHREADS) {
-        const int cg = idx / (ROWS * 16), rem = idx - cg * ROWS * 16;
-        const int mrow = rem >> 4, nl = rem & 15;
-        const int fb = it * CGN + cg;
-        const int m = m0 + mrow;
-        if (fb >= a.n_blocks || m >= M) continue;
-        const int segi = NBW == 2 ? 0 : (fb >= blk2 ? 2 : (fb >= blk1 ? 1 : 0));
-        const int nb = fb - (NBW == 2 ? 0 : a.seg[segi].blk_start);
-        const GemvSeg& sg = a.seg[segi];
+      // ---- CGN n-blocks x ROWS rows x 16 columns, handled as 8-column vectors (16 B stores; a scalar loop over single
+      // outputs exposed one global round trip per output: ~35 us).  Sum the KS partial tiles; with K slices publish to the
+      // slab and let the last-arriving workgroup finish.
+      const int nunits = CGN * ROWS * 2;
+      const int Mpad = (int)gridDim.y * ROWS, NC16 = a.n_blocks * 16;
+      const float* rf = reinterpret_cast<const float*>(red);
+      auto unit_geom = [&](int u, int& cgi, int& mrow, int& nl0) {
+        cgi = u / (ROWS * 2);
+        const int rem = u - cgi * ROWS * 2;
+        mrow = rem >> 1;
+        nl0 = (rem & 1) * 8;
+      };
+      auto lds_sum = [&](int cgi, int mrow, int nl0, float (&v)[8], float (&v2)[8]) {
         const int mt = mrow >> 4, mm = mrow & 15;
-        const int lslot = ((mm >> 2) * 16 + nl) * 4 + (mm & 3);  // D layout: column = lane&15, row = (lane>>4)*4 + reg
-        const float* rf = reinterpret_cast<const float*>(red);
-        float v = 0.f, v2 = 0.f;
-        for (int q = 0; q < KS; q++) {
-          const int w = cg * KS + q;
-          v += rf[(size_t)((w * NBW + 0) * MT + mt) * 256 + lslot];
-          if (NBW > 1) v2 += rf[(size_t)((w * NBW + (NBW - 1)) * MT + mt) * 256 + lslot];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const int lslot = ((mm >> 2) * 16 + nl0 + e) * 4 + (mm & 3);  // D layout: column = lane&15, row = (lane>>4)*4 + reg
+          float s0 = 0.f, s1 = 0.f;
+          for (int q = 0; q < KS; q++) {
+            const int w = cgi * KS + q;
+            s0 += rf[(size_t)((w * NBW + 0) * MT + mt) * 256 + lslot];
+            if (NBW > 1) s1 += rf[(size_t)((w * NBW + (NBW - 1)) * MT + mt) * 256 + lslot];
+          }
+          v[e] = s0;
+          v2[e] = s1;
         }
-        const int n = nb * 16 + nl;
-        v = rnd_dt<DT>(v);
-        if (sg.bias) v = rnd_dt<DT>(v + DT::to_f32(static_cast<const uint16_t*>(sg.bias)[n]));
-        if (NBW == 2) {
-          v2 = rnd_dt<DT>(v2);
-          if (a.seg[1].bias) v2 = rnd_dt<DT>(v2 + DT::to_f32(static_cast<const uint16_t*>(a.seg[1].bias)[n]));
-          const float sl = rnd_dt<DT>(v / (1.0f + expf(-v)));
-          v = sl * v2;
+      };
+      bool finish = true;
+      if (KZ > 1) {
+        float* slab = a.slabs + (size_t)zi * NBW * Mpad * NC16;
+        for (int u = pt; u < nunits; u += PTHREADS) {
+          int cgi, mrow, nl0;
+          unit_geom(u, cgi, mrow, nl0);
+          const int fb = it * CGN + cgi;
+          if (fb >= a.n_blocks) continue;
+          float v[8], v2[8];
+          lds_sum(cgi, mrow, nl0, v, v2);
+          float* d0 = slab + ((size_t)0 * Mpad + m0 + mrow) * NC16 + fb * 16 + nl0;
+          *reinterpret_cast<f32x4*>(d0) = f32x4{v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(d0 + 4) = f32x4{v[4], v[5], v[6], v[7]};
+          if (NBW > 1) {
+            float* d1 = slab + ((size_t)1 * Mpad + m0 + mrow) * NC16 + fb * 16 + nl0;
+            *reinterpret_cast<f32x4*>(d1) = f32x4{v2[0], v2[1], v2[2], v2[3]};
+            *reinterpret_cast<f32x4*>(d1 + 4) = f32x4{v2[4], v2[5], v2[6], v2[7]};
+          }
         }
-        if (a.residual) v = rnd_dt<DT>(v) + DT::to_f32(static_cast<const uint16_t*>(a.residual)[(size_t)m * a.res_ld + n]);
-        if (a.out_f32) static_cast<float*>(sg.out)[(size_t)m * sg.out_ld + n] = rnd_dt<DT>(v);
-        else static_cast<uint16_t*>(sg.out)[(size_t)m * sg.out_ld + n] = DT::from_f32(v);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (pt == 0) {  // agent-scope release / acquire around the arrival counter (cdna_hip_programming.md §6 G16)
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          uint32_t* ctr = a.counters + (size_t)it * gridDim.y + blockIdx.y;
+          const uint32_t prev = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int last = prev == (uint32_t)(KZ - 1);
+          if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          *flag = last;
+        }
+        __syncthreads();
+        finish = *flag != 0;
+      }
+      if (finish) {
+        for (int u = pt; u < nunits; u += PTHREADS) {
+          int cgi, mrow, nl0;
+          unit_geom(u, cgi, mrow, nl0);
+          const int fb = it * CGN + cgi;
+          const int m = m0 + mrow;
+          if (fb >= a.n_blocks || m >= M) continue;
+          const int segi = NBW == 2 ? 0 : (fb >= blk2 ? 2 : (fb >= blk1 ? 1 : 0));
+          const int nb = fb - (NBW == 2 ? 0 : a.seg[segi].blk_start);
+          const GemvSeg& sg = a.seg[segi];
+          const int n = nb * 16 + nl0;
+          // every global load of this unit goes out before anything is consumed
+          u32x4 bw = {0u, 0u, 0u, 0u}, bw2 = {0u, 0u, 0u, 0u}, rw = {0u, 0u, 0u, 0u};
+          if (sg.bias) bw = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(sg.bias) + n);
+          if (NBW == 2 && a.seg[1].bias) bw2 = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.seg[1].bias) + n);
+          if (a.residual) rw = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.residual) + (size_t)m * a.res_ld + n);
+          float v[8], v2[8];
+          if (KZ > 1) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = v2[e] = 0.f;
+            for (int z = 0; z < KZ; z++) {  // fixed slice order: deterministic
+              const float* s0 = a.slabs + ((size_t)z * NBW * Mpad + m) * NC16 + fb * 16 + nl0;
+              const f32x4 p0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(s0));
+              const f32x4 p1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(s0 + 4));
+#pragma unroll
+              for (int e = 0; e < 4; e++) {
+                v[e] += p0[e];
+                v[4 + e] += p1[e];
+              }
+              if (NBW > 1) {
+                const float* s1 = s0 + (size_t)Mpad * NC16;
+                const f32x4 q0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(s1));
+                const f32x4 q1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(s1 + 4));
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                  v2[e] += q0[e];
+                  v2[4 + e] += q1[e];
+                }
+              }
+            }
+          } else {
+            lds_sum(cgi, mrow, nl0, v, v2);
+          }
+          float bf[8], bf2[8], rf8[8], o8[8];
+          unpack8<DT>(bw, bf);
+          unpack8<DT>(bw2, bf2);
+          unpack8<DT>(rw, rf8);
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            float t = rnd_dt<DT>(v[e]);
+            if (sg.bias) t = rnd_dt<DT>(t + bf[e]);
+            if (NBW == 2) {
+              float t2 = rnd_dt<DT>(v2[e]);
+              if (a.seg[1].bias) t2 = rnd_dt<DT>(t2 + bf2[e]);
+              const float sl = rnd_dt<DT>(t / (1.0f + expf(-t)));
+              t = sl * t2;
+            }
+            if (a.residual) t = rnd_dt<DT>(t) + rf8[e];
+            o8[e] = t;
+          }
+          if (a.out_f32) {
+            float* op = static_cast<float*>(sg.out) + (size_t)m * sg.out_ld + n;
+            *reinterpret_cast<f32x4*>(op) = f32x4{rnd_dt<DT>(o8[0]), rnd_dt<DT>(o8[1]), rnd_dt<DT>(o8[2]), rnd_dt<DT>(o8[3])};
+            *reinterpret_cast<f32x4*>(op + 4) = f32x4{rnd_dt<DT>(o8[4]), rnd_dt<DT>(o8[5]), rnd_dt<DT>(o8[6]), rnd_dt<DT>(o8[7])};
+          } else {
+            *reinterpret_cast<u32x4*>(static_cast<uint16_t*>(sg.out) + (size_t)m * sg.out_ld + n) = pack8<DT>(o8);
+          }
+        }
       }
     }
     return;
@@ -186,10 +291,13 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
       qp[0] = sg.qzeros;
       ncols[0] = sg.n;
     }
-    u32x4 wb[2][NBW];
-    uint32_t sb[2][NBW], zb[2][NBW];
+    // ring depth: only 8 streaming waves per workgroup (and one workgroup per CU when LDS is full): 8 KiB per wave in
+    // flight = 64 KiB per CU (a 2-step ring measured a ~34 us latency floor: every step waited for HBM)
+    constexpr int D = 8 / NBW;
+    u32x4 wb[D][NBW];
+    uint32_t sb[D][NBW], zb[D][NBW];
     auto issue = [&](int i, u32x4 (&w)[NBW], uint32_t (&sc)[NBW], uint32_t (&zp)[NBW]) {
-      const int kt = ksi + KS * min(i, T - 1);  // steps past the end re-read the last tile (never consumed)
+      const int kt = kt0 + ksi + KS * min(i, T - 1);  // steps past the end re-read the last tile (never consumed)
 #pragma unroll
       for (int b = 0; b < NBW; b++) {
         w[b] = __builtin_nontemporal_load(wp[b] + (size_t)kt * 64);
@@ -200,8 +308,8 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
         else zp[b] = 0;
       }
     };
-    issue(0, wb[0], sb[0], zb[0]);
-    issue(1, wb[1], sb[1], zb[1]);
+#pragma unroll
+    for (int r = 0; r < D; r++) issue(r, wb[r], sb[r], zb[r]);
 
     f32x4 acc[NBW][MT];
 #pragma unroll
@@ -209,15 +317,15 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
 #pragma unroll
       for (int mt = 0; mt < MT; mt++) acc[b][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int T_pad = (T + 1) & ~1;
-    for (int i0 = 0; i0 < T_pad; i0 += 2) {
+    const int T_pad = (T + D - 1) / D * D;
+    for (int i0 = 0; i0 < T_pad; i0 += D) {
 #pragma unroll
-      for (int r = 0; r < 2; r++) {
+      for (int r = 0; r < D; r++) {
         const int i = i0 + r;
         if (i < T && (i % SC) == 0) __syncthreads();  // chunk i/SC is staged (and chunk i/SC - 2's buffer is free)
         if (i < T) {
-          const int kt = ksi + KS * i;
-          const int c = kt / TPC, tl = kt - c * TPC;
+          const int ktl = ksi + KS * i;  // tile within this workgroup's K slice
+          const int c = ktl / TPC, tl = ktl - c * TPC;
           const uint32_t* xb = xs + (size_t)(c & 1) * XS_U32;
           const float* sxb = xsum + ((size_t)(c & 1) * TPC + tl) * ROWS;
           f32x4 ag[NBW][MT];
@@ -253,7 +361,7 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
             }
           }
         }
-        issue(i + 2, wb[r], sb[r], zb[r]);  // unconditional refill (clamped)
+        issue(i + D, wb[r], sb[r], zb[r]);  // unconditional refill (clamped)
       }
     }
     // ---- hand the partial tiles to the producer waves
@@ -262,5 +370,9 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
 #pragma unroll
       for (int mt = 0; mt < MT; mt++) red[(size_t)((wave * NBW + b) * MT + mt) * 64 + lane] = acc[b][mt];
     __syncthreads();
+    if (KZ > 1) {  // the producers' slab / counter handshake uses two more workgroup barriers
+      __syncthreads();
+      __syncthreads();
+    }
   }
 }

@@ -364,12 +364,10 @@ bool vra_gemm_q4_fits(int nbw, int M, int K, int group_size) {
   static const char* off = getenv("VRA_NO_KERNEL_C");  // tuning aid
   if (off && atoi(off)) return false;
   if (M < 9 || M > 32) return false;
-  // the n-block-major decomposition re-reads all of x (M*K*2 bytes) per work item: it pays for the wide gate/up pair
-  // (N = 14336: x traffic ~ weight traffic) and not for N = 4096..6144 (x traffic 4..8x the weights: measured 26..80 us)
-  if (nbw != 2) return false;
   if (group_size > 0 && group_size < K && (group_size < 128 || (group_size & (group_size - 1)))) return false;
-  const int kc = (nbw == 1 && K % 1024 == 0) ? 1024 : 512;
-  return K % kc == 0 && (K >> 7) % 8 == 0;
+  if ((K >> 7) % 8) return false;
+  if (nbw == 1 && (!vra_scratch_slabs() || !vra_scratch_counters())) return false;  // narrow GEMMs slice K across workgroups
+  return true;
 }
 template <class DT, int NBW, int MT>
 static void launch_gemm_q4_t(const GemmCArgs& a, bool awq, dim3 grid, size_t lds, hipStream_t st) {
@@ -385,15 +383,37 @@ static void launch_gemm_q4_t(const GemmCArgs& a, bool awq, dim3 grid, size_t lds
 void vra_launch_gemm_q4(GemmCArgs a, bool awq, int dtype, int64_t stream) {
   const int nbw = a.silu_dual ? 2 : 1;
   const int mt = a.M <= 16 ? 1 : 2;
-  a.kc = (nbw == 1 && a.K % 1024 == 0) ? 1024 : 512;
-  const int tpc = a.kc >> 7;
-  // k-split inside the workgroup: the smallest that still yields >= ~3/4 of a workgroup per CU
   const int cus = num_cus();
-  int ks = 1;
-  while (ks < 8 && ks * 2 <= tpc && (a.n_blocks + (GC_CW / ks) - 1) / (GC_CW / ks) < cus * 3 / 4) ks *= 2;
+  const int KT = a.K >> 7;
+  int items, ks = 1, kz = 1;
+  if (nbw == 2) {
+    // wide gate/up pair: n-block-major, k split inside the workgroup until there is ~a workgroup per CU
+    a.kc = 512;
+    const int tpc = a.kc >> 7;
+    while (ks < 8 && ks * 2 <= tpc && (a.n_blocks + (GC_CW / ks) - 1) / (GC_CW / ks) < cus * 3 / 4) ks *= 2;
+    items = (a.n_blocks + (GC_CW / ks) - 1) / (GC_CW / ks);
+  } else {
+    // narrow GEMMs (N = 4096..6144): every wave owns an n-block (CG = 8), K is sliced across workgroups so that each
+    // stages only its slice of x; slices of >= 4 tiles, ~a workgroup per CU
+    items = (a.n_blocks + GC_CW - 1) / GC_CW;
+    for (int z = 2; z <= 16; z++) {
+      if (KT % z || (KT / z) % 4) continue;
+      if (items * z > cus + cus / 4) break;
+      kz = z;
+    }
+    static const char* kz_env = getenv("VRA_GC_KZ");  // tuning aid
+    if (kz_env && atoi(kz_env) >= 1 && KT % atoi(kz_env) == 0 && (KT / atoi(kz_env)) % 4 == 0) kz = atoi(kz_env);
+    const int ktz = KT / kz;
+    a.kc = (ktz % 8 == 0) ? 1024 : 512;
+    size_t slab = (size_t)kz * ((a.M + 16 * mt - 1) / (16 * mt)) * 16 * mt * a.n_blocks * 16 * 4;
+    if (kz > 1 && (slab > vra_scratch_slab_bytes() || (size_t)items * ((a.M + 16 * mt - 1) / (16 * mt)) > vra_scratch_counter_count())) kz = 1;
+    if (kz == 1) a.kc = (KT % 8 == 0) ? 1024 : 512;
+  }
   a.ks = ks;
-  const int items = (a.n_blocks + (GC_CW / ks) - 1) / (GC_CW / ks);
-  dim3 grid(items < cus ? items : cus, (a.M + 16 * mt - 1) / (16 * mt));
+  a.kz = kz;
+  a.slabs = kz > 1 ? vra_scratch_slabs() : nullptr;
+  a.counters = kz > 1 ? vra_scratch_counters() : nullptr;
+  dim3 grid(items < cus || kz > 1 ? items : cus, (a.M + 16 * mt - 1) / (16 * mt), kz);
   const size_t lds = gemm_q4_lds_bytes(nbw, mt, a.kc);
   hipStream_t st = as_stream(stream);
   const bool bf = dtype == VRA_BF16;
