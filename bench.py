@@ -195,8 +195,14 @@ def main():
             tot_b += b
             tot_ms += ms
         dom = per["norm+gate_up+silu"]
+        traffic = None  # HBM bytes per launch from the PMC pass (rocprofv3 --pmc FETCH_SIZE, corrected per the microarch guide)
+        try:
+            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc.json")))
+            traffic = pmc["kernels"]["gemv_q4_kernel<BF16,2,1,false>"]["hbm_bytes_per_launch"] if a.batch == 1 else None
+        except Exception:
+            pass
         line["roofline"] = {"bound": "hbm", "kernel": "gemv_q4_kernel<BF16,NBW=2,SPT=1,AWQ=false> (RMSNorm + gate/up int4 GEMV + SiLU*mul)", "achieved": dom["GBps"],
-                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": None,
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
                             "algorithmic_bytes_per_launch": dom["bytes"], "avg_launch_ms": dom["ms"],
                             "family": per, "family_GBps": tot_b / tot_ms / 1e6, "family_frac": tot_b / tot_ms / 1e6 / HBM_PEAK_GBS,
                             "family_ms_per_token": tot_ms * cfg["num_layers"]}
