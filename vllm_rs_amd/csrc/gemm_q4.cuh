@@ -46,7 +46,8 @@ struct GemmCArgs {
 
 static inline size_t gemm_q4_lds_bytes(int nbw, int mt, int kc) {
   const int rows = 16 * mt;
-  return (size_t)2 * rows * kc * 2 + (size_t)2 * (kc / 128) * rows * 4 + (size_t)GC_CW * nbw * mt * 64 * 16 + 64;  // x | Σx | red | flag
+  const size_t x2 = (size_t)2 * rows * kc * 2, red = (size_t)GC_CW * nbw * mt * 64 * 16;  // red aliases the x buffers
+  return (x2 > red ? x2 : red) + (size_t)2 * (kc / 128) * rows * 4 + 64;  // x (| red) | Σx | flag
 }
 
 template <class DT, int NBW, int MT, bool AWQ>
@@ -73,8 +74,10 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
   const int XS_U32 = OPC * ROWS * 4;  // one x buffer in u32
   uint32_t* xs = reinterpret_cast<uint32_t*>(smem);
   float* xsum = reinterpret_cast<float*>(smem + (size_t)2 * XS_U32 * 4);  // [2][TPC][ROWS]
-  f32x4* red = reinterpret_cast<f32x4*>(smem + (size_t)2 * XS_U32 * 4 + (size_t)2 * TPC * ROWS * 4);  // [GC_CW][NBW][MT][64]
-  int* flag = reinterpret_cast<int*>(smem + (size_t)2 * XS_U32 * 4 + (size_t)2 * TPC * ROWS * 4 + (size_t)GC_CW * NBW * MT * 64 * 16);
+  // the partial tiles of an item ALIAS the x buffers: they are written after the item's last chunk has been consumed
+  // and read by the producers before they stage the next item's first chunk
+  f32x4* red = reinterpret_cast<f32x4*>(smem);  // [GC_CW][NBW][MT][64] (<= 32 KiB <= one x buffer)
+  int* flag = reinterpret_cast<int*>(smem + (size_t)2 * XS_U32 * 4 + (size_t)2 * TPC * ROWS * 4);
 
   const int nseg = a.nseg;
   const int blk1 = nseg > 1 ? a.seg[1].blk_start : 0x7fffffff, blk2 = nseg > 2 ? a.seg[2].blk_start : 0x7fffffff;
@@ -88,10 +91,11 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
     auto stage = [&](int c, int buf) {
       uint32_t* dst = xs + (size_t)buf * XS_U32;
       float* sdst = xsum + (size_t)buf * TPC * ROWS;
-      for (int r0 = 0; r0 < per; r0 += 8) {  // 8 loads in flight per lane (per is 4, 8 or 16)
-        u32x4 v[8];
+      for (int r0 = 0; r0 < per; r0 += 16) {  // the lane's whole share of the chunk in flight (per is 4, 8 or 16): staging
+                                                // throughput = bytes per L2 round trip
+        u32x4 v[16];
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
+        for (int r = 0; r < 16; r++) {
           if (r0 + r < per) {
             const int i = pt + (r0 + r) * PTHREADS;
             const int row = i >> osh, o = i & (OPC - 1);
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
           }
         }
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
+        for (int r = 0; r < 16; r++) {
           if (r0 + r < per) {
             const int i = pt + (r0 + r) * PTHREADS;
             const int row = i >> osh, o = i & (OPC - 1);
@@ -122,6 +126,7 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
         stage(c, c & 1);
         __syncthreads();
       }
+      __syncthreads();  // every compute wave has consumed the last chunk
       __syncthreads();  // the item's partial tiles are in `red`
       // ---- CGN n-blocks x ROWS rows x 16 columns, handled as 8-column vectors (16 B stores; a scalar loop over single
       // outputs exposed one global round trip per output: ~35 us).  Sum the KS partial tiles; with K slices publish to the
@@ -364,7 +369,8 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
         issue(i + D, wb[r], sb[r], zb[r]);  // unconditional refill (clamped)
       }
     }
-    // ---- hand the partial tiles to the producer waves
+    // ---- hand the partial tiles to the producer waves (they alias the x buffers: every wave must be done reading x)
+    __syncthreads();
 #pragma unroll
     for (int b = 0; b < NBW; b++)
 #pragma unroll

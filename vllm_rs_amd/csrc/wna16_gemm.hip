@@ -388,7 +388,7 @@ void vra_launch_gemm_q4(GemmCArgs a, bool awq, int dtype, int64_t stream) {
   int items, ks = 1, kz = 1;
   if (nbw == 2) {
     // wide gate/up pair: n-block-major, k split inside the workgroup until there is ~a workgroup per CU
-    a.kc = 512;
+    a.kc = (KT % 8 == 0) ? 1024 : 512;  // fewer, larger x chunks: the producers' staging is latency bound
     const int tpc = a.kc >> 7;
     while (ks < 8 && ks * 2 <= tpc && (a.n_blocks + (GC_CW / ks) - 1) / (GC_CW / ks) < cus * 3 / 4) ks *= 2;
     items = (a.n_blocks + (GC_CW / ks) - 1) / (GC_CW / ks);
