@@ -110,7 +110,31 @@ __device__ __forceinline__ u32x4 pack8(const float* f) {
   return v;
 }
 
+// Σ of the 8 16-bit floats of one octet in f32, fixed pairwise order.  (v_dot2_f32_bf16 against (1,1) would be 4 ops
+// instead of ~15, but on gfx950 / ROCm 7.2 `__builtin_amdgcn_fdot2_f32_bf16` returned sums that are off by up to
+// several units for |x| < 2 — measured with exp/dot2.hip — so the conversion + add form stays.)
+template <class DT>
+__device__ __forceinline__ float octet_sum(const u32x4& v);
+
 // ---------------------------------------------------------------- reductions
+// Sum over aligned groups of 4 / 16 consecutive lanes with DPP modifiers (1 VALU op per step, no LDS traffic):
+// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror.  `__shfl_xor` lowers to ds_bpermute_b32 on
+// gfx950 — an LDS-pipeline round trip per step, which made the x staging of kernel C 4x slower than its loads.
+template <int CTRL>
+__device__ __forceinline__ float vra_dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_sum(float v) {  // every lane of an aligned quad gets the quad's sum
+  v += vra_dpp_f<0xB1>(v);
+  v += vra_dpp_f<0x4E>(v);
+  return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {  // every lane of an aligned group of 16 gets the group's sum
+  v = quad_sum(v);
+  v += vra_dpp_f<0x141>(v);  // row_half_mirror: lane i <-> 7-i (the other quad of the half row)
+  v += vra_dpp_f<0x140>(v);  // row_mirror: lane i <-> 15-i (the other half row)
+  return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -120,6 +144,13 @@ __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
+}
+
+template <class DT>
+__device__ __forceinline__ float octet_sum(const u32x4& v) {
+  float f[8];
+  unpack8<DT>(v, f);
+  return ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
 }
 
 // ---------------------------------------------------------------- counter-based RNG (== oracle hash32)

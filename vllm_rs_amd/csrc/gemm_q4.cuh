@@ -42,7 +42,19 @@ struct GemmCArgs {
                  // workgroup of an (item, m-chunk) reduces them in slice order (deterministic) and runs the epilogue
   float* slabs;        // [kz][NBW][Mpad][n_blocks*16]
   uint32_t* counters;  // one per (item, m-chunk): zero on entry, zero on exit
+  unsigned long long* ts;  // VRA_GEMV_TS builds: [grid.x][32] wall-clock stamps (compute wave 0: 0..15, producer wave 0: 16..31)
 };
+#ifdef VRA_GEMV_TS
+#define GC_STAMP(i)                                                                                   \
+  do {                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    if (a.ts && lane == 0 && (wave == 0 || wave == GC_CW) && blockIdx.z == 0)                         \
+      a.ts[(size_t)blockIdx.x * 32 + (i)] = wall_clock64();                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+  } while (0)
+#else
+#define GC_STAMP(i) do {} while (0)
+#endif
 
 static inline size_t gemm_q4_lds_bytes(int nbw, int mt, int kc) {
   const int rows = 16 * mt;
@@ -109,25 +121,25 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
             const int i = pt + (r0 + r) * PTHREADS;
             const int row = i >> osh, o = i & (OPC - 1);
             *reinterpret_cast<u32x4*>(dst + ((size_t)o * ROWS + (row ^ (o & 7))) * 4) = v[r];
-            float f[8];
-            unpack8<DT>(v[r], f);
-            float s8 = ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
-#pragma unroll
-            for (int d = 1; d < 16; d <<= 1) s8 += __shfl_xor(s8, d, 64);   // 16 consecutive octets = one k-tile of one row
+            const float s8 = row16_sum(octet_sum<DT>(v[r]));  // 16 consecutive octets (lanes) = one k-tile of one row
             if ((o & 15) == 0) sdst[(o >> 4) * ROWS + row] = s8;
           }
         }
       }
     };
     for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+      GC_STAMP(16);
       stage(0, 0);
+      GC_STAMP(17);
       __syncthreads();
       for (int c = 1; c < NC; c++) {
         stage(c, c & 1);
+        GC_STAMP(17 + (c < 6 ? c : 6));
         __syncthreads();
       }
       __syncthreads();  // every compute wave has consumed the last chunk
       __syncthreads();  // the item's partial tiles are in `red`
+      GC_STAMP(24);
       // ---- CGN n-blocks x ROWS rows x 16 columns, handled as 8-column vectors (16 B stores; a scalar loop over single
       // outputs exposed one global round trip per output: ~35 us).  Sum the KS partial tiles; with K slices publish to the
       // slab and let the last-arriving workgroup finish.
@@ -259,6 +271,7 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
           }
         }
       }
+      GC_STAMP(25);
     }
     return;
   }
@@ -298,7 +311,7 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
     }
     // ring depth: only 8 streaming waves per workgroup (and one workgroup per CU when LDS is full): 8 KiB per wave in
     // flight = 64 KiB per CU (a 2-step ring measured a ~34 us latency floor: every step waited for HBM)
-    constexpr int D = 8 / NBW;
+    constexpr int D = (MT == 2 ? 6 : 8) / NBW;  // (MT = 2 holds twice the accumulators and x fragments: a shorter ring avoids spills)
     u32x4 wb[D][NBW];
     uint32_t sb[D][NBW], zb[D][NBW];
     auto issue = [&](int i, u32x4 (&w)[NBW], uint32_t (&sc)[NBW], uint32_t (&zp)[NBW]) {
@@ -313,8 +326,10 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
         else zp[b] = 0;
       }
     };
+    GC_STAMP(0);
 #pragma unroll
     for (int r = 0; r < D; r++) issue(r, wb[r], sb[r], zb[r]);
+    GC_STAMP(1);
 
     f32x4 acc[NBW][MT];
 #pragma unroll
@@ -327,7 +342,11 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
 #pragma unroll
       for (int r = 0; r < D; r++) {
         const int i = i0 + r;
-        if (i < T && (i % SC) == 0) __syncthreads();  // chunk i/SC is staged (and chunk i/SC - 2's buffer is free)
+        if (i < T && (i % SC) == 0) {
+          GC_STAMP(2 + 2 * ((i / SC) < 5 ? (i / SC) : 5));
+          __syncthreads();  // chunk i/SC is staged (and chunk i/SC - 2's buffer is free)
+          GC_STAMP(3 + 2 * ((i / SC) < 5 ? (i / SC) : 5));
+        }
         if (i < T) {
           const int ktl = ksi + KS * i;  // tile within this workgroup's K slice
           const int c = ktl / TPC, tl = ktl - c * TPC;
@@ -338,16 +357,30 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
           for (int b = 0; b < NBW; b++)
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) ag[b][mt] = vra_zero_acc();
+          // LDS reads run one k-step (j) ahead of the MFMAs that consume them
+          u32x4 xv[2][MT];
+          f32x4 sxv[MT];
+#pragma unroll
+          for (int mt = 0; mt < MT; mt++) {
+            const int o = tl * 16 + oct;
+            xv[0][mt] = *reinterpret_cast<const u32x4*>(xb + ((size_t)o * ROWS + ((mt * 16 + nn) ^ (o & 7))) * 4);
+          }
 #pragma unroll
           for (int j = 0; j < 4; j++) {
-            const int o = tl * 16 + j * 4 + oct;
+            if (j < 3) {
+              const int o = tl * 16 + (j + 1) * 4 + oct;
+#pragma unroll
+              for (int mt = 0; mt < MT; mt++) xv[(j + 1) & 1][mt] = *reinterpret_cast<const u32x4*>(xb + ((size_t)o * ROWS + ((mt * 16 + nn) ^ (o & 7))) * 4);
+            } else {
+#pragma unroll
+              for (int mt = 0; mt < MT; mt++) sxv[mt] = *reinterpret_cast<const f32x4*>(sxb + mt * 16 + oct * 4);
+            }
             s16x8 bfrag[NBW];
 #pragma unroll
             for (int b = 0; b < NBW; b++) bfrag[b] = magic_word<DT>(wb[r][b][j]);
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
-              const u32x4 xv = *reinterpret_cast<const u32x4*>(xb + ((size_t)o * ROWS + ((mt * 16 + nn) ^ (o & 7))) * 4);
-              const s16x8 afrag = __builtin_bit_cast(s16x8, xv);
+              const s16x8 afrag = __builtin_bit_cast(s16x8, xv[j & 1][mt]);
 #pragma unroll
               for (int b = 0; b < NBW; b++) DT::mfma(ag[b][mt], afrag, bfrag[b]);
             }
@@ -360,7 +393,7 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
             const float zc = AWQ ? CB + (float)((zb[r][b] >> zsh) & 0xFu) : CB + 8.f;
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
-              const f32x4 sx = *reinterpret_cast<const f32x4*>(sxb + mt * 16 + oct * 4);
+              const f32x4 sx = sxv[mt];
 #pragma unroll
               for (int e = 0; e < 4; e++) acc[b][mt][e] = fmaf(s, fmaf(-zc, sx[e], ag[b][mt][e]), acc[b][mt][e]);
             }
@@ -370,7 +403,9 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
       }
     }
     // ---- hand the partial tiles to the producer waves (they alias the x buffers: every wave must be done reading x)
+    GC_STAMP(14);
     __syncthreads();
+    GC_STAMP(15);
 #pragma unroll
     for (int b = 0; b < NBW; b++)
 #pragma unroll

@@ -88,11 +88,8 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
       const int row = i >> 5, o = i & 31;
       *reinterpret_cast<u32x4*>(dst + ((size_t)o * ROWS + (row ^ (o & 7))) * 4) = xr[r];
       if (INT4) {  // every lane takes part in the shuffles
-        float f[8];
-        unpack8<DT>(xr[r], f);
-        float s8 = ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
-#pragma unroll
-        for (int d = 1; d < OPG; d <<= 1) s8 += __shfl_xor(s8, d, 64);
+        float s8 = octet_sum<DT>(xr[r]);
+        s8 = OPG == 4 ? quad_sum(s8) : row16_sum(s8);
         if ((o % OPG) == 0) xsum[((size_t)buf * ROWS + row) * FPC + o / OPG] = s8;
       }
     }

@@ -202,19 +202,17 @@ __global__ __launch_bounds__(1024) void gemv_q4_kernel(const GemvArgs a) {
   auto row_of = [&](int c) { return min((c * nthr + (wave << 6)) / octs, M - 1); };  // octs % 64 == 0: a wave never straddles rows
   auto stage_octet = [&](int c, u32x4 v, u32x4 nv, float rs) {  // normalise (optional), write the LDS image and Σx
     const int m = row_of(c), o = c * nthr + tid, oo = o - m * octs;
-    float f[8];
-    unpack8<DT>(v, f);
     if (norm) {
-      float g[8];
+      float f[8], g[8];
+      unpack8<DT>(v, f);
       unpack8<DT>(nv, g);
 #pragma unroll
       for (int i = 0; i < 8; i++) f[i] = f[i] * rs * g[i];
       v = pack8<DT>(f);
-      unpack8<DT>(v, f);  // sums are taken over the ROUNDED values the MFMA will see
     }
     if (o < OC) *reinterpret_cast<u32x4*>(xs + ((size_t)oo * M + m) * 4) = v;
-    float s8 = ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
-    for (int d = 1; d < opg; d <<= 1) s8 += __shfl_xor(s8, d, 64);
+    float s8 = octet_sum<DT>(v);  // over the ROUNDED values the MFMA will see
+    s8 = SPT == 4 ? quad_sum(s8) : row16_sum(s8);  // opg = 4 or 16 consecutive octets (lanes)
     if (o < OC && (oo & (opg - 1)) == 0) xsum[(oo / opg) * 16 + m] = s8;
   };
   auto octet_ss = [&](u32x4 v) {

@@ -413,6 +413,11 @@ void vra_launch_gemm_q4(GemmCArgs a, bool awq, int dtype, int64_t stream) {
   a.kz = kz;
   a.slabs = kz > 1 ? vra_scratch_slabs() : nullptr;
   a.counters = kz > 1 ? vra_scratch_counters() : nullptr;
+#ifdef VRA_GEMV_TS
+  a.ts = vra_gemv_ts_buf();
+#else
+  a.ts = nullptr;
+#endif
   dim3 grid(items < cus || kz > 1 ? items : cus, (a.M + 16 * mt - 1) / (16 * mt), kz);
   const size_t lds = gemm_q4_lds_bytes(nbw, mt, a.kc);
   hipStream_t st = as_stream(stream);
