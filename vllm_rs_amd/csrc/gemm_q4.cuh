@@ -58,7 +58,7 @@ struct GemmCArgs {
 
 static inline size_t gemm_q4_lds_bytes(int nbw, int mt, int kc) {
   const int rows = 16 * mt;
-  const size_t x2 = (size_t)2 * rows * kc * 2, red = (size_t)GC_CW * nbw * mt * 64 * 16;  // red aliases the x buffers
+  const size_t x2 = (size_t)2 * rows * (kc / 8 + 1) * 16, red = (size_t)GC_CW * nbw * mt * 64 * 16;  // red aliases the x buffers
   return (x2 > red ? x2 : red) + (size_t)2 * (kc / 128) * rows * 4 + 64;  // x (| red) | Σx | flag
 }
 
@@ -83,7 +83,11 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
   const int n_items = (a.n_blocks + CGN - 1) / CGN;
 
   // ---- LDS
-  const int XS_U32 = OPC * ROWS * 4;  // one x buffer in u32
+  // x buffer: row-major with one octet of padding per row — the producers write 64 consecutive octets of a row per wave
+  // (consecutive LDS addresses), the MFMA fragment reads (16 rows x 4 octets) hit 16 distinct bank quads per quarter wave.
+  // (The [octet][row] XOR-swizzled layout of kernel B made every producer ds_write_b128 an 8-way bank conflict.)
+  const int RS = (OPC + 1) * 4;       // row stride in u32
+  const int XS_U32 = ROWS * RS;       // one x buffer in u32
   uint32_t* xs = reinterpret_cast<uint32_t*>(smem);
   float* xsum = reinterpret_cast<float*>(smem + (size_t)2 * XS_U32 * 4);  // [2][TPC][ROWS]
   // the partial tiles of an item ALIAS the x buffers: they are written after the item's last chunk has been consumed
@@ -102,7 +106,6 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
     const int osh = OPC == 128 ? 7 : 6;                 // OPC is 64 or 128
     auto stage = [&](int c, int buf) {
       uint32_t* dst = xs + (size_t)buf * XS_U32;
-      float* sdst = xsum + (size_t)buf * TPC * ROWS;
       for (int r0 = 0; r0 < per; r0 += 16) {  // the lane's whole share of the chunk in flight (per is 4, 8 or 16): staging
                                                 // throughput = bytes per L2 round trip
         u32x4 v[16];
@@ -120,9 +123,7 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
           if (r0 + r < per) {
             const int i = pt + (r0 + r) * PTHREADS;
             const int row = i >> osh, o = i & (OPC - 1);
-            *reinterpret_cast<u32x4*>(dst + ((size_t)o * ROWS + (row ^ (o & 7))) * 4) = v[r];
-            const float s8 = row16_sum(octet_sum<DT>(v[r]));  // 16 consecutive octets (lanes) = one k-tile of one row
-            if ((o & 15) == 0) sdst[(o >> 4) * ROWS + row] = s8;
+            *reinterpret_cast<u32x4*>(dst + (size_t)row * RS + o * 4) = v[r];
           }
         }
       }
@@ -281,6 +282,10 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
   const int zsh = 4 * awq_rev(nn & 7);
   const bool shalf = nn & 1;
   constexpr float CB = Magic<DT>::bias;
+  u32x4 ones_w;
+  ones_w[0] = ones_w[1] = ones_w[2] = ones_w[3] = DT::id == VRA_BF16 ? 0x3F803F80u : 0x3C003C00u;  // eight 1.0
+  asm volatile("" : "+v"(ones_w));
+  const s16x8 ones = __builtin_bit_cast(s16x8, ones_w);
 
   for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
     const int fb = it * CGN + cg;
@@ -351,29 +356,29 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
           const int ktl = ksi + KS * i;  // tile within this workgroup's K slice
           const int c = ktl / TPC, tl = ktl - c * TPC;
           const uint32_t* xb = xs + (size_t)(c & 1) * XS_U32;
-          const float* sxb = xsum + ((size_t)(c & 1) * TPC + tl) * ROWS;
           f32x4 ag[NBW][MT];
 #pragma unroll
           for (int b = 0; b < NBW; b++)
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) ag[b][mt] = vra_zero_acc();
-          // LDS reads run one k-step (j) ahead of the MFMAs that consume them
+          // LDS reads run one k-step (j) ahead of the MFMAs that consume them.  The row sums Σx of the zero-point fix-up
+          // come from one extra MFMA per (j, m-tile) against an all-ones B fragment: D[m][n] = Σ_k x[m][k] lands in
+          // exactly the lanes that need it, and the producers only have to move bytes.
           u32x4 xv[2][MT];
           f32x4 sxv[MT];
 #pragma unroll
+          for (int mt = 0; mt < MT; mt++) sxv[mt] = vra_zero_acc();
+#pragma unroll
           for (int mt = 0; mt < MT; mt++) {
             const int o = tl * 16 + oct;
-            xv[0][mt] = *reinterpret_cast<const u32x4*>(xb + ((size_t)o * ROWS + ((mt * 16 + nn) ^ (o & 7))) * 4);
+            xv[0][mt] = *reinterpret_cast<const u32x4*>(xb + (size_t)(mt * 16 + nn) * RS + o * 4);
           }
 #pragma unroll
           for (int j = 0; j < 4; j++) {
             if (j < 3) {
               const int o = tl * 16 + (j + 1) * 4 + oct;
 #pragma unroll
-              for (int mt = 0; mt < MT; mt++) xv[(j + 1) & 1][mt] = *reinterpret_cast<const u32x4*>(xb + ((size_t)o * ROWS + ((mt * 16 + nn) ^ (o & 7))) * 4);
-            } else {
-#pragma unroll
-              for (int mt = 0; mt < MT; mt++) sxv[mt] = *reinterpret_cast<const f32x4*>(sxb + mt * 16 + oct * 4);
+              for (int mt = 0; mt < MT; mt++) xv[(j + 1) & 1][mt] = *reinterpret_cast<const u32x4*>(xb + (size_t)(mt * 16 + nn) * RS + o * 4);
             }
             s16x8 bfrag[NBW];
 #pragma unroll
@@ -383,6 +388,7 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
               const s16x8 afrag = __builtin_bit_cast(s16x8, xv[j & 1][mt]);
 #pragma unroll
               for (int b = 0; b < NBW; b++) DT::mfma(ag[b][mt], afrag, bfrag[b]);
+              DT::mfma(sxv[mt], afrag, ones);
             }
           }
           VRA_MFMA_DRAIN();

@@ -4,8 +4,8 @@
 // Workgroup = 512 threads = 8 waves; wave w owns n-block (blockIdx.x*8 + w) = 16 output columns
 // (DUAL: the same block of the gate AND the up tensor) and walks ALL k-tiles of its K slice, so
 // each weight byte is read once per 16*MT rows.  The x chunk (16*MT rows x 256 k) is staged through
-// LDS (double buffered, XOR-swizzled so both the 16 B stores and the MFMA B-fragment `ds_read_b128`
-// are conflict-free) and shared by the 8 waves.  grid.y = M chunks, grid.z = K slices (split-K):
+// LDS (double buffered, row-major with one octet of padding per row so both the 16 B stores and the MFMA
+// B-fragment `ds_read_b128` are conflict-free) and shared by the 8 waves.  grid.y = M chunks, grid.z = K slices (split-K):
 // slice partials go to fp32 slabs and the last-arriving workgroup of a tile reduces them in fixed
 // slice order (deterministic) and applies the epilogue — agent-scope release/acquire per
 // cdna_hip_programming.md §6 G16.
@@ -44,7 +44,11 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int ROWS = MT * 16;
   constexpr int NW = DUAL ? 2 : 1;
-  constexpr int XS_U32 = (GB_KC / 8) * ROWS * 4;  // one x buffer, in u32
+  // x buffer: row-major, one octet of padding per row — the staging stores of a wave are consecutive in LDS and the
+  // MFMA fragment reads (16 rows x 4 octets) are conflict-free per quarter wave (the former [octet][row] XOR-swizzled
+  // layout made every staging ds_write_b128 a multi-way bank conflict: measured on kernel C, -25 % kernel time)
+  constexpr int RS = (GB_KC / 8 + 1) * 4;  // row stride, in u32
+  constexpr int XS_U32 = ROWS * RS;        // one x buffer, in u32
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches, no exec masking
   const int nn = lane & 15, oct = lane >> 4;
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
     for (int r = 0; r < XPT; r++) {
       const int i = tid + r * GB_THREADS;
       const int row = i >> 5, o = i & 31;
-      *reinterpret_cast<u32x4*>(dst + ((size_t)o * ROWS + (row ^ (o & 7))) * 4) = xr[r];
+      *reinterpret_cast<u32x4*>(dst + (size_t)row * RS + o * 4) = xr[r];
       if (INT4) {  // every lane takes part in the shuffles
         float s8 = octet_sum<DT>(xr[r]);
         s8 = OPG == 4 ? quad_sum(s8) : row16_sum(s8);
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
         }
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
-          const u32x4 xv = *reinterpret_cast<const u32x4*>(xb + ((size_t)o * ROWS + ((mt * 16 + nn) ^ (o & 7))) * 4);
+          const u32x4 xv = *reinterpret_cast<const u32x4*>(xb + (size_t)(mt * 16 + nn) * RS + o * 4);
           const s16x8 bfrag = __builtin_bit_cast(s16x8, xv);
 #pragma unroll
           for (int w = 0; w < NW; w++) {
@@ -307,5 +311,5 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
 }
 
 static inline size_t gemm_skinny_lds_bytes(int mt, int spt) {
-  return (size_t)2 * (GB_KC / 8) * mt * 16 * 16 + (size_t)2 * mt * 16 * (GB_KC / 128) * spt * 4 + 16;
+  return (size_t)2 * (GB_KC / 8 + 1) * mt * 16 * 16 + (size_t)2 * mt * 16 * (GB_KC / 128) * spt * 4 + 16;
 }
