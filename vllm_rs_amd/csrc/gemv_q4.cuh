@@ -28,7 +28,7 @@
 
 #define GQ_MAX_WAVES 16
 #define GQ_ROWS 16  // max rows of x per workgroup = one MFMA tile (LDS holds rows * K * 2 bytes)
-#define GQ_XR 2  // x octets per compute thread the fast prologue keeps in registers
+#define GQ_XR 2  // x octets per compute thread the fast prologue keeps in registers (5 measured: bs 8 -5 %, bs 1 +12 % time)
 #define GQ_MAX_CHUNKS 16  // x octets per compute thread at most (loop-staged prologue)
 #ifndef GQ_RING_KIB
 #define GQ_RING_KIB 2  // weights in flight per wave (deeper rings measured SLOWER: see DESIGN.md §4.1)
@@ -77,7 +77,7 @@ __device__ __forceinline__ float gq_row16_elem(const uint16_t* base_uniform, int
 // LDS: xs | xsum [NF][16] | red [1 or 2][NW][NBW][RL] f32x4 (RL = 32 lanes for <= 8 rows, 64 above) | part + rstd
 static inline size_t gemv_q4_lds_bytes(int nbw, int nw, int M, int K, int group_size, bool single_red = false) {
   const int spt = (group_size > 0 && group_size < 128) ? 4 : 1;
-  size_t b = (((size_t)M * K * 2 + 15) & ~(size_t)15);
+  size_t b = (size_t)M * (K / 8 + 1) * 16;  // x image: row-major, one octet of padding per row
   b += (size_t)(K / 128) * spt * 16 * 4;
   b += (size_t)(single_red ? 1 : 2) * nw * nbw * (M > 8 ? 64 : 32) * 16;
   b += (GQ_MAX_CHUNKS * GQ_MAX_WAVES + 16) * 4;
@@ -113,8 +113,12 @@ __global__ __launch_bounds__(1024) void gemv_q4_kernel(const GemvArgs a) {
   GEMV_STAMP(0);
 
   // ---- LDS carve-up
-  uint32_t* xs = reinterpret_cast<uint32_t*>(smem);  // image: xs[(o*M + m)*4 .. +4] = x[m][o*8 .. +8]
-  size_t off = ((size_t)M * K * 2 + 15) & ~(size_t)15;
+  // x image: xs[(m*(octs+1) + o)*4 .. +4] = x[m][o*8 .. +8] — row-major with one octet of padding per row: the staging
+  // stores of a wave (consecutive octets of a row) are consecutive in LDS, and the 16 rows of an MFMA fragment read are 4
+  // banks apart.  (The former [octet][row] image made every staging store a 32-way bank conflict at 8 rows.)
+  uint32_t* xs = reinterpret_cast<uint32_t*>(smem);
+  const int XRS = ((K >> 3) + 1) * 4;  // row stride in u32
+  size_t off = (size_t)M * XRS * 4;
   float* xsum = reinterpret_cast<float*>(smem + off);  // [NF][16]: Σx of row m over fix-up step f
   off += (size_t)NF * 16 * 4;
   const int RL = M > 8 ? 64 : 32;  // lanes of a partial tile that carry rows < M
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(1024) void gemv_q4_kernel(const GemvArgs a) {
       for (int i = 0; i < 8; i++) f[i] = f[i] * rs * g[i];
       v = pack8<DT>(f);
     }
-    if (o < OC) *reinterpret_cast<u32x4*>(xs + ((size_t)oo * M + m) * 4) = v;
+    if (o < OC) *reinterpret_cast<u32x4*>(xs + (size_t)m * XRS + oo * 4) = v;
     float s8 = octet_sum<DT>(v);  // over the ROUNDED values the MFMA will see
     s8 = SPT == 4 ? quad_sum(s8) : row16_sum(s8);  // opg = 4 or 16 consecutive octets (lanes)
     if (o < OC && (oo & (opg - 1)) == 0) xsum[(oo / opg) * 16 + m] = s8;
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(1024) void gemv_q4_kernel(const GemvArgs a) {
               const float ss = octet_ss(xv[i]);
               if (lane == 0) part[c * GQ_MAX_WAVES + wave] = ss;
               const int m = row_of(c), o = c * nthr + tid, oo = o - m * octs;
-              if (o < OC) *reinterpret_cast<u32x4*>(xs + ((size_t)oo * M + m) * 4) = xv[i];  // raw, rescaled in pass 2
+              if (o < OC) *reinterpret_cast<u32x4*>(xs + (size_t)m * XRS + oo * 4) = xv[i];  // raw, rescaled in pass 2
             } else {
               stage_octet(c, xv[i], xv[i], 1.0f);
             }
@@ -336,7 +340,7 @@ __global__ __launch_bounds__(1024) void gemv_q4_kernel(const GemvArgs a) {
             const int c = c0 + i;
             if (c < nch) {
               const int m = row_of(c), o = c * nthr + tid, oo = min(o - m * octs, octs - 1);
-              const u32x4 raw = *reinterpret_cast<const u32x4*>(xs + ((size_t)oo * M + m) * 4);
+              const u32x4 raw = *reinterpret_cast<const u32x4*>(xs + (size_t)m * XRS + oo * 4);
               const float rs = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(rstd_s[m])));
               stage_octet(c, raw, nv[i], rs);
             }
@@ -423,8 +427,8 @@ __global__ __launch_bounds__(1024) void gemv_q4_kernel(const GemvArgs a) {
 
   // ================= compute waves
   // A-fragment addressing: lanes whose batch row does not exist alias row M-1 (their D rows are never stored)
-  const uint32_t xbase = (uint32_t)(oct * M + min(nn, M - 1)) * 4u;
-  const uint32_t xstep = (uint32_t)M * 16u;  // u32 per 4 octets (one j step)
+  const uint32_t xbase = (uint32_t)min(nn, M - 1) * (uint32_t)XRS + (uint32_t)oct * 4u;
+  constexpr uint32_t xstep = 16u;  // u32 per 4 octets (one j step)
   const int zsh = 4 * awq_rev(nn & 7);
   // which half of the loaded word is this lane's scale
   const bool shalf = nn & 1;
@@ -447,7 +451,7 @@ __global__ __launch_bounds__(1024) void gemv_q4_kernel(const GemvArgs a) {
         const int ktr = wave + NW * ci;
         const bool valid = ktr < KT;
         const int kt = min(ktr, KT - 1);
-        const uint32_t* xp = xs + xbase + (uint32_t)(kt * 4) * xstep;
+        const uint32_t* xp = xs + xbase + (uint32_t)(kt * 4) * xstep;  // tile kt = octets kt*16 ..
         const f32x4* sxp = reinterpret_cast<const f32x4*>(xsum + (size_t)kt * SPT * 16) + oct;
         f32x4 ag[NBW];
 #pragma unroll
