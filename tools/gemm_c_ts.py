@@ -36,3 +36,13 @@ for i in sorted(names):
     if ok.sum() == 0: continue
     r = (col[ok] - base) / 100.0
     print(f"{names[i]:12s} n={ok.sum():4d} min {r.min():7.2f} p50 {np.median(r):7.2f} p90 {np.percentile(r,90):7.2f} max {r.max():7.2f}")
+items = {"gate_up": None, "o": 32, "down": 32, "qkv": 48}[which]
+if items and g % items == 0 and g > items:
+    kz = g // items
+    for z in (0, kz // 2, kz - 1):
+        r = (t[z * items:(z + 1) * items, 25] - base) / 100.0
+        s0 = (t[z * items:(z + 1) * items, 16] - base) / 100.0
+        for st, nm in ((26, "handshake done"), (27, "slabs summed (last unit)")):
+            c = t[z * items:(z + 1) * items, st]
+            if (c != 0).all(): print(f"   z={z} {nm}: p50 {np.median((c - base) / 100.0):6.2f} max {((c - base) / 100.0).max():6.2f}")
+        print(f"slice z={z}: p:start p50 {np.median(s0):6.2f} max {s0.max():6.2f}   p:epilogue min {r.min():6.2f} p50 {np.median(r):6.2f} max {r.max():6.2f}" + ("   <- owner (sums the slabs)" if z == kz - 1 else ""))

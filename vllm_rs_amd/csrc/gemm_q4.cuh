@@ -40,16 +40,16 @@ struct GemmCArgs {
   int kc;        // k per staged chunk: 512 or 1024 ((K/kz) % kc == 0, (kc/128) % ks == 0)
   int kz;        // K slices across workgroups (grid.z): 1 = none.  Slice partials go to fp32 slabs and the last-arriving
                  // workgroup of an (item, m-chunk) reduces them in slice order (deterministic) and runs the epilogue
-  float* slabs;        // [kz][NBW][Mpad][n_blocks*16]
-  uint32_t* counters;  // one per (item, m-chunk): zero on entry, zero on exit
-  unsigned long long* ts;  // VRA_GEMV_TS builds: [grid.x][32] wall-clock stamps (compute wave 0: 0..15, producer wave 0: 16..31)
+  float* slabs;        // [kz][row tile][item][NBW][half][unit][4] f32 partial tiles of the K slices
+  uint32_t* counters;  // arrival flags, 16 words apart, one per (item, row tile, slice): zero on entry, zero on exit
+  unsigned long long* ts;  // VRA_GEMV_TS builds: [grid.z][grid.x][32] wall-clock stamps (compute wave 0: 0..15, producer wave 0: 16..31)
 };
 #ifdef VRA_GEMV_TS
 #define GC_STAMP(i)                                                                                   \
   do {                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                \
-    if (a.ts && lane == 0 && (wave == 0 || wave == GC_CW) && blockIdx.z == 0)                         \
-      a.ts[(size_t)blockIdx.x * 32 + (i)] = wall_clock64();                                           \
+    if (a.ts && lane == 0 && (wave == 0 || wave == GC_CW))                                            \
+      a.ts[((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 32 + (i)] = wall_clock64();               \
     __builtin_amdgcn_sched_barrier(0);                                                                \
   } while (0)
 #else
@@ -145,7 +145,6 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
       // outputs exposed one global round trip per output: ~35 us).  Sum the KS partial tiles; with K slices publish to the
       // slab and let the last-arriving workgroup finish.
       const int nunits = CGN * ROWS * 2;
-      const int Mpad = (int)gridDim.y * ROWS, NC16 = a.n_blocks * 16;
       const float* rf = reinterpret_cast<const float*>(red);
       auto unit_geom = [&](int u, int& cgi, int& mrow, int& nl0) {
         cgi = u / (ROWS * 2);
@@ -168,40 +167,60 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
           v2[e] = s1;
         }
       };
+      // slab of (slice z, this item, this row tile): [tensor][half][unit][4] f32 — a wave's 16-byte accesses are contiguous.
+      // Accessed with buffer instructions carrying sc1 (agent scope: write through / re-fetch, the L2s of the XCDs are not
+      // coherent with each other); 16-byte accesses — 8-byte agent-scope atomics re-fetched every line four times (+6 us).
+      const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a.slabs, 0, 0x7FFFFFF0, 0x00020000);
+      auto slab_off = [&](int z) {
+        return (uint32_t)(((z * (int)gridDim.y + (int)blockIdx.y) * n_items + it) * NBW) * (uint32_t)nunits * 32u;  // bytes
+      };
       bool finish = true;
       if (KZ > 1) {
-        float* slab = a.slabs + (size_t)zi * NBW * Mpad * NC16;
-        for (int u = pt; u < nunits; u += PTHREADS) {
-          int cgi, mrow, nl0;
-          unit_geom(u, cgi, mrow, nl0);
-          const int fb = it * CGN + cgi;
-          if (fb >= a.n_blocks) continue;
-          float v[8], v2[8];
-          lds_sum(cgi, mrow, nl0, v, v2);
-          float* d0 = slab + ((size_t)0 * Mpad + m0 + mrow) * NC16 + fb * 16 + nl0;
-          *reinterpret_cast<f32x4*>(d0) = f32x4{v[0], v[1], v[2], v[3]};
-          *reinterpret_cast<f32x4*>(d0 + 4) = f32x4{v[4], v[5], v[6], v[7]};
-          if (NBW > 1) {
-            float* d1 = slab + ((size_t)1 * Mpad + m0 + mrow) * NC16 + fb * 16 + nl0;
-            *reinterpret_cast<f32x4*>(d1) = f32x4{v2[0], v2[1], v2[2], v2[3]};
-            *reinterpret_cast<f32x4*>(d1 + 4) = f32x4{v2[4], v2[5], v2[6], v2[7]};
+        // K slices meet through memory (the XCDs' L2s are not coherent with each other).  Measured on MI355X:
+        //  * an arrival COUNTER serialises — agent-scope atomics of 8 slices on one address completed ~1.3 us apart;
+        //  * plain stores + a release fence (buffer_wbl2: write back the whole L2) took 2..8 us per workgroup when every
+        //    workgroup of the XCD does it at once.
+        // So: partials go out as agent-scope (write-through, sc1) stores, every slice raises its own flag (one 64-byte line
+        // each) after they are acknowledged, and the slice dispatched LAST (z = KZ-1: workgroups are dispatched in linear-id
+        // order, so every other slice is already resident or done) polls the flags, sums the slabs with agent-scope loads
+        // (its own partial comes straight from LDS, last in the fixed order) and resets the flags.  No fences.
+        uint32_t* fl = a.counters + ((size_t)(it * gridDim.y + blockIdx.y) * KZ) * 16;
+        const bool owner = zi == KZ - 1;
+        if (!owner) {
+          for (int u = pt; u < nunits; u += PTHREADS) {
+            int cgi, mrow, nl0;
+            unit_geom(u, cgi, mrow, nl0);
+            if (it * CGN + cgi >= a.n_blocks) continue;
+            float v[8], v2[8];
+            lds_sum(cgi, mrow, nl0, v, v2);
+            const uint32_t o = slab_off(zi) + (uint32_t)u * 16u;
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, srs, o, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, srs,
+                                                   o + (uint32_t)nunits * 16u, 0, 16);
+            if (NBW > 1) {
+              __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v2[0]), __float_as_uint(v2[1]), __float_as_uint(v2[2]), __float_as_uint(v2[3])}, srs,
+                                                     o + (uint32_t)nunits * 32u, 0, 16);
+              __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v2[4]), __float_as_uint(v2[5]), __float_as_uint(v2[6]), __float_as_uint(v2[7])}, srs,
+                                                     o + (uint32_t)nunits * 48u, 0, 16);
+            }
           }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (pt == 0) {  // agent-scope release / acquire around the arrival counter (cdna_hip_programming.md §6 G16)
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-          uint32_t* ctr = a.counters + (size_t)it * gridDim.y + blockIdx.y;
-          const uint32_t prev = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const int last = prev == (uint32_t)(KZ - 1);
-          if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // write-through stores: acknowledged by memory
+          __syncthreads();
+          if (pt == 0) __hip_atomic_store(fl + zi * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          if (pt < KZ - 1) {
+            const uint64_t t0 = __builtin_readcyclecounter();
+            while (__hip_atomic_load(fl + pt * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+              __builtin_amdgcn_s_sleep(1);
+              if (__builtin_readcyclecounter() - t0 > (1ull << 31)) break;  // never hang the device on a lost slice
+            }
+            __hip_atomic_store(fl + pt * 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
-          *flag = last;
+          __syncthreads();
         }
         __syncthreads();
-        finish = *flag != 0;
+        GC_STAMP(26);
+        finish = owner;
       }
       if (finish) {
         for (int u = pt; u < nunits; u += PTHREADS) {
@@ -221,28 +240,41 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
           if (a.residual) rw = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.residual) + (size_t)m * a.res_ld + n);
           float v[8], v2[8];
           if (KZ > 1) {
+            // the other K slices of the unit, all in flight at once (a loop of dependent loads costs a memory round trip
+            // per slice), summed in slice order: deterministic
+            auto slab_sum = [&](uint32_t toff, float (&acc)[8]) {
 #pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = v2[e] = 0.f;
-            for (int z = 0; z < KZ; z++) {  // fixed slice order: deterministic
-              const float* s0 = a.slabs + ((size_t)z * NBW * Mpad + m) * NC16 + fb * 16 + nl0;
-              const f32x4 p0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(s0));
-              const f32x4 p1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(s0 + 4));
+              for (int e = 0; e < 8; e++) acc[e] = 0.f;
+              for (int z0 = 0; z0 < KZ - 1; z0 += 8) {
+                u32x4 p[8][2];
 #pragma unroll
-              for (int e = 0; e < 4; e++) {
-                v[e] += p0[e];
-                v[4 + e] += p1[e];
-              }
-              if (NBW > 1) {
-                const float* s1 = s0 + (size_t)Mpad * NC16;
-                const f32x4 q0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(s1));
-                const f32x4 q1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(s1 + 4));
+                for (int j = 0; j < 8; j++) {
+                  const uint32_t o = slab_off(min(z0 + j, KZ - 2)) + toff + (uint32_t)u * 16u;
+                  p[j][0] = __builtin_amdgcn_raw_buffer_load_b128(srs, o, 0, 16);
+                  p[j][1] = __builtin_amdgcn_raw_buffer_load_b128(srs, o + (uint32_t)nunits * 16u, 0, 16);
+                }
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                  v2[e] += q0[e];
-                  v2[4 + e] += q1[e];
+                for (int j = 0; j < 8; j++) {
+                  if (z0 + j < KZ - 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                      acc[e] += __uint_as_float(p[j][0][e]);
+                      acc[4 + e] += __uint_as_float(p[j][1][e]);
+                    }
+                  }
                 }
               }
+            };
+            float own[8], own2[8];
+            lds_sum(cgi, mrow, nl0, own, own2);
+            slab_sum(0u, v);
+            if (NBW > 1) slab_sum((uint32_t)nunits * 32u, v2);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+              v[e] += own[e];
+              v2[e] = NBW > 1 ? v2[e] + own2[e] : 0.f;
             }
+            GC_STAMP(27);
           } else {
             lds_sum(cgi, mrow, nl0, v, v2);
           }

@@ -278,6 +278,7 @@ __global__ __launch_bounds__(1024) void gemv_q4_kernel(const GemvArgs a) {
     float rs1 = 1.0f;
     if (norm) {
       __syncthreads();
+      GEMV_STAMP(18);
       if (M > 1) {
         reduce_rows();
         __syncthreads();

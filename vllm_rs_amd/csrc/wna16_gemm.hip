@@ -405,8 +405,8 @@ void vra_launch_gemm_q4(GemmCArgs a, bool awq, int dtype, int64_t stream) {
     if (kz_env && atoi(kz_env) >= 1 && KT % atoi(kz_env) == 0 && (KT / atoi(kz_env)) % 4 == 0) kz = atoi(kz_env);
     const int ktz = KT / kz;
     a.kc = (ktz % 8 == 0) ? 1024 : 512;
-    size_t slab = (size_t)kz * ((a.M + 16 * mt - 1) / (16 * mt)) * 16 * mt * a.n_blocks * 16 * 4;
-    if (kz > 1 && (slab > vra_scratch_slab_bytes() || (size_t)items * ((a.M + 16 * mt - 1) / (16 * mt)) > vra_scratch_counter_count())) kz = 1;
+    size_t slab = (size_t)kz * ((a.M + 16 * mt - 1) / (16 * mt)) * items * nbw * (GC_CW * 16 * mt * 2) * 32;  // [slice][row tile][item][tensor][unit] x 32 B
+    if (kz > 1 && (slab > vra_scratch_slab_bytes() || (size_t)items * ((a.M + 16 * mt - 1) / (16 * mt)) * kz * 16 > vra_scratch_counter_count())) kz = 1;
     if (kz == 1) a.kc = (KT % 8 == 0) ? 1024 : 512;
   }
   a.ks = ks;
