@@ -6,6 +6,6 @@
 bool vra_gemv_fits(bool int4, int nbw, int M, int K, int group_size);
 void vra_launch_gemv(const GemvArgs& a, bool int4, int dtype, int64_t stream);
 void vra_launch_skinny(GemmBArgs a, bool int4, bool dual, int dtype, int64_t stream);
-// kernel C (gemm_q4.cuh): int4, 9..32 rows, scale groups >= 128.  `a.ks` / `a.kc` are chosen by the launcher.
+// kernel C (gemm_q4.cuh): int4, 5..32 rows, scale groups >= 128.  `a.ks` / `a.kc` are chosen by the launcher.
 bool vra_gemm_q4_fits(int nbw, int M, int K, int group_size);
 void vra_launch_gemm_q4(GemmCArgs a, bool awq, int dtype, int64_t stream);

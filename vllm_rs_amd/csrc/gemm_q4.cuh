@@ -1,4 +1,4 @@
-// gemm_q4.cuh — "kernel C": int4 GEMM for 9..32 activation rows (decode batches) that streams every packed weight
+// gemm_q4.cuh — "kernel C": int4 GEMM for 5..32 activation rows (decode batches) that streams every packed weight
 // byte ONCE and dequantises it ONCE for all rows.
 //
 // Roofline: HBM.  Algorithmic bytes per call as for kernel A: K*N/2 + (K/g)*N*2 [+ AWQ zeros] + M*K*2 + M*N*2.
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
   const bool is_prod = wave >= GC_CW;
   const int nn = lane & 15, oct = lane >> 4;
   const int K = a.K, M = a.M, KT = K >> 7;
-  const int KZ = a.kz > 1 ? a.kz : 1, zi = (int)blockIdx.z;
+  const int KZ = (NBW == 1 && a.kz > 1) ? a.kz : 1, zi = (int)blockIdx.z;  // K slices across workgroups: narrow GEMMs only
   const int KTZ = KT / KZ, kt0 = zi * KTZ;          // this workgroup's K slice, in tiles
   const int KC = a.kc, TPC = KC >> 7, NC = KTZ / TPC, OPC = KC >> 3;  // tiles, chunks, octets per chunk
   const int KS = a.ks, CGN = GC_CW / KS;
@@ -98,6 +98,147 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
   const int nseg = a.nseg;
   const int blk1 = nseg > 1 ? a.seg[1].blk_start : 0x7fffffff, blk2 = nseg > 2 ? a.seg[2].blk_start : 0x7fffffff;
 
+  // ---- CGN n-blocks x ROWS rows x 16 columns, handled as 8-column vectors (16 B stores; a scalar loop over single
+  // outputs exposed one global round trip per output: ~35 us).  Sum the KS partial tiles; with K slices publish to the
+  // slab and let the last-arriving workgroup finish.
+  const int nunits = CGN * ROWS * 2;
+  const float* rf = reinterpret_cast<const float*>(red);
+  auto unit_geom = [&](int u, int& cgi, int& mrow, int& nl0) {
+    cgi = u / (ROWS * 2);
+    const int rem = u - cgi * ROWS * 2;
+    mrow = rem >> 1;
+    nl0 = (rem & 1) * 8;
+  };
+  auto lds_sum = [&](int cgi, int mrow, int nl0, float (&v)[8], float (&v2)[8]) {
+    const int mt = mrow >> 4, mm = mrow & 15;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const int lslot = ((mm >> 2) * 16 + nl0 + e) * 4 + (mm & 3);  // D layout: column = lane&15, row = (lane>>4)*4 + reg
+      float s0 = 0.f, s1 = 0.f;
+      for (int q = 0; q < KS; q++) {
+        const int w = cgi * KS + q;
+        s0 += rf[(size_t)((w * NBW + 0) * MT + mt) * 256 + lslot];
+        if (NBW > 1) s1 += rf[(size_t)((w * NBW + (NBW - 1)) * MT + mt) * 256 + lslot];
+      }
+      v[e] = s0;
+      v2[e] = s1;
+    }
+  };
+  // slab of (slice z, this item, this row tile): [tensor][half][unit][4] f32 — a wave's 16-byte accesses are contiguous.
+  // Accessed with buffer instructions carrying sc1 (agent scope: write through / re-fetch, the L2s of the XCDs are not
+  // coherent with each other); 16-byte accesses — 8-byte agent-scope atomics re-fetched every line four times (+6 us).
+  const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a.slabs, 0, 0x7FFFFFF0, 0x00020000);
+  auto slab_off = [&](int it, int z) {
+    return (uint32_t)(((z * (int)gridDim.y + (int)blockIdx.y) * n_items + it) * NBW) * (uint32_t)nunits * 32u;  // bytes
+  };
+  // partial tiles of this slice -> its slab (agent-scope, write-through stores)
+  auto store_units = [&](int it, int et, int ET) {
+    for (int u = et; u < nunits; u += ET) {
+      int cgi, mrow, nl0;
+      unit_geom(u, cgi, mrow, nl0);
+      if (it * CGN + cgi >= a.n_blocks) continue;
+      float v[8], v2[8];
+      lds_sum(cgi, mrow, nl0, v, v2);
+      const uint32_t o = slab_off(it, zi) + (uint32_t)u * 16u;
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, srs, o, 0, 16);
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, srs,
+                                             o + (uint32_t)nunits * 16u, 0, 16);
+      if (NBW > 1) {
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v2[0]), __float_as_uint(v2[1]), __float_as_uint(v2[2]), __float_as_uint(v2[3])}, srs,
+                                               o + (uint32_t)nunits * 32u, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v2[4]), __float_as_uint(v2[5]), __float_as_uint(v2[6]), __float_as_uint(v2[7])}, srs,
+                                               o + (uint32_t)nunits * 48u, 0, 16);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // write-through stores: acknowledged by memory
+  };
+  // sum (the KS partial tiles in LDS, plus the other slices' slabs), fused epilogue, store
+  auto finish_units = [&](int it, int et, int ET) {
+    for (int u = et; u < nunits; u += ET) {
+      int cgi, mrow, nl0;
+      unit_geom(u, cgi, mrow, nl0);
+      const int fb = it * CGN + cgi;
+      const int m = m0 + mrow;
+      if (fb >= a.n_blocks || m >= M) continue;
+      const int segi = NBW == 2 ? 0 : (fb >= blk2 ? 2 : (fb >= blk1 ? 1 : 0));
+      const int nb = fb - (NBW == 2 ? 0 : a.seg[segi].blk_start);
+      const GemvSeg& sg = a.seg[segi];
+      const int n = nb * 16 + nl0;
+      // every global load of this unit goes out before anything is consumed
+      u32x4 bw = {0u, 0u, 0u, 0u}, bw2 = {0u, 0u, 0u, 0u}, rw = {0u, 0u, 0u, 0u};
+      if (sg.bias) bw = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(sg.bias) + n);
+      if (NBW == 2 && a.seg[1].bias) bw2 = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.seg[1].bias) + n);
+      if (a.residual) rw = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.residual) + (size_t)m * a.res_ld + n);
+      float v[8], v2[8];
+      if (KZ > 1) {
+        // the other K slices of the unit, all in flight at once (a loop of dependent loads costs a memory round trip
+        // per slice), summed in slice order: deterministic
+        auto slab_sum = [&](uint32_t toff, float (&acc)[8]) {
+#pragma unroll
+          for (int e = 0; e < 8; e++) acc[e] = 0.f;
+          for (int z0 = 0; z0 < KZ - 1; z0 += 8) {
+            u32x4 p[8][2];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+              const uint32_t o = slab_off(it, min(z0 + j, KZ - 2)) + toff + (uint32_t)u * 16u;
+              p[j][0] = __builtin_amdgcn_raw_buffer_load_b128(srs, o, 0, 16);
+              p[j][1] = __builtin_amdgcn_raw_buffer_load_b128(srs, o + (uint32_t)nunits * 16u, 0, 16);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+              if (z0 + j < KZ - 1) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                  acc[e] += __uint_as_float(p[j][0][e]);
+                  acc[4 + e] += __uint_as_float(p[j][1][e]);
+                }
+              }
+            }
+          }
+        };
+        float own[8], own2[8];
+        lds_sum(cgi, mrow, nl0, own, own2);
+        slab_sum(0u, v);
+        if (NBW > 1) slab_sum((uint32_t)nunits * 32u, v2);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          v[e] += own[e];
+          v2[e] = NBW > 1 ? v2[e] + own2[e] : 0.f;
+        }
+        GC_STAMP(27);
+      } else {
+        lds_sum(cgi, mrow, nl0, v, v2);
+      }
+      float bf[8], bf2[8], rf8[8], o8[8];
+      unpack8<DT>(bw, bf);
+      unpack8<DT>(bw2, bf2);
+      unpack8<DT>(rw, rf8);
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        float t = rnd_dt<DT>(v[e]);
+        if (sg.bias) t = rnd_dt<DT>(t + bf[e]);
+        if (NBW == 2) {
+          float t2 = rnd_dt<DT>(v2[e]);
+          if (a.seg[1].bias) t2 = rnd_dt<DT>(t2 + bf2[e]);
+          const float sl = rnd_dt<DT>(t / (1.0f + expf(-t)));
+          t = sl * t2;
+        }
+        if (a.residual) t = rnd_dt<DT>(t) + rf8[e];
+        o8[e] = t;
+      }
+      if (a.out_f32) {
+        float* op = static_cast<float*>(sg.out) + (size_t)m * sg.out_ld + n;
+        *reinterpret_cast<f32x4*>(op) = f32x4{rnd_dt<DT>(o8[0]), rnd_dt<DT>(o8[1]), rnd_dt<DT>(o8[2]), rnd_dt<DT>(o8[3])};
+        *reinterpret_cast<f32x4*>(op + 4) = f32x4{rnd_dt<DT>(o8[4]), rnd_dt<DT>(o8[5]), rnd_dt<DT>(o8[6]), rnd_dt<DT>(o8[7])};
+      } else {
+        *reinterpret_cast<u32x4*>(static_cast<uint16_t*>(sg.out) + (size_t)m * sg.out_ld + n) = pack8<DT>(o8);
+      }
+    }
+  };
+  // With K slices every thread of the workgroup takes part in the exchange (one item per workgroup: nothing to overlap it
+  // with): team index of this thread, producers first
+  const int ET_ALL = GC_THREADS, et_all = is_prod ? tid - GC_CW * 64 : tid + GC_PW * 64;
+  const bool owner = zi == KZ - 1;
   if (is_prod) {
     // ============================== producer waves: x chunks -> LDS, then the epilogue of every item
     const int pt = tid - GC_CW * 64;                   // 0..255
@@ -141,41 +282,7 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
       __syncthreads();  // every compute wave has consumed the last chunk
       __syncthreads();  // the item's partial tiles are in `red`
       GC_STAMP(24);
-      // ---- CGN n-blocks x ROWS rows x 16 columns, handled as 8-column vectors (16 B stores; a scalar loop over single
-      // outputs exposed one global round trip per output: ~35 us).  Sum the KS partial tiles; with K slices publish to the
-      // slab and let the last-arriving workgroup finish.
-      const int nunits = CGN * ROWS * 2;
-      const float* rf = reinterpret_cast<const float*>(red);
-      auto unit_geom = [&](int u, int& cgi, int& mrow, int& nl0) {
-        cgi = u / (ROWS * 2);
-        const int rem = u - cgi * ROWS * 2;
-        mrow = rem >> 1;
-        nl0 = (rem & 1) * 8;
-      };
-      auto lds_sum = [&](int cgi, int mrow, int nl0, float (&v)[8], float (&v2)[8]) {
-        const int mt = mrow >> 4, mm = mrow & 15;
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-          const int lslot = ((mm >> 2) * 16 + nl0 + e) * 4 + (mm & 3);  // D layout: column = lane&15, row = (lane>>4)*4 + reg
-          float s0 = 0.f, s1 = 0.f;
-          for (int q = 0; q < KS; q++) {
-            const int w = cgi * KS + q;
-            s0 += rf[(size_t)((w * NBW + 0) * MT + mt) * 256 + lslot];
-            if (NBW > 1) s1 += rf[(size_t)((w * NBW + (NBW - 1)) * MT + mt) * 256 + lslot];
-          }
-          v[e] = s0;
-          v2[e] = s1;
-        }
-      };
-      // slab of (slice z, this item, this row tile): [tensor][half][unit][4] f32 — a wave's 16-byte accesses are contiguous.
-      // Accessed with buffer instructions carrying sc1 (agent scope: write through / re-fetch, the L2s of the XCDs are not
-      // coherent with each other); 16-byte accesses — 8-byte agent-scope atomics re-fetched every line four times (+6 us).
-      const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a.slabs, 0, 0x7FFFFFF0, 0x00020000);
-      auto slab_off = [&](int z) {
-        return (uint32_t)(((z * (int)gridDim.y + (int)blockIdx.y) * n_items + it) * NBW) * (uint32_t)nunits * 32u;  // bytes
-      };
-      bool finish = true;
-      if (KZ > 1) {
+      if (NBW == 1 && KZ > 1) {
         // K slices meet through memory (the XCDs' L2s are not coherent with each other).  Measured on MI355X:
         //  * an arrival COUNTER serialises — agent-scope atomics of 8 slices on one address completed ~1.3 us apart;
         //  * plain stores + a release fence (buffer_wbl2: write back the whole L2) took 2..8 us per workgroup when every
@@ -185,26 +292,8 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
         // order, so every other slice is already resident or done) polls the flags, sums the slabs with agent-scope loads
         // (its own partial comes straight from LDS, last in the fixed order) and resets the flags.  No fences.
         uint32_t* fl = a.counters + ((size_t)(it * gridDim.y + blockIdx.y) * KZ) * 16;
-        const bool owner = zi == KZ - 1;
         if (!owner) {
-          for (int u = pt; u < nunits; u += PTHREADS) {
-            int cgi, mrow, nl0;
-            unit_geom(u, cgi, mrow, nl0);
-            if (it * CGN + cgi >= a.n_blocks) continue;
-            float v[8], v2[8];
-            lds_sum(cgi, mrow, nl0, v, v2);
-            const uint32_t o = slab_off(zi) + (uint32_t)u * 16u;
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, srs, o, 0, 16);
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, srs,
-                                                   o + (uint32_t)nunits * 16u, 0, 16);
-            if (NBW > 1) {
-              __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v2[0]), __float_as_uint(v2[1]), __float_as_uint(v2[2]), __float_as_uint(v2[3])}, srs,
-                                                     o + (uint32_t)nunits * 32u, 0, 16);
-              __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v2[4]), __float_as_uint(v2[5]), __float_as_uint(v2[6]), __float_as_uint(v2[7])}, srs,
-                                                     o + (uint32_t)nunits * 48u, 0, 16);
-            }
-          }
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // write-through stores: acknowledged by memory
+          store_units(it, et_all, ET_ALL);
           __syncthreads();
           if (pt == 0) __hip_atomic_store(fl + zi * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
@@ -220,89 +309,9 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
         }
         __syncthreads();
         GC_STAMP(26);
-        finish = owner;
-      }
-      if (finish) {
-        for (int u = pt; u < nunits; u += PTHREADS) {
-          int cgi, mrow, nl0;
-          unit_geom(u, cgi, mrow, nl0);
-          const int fb = it * CGN + cgi;
-          const int m = m0 + mrow;
-          if (fb >= a.n_blocks || m >= M) continue;
-          const int segi = NBW == 2 ? 0 : (fb >= blk2 ? 2 : (fb >= blk1 ? 1 : 0));
-          const int nb = fb - (NBW == 2 ? 0 : a.seg[segi].blk_start);
-          const GemvSeg& sg = a.seg[segi];
-          const int n = nb * 16 + nl0;
-          // every global load of this unit goes out before anything is consumed
-          u32x4 bw = {0u, 0u, 0u, 0u}, bw2 = {0u, 0u, 0u, 0u}, rw = {0u, 0u, 0u, 0u};
-          if (sg.bias) bw = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(sg.bias) + n);
-          if (NBW == 2 && a.seg[1].bias) bw2 = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.seg[1].bias) + n);
-          if (a.residual) rw = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.residual) + (size_t)m * a.res_ld + n);
-          float v[8], v2[8];
-          if (KZ > 1) {
-            // the other K slices of the unit, all in flight at once (a loop of dependent loads costs a memory round trip
-            // per slice), summed in slice order: deterministic
-            auto slab_sum = [&](uint32_t toff, float (&acc)[8]) {
-#pragma unroll
-              for (int e = 0; e < 8; e++) acc[e] = 0.f;
-              for (int z0 = 0; z0 < KZ - 1; z0 += 8) {
-                u32x4 p[8][2];
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                  const uint32_t o = slab_off(min(z0 + j, KZ - 2)) + toff + (uint32_t)u * 16u;
-                  p[j][0] = __builtin_amdgcn_raw_buffer_load_b128(srs, o, 0, 16);
-                  p[j][1] = __builtin_amdgcn_raw_buffer_load_b128(srs, o + (uint32_t)nunits * 16u, 0, 16);
-                }
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                  if (z0 + j < KZ - 1) {
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                      acc[e] += __uint_as_float(p[j][0][e]);
-                      acc[4 + e] += __uint_as_float(p[j][1][e]);
-                    }
-                  }
-                }
-              }
-            };
-            float own[8], own2[8];
-            lds_sum(cgi, mrow, nl0, own, own2);
-            slab_sum(0u, v);
-            if (NBW > 1) slab_sum((uint32_t)nunits * 32u, v2);
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-              v[e] += own[e];
-              v2[e] = NBW > 1 ? v2[e] + own2[e] : 0.f;
-            }
-            GC_STAMP(27);
-          } else {
-            lds_sum(cgi, mrow, nl0, v, v2);
-          }
-          float bf[8], bf2[8], rf8[8], o8[8];
-          unpack8<DT>(bw, bf);
-          unpack8<DT>(bw2, bf2);
-          unpack8<DT>(rw, rf8);
-#pragma unroll
-          for (int e = 0; e < 8; e++) {
-            float t = rnd_dt<DT>(v[e]);
-            if (sg.bias) t = rnd_dt<DT>(t + bf[e]);
-            if (NBW == 2) {
-              float t2 = rnd_dt<DT>(v2[e]);
-              if (a.seg[1].bias) t2 = rnd_dt<DT>(t2 + bf2[e]);
-              const float sl = rnd_dt<DT>(t / (1.0f + expf(-t)));
-              t = sl * t2;
-            }
-            if (a.residual) t = rnd_dt<DT>(t) + rf8[e];
-            o8[e] = t;
-          }
-          if (a.out_f32) {
-            float* op = static_cast<float*>(sg.out) + (size_t)m * sg.out_ld + n;
-            *reinterpret_cast<f32x4*>(op) = f32x4{rnd_dt<DT>(o8[0]), rnd_dt<DT>(o8[1]), rnd_dt<DT>(o8[2]), rnd_dt<DT>(o8[3])};
-            *reinterpret_cast<f32x4*>(op + 4) = f32x4{rnd_dt<DT>(o8[4]), rnd_dt<DT>(o8[5]), rnd_dt<DT>(o8[6]), rnd_dt<DT>(o8[7])};
-          } else {
-            *reinterpret_cast<u32x4*>(static_cast<uint16_t*>(sg.out) + (size_t)m * sg.out_ld + n) = pack8<DT>(o8);
-          }
-        }
+        if (owner) finish_units(it, et_all, ET_ALL);
+      } else {
+        finish_units(it, pt, PTHREADS);
       }
       GC_STAMP(25);
     }
@@ -449,9 +458,11 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
 #pragma unroll
       for (int mt = 0; mt < MT; mt++) red[(size_t)((wave * NBW + b) * MT + mt) * 64 + lane] = acc[b][mt];
     __syncthreads();
-    if (KZ > 1) {  // the producers' slab / counter handshake uses two more workgroup barriers
+    if (NBW == 1 && KZ > 1) {  // the slab / flag exchange (see the producers' side): same two workgroup barriers
+      if (!owner) store_units(it, et_all, ET_ALL);
       __syncthreads();
       __syncthreads();
+      if (owner) finish_units(it, et_all, ET_ALL);
     }
   }
 }

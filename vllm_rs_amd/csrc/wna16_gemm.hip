@@ -264,7 +264,7 @@ bool vra_gemv_fits(bool int4, int nbw, int M, int K, int group_size) {
   if (!int4) return M <= 8 && gemv_lds_bytes(false, nbw, M, K, group_size) <= (size_t)72 * 1024;
   static const char* mm_env = getenv("VRA_GEMV_MAX_M");  // tuning aid: largest M routed to the streaming kernel
   if (M > (mm_env ? atoi(mm_env) : 32)) return false;
-  if (vra_gemm_q4_fits(nbw, M, K, group_size)) return false;  // 9..32 rows: kernel C dequantises once for all rows
+  if (vra_gemm_q4_fits(nbw, M, K, group_size)) return false;  // 5..32 rows: kernel C dequantises once for all rows
   if (K % 512) return false;  // a wave of the x staging must not straddle rows
   if (group_size > 0 && group_size < K && (group_size & (group_size - 1))) return false;  // power-of-two groups only
   const int rpg = gemv_q4_rows_per_group(nbw, M, K, group_size);
@@ -363,7 +363,10 @@ void vra_launch_skinny(GemmBArgs a, bool int4, bool dual, int dtype, int64_t str
 bool vra_gemm_q4_fits(int nbw, int M, int K, int group_size) {
   static const char* off = getenv("VRA_NO_KERNEL_C");  // tuning aid
   if (off && atoi(off)) return false;
-  if (M < 9 || M > 32) return false;
+  // 5..32 rows (measured on Llama-3-8B decode, ms/step, kernel A row groups vs kernel C: bs 4 2.76 / 2.82, bs 6 3.24 / 2.81,
+  // bs 8 3.73 / 2.92)
+  static const char* mn_env = getenv("VRA_GC_MIN_M");  // tuning aid: fewest rows routed to kernel C
+  if (M < (mn_env ? atoi(mn_env) : 5) || M > 32) return false;
   if (group_size > 0 && group_size < K && (group_size < 128 || (group_size & (group_size - 1)))) return false;
   if ((K >> 7) % 8) return false;
   if (nbw == 1 && (!vra_scratch_slabs() || !vra_scratch_counters())) return false;  // narrow GEMMs slice K across workgroups
@@ -405,6 +408,8 @@ void vra_launch_gemm_q4(GemmCArgs a, bool awq, int dtype, int64_t stream) {
     if (kz_env && atoi(kz_env) >= 1 && KT % atoi(kz_env) == 0 && (KT / atoi(kz_env)) % 4 == 0) kz = atoi(kz_env);
     const int ktz = KT / kz;
     a.kc = (ktz % 8 == 0) ? 1024 : 512;
+    static const char* kc_env = getenv("VRA_GC_KC");  // tuning aid
+    if (kc_env && (atoi(kc_env) == 512 || (atoi(kc_env) == 1024 && ktz % 8 == 0))) a.kc = atoi(kc_env);
     size_t slab = (size_t)kz * ((a.M + 16 * mt - 1) / (16 * mt)) * items * nbw * (GC_CW * 16 * mt * 2) * 32;  // [slice][row tile][item][tensor][unit] x 32 B
     if (kz > 1 && (slab > vra_scratch_slab_bytes() || (size_t)items * ((a.M + 16 * mt - 1) / (16 * mt)) * kz * 16 > vra_scratch_counter_count())) kz = 1;
     if (kz == 1) a.kc = (KT % 8 == 0) ? 1024 : 512;

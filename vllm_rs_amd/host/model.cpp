@@ -422,7 +422,7 @@ bool Model::linear_fused_norm(const QLinear* ls, int nl, void* const* outs, cons
   vra_rms_norm(x, norm_w, xn_, M, K, mc_.rms_norm_eps, dt_, stream);
   bool same = ls[0].quant && nl <= GEMV_MAX_SEG;
   for (int i = 1; i < nl; i++) same = same && ls[i].quant && ls[i].K == K && ls[i].awq == ls[0].awq;
-  if (same && vra_gemm_q4_fits(1, M, K, mc_.group_size)) {  // decode batches 9..32: q/k/v in ONE launch of kernel C
+  if (same && vra_gemm_q4_fits(1, M, K, mc_.group_size)) {  // decode batches 5..32: q/k/v in ONE launch of kernel C
     GemmCArgs c = {};
     c.nseg = nl;
     int blk = 0;
