@@ -6,9 +6,8 @@
 // each weight byte is read once per 16*MT rows.  The x chunk (16*MT rows x 256 k) is staged through
 // LDS (double buffered, row-major with one octet of padding per row so both the 16 B stores and the MFMA
 // B-fragment `ds_read_b128` are conflict-free) and shared by the 8 waves.  grid.y = M chunks, grid.z = K slices (split-K):
-// slice partials go to fp32 slabs and the last-arriving workgroup of a tile reduces them in fixed
-// slice order (deterministic) and applies the epilogue — agent-scope release/acquire per
-// cdna_hip_programming.md §6 G16.
+// slice partials go to fp32 slabs (write-through) and the last-dispatched slice of a tile reduces them in fixed
+// slice order (deterministic) and applies the epilogue.
 #pragma once
 #include "wna16.cuh"
 
@@ -34,8 +33,8 @@ struct GemmBArgs {
   int M, N, K;
   int group_size, is_awq, scales_layout, out_f32;
   int splitk;         // grid.z
-  float* slabs;       // [splitk][Mpad][Npad(,2)] fp32 partials (splitk > 1)
-  uint32_t* counters;  // one per (m-chunk, n-group) tile, zero on entry, zero on exit
+  float* slabs;       // [splitk][tile][tensor][m-tile][thread][4] fp32 partials (splitk > 1)
+  uint32_t* counters;  // arrival flags, 16 words apart, one per (tile, slice): zero on entry, zero on exit
 };
 
 // SPT = scale groups per 128-row k-tile held in registers (1: group_size >= 128 or -1; 4: 32/64).
@@ -69,7 +68,6 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
   constexpr int OPG = 16 / SPT;      // octets per fix-up step
   uint32_t* xs = reinterpret_cast<uint32_t*>(smem);                      // 2 buffers
   float* xsum = reinterpret_cast<float*>(smem + 2 * XS_U32 * 4);          // [2][ROWS][FPC]: Σx per row and fix-up step
-  int* flag = reinterpret_cast<int*>(smem + 2 * XS_U32 * 4 + 2 * ROWS * FPC * 4);
 
   // ---- x chunk staging, split in two so that the global loads are issued BEFORE the weight loads of the same
   // iteration and consumed after the MFMAs: everything on the load path is straight-line code with clamped
@@ -238,45 +236,67 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
   }
 
   if (!INT4) VRA_MFMA_DRAIN();  // the dense path accumulates straight into acc
-  // ---- split-K: publish the partial slab, last arriver reduces (deterministic slice order)
-  const int Mpad = gridDim.y * ROWS, Npad = gridDim.x * 128;
+  // ---- split-K: K slices meet through memory, as in kernel C (gemm_q4.cuh): partial tiles go out as agent-scope
+  // (write-through, sc1) 16-byte stores — one contiguous KiB per wave —, every slice raises its own flag (one 64-byte
+  // line each) once they are acknowledged, and the slice dispatched LAST (z = splitk-1) polls the flags, sums the slabs in
+  // fixed slice order (its own partial last: deterministic) and resets the flags.  No arrival counter (agent-scope
+  // atomics on one address serialise, ~1.3 us each), no L2 write-back fences.
   if (a.splitk > 1) {
-    float* slab = a.slabs + (size_t)blockIdx.z * NW * Mpad * Npad;
+    const int SK = a.splitk, zi = (int)blockIdx.z;
+    const int tile = (int)(blockIdx.y * gridDim.x + blockIdx.x), ntiles = (int)(gridDim.x * gridDim.y);
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a.slabs, 0, 0x7FFFFFF0, 0x00020000);
+    auto slab_off = [&](int z, int w, int mt) {  // bytes: [slice][tile][tensor][m-tile][thread] x 16 B
+      return (uint32_t)((((z * ntiles + tile) * NW + w) * MT + mt) * GB_THREADS + tid) * 16u;
+    };
+    uint32_t* fl = a.counters + (size_t)tile * SK * 16;
+    if (zi != SK - 1) {
 #pragma unroll
-    for (int w = 0; w < NW; w++)
+      for (int w = 0; w < NW; w++)
 #pragma unroll
-      for (int mt = 0; mt < MT; mt++) {
-        int m = m0 + mt * 16 + nn, n = nb * 16 + oct * 4;
-        *reinterpret_cast<f32x4*>(slab + ((size_t)w * Mpad + m) * Npad + n) = acc[w][mt];
+        for (int mt = 0; mt < MT; mt++)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[w][mt]), srs, slab_off(zi, w, mt), 0, 16);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // write-through stores: acknowledged by memory
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(fl + zi * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    if (tid < SK - 1) {
+      const uint64_t t0 = __builtin_readcyclecounter();
+      while (__hip_atomic_load(fl + tid * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        __builtin_amdgcn_s_sleep(1);
+        if (__builtin_readcyclecounter() - t0 > (1ull << 31)) break;  // never hang the device on a lost slice
       }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      uint32_t prev = __hip_atomic_fetch_add(a.counters + blockIdx.y * gridDim.x + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      int last = prev == (uint32_t)(a.splitk - 1);
-      if (last) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __hip_atomic_store(a.counters + blockIdx.y * gridDim.x + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      *flag = last;
+      __hip_atomic_store(fl + tid * 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    if (!*flag) return;
+    f32x4 sum[NW][MT];
 #pragma unroll
     for (int w = 0; w < NW; w++)
 #pragma unroll
-      for (int mt = 0; mt < MT; mt++) {
-        int m = m0 + mt * 16 + nn, n = nb * 16 + oct * 4;
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        for (int z = 0; z < a.splitk; z++) {
-          const float* sl = a.slabs + (size_t)z * NW * Mpad * Npad;
-          f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sl + ((size_t)w * Mpad + m) * Npad + n));
-          s += v;
+      for (int mt = 0; mt < MT; mt++) sum[w][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int ZLD = SPT == 4 ? 4 : 16;  // loads of 16 B in flight (the fine-group kernels sit at the VGPR limit)
+    constexpr int ZB = (ZLD / (NW * MT)) < 1 ? 1 : ZLD / (NW * MT);  // slices per round trip
+    for (int z0 = 0; z0 < SK - 1; z0 += ZB) {
+      u32x4 p[ZB][NW][MT];
+#pragma unroll
+      for (int j = 0; j < ZB; j++)
+#pragma unroll
+        for (int w = 0; w < NW; w++)
+#pragma unroll
+          for (int mt = 0; mt < MT; mt++) p[j][w][mt] = __builtin_amdgcn_raw_buffer_load_b128(srs, slab_off(min(z0 + j, SK - 2), w, mt), 0, 16);
+#pragma unroll
+      for (int j = 0; j < ZB; j++)
+        if (z0 + j < SK - 1) {
+#pragma unroll
+          for (int w = 0; w < NW; w++)
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) sum[w][mt] += __builtin_bit_cast(f32x4, p[j][w][mt]);
         }
-        acc[w][mt] = s;
-      }
+    }
+#pragma unroll
+    for (int w = 0; w < NW; w++)
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++) acc[w][mt] = sum[w][mt] + acc[w][mt];
   }
 
   // ---- epilogue: D[row = 16-col index (lane>>4)*4 + r][col = m = lane&15]

@@ -327,7 +327,7 @@ static int choose_splitk(int M, int N, int K, int mt, bool dual) {
   if (force) s = atoi(force) < 1 ? 1 : (atoi(force) > nchunk ? nchunk : atoi(force));
   size_t slab = (size_t)(dual ? 2 : 1) * gy * mt * 16 * gx * 128 * 4;
   while (s > 1 && slab * s > vra_scratch_slab_bytes()) s /= 2;
-  if (wg > (int)vra_scratch_counter_count()) s = 1;
+  while (s > 1 && (size_t)wg * s * 16 > vra_scratch_counter_count()) s /= 2;
   return s;
 }
 
