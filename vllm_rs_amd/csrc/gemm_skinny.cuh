@@ -10,6 +10,7 @@
 // slice order (deterministic) and applies the epilogue.
 #pragma once
 #include "wna16.cuh"
+#include "gemv.cuh"  // GemvSeg
 
 #define GB_THREADS 512
 #define GB_WAVES 8
@@ -35,6 +36,10 @@ struct GemmBArgs {
   int splitk;         // grid.z
   float* slabs;       // [splitk][tile][tensor][m-tile][thread][4] fp32 partials (splitk > 1)
   uint32_t* counters;  // arrival flags, 16 words apart, one per (tile, slice): zero on entry, zero on exit
+  // more tensors with the same x in ONE launch (q/k/v): segment 0 is w0/sc0/qz0/bias0/out/N above, segments 1..nseg-1
+  // follow; `blk_start` = first n-block of the segment in the flattened n-block space (not with DUAL / residual)
+  int nseg;
+  GemvSeg xseg[2];
 };
 
 // SPT = scale groups per 128-row k-tile held in registers (1: group_size >= 128 or -1; 4: 32/64).
@@ -51,11 +56,26 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches, no exec masking
   const int nn = lane & 15, oct = lane >> 4;
-  const int K = a.K, N = a.N, M = a.M;
+  const int K = a.K, M = a.M;
   const int KT = K >> 7;
   const int g = a.group_size > 0 ? a.group_size : K;
   const bool grouped = a.group_size > 0 && a.group_size < K;
-  const int nb = blockIdx.x * GB_WAVES + wave;  // this wave's n-block
+  // this wave's tensor (wave-uniform) and n-block within it
+  const void* w0p = a.w0;
+  const void* sc0p = a.sc0;
+  const uint32_t* qz0p = a.qz0;
+  const void* bias0p = a.bias0;
+  void* outp = a.out;
+  int N = a.N, out_ld = a.out_ld;
+  int nb = blockIdx.x * GB_WAVES + wave;
+  if (!DUAL && a.nseg > 1) {
+    const int s = (a.nseg > 2 && nb >= a.xseg[1].blk_start) ? 1 : (nb >= a.xseg[0].blk_start ? 0 : -1);
+    if (s >= 0) {
+      const GemvSeg& sg = a.xseg[s];
+      w0p = sg.w, sc0p = sg.scales, qz0p = sg.qzeros, bias0p = sg.bias, outp = sg.out, N = sg.n, out_ld = sg.out_ld;
+      nb -= sg.blk_start;
+    }
+  }
   const bool nb_ok = nb * 16 < N;
   const int m0 = blockIdx.y * ROWS;
   // K slice of this workgroup, in chunks of GB_KC (slices are chunk aligned)
@@ -108,11 +128,11 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
   const int nbc = nb_ok ? nb : 0;
   const u32x4* wp[NW];
   if (INT4) {
-    wp[0] = reinterpret_cast<const u32x4*>(a.w0) + ((size_t)nbc * KT) * 64 + lane;
+    wp[0] = reinterpret_cast<const u32x4*>(w0p) + ((size_t)nbc * KT) * 64 + lane;
     if (DUAL) wp[NW - 1] = reinterpret_cast<const u32x4*>(a.w1) + ((size_t)nbc * KT) * 64 + lane;
   } else {
     int n = min(nb * 16 + nn, N - 1);
-    wp[0] = reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.w0) + (size_t)n * K) + oct;
+    wp[0] = reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(w0p) + (size_t)n * K) + oct;
     if (DUAL) wp[NW - 1] = reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.w1) + (size_t)n * K) + oct;
   }
   // INT4: one u32x4 per tile; dense: four u32x4 per tile
@@ -124,7 +144,7 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
   uint32_t czp[TPC][NW][SPT], nzp[TPC][NW][SPT];
   const int n4 = min(nbc * 16 + oct * 4, N - 4);
   const int G = grouped ? K / g : 1;
-  const bool awq = a.is_awq != 0 && a.qz0 != nullptr;
+  const bool awq = a.is_awq != 0 && qz0p != nullptr;
   auto load_chunk = [&](int c, u32x4 (&dst)[TPC][NW][LPT], u32x2 (&dsc)[TPC][NW][SPT], uint32_t (&dzp)[TPC][NW][SPT]) {
 #pragma unroll
     for (int t = 0; t < TPC; t++) {
@@ -140,9 +160,9 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
 #pragma unroll
           for (int q = 0; q < SPT; q++) {
             const int grp = min(grouped ? (kt * 128 + q * (128 / SPT)) / g : 0, G - 1);
-            const uint16_t* sp = static_cast<const uint16_t*>(w ? a.sc1 : a.sc0);
+            const uint16_t* sp = static_cast<const uint16_t*>(w ? a.sc1 : sc0p);
             dsc[t][w][q] = *reinterpret_cast<const u32x2*>(sp + (size_t)grp * N + n4);
-            if (SPT > 0 && awq) dzp[t][w][q] = (w ? a.qz1 : a.qz0)[(size_t)grp * (N >> 3) + (n4 >> 3)];
+            if (SPT > 0 && awq) dzp[t][w][q] = (w ? a.qz1 : qz0p)[(size_t)grp * (N >> 3) + (n4 >> 3)];
             else dzp[t][w][q] = 0x88888888u;
           }
         }
@@ -310,7 +330,7 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       float t = rnd_dt<DT>(acc[0][mt][r]);
-      if (a.bias0) t = rnd_dt<DT>(t + DT::to_f32(static_cast<const uint16_t*>(a.bias0)[n + r]));
+      if (bias0p) t = rnd_dt<DT>(t + DT::to_f32(static_cast<const uint16_t*>(bias0p)[n + r]));
       if (DUAL) {
         float u = rnd_dt<DT>(acc[NW - 1][mt][r]);
         if (a.bias1) u = rnd_dt<DT>(u + DT::to_f32(static_cast<const uint16_t*>(a.bias1)[n + r]));
@@ -322,10 +342,10 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
     }
     if (a.out_f32) {
       f32x4 o = {rnd_dt<DT>(v[0]), rnd_dt<DT>(v[1]), rnd_dt<DT>(v[2]), rnd_dt<DT>(v[3])};
-      *reinterpret_cast<f32x4*>(static_cast<float*>(a.out) + (size_t)m * a.out_ld + n) = o;
+      *reinterpret_cast<f32x4*>(static_cast<float*>(outp) + (size_t)m * out_ld + n) = o;
     } else {
       u32x2 o = {DT::pack2(v[0], v[1]), DT::pack2(v[2], v[3])};
-      *reinterpret_cast<u32x2*>(static_cast<uint16_t*>(a.out) + (size_t)m * a.out_ld + n) = o;
+      *reinterpret_cast<u32x2*>(static_cast<uint16_t*>(outp) + (size_t)m * out_ld + n) = o;
     }
   }
 }

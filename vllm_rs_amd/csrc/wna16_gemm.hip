@@ -292,11 +292,13 @@ void vra_launch_gemv(const GemvArgs& a, bool int4, int dtype, int64_t stream) {
   }
 }
 
+// columns of the flattened n-block space (all segments)
+static inline int skinny_cols(const GemmBArgs& a) { return a.nseg > 1 ? a.xseg[a.nseg - 2].blk_start * 16 + a.xseg[a.nseg - 2].n : a.N; }
 template <class DT, bool INT4, bool DUAL, int MT>
 static void launch_skinny_t(GemmBArgs a, hipStream_t st) {
   const bool fine = INT4 && a.group_size > 0 && a.group_size < 128;  // several groups per k-tile
   size_t lds = gemm_skinny_lds_bytes(MT, fine ? 4 : 1);
-  dim3 grid((a.N + 127) / 128, (a.M + MT * 16 - 1) / (MT * 16), a.splitk);
+  dim3 grid((skinny_cols(a) + 127) / 128, (a.M + MT * 16 - 1) / (MT * 16), a.splitk);
   // fine scale groups (SPT=4) carry 4x the scale registers: (DUAL, MT>=2) and (single, MT=4) would need > 256
   // VGPRs (spills next to MFMAs) and are never instantiated — vra_launch_skinny caps MT accordingly
   constexpr bool kHasFine = INT4 && !(DUAL && MT >= 2) && !(!DUAL && MT == 4);
@@ -335,7 +337,7 @@ void vra_launch_skinny(GemmBArgs a, bool int4, bool dual, int dtype, int64_t str
   hipStream_t st = as_stream(stream);
   int mt = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
   if (int4 && a.group_size > 0 && a.group_size < 128) mt = dual ? 1 : (mt > 2 ? 2 : mt);  // see launch_skinny_t
-  a.splitk = choose_splitk(a.M, a.N, a.K, mt, dual);
+  a.splitk = choose_splitk(a.M, skinny_cols(a), a.K, mt, dual);
   a.slabs = a.splitk > 1 ? vra_scratch_slabs() : nullptr;
   a.counters = a.splitk > 1 ? vra_scratch_counters() : nullptr;
   if (a.splitk > 1 && (!a.slabs || !a.counters)) a.splitk = 1;

@@ -439,6 +439,26 @@ bool Model::linear_fused_norm(const QLinear* ls, int nl, void* const* outs, cons
     vra_launch_gemm_q4(c, ls[0].awq, dt_, stream);
     return !take_err(error, "norm + gemm_q4");
   }
+  if (same && nl <= 3 && M > 8) {  // prefill: q/k/v in ONE launch of kernel B (k and v alone are 8 workgroups wide)
+    GemmBArgs b = {};
+    b.w0 = ls[0].w, b.sc0 = ls[0].scales, b.qz0 = ls[0].qzeros, b.bias0 = ls[0].bias;
+    b.out = outs[0], b.out_ld = ls[0].N, b.N = ls[0].N;
+    int blk = (ls[0].N + 15) / 16;
+    b.nseg = nl;
+    for (int i = 1; i < nl; i++) {
+      b.xseg[i - 1] = GemvSeg{ls[i].w, ls[i].scales, ls[i].qzeros, ls[i].bias, outs[i], ls[i].N, ls[i].N, blk};
+      blk += (ls[i].N + 15) / 16;
+    }
+    b.x = xn_;
+    b.x_ld = K;
+    b.M = M;
+    b.K = K;
+    b.group_size = mc_.group_size;
+    b.is_awq = ls[0].awq ? 1 : 0;
+    b.scales_layout = VRA_SCALES_ROWMAJOR;
+    vra_launch_skinny(b, true, false, dt_, stream);
+    return !take_err(error, "norm + gemm_skinny (segments)");
+  }
   for (int i = 0; i < nl; i++)
     if (!linear(ls[i], xn_, outs[i], M, nullptr, stream)) return false;
   return !take_err(error, "norm + linear");
