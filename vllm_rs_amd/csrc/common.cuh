@@ -77,6 +77,9 @@ struct BF16 {
   static __device__ __forceinline__ void mfma(f32x4& acc, s16x8 a, s16x8 b) {  // acc += A·B
     asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
   }
+  static __device__ __forceinline__ void mfma0(f32x4& acc, s16x8 a, s16x8 b) {  // acc = A·B (early clobber: D never on A/B)
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+  }
 };
 struct F16 {
   static constexpr int id = VRA_F16;
@@ -89,6 +92,9 @@ struct F16 {
   }
   static __device__ __forceinline__ void mfma(f32x4& acc, s16x8 a, s16x8 b) {  // acc += A·B
     asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+  }
+  static __device__ __forceinline__ void mfma0(f32x4& acc, s16x8 a, s16x8 b) {  // acc = A·B (early clobber: D never on A/B)
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
   }
 };
 template <class DT>

@@ -3,9 +3,14 @@
 #include "gemm_skinny.cuh"
 #include "gemv.cuh"
 #include "gemm_q4.cuh"
+#include "gemm_q4_big.cuh"
 bool vra_gemv_fits(bool int4, int nbw, int M, int K, int group_size);
 void vra_launch_gemv(const GemvArgs& a, bool int4, int dtype, int64_t stream);
 void vra_launch_skinny(GemmBArgs a, bool int4, bool dual, int dtype, int64_t stream);
 // kernel C (gemm_q4.cuh): int4, 5..32 rows, scale groups >= 128.  `a.ks` / `a.kc` are chosen by the launcher.
 bool vra_gemm_q4_fits(int nbw, int M, int K, int group_size);
 void vra_launch_gemm_q4(GemmCArgs a, bool awq, int dtype, int64_t stream);
+// kernel D (gemm_q4_big.cuh): int4, many rows (prefill), scale groups >= 128.  `cols` = output columns over all segments
+// (DUAL: of one tensor).  Returns the m-tiles per wave to launch with (2 or 4), or 0 when the shape belongs to kernel B.
+int vra_gemm_q4_big_fits(bool dual, int M, int cols, int K, int group_size, const GemmDArgs* segs);
+void vra_launch_gemm_q4_big(const GemmDArgs& a, bool dual, bool awq, int mb, int dtype, int64_t stream);

@@ -1,0 +1,296 @@
+// gemm_q4_big.cuh — "kernel D": int4 GEMM for many activation rows (prefill), register blocked.
+//
+// Roofline: MFMA.  Kernels B/C give every wave ONE n-block (16 output columns), so every MFMA needs a fresh x fragment
+// from LDS (`ds_read_b128`, 1 KiB per wave): at 64+ rows kernel B is LDS-bandwidth bound at ~22 % of the MFMA peak
+// (measured: 560 TFLOP/s at M = 4096), and its 64 x 128 workgroup tile re-reads x and the weights from L2 at 87 FLOP/B.
+// Here a wave owns GD_NB = 4 n-blocks x MB m-tiles:
+//   * every x fragment read from LDS feeds 4 MFMAs (LDS traffic per MFMA / 4);
+//   * workgroup = 8 waves as 4 (n) x 2 (m): tile 256 columns x 32*MB rows — packed weights are a quarter of the size of
+//     x per element, so the tile is wide in n: 175 FLOP per byte fetched from L2 at MB = 4;
+//   * the 4 x 4 weight fragments of a k-tile are dequantised ONCE per k-tile ((C + q) "magic" words, wna16.cuh: 7 VALU
+//     ops per 8 weights, amortised over MB m-tiles) and kept in registers; the exact per-group fix-up
+//     acc += s·(acc_g − (C + z)·Σx)  runs per m-tile (16 group-accumulator registers instead of 64);
+//   * Σx of every (row, k-tile) comes from a table computed once per GEMM by `xsum_rows_kernel` (every one of the
+//     16..112 workgroups of an m-tile would otherwise redo the same DPP reductions while staging);
+//   * every global access is a buffer instruction with a wave-uniform (SGPR) offset and ONE shared VGPR offset per
+//     stream — 64-bit per-lane addresses for 4 weight, 4 scale and MB x streams cost ~30 VGPRs the tile needs.
+// Operand roles as in kernel B: A = weights (16 columns x 32 k), B = x (16 rows x 32 k), D[column][row].
+// x chunks (32*MB rows x 128 k) are staged through LDS, double buffered, one workgroup barrier per k-tile
+// (16*MB MFMAs per wave between barriers).  Scale groups of >= 128 (or per channel) only; row-major scales.
+// DUAL: a wave owns 2 gate + 2 up n-blocks of the same columns and the epilogue is silu(gate)·up (mlp.rs:451-469).
+#pragma once
+#include "gemv.cuh"  // GemvSeg
+#include "wna16.cuh"
+
+#define GD_THREADS 512
+#define GD_NB 4
+
+struct GemmDArgs {
+  const void* w0;  // int4 tiled
+  const void* w1;  // DUAL: up tensor
+  const void* sc0;
+  const void* sc1;
+  const uint32_t* qz0;
+  const uint32_t* qz1;
+  const void* bias0;
+  const void* bias1;
+  const void* x;  // [M, x_ld]
+  int x_ld;
+  const void* residual;
+  int res_ld;
+  void* out;  // [M, out_ld]
+  int out_ld;
+  int M, N, K;
+  int group_size, out_f32;
+  // more tensors with the same x in ONE launch (q/k/v): segment 0 is w0/sc0/qz0/bias0/out/N above; every segment's
+  // column count is a multiple of 64 (a wave's 4 n-blocks never straddle tensors); not with DUAL / residual
+  int nseg;
+  GemvSeg xseg[2];
+  const float* xsum;  // [M][K/128] row sums of x per k-tile (xsum_rows_kernel), set by the launcher
+};
+
+static inline size_t gemm_q4_big_lds_bytes(int mb) { return (size_t)3 * (32 * mb) * (16 + 1) * 16; }
+
+// Σ over each (row, k-tile) of x, from the 16-bit values the MFMA sees: 16 lanes per (row, k-tile), one octet each.
+template <class DT>
+__global__ __launch_bounds__(256) void xsum_rows_kernel(const void* x, int x_ld, int M, int KT, float* out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)M * KT * 16;
+  const int64_t ic = i < total ? i : total - 1;  // every lane takes part in the DPP sums
+  const int o = (int)(ic & 15);
+  const int64_t rt = ic >> 4;
+  const int m = (int)(rt / KT), kt = (int)(rt - (int64_t)m * KT);
+  const u32x4 v = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(x) + (size_t)m * x_ld + (size_t)kt * 128 + o * 8);
+  const float s = row16_sum(octet_sum<DT>(v));
+  if (o == 0 && i < total) out[rt] = s;
+}
+
+template <class DT, bool DUAL, bool AWQ, int MB>
+__global__ __launch_bounds__(GD_THREADS) void gemm_q4_big_kernel(const GemmDArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NB = GD_NB;
+  constexpr int ROWS = 32 * MB;       // rows of x per workgroup
+  constexpr int RS = (16 + 1) * 4;    // LDS row stride in u32: 16 octets + one of padding (see gemm_skinny.cuh)
+  constexpr int XS_U32 = ROWS * RS;   // one x buffer
+  constexpr uint32_t RSRC3 = 0x00020000u;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nn = lane & 15, oct = lane >> 4;
+  const int wn = wave & 3, wm = wave >> 2;
+  const int K = a.K, M = a.M, KT = K >> 7;
+  const bool grouped = a.group_size > 0 && a.group_size < K;
+  const int gsh = grouped ? 31 - __builtin_clz(a.group_size) : 31;
+  const int m0 = (int)blockIdx.y * ROWS;
+
+  uint32_t* xs = reinterpret_cast<uint32_t*>(smem);  // [3][ROWS][RS]
+
+  // ---- this wave's tensor(s) and n-blocks (wave-uniform)
+  const void* wt[2] = {a.w0, a.w1};
+  const void* sct[2] = {a.sc0, a.sc1};
+  const uint32_t* qzt[2] = {a.qz0, a.qz1};
+  const void* biast[2] = {a.bias0, a.bias1};
+  void* outp = a.out;
+  int N = a.N, out_ld = a.out_ld;
+  int nb0;  // first n-block of the wave within its tensor
+  if (DUAL) {
+    nb0 = (int)blockIdx.x * 8 + wn * 2;
+  } else {
+    nb0 = (int)blockIdx.x * 16 + wn * 4;
+    if (a.nseg > 1) {
+      const int s = (a.nseg > 2 && nb0 >= a.xseg[1].blk_start) ? 1 : (nb0 >= a.xseg[0].blk_start ? 0 : -1);
+      if (s >= 0) {
+        const GemvSeg& sg = a.xseg[s];
+        wt[0] = sg.w, sct[0] = sg.scales, qzt[0] = sg.qzeros, biast[0] = sg.bias, outp = sg.out, N = sg.n, out_ld = sg.out_ld;
+        nb0 -= sg.blk_start;
+      }
+    }
+  }
+  // n-block b of the wave: tensor tb(b), block nbv(b); a missing block streams block 0 with zeroed scales
+  auto tb = [&](int b) { return DUAL ? (b >> 1) : 0; };
+  auto nbv = [&](int b) { return nb0 + (DUAL ? (b & 1) : b); };
+  bool ok[NB];
+  int nbc[NB];
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    ok[b] = nbv(b) * 16 < N;
+    nbc[b] = ok[b] ? nbv(b) : 0;
+  }
+  // ---- buffer resources (SGPRs) and the per-stream VGPR offsets
+  constexpr int NT = DUAL ? 2 : 1;
+  __amdgpu_buffer_rsrc_t rw[NT], rsc[NT], rqz[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    rw[t] = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wt[t]), 0, 0x7FFFFFF0, RSRC3);
+    rsc[t] = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(sct[t]), 0, 0x7FFFFFF0, RSRC3);
+    rqz[t] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(AWQ ? qzt[t] : reinterpret_cast<const uint32_t*>(sct[t])), 0, 0x7FFFFFF0, RSRC3);
+  }
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, 0x7FFFFFF0, RSRC3);
+  const __amdgpu_buffer_rsrc_t rsum = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.xsum), 0, 0x7FFFFFF0, RSRC3);
+  const uint32_t vo_w = (uint32_t)lane * 16u;                                        // weights: lane's 16 bytes of a tile
+  const uint32_t vo_s = (uint32_t)oct * 8u;                                          // scales: the lane's 4 output columns
+  const uint32_t vo_z = (uint32_t)(oct >> 1) * 4u;                                   // awq zero word of those columns
+  const int Nt = DUAL ? a.N : N;
+  constexpr int XPT = ROWS * 16 / GD_THREADS;  // octets per thread per k-tile (= MB)
+  // x: rows m0 + r*32 + tid/16, octet tid%16; Σx: the lane's row of every m-tile.  Rows >= M alias row M-1 (never stored).
+  uint32_t vo_x[XPT], vo_sum[MB];
+#pragma unroll
+  for (int r = 0; r < XPT; r++) vo_x[r] = ((uint32_t)min(m0 + r * 32 + (tid >> 4), M - 1) * (uint32_t)a.x_ld + (uint32_t)(tid & 15) * 8u) * 2u;
+#pragma unroll
+  for (int mt = 0; mt < MB; mt++) vo_sum[mt] = (uint32_t)min(m0 + wm * (MB * 16) + mt * 16 + nn, M - 1) * (uint32_t)KT * 4u;
+  // x tiles go global -> registers at the START of an iteration and registers -> LDS at its END, two k-tiles ahead of
+  // their use (three LDS buffers): a whole iteration of MFMAs hides the load, and the buffer written is the one read in
+  // the PREVIOUS iteration (every wave has passed that iteration's barrier)
+  auto x_load = [&](int kt, u32x4 (&xr)[XPT]) {
+#pragma unroll
+    for (int r = 0; r < XPT; r++) xr[r] = __builtin_amdgcn_raw_buffer_load_b128(rx, vo_x[r], (uint32_t)(kt * 256), 0);
+  };
+  auto x_store = [&](int buf, const u32x4 (&xr)[XPT]) {
+    uint32_t* dst = xs + (size_t)buf * XS_U32 + (size_t)(tid >> 4) * RS + (tid & 15) * 4;
+#pragma unroll
+    for (int r = 0; r < XPT; r++) *reinterpret_cast<u32x4*>(dst + (size_t)(r * 32) * RS) = xr[r];
+  };
+  // weight stream: one 16-byte word per (n-block, k-tile) and lane; scales / zero points in the MFMA OUTPUT layout
+  auto w_load = [&](int kt, u32x4 (&wq)[NB], u32x2 (&sc)[NB], uint32_t (&zw)[NB]) {
+    const int grp = grouped ? (kt * 128) >> gsh : 0;
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      wq[b] = __builtin_amdgcn_raw_buffer_load_b128(rw[tb(b)], vo_w, (uint32_t)((nbc[b] * KT + kt) * 1024), 2);  // nt
+      sc[b] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsc[tb(b)], vo_s, (uint32_t)((grp * Nt + nbc[b] * 16) * 2), 0));
+      zw[b] = AWQ ? __builtin_amdgcn_raw_buffer_load_b32(rqz[tb(b)], vo_z, (uint32_t)((grp * (Nt >> 3) + nbc[b] * 2) * 4), 0) : 0x88888888u;
+    }
+  };
+  auto sum_load = [&](int kt, float (&sx)[MB]) {
+#pragma unroll
+    for (int mt = 0; mt < MB; mt++)
+      sx[mt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsum, vo_sum[mt], (uint32_t)(kt * 4), 0));
+  };
+
+  f32x2 acc[NB][MB][2];
+#pragma unroll
+  for (int b = 0; b < NB; b++)
+#pragma unroll
+    for (int t = 0; t < MB; t++) acc[b][t][0] = acc[b][t][1] = f32x2{0.f, 0.f};
+
+  u32x4 wq[NB];
+  u32x2 scw[NB];
+  uint32_t zw[NB];
+  float sxn[MB];
+  {
+    u32x4 x0[XPT], x1[XPT];
+    x_load(0, x0);
+    x_load(min(1, KT - 1), x1);
+    w_load(0, wq, scw, zw);
+    sum_load(0, sxn);
+    x_store(0, x0);
+    x_store(1, x1);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < KT; kt++) {
+    const int buf = kt % 3;
+    // ---- the k-tile's 4 x 4 weight fragments (C + q), its scales and row sums; then the loads of the next k-tile
+    s16x8 af[NB][4];
+    f32x2 sc2[NB][2], nzc2[NB][2];
+    float sxc[MB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) af[b][j] = magic_word<DT>(wq[b][j]);
+      float s4[4], z4[4];
+      unpack_scale4<DT>(scw[b], zw[b], nbc[b] * 16 + oct * 4, s4, z4);
+#pragma unroll
+      for (int r = 0; r < 4; r++) s4[r] = ok[b] ? s4[r] : 0.f;
+      sc2[b][0] = f32x2{s4[0], s4[1]}, sc2[b][1] = f32x2{s4[2], s4[3]};
+      nzc2[b][0] = f32x2{-z4[0], -z4[1]}, nzc2[b][1] = f32x2{-z4[2], -z4[3]};
+    }
+#pragma unroll
+    for (int mt = 0; mt < MB; mt++) sxc[mt] = sxn[mt];
+    const int ktn = min(kt + 1, KT - 1);  // the last iteration re-loads its own tile (never consumed)
+    u32x4 xr[XPT];
+    x_load(min(kt + 2, KT - 1), xr);
+    w_load(ktn, wq, scw, zw);
+    sum_load(ktn, sxn);
+    const uint32_t* xb = xs + (size_t)buf * XS_U32 + (size_t)(wm * (MB * 16) + nn) * RS + oct * 4;
+    // 4*MB steps (m-tile, j): the x fragment of step s+1 is read from LDS BEFORE the MFMAs of step s are issued (the
+    // chain ds_read -> wait -> 4 MFMAs per step left the matrix pipe idle for the LDS latency: 3.4 us per k-tile)
+    auto frag = [&](int s) { return *reinterpret_cast<const u32x4*>(xb + (size_t)((s >> 2) * 16) * RS + (s & 3) * 16); };
+    u32x4 xv[2];
+    xv[0] = frag(0);
+    f32x4 ag[NB];
+#pragma unroll
+    for (int s = 0; s < 4 * MB; s++) {
+      const int mt = s >> 2, j = s & 3;
+      if (s + 1 < 4 * MB) xv[(s + 1) & 1] = frag(s + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const s16x8 bfrag = __builtin_bit_cast(s16x8, xv[s & 1]);
+#pragma unroll
+      for (int b = 0; b < NB; b++) {
+        if (j == 0) DT::mfma0(ag[b], af[b][j], bfrag);
+        else DT::mfma(ag[b], af[b][j], bfrag);
+      }
+      if (j == 3) {
+        VRA_MFMA_DRAIN();
+        const f32x2 sx2 = {sxc[mt], sxc[mt]};
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+          const f32x2 g0 = {ag[b][0], ag[b][1]}, g1 = {ag[b][2], ag[b][3]};
+          acc[b][mt][0] = __builtin_elementwise_fma(sc2[b][0], __builtin_elementwise_fma(nzc2[b][0], sx2, g0), acc[b][mt][0]);
+          acc[b][mt][1] = __builtin_elementwise_fma(sc2[b][1], __builtin_elementwise_fma(nzc2[b][1], sx2, g1), acc[b][mt][1]);
+        }
+      }
+    }
+    x_store((kt + 2) % 3, xr);
+    __syncthreads();
+  }
+
+  // ---- epilogue: D[column (lane>>4)*4 + r][row lane&15] of tile (b, mt)
+  constexpr int NBO = DUAL ? 2 : NB;  // output n-blocks of the wave
+#pragma unroll
+  for (int b = 0; b < NBO; b++) {
+    if (!ok[b]) continue;
+    const int n = nbv(b) * 16 + oct * 4;
+    float bs[4] = {0.f, 0.f, 0.f, 0.f}, bs2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (biast[0]) {
+      const u32x2 bw = *reinterpret_cast<const u32x2*>(static_cast<const uint16_t*>(biast[0]) + n);
+      bs[0] = DT::to_f32((uint16_t)(bw[0] & 0xffffu)), bs[1] = DT::to_f32((uint16_t)(bw[0] >> 16));
+      bs[2] = DT::to_f32((uint16_t)(bw[1] & 0xffffu)), bs[3] = DT::to_f32((uint16_t)(bw[1] >> 16));
+    }
+    if (DUAL && biast[1]) {
+      const u32x2 bw = *reinterpret_cast<const u32x2*>(static_cast<const uint16_t*>(biast[1]) + n);
+      bs2[0] = DT::to_f32((uint16_t)(bw[0] & 0xffffu)), bs2[1] = DT::to_f32((uint16_t)(bw[0] >> 16));
+      bs2[2] = DT::to_f32((uint16_t)(bw[1] & 0xffffu)), bs2[3] = DT::to_f32((uint16_t)(bw[1] >> 16));
+    }
+#pragma unroll
+    for (int mt = 0; mt < MB; mt++) {
+      const int m = m0 + wm * (MB * 16) + mt * 16 + nn;
+      if (m >= M) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        float t = rnd_dt<DT>(acc[b][mt][r >> 1][r & 1]);
+        if (biast[0]) t = rnd_dt<DT>(t + bs[r]);
+        if (DUAL) {
+          float u = rnd_dt<DT>(acc[b + 2][mt][r >> 1][r & 1]);
+          if (biast[1]) u = rnd_dt<DT>(u + bs2[r]);
+          const float sl = rnd_dt<DT>(t / (1.0f + expf(-t)));
+          t = sl * u;
+        }
+        v[r] = t;
+      }
+      if (a.residual) {
+        const u32x2 rw2 = *reinterpret_cast<const u32x2*>(static_cast<const uint16_t*>(a.residual) + (size_t)m * a.res_ld + n);
+        v[0] = rnd_dt<DT>(v[0]) + DT::to_f32((uint16_t)(rw2[0] & 0xffffu));
+        v[1] = rnd_dt<DT>(v[1]) + DT::to_f32((uint16_t)(rw2[0] >> 16));
+        v[2] = rnd_dt<DT>(v[2]) + DT::to_f32((uint16_t)(rw2[1] & 0xffffu));
+        v[3] = rnd_dt<DT>(v[3]) + DT::to_f32((uint16_t)(rw2[1] >> 16));
+      }
+      if (a.out_f32) {
+        const f32x4 o = {rnd_dt<DT>(v[0]), rnd_dt<DT>(v[1]), rnd_dt<DT>(v[2]), rnd_dt<DT>(v[3])};
+        *reinterpret_cast<f32x4*>(static_cast<float*>(outp) + (size_t)m * out_ld + n) = o;
+      } else {
+        const u32x2 o = {DT::pack2(v[0], v[1]), DT::pack2(v[2], v[3])};
+        *reinterpret_cast<u32x2*>(static_cast<uint16_t*>(outp) + (size_t)m * out_ld + n) = o;
+      }
+    }
+  }
+}

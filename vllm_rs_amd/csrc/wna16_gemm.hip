@@ -361,6 +361,72 @@ void vra_launch_skinny(GemmBArgs a, bool int4, bool dual, int dtype, int64_t str
 #undef VRA_SK
 }
 
+// ---- kernel D launcher
+int vra_gemm_q4_big_fits(bool dual, int M, int cols, int K, int group_size, const GemmDArgs* segs) {
+  static const char* off = getenv("VRA_NO_KERNEL_D");  // tuning aid
+  if (off && atoi(off)) return 0;
+  if (M < 64 || K % 128 || cols % 16) return 0;
+  static const char* mb_env = getenv("VRA_GD_MB");  // tuning / test aid: force kernel D with 2 or 4 m-tiles per wave
+  if (group_size > 0 && group_size < K && (group_size < 128 || (group_size & (group_size - 1)))) return 0;
+  if (segs && segs->nseg > 1) {  // a wave's 4 n-blocks must not straddle tensors
+    if (dual || segs->residual || segs->N % 64) return 0;
+    for (int i = 0; i + 1 < segs->nseg; i++)
+      if (segs->xseg[i].n % 64) return 0;
+  }
+  // enough workgroups to fill the chip without slicing K (kernel B slices K and wins on narrow / short problems)
+  const int gx = dual ? (cols + 127) / 128 : (cols + 255) / 256;
+  const int cus = num_cus();
+  if (mb_env && (atoi(mb_env) == 2 || atoi(mb_env) == 4)) return atoi(mb_env);
+  // measured (Llama-3-8B shapes, TFLOP/s, kernel B -> D): M = 4096 gate/up 526 -> 692, o 410 -> 671, down 446 -> 705;
+  // M = 128 gate/up 401 -> 330 (kernel B slices K and keeps every CU busy; D has 112 workgroups there)
+  if (M >= 256 && gx * ((M + 127) / 128) >= cus * 3 / 4) return 4;
+  return 0;
+}
+template <class DT, bool DUAL, int MB>
+static void launch_gemm_q4_big_t(const GemmDArgs& a, bool awq, dim3 grid, hipStream_t st) {
+  const size_t lds = gemm_q4_big_lds_bytes(MB);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_q4_big_kernel<DT, DUAL, false, MB>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_q4_big_kernel<DT, DUAL, true, MB>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+    attr_set = true;
+  }
+  if (awq) gemm_q4_big_kernel<DT, DUAL, true, MB><<<grid, GD_THREADS, lds, st>>>(a);
+  else gemm_q4_big_kernel<DT, DUAL, false, MB><<<grid, GD_THREADS, lds, st>>>(a);
+}
+void vra_launch_gemm_q4_big(const GemmDArgs& a0, bool dual, bool awq, int mb, int dtype, int64_t stream) {
+  GemmDArgs a = a0;
+  {  // row sums of x per k-tile, once per GEMM (scratch: the split-K slab region — kernel D does not slice K)
+    float* tbl = vra_scratch_slabs();
+    const int KT = a.K >> 7;
+    if (!tbl || (size_t)a.M * KT * 4 > vra_scratch_slab_bytes()) {
+      vra_set_error("gemm_q4_big: scratch for the row sums unavailable (%d x %d)", a.M, KT);
+      return;
+    }
+    const int64_t total = (int64_t)a.M * KT * 16;
+    if (dtype == VRA_BF16) xsum_rows_kernel<BF16><<<(unsigned)((total + 255) / 256), 256, 0, as_stream(stream)>>>(a.x, a.x_ld, a.M, KT, tbl);
+    else xsum_rows_kernel<F16><<<(unsigned)((total + 255) / 256), 256, 0, as_stream(stream)>>>(a.x, a.x_ld, a.M, KT, tbl);
+    a.xsum = tbl;
+  }
+  const int cols = dual ? a.N : (a.nseg > 1 ? a.xseg[a.nseg - 2].blk_start * 16 + a.xseg[a.nseg - 2].n : a.N);
+  dim3 grid(dual ? (cols + 127) / 128 : (cols + 255) / 256, (a.M + 32 * mb - 1) / (32 * mb));
+  hipStream_t st = as_stream(stream);
+  const bool bf = dtype == VRA_BF16;
+#define VRA_GD(DU, MBV)                                                   \
+  do {                                                                    \
+    if (bf) launch_gemm_q4_big_t<BF16, DU, MBV>(a, awq, grid, st);        \
+    else launch_gemm_q4_big_t<F16, DU, MBV>(a, awq, grid, st);            \
+  } while (0)
+  if (dual) {
+    if (mb == 4) VRA_GD(true, 4);
+    else VRA_GD(true, 2);
+  } else {
+    if (mb == 4) VRA_GD(false, 4);
+    else VRA_GD(false, 2);
+  }
+#undef VRA_GD
+}
+
 // ---- kernel C launcher
 bool vra_gemm_q4_fits(int nbw, int M, int K, int group_size) {
   static const char* off = getenv("VRA_NO_KERNEL_C");  // tuning aid
@@ -526,6 +592,12 @@ extern "C" void vra_wna16_gemm(const void* in, const void* qweight_tiled, const 
     c.group_size = group_size;
     c.n_blocks = n / 16;
     vra_launch_gemm_q4(c, is_awq != 0 && qzeros != nullptr, dtype, stream);
+  } else if (int mb = vra_gemm_q4_big_fits(false, m, n, k, group_size, nullptr)) {
+    GemmDArgs d = {};
+    d.w0 = qweight_tiled, d.sc0 = scales, d.qz0 = (const uint32_t*)qzeros, d.bias0 = bias;
+    d.x = in, d.x_ld = k, d.residual = residual, d.res_ld = n, d.out = out, d.out_ld = n;
+    d.M = m, d.N = n, d.K = k, d.group_size = group_size;
+    vra_launch_gemm_q4_big(d, false, is_awq != 0 && qzeros != nullptr, mb, dtype, stream);
   } else {
     GemmBArgs b = {};
     b.w0 = qweight_tiled;
@@ -591,6 +663,12 @@ extern "C" void vra_wna16_gate_up_silu(const void* in, const void* qw_gate, cons
     c.group_size = group_size;
     c.n_blocks = n / 16;
     vra_launch_gemm_q4(c, is_awq != 0 && qz_gate != nullptr, dtype, stream);
+  } else if (int mb = vra_gemm_q4_big_fits(true, m, n, k, group_size, nullptr)) {
+    GemmDArgs d = {};
+    d.w0 = qw_gate, d.w1 = qw_up, d.sc0 = sc_gate, d.sc1 = sc_up, d.qz0 = (const uint32_t*)qz_gate, d.qz1 = (const uint32_t*)qz_up;
+    d.x = in, d.x_ld = k, d.out = out, d.out_ld = n;
+    d.M = m, d.N = n, d.K = k, d.group_size = group_size;
+    vra_launch_gemm_q4_big(d, true, is_awq != 0 && qz_gate != nullptr, mb, dtype, stream);
   } else {
     GemmBArgs b = {};
     b.w0 = qw_gate;

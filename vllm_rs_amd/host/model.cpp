@@ -439,7 +439,23 @@ bool Model::linear_fused_norm(const QLinear* ls, int nl, void* const* outs, cons
     vra_launch_gemm_q4(c, ls[0].awq, dt_, stream);
     return !take_err(error, "norm + gemm_q4");
   }
-  if (same && nl <= 3 && M > 8) {  // prefill: q/k/v in ONE launch of kernel B (k and v alone are 8 workgroups wide)
+  if (same && nl <= 3 && M > 8) {  // prefill: q/k/v in ONE launch — kernel D when the problem fills the chip, else kernel B
+    GemmDArgs d = {};
+    d.w0 = ls[0].w, d.sc0 = ls[0].scales, d.qz0 = ls[0].qzeros, d.bias0 = ls[0].bias;
+    d.out = outs[0], d.out_ld = ls[0].N, d.N = ls[0].N;
+    d.nseg = nl;
+    int cols = ls[0].N;
+    for (int i = 1; i < nl; i++) {
+      d.xseg[i - 1] = GemvSeg{ls[i].w, ls[i].scales, ls[i].qzeros, ls[i].bias, outs[i], ls[i].N, ls[i].N, cols / 16};
+      cols += ls[i].N;
+    }
+    d.x = xn_, d.x_ld = K, d.M = M, d.K = K, d.group_size = mc_.group_size;
+    if (const int mb = vra_gemm_q4_big_fits(false, M, cols, K, mc_.group_size, &d)) {
+      vra_launch_gemm_q4_big(d, false, ls[0].awq, mb, dt_, stream);
+      return !take_err(error, "norm + gemm_q4_big (segments)");
+    }
+  }
+  if (same && nl <= 3 && M > 8) {  // q/k/v in ONE launch of kernel B (k and v alone are 8 workgroups wide)
     GemmBArgs b = {};
     b.w0 = ls[0].w, b.sc0 = ls[0].scales, b.qz0 = ls[0].qzeros, b.bias0 = ls[0].bias;
     b.out = outs[0], b.out_ld = ls[0].N, b.N = ls[0].N;
