@@ -112,6 +112,24 @@ def test_forward_prefill_then_decode(variant):
     eng.close()
 
 
+@pytest.mark.parametrize("arch,qm", [("llama", "gptq"), ("qwen2", "awq")])
+def test_forward_long_prefill_wide_projections(arch, qm):
+    """a 1100-token prefill on a layer with Llama-3-8B's attention geometry (q/k/v = 6144 columns) and a 14336-wide MLP:
+    q/k/v go out as ONE launch of kernel D with tensor segments, gate/up through kernel D's dual path, o/down through
+    kernel B (narrow)"""
+    cfg = small_cfg(arch=arch, quant_method=qm, attention_bias=(arch == "qwen2"), hidden_size=512, num_heads=32, num_kv_heads=8,
+                    head_dim=128, intermediate_size=14336, num_layers=1, vocab_size=256, max_position_embeddings=2048)
+    eng, oracle = build(cfg, seed=9, num_gpu_blocks=40, max_num_seqs=4, max_model_len=2048)
+    r = np.random.default_rng(2)
+    prompts = [r.integers(0, cfg["vocab_size"], size=n).tolist() for n in (700, 400)]
+    bt = simple_tables([len(p) + 8 for p in prompts])
+    ids, pos, slots, ctx, cu = prefill_inputs(prompts, bt)
+    got = eng.forward_raw(ids, pos, slots, bt, ctx, cu)
+    ref = oracle.forward(ids, pos, slots, bt, ctx, cu)
+    check_logits(got, ref, f"{arch}/{qm} long prefill", cfg["dtype"])
+    eng.close()
+
+
 @pytest.mark.parametrize("B", [9, 16, 32])
 def test_forward_decode_large_batch(B):
     """batches > 8 take the split-K skinny GEMM path (kernel B) for every projection"""

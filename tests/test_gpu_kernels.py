@@ -118,6 +118,45 @@ def test_gate_up_silu(M):
     assert_close_dt(got, ref, BF16, max_ulp=3.0, max_mismatch_frac=0.04, name="gate_up_silu", abs_floor=4e-3)
 
 
+# ---------------------------------------------------------------- kernel D (many rows: prefill)
+# shapes that the default dispatch routes to gemm_q4_big_kernel: M >= 256 and >= 192 workgroup tiles (256 columns x 128 rows)
+@pytest.mark.parametrize("dt,awq,gs", [(BF16, False, 128), (F16, False, 128), (BF16, True, 128), (BF16, False, -1), (F16, True, 256)])
+def test_wna16_gemm_many_rows(dt, awq, gs):
+    M, K, N = 300, 512, 16384            # 3 row tiles (the last one ragged: 44 rows) x 64 column tiles
+    r = rng(11 + dt + awq + gs)
+    q = make_quant(r, K, N, gs, dt, awq)
+    x, bias, res = rand_dt(r, (M, K), dt), rand_dt(r, (N,), dt), rand_dt(r, (M, N), dt)
+    tiled = ops.marlin_weight_repack(ops.dev(q["qweight"]), q["qweight"].shape, 4, awq)
+    qz = ops.dev(q["qzeros"]) if awq else None
+    out = ops.wna16_gemm(ops.dev(x), tiled, ops.dev(q["scales"]), qz, M, K, N, gs, awq, 0, None, None, dt)
+    ref = orc.wna16_gemm(x, q["idx"], q["zeros"] if awq else None, q["scales"], gs, dt)
+    assert_close_dt(out.numpy(np.uint16, (M, N)), ref, dt, name="kernel D", abs_floor=2e-3)
+    out = ops.wna16_gemm(ops.dev(x), tiled, ops.dev(q["scales"]), qz, M, K, N, gs, awq, 0, ops.dev(bias), ops.dev(res), dt)
+    ref2 = orc.wna16_gemm(x, q["idx"], q["zeros"] if awq else None, q["scales"], gs, dt, bias, res)
+    g0 = orc.from_dt(ref, dt)
+    mag = np.maximum(np.abs(g0), np.abs(g0 + orc.from_dt(bias, dt)[None, :]))
+    # 4.9 M outputs and three roundings (GEMM, +bias, +residual), each of which may land on the neighbouring value:
+    # ~5e-5 of the outputs see two flips, ~2e-7 all three (measured: 263 and 1 elements) => bound 3 ulp of the
+    # intermediate magnitude (the 10 k-element test above never sees a double flip)
+    assert_close_dt(out.numpy(np.uint16, (M, N)), ref2, dt, max_ulp=3.0, name="kernel D bias+residual", mag=mag)
+
+
+@pytest.mark.parametrize("awq", [False, True])
+def test_gate_up_silu_many_rows(awq):
+    M, K, N = 260, 512, 8192             # dual: 64 column tiles of 128 x 3 row tiles
+    r = rng(23 + awq)
+    qg, qu = make_quant(r, K, N, 128, BF16, awq), make_quant(r, K, N, 128, BF16, awq)
+    x = rand_dt(r, (M, K), BF16)
+    tg = ops.marlin_weight_repack(ops.dev(qg["qweight"]), qg["qweight"].shape, 4, awq)
+    tu = ops.marlin_weight_repack(ops.dev(qu["qweight"]), qu["qweight"].shape, 4, awq)
+    zg, zu = (ops.dev(qg["qzeros"]), ops.dev(qu["qzeros"])) if awq else (None, None)
+    out = ops.wna16_gate_up_silu(ops.dev(x), tg, ops.dev(qg["scales"]), zg, tu, ops.dev(qu["scales"]), zu, M, K, N, 128, awq)
+    g = orc.wna16_gemm(x, qg["idx"], qg["zeros"] if awq else None, qg["scales"], 128, BF16)
+    u = orc.wna16_gemm(x, qu["idx"], qu["zeros"] if awq else None, qu["scales"], 128, BF16)
+    ref = orc.silu_mul(g, u, BF16)
+    assert_close_dt(out.numpy(np.uint16, (M, N)), ref, BF16, max_ulp=3.0, max_mismatch_frac=0.04, name="kernel D gate_up_silu", abs_floor=4e-3)
+
+
 def test_gemm_half_q_half_alt():
     M, K, N = 3, 256, 128
     r = rng(5)
