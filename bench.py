@@ -47,9 +47,11 @@ def make_prompts(n, length, vocab, seed=42):
 def run_decode(eng, prompts, warmup, steps, sync):
     """prefill the prompts (untimed), `warmup` decode steps (untimed), then time exactly `steps` steps."""
     rids = [eng.add_request(p, max_tokens=warmup + steps + 8, ignore_eos=True) for p in prompts]
-    while True:  # all prompts through prefill
+    # all prompts through prefill: the scheduler alternates prefill and decode steps once something is running (A14),
+    # so "the first decode step" is not enough for batches whose prompts exceed one 8192-token prefill step
+    while True:
         n, is_prefill = eng.step()
-        if not is_prefill:
+        if not is_prefill and n == len(prompts):
             break
     done = 1
     while done < warmup:
@@ -211,6 +213,13 @@ def main():
             dt32, _, _ = run_decode(eng, make_prompts(32, a.prompt_len, V, seed=43), 8, 64, lambda: L.vra_device_sync())
             line["bs32_tokens_per_s_per_gpu"] = 32 * 64 / dt32
             line["bs32_ms_per_step"] = dt32 * 1e3 / 64
+        # ---------------- the KV term ("also ctx in {1k, 8k}"): decode at long contexts
+        lc = {}
+        for bs, ctx in ((1, 1024), (1, 8000), (32, 1024), (32, 4096)):
+            dtl, _, _ = run_decode(eng, make_prompts(bs, ctx, V, seed=77 + ctx), 4, 16, lambda: L.vra_device_sync())
+            kv = bs * (ctx + 10) * 131072  # bytes of K and V read per step (131 072 B per token and sequence)
+            lc[f"bs{bs}_ctx{ctx}"] = {"tokens_per_s": bs * 16 / dtl, "ms_per_step": dtl * 1e3 / 16, "kv_GB_per_step": kv / 1e9}
+        line["long_context_decode"] = lc
         line["ttft_p50_ms"] = {"bs1_prompt128": ttft_p50(eng, 128, V, 1), "bs32_prompt128": ttft_p50(eng, 128, V, 32, reps=2),
                                "bs1_prompt2048": ttft_p50(eng, 2048, V, 1, reps=3)}
         line["step_bytes_roofline"] = {"algorithmic_bytes_per_step": 3625975808 + 1050673152 + 532480,
