@@ -83,6 +83,10 @@ void awq_repack(const void* in, void* out, int32_t rows, int32_t cols, int32_t b
 /* side channel: last argument error recorded by any entry point on this thread ("" if none) */
 const char* vra_last_error(void);
 void vra_clear_error(void);
+/* Device-side error word: 1 if a split-K exchange of the GEMM kernels gave up waiting for a slice (a lost workgroup;
+ * the wait is bounded so that the device never hangs, the results of that launch are invalid).  Reads and clears the
+ * word; synchronises the device.  The native engine polls it (every prefill step, every 64th decode step). */
+int32_t vra_take_device_error(void);
 /* library/ABI version and the gfx target it was built for */
 const char* vra_version(void);
 

@@ -374,3 +374,9 @@ def test_from_pretrained_checkpoint_directory(tmp_path, qm):
     args = (prompt, np.arange(n, dtype=np.int64), 2 * 64 + np.arange(n, dtype=np.int64), bt, np.array([n], np.uint32), np.array([0, n], np.uint32))
     check_logits(eng.forward_raw(*args), oracle.forward(*args), f"from_pretrained {qm}")
     eng.close()
+
+
+def test_no_device_side_timeouts():
+    """runs last in this file: no split-K exchange of the engine's GEMMs timed out"""
+    from vllm_rs_amd import ops
+    assert ops.lib().vra_take_device_error() == 0

@@ -454,3 +454,8 @@ def test_argument_errors_are_reported():
     L.gptq_repack(d.ptr, d.ptr, 3, 16, 0)  # K = 24, not a multiple of 128
     assert L.vra_last_error() != b""
     L.vra_clear_error()
+
+
+def test_no_device_side_timeouts():
+    """runs last in this file: none of the split-K exchanges above gave up waiting for a slice"""
+    assert ops.lib().vra_take_device_error() == 0

@@ -80,6 +80,7 @@ def load():
     _sig(lib, "awq_repack", None, P, P, c_i32, c_i32, c_i32, c_i64)
     _sig(lib, "vra_last_error", C.c_char_p)
     _sig(lib, "vra_clear_error", None)
+    _sig(lib, "vra_take_device_error", C.c_int32)
     _sig(lib, "vra_version", C.c_char_p)
     _sig(lib, "vra_wna16_gemm", None, P, P, P, P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64)
     _sig(lib, "vra_wna16_gate_up_silu", None, P, P, P, P, P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64)

@@ -18,6 +18,7 @@ void vra_set_error(const char* fmt, ...) {
 }
 extern "C" const char* vra_last_error(void) { return g_err; }
 extern "C" void vra_clear_error(void) { g_err[0] = 0; }
+extern "C" int32_t vra_take_device_error(void) { return vra_scratch_take_error(); }
 extern "C" const char* vra_version(void) { return "vllm_rs_amd 0.1.0 (gfx950, hip)"; }
 
 static int hip_ok(hipError_t e, const char* what) {
@@ -102,11 +103,11 @@ bool vra_scratch_init() {
   void* p = nullptr;
   if (hipMalloc(&p, kSlabBytes) != hipSuccess) return false;
   g_slabs = (float*)p;
-  if (hipMalloc(&p, kCounters * sizeof(uint32_t)) != hipSuccess) return false;
+  if (hipMalloc(&p, (kCounters + 16) * sizeof(uint32_t)) != hipSuccess) return false;
   g_counters = (uint32_t*)p;
   if (hipMalloc(&p, 2 * kScaleBytes) != hipSuccess) return false;
   g_scales = (unsigned char*)p;
-  if (hipMemset(g_counters, 0, kCounters * sizeof(uint32_t)) != hipSuccess) return false;
+  if (hipMemset(g_counters, 0, (kCounters + 16) * sizeof(uint32_t)) != hipSuccess) return false;
   return true;
 }
 float* vra_scratch_slabs() {
@@ -124,3 +125,14 @@ void* vra_scratch_scales(int which) {
 size_t vra_scratch_scale_bytes() { return kScaleBytes; }
 size_t vra_scratch_slab_bytes() { return kSlabBytes; }
 size_t vra_scratch_counter_count() { return kCounters; }
+uint32_t* vra_scratch_error_word() {
+  if (!g_counters) vra_scratch_init();
+  return g_counters ? g_counters + kCounters : nullptr;
+}
+int vra_scratch_take_error() {
+  if (!g_counters) return 0;
+  uint32_t v = 0;
+  if (hipMemcpy(&v, g_counters + kCounters, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  if (v) (void)hipMemset(g_counters + kCounters, 0, sizeof(v));
+  return v != 0;
+}

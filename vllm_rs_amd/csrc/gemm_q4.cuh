@@ -42,6 +42,7 @@ struct GemmCArgs {
                  // workgroup of an (item, m-chunk) reduces them in slice order (deterministic) and runs the epilogue
   float* slabs;        // [kz][row tile][item][NBW][half][unit][4] f32 partial tiles of the K slices
   uint32_t* counters;  // arrival flags, 16 words apart, one per (item, row tile, slice): zero on entry, zero on exit
+  uint32_t* err;       // scratch error word: set when a slice wait timed out (vra_scratch_error)
   unsigned long long* ts;  // VRA_GEMV_TS builds: [grid.z][grid.x][32] wall-clock stamps (compute wave 0: 0..15, producer wave 0: 16..31)
 };
 #ifdef VRA_GEMV_TS
@@ -288,9 +289,12 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
         //  * plain stores + a release fence (buffer_wbl2: write back the whole L2) took 2..8 us per workgroup when every
         //    workgroup of the XCD does it at once.
         // So: partials go out as agent-scope (write-through, sc1) stores, every slice raises its own flag (one 64-byte line
-        // each) after they are acknowledged, and the slice dispatched LAST (z = KZ-1: workgroups are dispatched in linear-id
-        // order, so every other slice is already resident or done) polls the flags, sums the slabs with agent-scope loads
-        // (its own partial comes straight from LDS, last in the fixed order) and resets the flags.  No fences.
+        // each) after they are acknowledged, and the LAST slice (z = KZ-1, the "owner") polls the flags, sums the slabs
+        // with agent-scope loads (its own partial comes straight from LDS, last in the fixed order) and resets the flags.
+        // No fences.  Progress: only owners wait, and there are fewer owners (items x row tiles <= 48) than CUs, so in
+        // any dispatch order some non-owner is resident, finishes without waiting and frees its slot (the launcher
+        // checks owners < CUs; in practice workgroups are dispatched in linear-id order and owners start last).  A lost
+        // slice ends the wait after ~1 s instead of hanging the device and raises the scratch error word.
         uint32_t* fl = a.counters + ((size_t)(it * gridDim.y + blockIdx.y) * KZ) * 16;
         if (!owner) {
           store_units(it, et_all, ET_ALL);
@@ -301,7 +305,10 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
             const uint64_t t0 = __builtin_readcyclecounter();
             while (__hip_atomic_load(fl + pt * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
               __builtin_amdgcn_s_sleep(1);
-              if (__builtin_readcyclecounter() - t0 > (1ull << 31)) break;  // never hang the device on a lost slice
+              if (__builtin_readcyclecounter() - t0 > (1ull << 31)) {  // never hang the device on a lost slice
+                __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+              }
             }
             __hip_atomic_store(fl + pt * 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }

@@ -36,6 +36,7 @@ struct GemmBArgs {
   int splitk;         // grid.z
   float* slabs;       // [splitk][tile][tensor][m-tile][thread][4] fp32 partials (splitk > 1)
   uint32_t* counters;  // arrival flags, 16 words apart, one per (tile, slice): zero on entry, zero on exit
+  uint32_t* err;       // scratch error word: set when a slice wait timed out (vra_scratch_error)
   // more tensors with the same x in ONE launch (q/k/v): segment 0 is w0/sc0/qz0/bias0/out/N above, segments 1..nseg-1
   // follow; `blk_start` = first n-block of the segment in the flattened n-block space (not with DUAL / residual)
   int nseg;
@@ -258,9 +259,10 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
   if (!INT4) VRA_MFMA_DRAIN();  // the dense path accumulates straight into acc
   // ---- split-K: K slices meet through memory, as in kernel C (gemm_q4.cuh): partial tiles go out as agent-scope
   // (write-through, sc1) 16-byte stores — one contiguous KiB per wave —, every slice raises its own flag (one 64-byte
-  // line each) once they are acknowledged, and the slice dispatched LAST (z = splitk-1) polls the flags, sums the slabs in
+  // line each) once they are acknowledged, and the LAST slice (z = splitk-1, the "owner") polls the flags, sums the slabs in
   // fixed slice order (its own partial last: deterministic) and resets the flags.  No arrival counter (agent-scope
-  // atomics on one address serialise, ~1.3 us each), no L2 write-back fences.
+  // atomics on one address serialise, ~1.3 us each), no L2 write-back fences.  Progress: only owners wait and the
+  // launcher keeps owners (tiles) below the number of resident workgroup slots, so some non-owner always runs.
   if (a.splitk > 1) {
     const int SK = a.splitk, zi = (int)blockIdx.z;
     const int tile = (int)(blockIdx.y * gridDim.x + blockIdx.x), ntiles = (int)(gridDim.x * gridDim.y);
@@ -284,7 +286,10 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
       const uint64_t t0 = __builtin_readcyclecounter();
       while (__hip_atomic_load(fl + tid * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
         __builtin_amdgcn_s_sleep(1);
-        if (__builtin_readcyclecounter() - t0 > (1ull << 31)) break;  // never hang the device on a lost slice
+        if (__builtin_readcyclecounter() - t0 > (1ull << 31)) {  // never hang the device on a lost slice
+          __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
       }
       __hip_atomic_store(fl + tid * 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

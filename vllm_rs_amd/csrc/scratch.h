@@ -7,6 +7,8 @@ bool vra_scratch_init();            // idempotent; false if allocation failed or
 float* vra_scratch_slabs();         // nullptr until initialised
 uint32_t* vra_scratch_counters();   // zeroed at init, every kernel leaves them zero
 size_t vra_scratch_slab_bytes();
-size_t vra_scratch_counter_count();
+size_t vra_scratch_counter_count();  // flag words usable by kernels (one more word behind them is the error word)
+uint32_t* vra_scratch_error_word();  // device word set by a kernel whose split-K wait timed out (a lost slice)
+int vra_scratch_take_error();        // host: read and clear that word (synchronises the device); 1 = a wait timed out
 void* vra_scratch_scales(int which);  // two regions for row-major copies of Marlin-permuted scale tensors
 size_t vra_scratch_scale_bytes();

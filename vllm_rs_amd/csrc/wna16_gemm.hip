@@ -324,7 +324,10 @@ static int choose_splitk(int M, int N, int K, int mt, bool dual) {
   int wg = gx * gy;
   int nchunk = (K + GB_KC - 1) / GB_KC;
   int s = 1;
-  while (wg * s < 384 && s * 2 <= nchunk && s < 16) s *= 2;
+  // slices only while the tiles (= owners of the exchange, the only workgroups that wait) stay well below the 2 resident
+  // workgroups per CU: some non-owner always runs, whatever the dispatch order
+  const int cus = num_cus();
+  while (wg * s < cus * 3 / 2 && s * 2 <= nchunk && s < 16) s *= 2;
   static const char* force = getenv("VRA_FORCE_SPLITK");  // debugging aid
   if (force) s = atoi(force) < 1 ? 1 : (atoi(force) > nchunk ? nchunk : atoi(force));
   size_t slab = (size_t)(dual ? 2 : 1) * gy * mt * 16 * gx * 128 * 4;
@@ -340,6 +343,7 @@ void vra_launch_skinny(GemmBArgs a, bool int4, bool dual, int dtype, int64_t str
   a.splitk = choose_splitk(a.M, skinny_cols(a), a.K, mt, dual);
   a.slabs = a.splitk > 1 ? vra_scratch_slabs() : nullptr;
   a.counters = a.splitk > 1 ? vra_scratch_counters() : nullptr;
+  a.err = vra_scratch_error_word();
   if (a.splitk > 1 && (!a.slabs || !a.counters)) a.splitk = 1;
   const bool bf = dtype == VRA_BF16;
 #define VRA_SK(DT, I4, DU)                                     \
@@ -480,12 +484,14 @@ void vra_launch_gemm_q4(GemmCArgs a, bool awq, int dtype, int64_t stream) {
     if (kc_env && (atoi(kc_env) == 512 || (atoi(kc_env) == 1024 && ktz % 8 == 0))) a.kc = atoi(kc_env);
     size_t slab = (size_t)kz * ((a.M + 16 * mt - 1) / (16 * mt)) * items * nbw * (GC_CW * 16 * mt * 2) * 32;  // [slice][row tile][item][tensor][unit] x 32 B
     if (kz > 1 && (slab > vra_scratch_slab_bytes() || (size_t)items * ((a.M + 16 * mt - 1) / (16 * mt)) * kz * 16 > vra_scratch_counter_count())) kz = 1;
+    if (items * ((a.M + 16 * mt - 1) / (16 * mt)) >= cus) kz = 1;  // owners (the only workgroups that wait) must stay below the CU count
     if (kz == 1) a.kc = (KT % 8 == 0) ? 1024 : 512;
   }
   a.ks = ks;
   a.kz = kz;
   a.slabs = kz > 1 ? vra_scratch_slabs() : nullptr;
   a.counters = kz > 1 ? vra_scratch_counters() : nullptr;
+  a.err = vra_scratch_error_word();
 #ifdef VRA_GEMV_TS
   a.ts = vra_gemv_ts_buf();
 #else

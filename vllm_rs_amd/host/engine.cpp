@@ -11,6 +11,7 @@
 #include <map>
 #include <memory>
 
+#include "../csrc/scratch.h"
 #include "core.h"
 #include "model.h"
 
@@ -368,9 +369,16 @@ class Engine {
     }
     std::vector<uint32_t> tokens;
     if (!run(ids, is_prefill, &tokens)) return -1;
+    // a split-K exchange whose wait timed out (a lost slice) produced wrong numbers: surface it, every prefill step and
+    // every 64th decode step (the check is a 4-byte device-to-host copy)
+    if ((is_prefill || (++steps_since_check_ & 63) == 0) && vra_scratch_take_error()) {
+      fail("split-K exchange timed out on the device (results of this step are invalid)");
+      return -1;
+    }
     finish_step(ids, is_prefill, tokens);
     return (int)ids.size();
   }
+  unsigned steps_since_check_ = 0;
   void collect() {
     for (auto& s : sched_->clear_finished()) {
       RequestResult& r = results_[s.id];
