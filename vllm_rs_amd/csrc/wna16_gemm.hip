@@ -440,8 +440,14 @@ bool vra_gemm_q4_fits(int nbw, int M, int K, int group_size) {
   static const char* mn_env = getenv("VRA_GC_MIN_M");  // tuning aid: fewest rows routed to kernel C
   if (M < (mn_env ? atoi(mn_env) : 5) || M > 32) return false;
   if (group_size > 0 && group_size < K && (group_size < 128 || (group_size & (group_size - 1)))) return false;
-  if ((K >> 7) % 8) return false;
-  if (nbw == 1 && (!vra_scratch_slabs() || !vra_scratch_counters())) return false;  // narrow GEMMs slice K across workgroups
+  const int KT = K >> 7;
+  if (KT % 4) return false;  // x chunks of 512 (4 k-tiles) or 1024
+  if (nbw == 1) {  // narrow GEMMs slice K across workgroups (slices of a multiple of 4 k-tiles): e.g. not K = 18944 (148 tiles)
+    if (!vra_scratch_slabs() || !vra_scratch_counters()) return false;
+    bool sliceable = false;
+    for (int z = 2; z <= 16; z++) sliceable = sliceable || (KT % z == 0 && (KT / z) % 4 == 0);
+    if (!sliceable) return false;
+  }
   return true;
 }
 template <class DT, int NBW, int MT>
