@@ -3,7 +3,7 @@ import sys, os, ctypes
 import numpy as np
 sys.path.insert(0, os.getcwd())
 from vllm_rs_amd import engine as E
-cfg = dict(E.LLAMA3_8B); cfg["num_layers"] = 8
+cfg = dict(E.LLAMA3_8B); cfg["num_layers"] = int(os.environ.get("TS_LAYERS", "8"))
 eng = E.Engine(cfg, max_num_seqs=8, max_model_len=2048, num_gpu_blocks=64, use_graph=False).init_synthetic()
 which = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 ms = eng.bench_gemm(which, 1, 50)

@@ -52,6 +52,10 @@ struct GemvArgs {
   int m_groups;   // int4 kernel: row-group families (1: all M rows in every workgroup)
   int rows_per_group;
   int single_red;  // int4 kernel: single-buffered cross-wave reduction (LDS-tight shapes)
+  // int4 kernel: wave-uniform quotients precomputed by the launcher (an integer division is ~25 VALU instructions on the
+  // way to the first load of every launch): steps per item, items per slot (quotient, remainder), x chunks per thread
+  // (m_groups == 1), log2 of the octets per row (or -1)
+  int steps_per_item, items_q, items_r, x_chunks, octs_shift;
   int dbg;        // experiment switches (VRA_EXP): 1 = prologue only, 2 = skip the x staging
   unsigned long long* ts;  // VRA_GEMV_TS builds: [grid][32] wall-clock stamps of wave 0
 };

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(1024) void gemv_q4_kernel(const GemvArgs a) {
   const int wg = (int)blockIdx.x;
   const int slot = MG > 1 ? (wg / (8 * MG)) * 8 + (wg & 7) : wg;  // persistent slot within its family
   const int mgrp = MG > 1 ? (wg >> 3) % MG : 0;
-  const int nslots = (int)gridDim.x / MG;
+  const int nslots = MG > 1 ? (int)gridDim.x / MG : (int)gridDim.x;
   const int m_base = mgrp * a.rows_per_group;
   const int K = a.K, M = min(a.M - m_base, MG > 1 ? a.rows_per_group : a.M), KT = K >> 7;
   const bool grouped = a.group_size > 0 && a.group_size < K;
@@ -129,8 +129,8 @@ __global__ __launch_bounds__(1024) void gemv_q4_kernel(const GemvArgs a) {
   float* rstd_s = part + GQ_MAX_CHUNKS * GQ_MAX_WAVES;  // [16]
 
   // ---- this workgroup's stream of tile-steps
-  const int T = (KT + NW - 1) / NW;  // steps per work item
-  const int my_items = (a.n_items - slot + nslots - 1) / nslots;
+  const int T = a.steps_per_item;  // = ceil(KT / NW)
+  const int my_items = a.items_q + (slot < a.items_r ? 1 : 0);  // = ceil((n_items - slot) / nslots)
   const int S = (a.dbg & 1) ? 0 : my_items * T;
 
   u32x4 wb[D][NBW];
@@ -199,11 +199,15 @@ __global__ __launch_bounds__(1024) void gemv_q4_kernel(const GemvArgs a) {
   // passes over L2 when the RMSNorm is fused) and the ring is filled afterwards.
   const int octs = K >> 3, OC = M * octs;
   const int opg = 16 / SPT;  // octets per fix-up step
-  const int nch = (OC + nthr - 1) / nthr;  // x chunks (one octet per compute thread each)
+  const int nch = MG > 1 ? (OC + nthr - 1) / nthr : a.x_chunks;  // x chunks (one octet per compute thread each)
   const bool fast = nch <= GQ_XR;
   const bool norm = a.norm_w != nullptr;
   const uint16_t* np = static_cast<const uint16_t*>(norm ? a.norm_w : a.x);
-  auto row_of = [&](int c) { return min((c * nthr + (wave << 6)) / octs, M - 1); };  // octs % 64 == 0: a wave never straddles rows
+  auto row_of = [&](int c) {  // octs % 64 == 0: a wave never straddles rows
+    if (M == 1) return 0;
+    const int o0 = c * nthr + (wave << 6);
+    return min(a.octs_shift >= 0 ? o0 >> a.octs_shift : o0 / octs, M - 1);
+  };
   auto stage_octet = [&](int c, u32x4 v, u32x4 nv, float rs) {  // normalise (optional), write the LDS image and Σx
     const int m = row_of(c), o = c * nthr + tid, oo = o - m * octs;
     if (norm) {
@@ -359,7 +363,7 @@ __global__ __launch_bounds__(1024) void gemv_q4_kernel(const GemvArgs a) {
   __syncthreads();
   GEMV_STAMP(2);
 
-  const int n_it = S / T;  // work items of this workgroup
+  const int n_it = (a.dbg & 1) ? 0 : my_items;  // work items of this workgroup
   if (is_epi) {
     // ================= epilogue wave: reduce the NW partial tiles of every work item, fused epilogue, store.
     // It owns ALL global stores (gfx9 counts loads and stores in one vmcnt and they retire out of order

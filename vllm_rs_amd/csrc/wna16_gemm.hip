@@ -236,6 +236,14 @@ static void launch_gemv_q4_v(GemvArgs a, int nblocks, hipStream_t st) {
   } else {
     grid = nblocks < cap ? nblocks : cap;
   }
+  {  // wave-uniform quotients the kernel would otherwise compute with VALU division sequences before its first load
+    const int KT = a.K >> 7, nslots = grid / mg, octs = a.K >> 3, nthr = nw * 64;
+    a.steps_per_item = (KT + nw - 1) / nw;
+    a.items_q = nblocks / nslots;
+    a.items_r = nblocks % nslots;
+    a.x_chunks = (rows * octs + nthr - 1) / nthr;
+    a.octs_shift = (octs & (octs - 1)) == 0 ? 31 - __builtin_clz((unsigned)octs) : -1;
+  }
   kern<<<grid, (nw + 1) * 64, lds, st>>>(a);
 }
 template <class DT, int NBW>
