@@ -91,6 +91,11 @@ __global__ __launch_bounds__(1024) void gemv_q4_kernel(const GemvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int DK = (SPT == 4 && AWQ) ? GQ_RING_KIB / 2 : GQ_RING_KIB;  // fine AWQ groups carry 9 registers per tile
   constexpr int D = DK / NBW < 1 ? 1 : DK / NBW;  // ring depth in tile-steps
+  // every kernel argument the way to the first load needs, requested in ONE batch of scalar loads (left to itself hipcc
+  // loads them where they are first used: ~7 dependent scalar-cache round trips before the first global load)
+  asm volatile("" ::"s"(a.x), "s"(a.x_ld), "s"(a.norm_w), "s"(a.K), "s"(a.M), "s"(a.group_size), "s"(a.m_groups), "s"(a.steps_per_item),
+               "s"(a.items_q), "s"(a.items_r), "s"(a.x_chunks), "s"(a.octs_shift), "s"(a.nseg), "s"(a.seg[0].w), "s"(a.seg[0].scales),
+               "s"(a.seg[0].n));
   const int tid = threadIdx.x, lane = tid & 63;
   const int NW = (int)(blockDim.x >> 6) - 1, nthr = NW << 6;  // NW compute waves + ONE epilogue wave (the last)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches, no exec masking
