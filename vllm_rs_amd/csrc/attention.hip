@@ -299,6 +299,7 @@ struct FusedDecodeArgs {
   const uint32_t* block_tables;  // [B, max_blocks]
   const uint32_t* context_lens;  // [B] (includes the new token)
   int B, Hq, Hkv, BS, max_blocks;
+  int bs_shift;  // log2(BS), or -1 when BS is not a power of two (set by the launcher)
   float scale_log2e;
   int nsplit;
   float* ws_o;   // [B, Hq, nsplit, D]
@@ -320,9 +321,27 @@ __global__ __launch_bounds__(PA_THREADS) void decode_attn_fused_kernel(const Fus
   const int ctx = (int)a.context_lens[b];
   const int64_t pos = a.positions[b];
   const int64_t slot = a.slots[b];
+  // block / in-block offset of the new token's slot and of a tile start: shifts when BS is a power of two (a 64-bit
+  // division is a ~130-instruction loop on the way to the first cache access)
+  const int slot32 = (int)slot;  // slots are < 2^31 (blocks * BS tokens)
+  const int slot_blk = a.bs_shift >= 0 ? slot32 >> a.bs_shift : slot32 / a.BS;
+  const int slot_off = slot32 - slot_blk * a.BS;
   const uint16_t* cosp = static_cast<const uint16_t*>(a.cosv) + pos * HALF;
   const uint16_t* sinp = static_cast<const uint16_t*>(a.sinv) + pos * HALF;
 
+  // ---- this wave's KV tiles (32 tokens each): split across workgroups, then across the 4 waves.  The block id of
+  // the first tile is requested NOW (it only needs ctx): one dependent round trip less before the first K / V load
+  const int ntiles = (ctx + 31) >> 5;
+  const int per_split = a.nsplit > 1 ? (ntiles + a.nsplit - 1) / a.nsplit : ntiles;
+  const int s0t = min(ntiles, split * per_split), s1t = min(ntiles, s0t + per_split);
+  const int n_s = s1t - s0t;
+  const int kv_w0 = s0t + ((n_s * wave) >> 2), kv_w1 = s0t + ((n_s * (wave + 1)) >> 2);
+  static_assert(PA_WAVES == 4, "tile split assumes 4 waves");
+  auto tile_blk_index = [&](int tile) {
+    const int T0 = tile << 5;
+    return (size_t)b * a.max_blocks + (a.bs_shift >= 0 ? T0 >> a.bs_shift : T0 / a.BS);
+  };
+  uint32_t blk_cur = a.block_tables[tile_blk_index(min(kv_w0, max(ntiles - 1, 0)))];
   // ---- new token: rotate k (threads 0 .. D/16-1), copy v (threads 64 .. 64+D/8-1); stage both in LDS
   if (tid < HALF / 8) {
     const uint16_t* kp = static_cast<const uint16_t*>(a.k) + ((size_t)b * a.Hkv + hk) * D;
@@ -341,7 +360,7 @@ __global__ __launch_bounds__(PA_THREADS) void decode_attn_fused_kernel(const Fus
     *reinterpret_cast<u32x4*>(knew + tid * 8) = r1;
     *reinterpret_cast<u32x4*>(knew + HALF + tid * 8) = r2;
     if (split == 0 && slot >= 0) {
-      uint16_t* kcp = static_cast<uint16_t*>(a.kc) + ((((size_t)(slot / a.BS)) * a.Hkv + hk) * a.BS + (int)(slot % a.BS)) * D;
+      uint16_t* kcp = static_cast<uint16_t*>(a.kc) + ((((size_t)slot_blk) * a.Hkv + hk) * a.BS + slot_off) * D;
       *reinterpret_cast<u32x4*>(kcp + tid * 8) = r1;
       *reinterpret_cast<u32x4*>(kcp + HALF + tid * 8) = r2;
     }
@@ -350,7 +369,7 @@ __global__ __launch_bounds__(PA_THREADS) void decode_attn_fused_kernel(const Fus
     const u32x4 vv = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.v) + ((size_t)b * a.Hkv + hk) * D + c * 8);
     *reinterpret_cast<u32x4*>(vnew + c * 8) = vv;
     if (split == 0 && slot >= 0) {
-      uint16_t* vcp = static_cast<uint16_t*>(a.vc) + (((size_t)(slot / a.BS)) * a.Hkv + hk) * D * a.BS + (int)(slot % a.BS);
+      uint16_t* vcp = static_cast<uint16_t*>(a.vc) + (((size_t)slot_blk) * a.Hkv + hk) * D * a.BS + slot_off;
 #pragma unroll
       for (int e = 0; e < 4; e++) {
         vcp[(size_t)(c * 8 + 2 * e) * a.BS] = (uint16_t)(vv[e] & 0xffffu);
@@ -390,12 +409,6 @@ __global__ __launch_bounds__(PA_THREADS) void decode_attn_fused_kernel(const Fus
   }
   __syncthreads();  // knew / vnew staged
 
-  // ---- this wave's KV tiles (32 tokens each): split across workgroups, then across the 4 waves
-  const int ntiles = (ctx + 31) >> 5;
-  const int per_split = (ntiles + a.nsplit - 1) / a.nsplit;
-  const int s0t = min(ntiles, split * per_split), s1t = min(ntiles, s0t + per_split);
-  const int n_s = s1t - s0t;
-  const int kv_w0 = s0t + (n_s * wave) / PA_WAVES, kv_w1 = s0t + (n_s * (wave + 1)) / PA_WAVES;
   const int last = ctx - 1;
 
   f32x4 o[DT16];
@@ -406,8 +419,9 @@ __global__ __launch_bounds__(PA_THREADS) void decode_attn_fused_kernel(const Fus
   const uint16_t* vcache = static_cast<const uint16_t*>(a.vc);
   for (int tile = kv_w0; tile < kv_w1; tile++) {
     const int T0 = tile << 5;
-    const uint32_t blk = a.block_tables[(size_t)b * a.max_blocks + T0 / a.BS];
-    const int off = T0 % a.BS;
+    const uint32_t blk = blk_cur;
+    const int off = a.bs_shift >= 0 ? T0 & (a.BS - 1) : T0 % a.BS;
+    blk_cur = a.block_tables[tile_blk_index(min(tile + 1, ntiles - 1))];  // next tile's block id, in flight during this tile
     const uint16_t* krow0 = kcache + (((size_t)blk * a.Hkv + hk) * a.BS + off + rq) * D;
     const uint16_t* krow1 = krow0 + 16 * D;
     const size_t vbase = (((size_t)blk * a.Hkv + hk) * D) * a.BS + off;
@@ -698,6 +712,7 @@ extern "C" void vra_rope_cache_attention_decode(void* out, const void* q, const 
   a.Hkv = kv_heads;
   a.BS = block_size;
   a.max_blocks = max_blocks_per_seq;
+  a.bs_shift = (block_size & (block_size - 1)) == 0 ? 31 - __builtin_clz((unsigned)block_size) : -1;
   a.scale_log2e = scale * 1.44269504088896f;
   a.nsplit = workspace ? decode_nsplit(batch, kv_heads, max_context_len) : 1;
   a.ws_o = static_cast<float*>(workspace);
