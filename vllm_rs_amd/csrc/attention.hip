@@ -16,6 +16,11 @@
 
 #define PA_THREADS 256
 #define PA_WAVES 4
+// the fused decode kernel: a 32-token tile costs a wave one dependent K/V round trip (~2 us) and the waves of a workgroup
+// split the tiles of their (sequence, kv head).  8 waves measured worse than 4 except at 8k context (bs 32: 3.84 vs 3.69
+// ms/step): the wider merge and the larger workgroup cost more than the shorter tile chains save.
+#define FD_WAVES 4
+#define FD_THREADS (FD_WAVES * 64)
 
 struct PagedAttnArgs {
   void* out;          // [Tq, Hq, D]
@@ -285,6 +290,25 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_kernel(const PagedAttnA
 // cache write.  q and k are READ ONLY (several workgroups read them concurrently; an in-place update would
 // race), i.e. unlike FusedRope::apply_inplace the rotated q / k never reach HBM — nothing reads them later.
 // `out` and the caches are bit-identical to the three separate calls.
+#ifdef VRA_ATTN_TS
+static unsigned long long* g_attn_ts = nullptr;
+static unsigned long long* attn_ts_buf() {
+  if (!g_attn_ts) {
+    (void)hipMalloc(&g_attn_ts, 4096 * 16 * 8);
+    (void)hipMemset(g_attn_ts, 0, 4096 * 16 * 8);
+  }
+  return g_attn_ts;
+}
+extern "C" void vra_debug_attn_ts(unsigned long long* host, int n) { (void)hipMemcpy(host, attn_ts_buf(), (size_t)n * 8, hipMemcpyDeviceToHost); }
+#define FD_STAMP(i)                                                                                                              \
+  do {                                                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                                           \
+    if (a.ts && tid == 0) a.ts[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + (i)] = wall_clock64(); \
+    __builtin_amdgcn_sched_barrier(0);                                                                                           \
+  } while (0)
+#else
+#define FD_STAMP(i) do {} while (0)
+#endif
 struct FusedDecodeArgs {
   void* out;          // [B, Hq, D]
   const void* q;      // [B, Hq, D]   un-rotated, read only
@@ -304,18 +328,20 @@ struct FusedDecodeArgs {
   int nsplit;
   float* ws_o;   // [B, Hq, nsplit, D]
   float* ws_ml;  // [B, Hq, nsplit, 2]
+  unsigned long long* ts;  // VRA_ATTN_TS builds: per-workgroup wall-clock stamps
 };
 
 template <class DT, int D>
-__global__ __launch_bounds__(PA_THREADS) void decode_attn_fused_kernel(const FusedDecodeArgs a) {
+__global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const FusedDecodeArgs a) {
   constexpr int DJ = D / 32, DT16 = D / 16, HALF = D / 2;
-  __shared__ __attribute__((aligned(16))) float lds_o[PA_WAVES][16][D + 4];
-  __shared__ float lds_ml[PA_WAVES][16][2];
+  __shared__ __attribute__((aligned(16))) float lds_o[FD_WAVES][16][D + 4];
+  __shared__ float lds_ml[FD_WAVES][16][2];
   __shared__ __attribute__((aligned(16))) uint16_t knew[D];
   __shared__ __attribute__((aligned(16))) uint16_t vnew[D];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rq = lane & 15, oct = lane >> 4;
+  FD_STAMP(0);
   const int G = a.Hq / a.Hkv;
   const int b = blockIdx.z, hk = blockIdx.y, split = blockIdx.x;
   const int ctx = (int)a.context_lens[b];
@@ -326,6 +352,7 @@ __global__ __launch_bounds__(PA_THREADS) void decode_attn_fused_kernel(const Fus
   const int slot32 = (int)slot;  // slots are < 2^31 (blocks * BS tokens)
   const int slot_blk = a.bs_shift >= 0 ? slot32 >> a.bs_shift : slot32 / a.BS;
   const int slot_off = slot32 - slot_blk * a.BS;
+  FD_STAMP(1);
   const uint16_t* cosp = static_cast<const uint16_t*>(a.cosv) + pos * HALF;
   const uint16_t* sinp = static_cast<const uint16_t*>(a.sinv) + pos * HALF;
 
@@ -336,7 +363,7 @@ __global__ __launch_bounds__(PA_THREADS) void decode_attn_fused_kernel(const Fus
   const int s0t = min(ntiles, split * per_split), s1t = min(ntiles, s0t + per_split);
   const int n_s = s1t - s0t;
   const int kv_w0 = s0t + ((n_s * wave) >> 2), kv_w1 = s0t + ((n_s * (wave + 1)) >> 2);
-  static_assert(PA_WAVES == 4, "tile split assumes 4 waves");
+  static_assert(FD_WAVES == 4, "tile split assumes 4 waves");
   auto tile_blk_index = [&](int tile) {
     const int T0 = tile << 5;
     return (size_t)b * a.max_blocks + (a.bs_shift >= 0 ? T0 >> a.bs_shift : T0 / a.BS);
@@ -378,6 +405,7 @@ __global__ __launch_bounds__(PA_THREADS) void decode_attn_fused_kernel(const Fus
     }
   }
 
+  FD_STAMP(2);
   // ---- Q fragments, rotated in registers: lane (row rq = q head of the group, octet oct)
   const bool row_valid = rq < G;
   const int qhead = hk * G + rq;
@@ -407,7 +435,9 @@ __global__ __launch_bounds__(PA_THREADS) void decode_attn_fused_kernel(const Fus
       qf[j + DJ / 2] = __builtin_bit_cast(s16x8, r2);
     }
   }
+  FD_STAMP(3);
   __syncthreads();  // knew / vnew staged
+  FD_STAMP(4);
 
   const int last = ctx - 1;
 
@@ -444,6 +474,7 @@ __global__ __launch_bounds__(PA_THREADS) void decode_attn_fused_kernel(const Fus
       vlo[t] = *reinterpret_cast<const u32x2*>(vp);
       vhi[t] = *reinterpret_cast<const u32x2*>(vp + 16);
     }
+    FD_STAMP(5);
     f32x4 s0 = vra_zero_acc(), s1 = vra_zero_acc();
 #pragma unroll
     for (int j = 0; j < DJ; j++) {
@@ -451,6 +482,7 @@ __global__ __launch_bounds__(PA_THREADS) void decode_attn_fused_kernel(const Fus
       DT::mfma(s1, __builtin_bit_cast(s16x8, k1[j]), qf[j]);
     }
     VRA_MFMA_DRAIN();
+    FD_STAMP(6);
     float sv[8];
     float tmax = -INFINITY;
 #pragma unroll
@@ -483,6 +515,7 @@ __global__ __launch_bounds__(PA_THREADS) void decode_attn_fused_kernel(const Fus
     pa[2] = DT::pack2(p[4], p[5]);
     pa[3] = DT::pack2(p[6], p[7]);
     const s16x8 pfrag = __builtin_bit_cast(s16x8, pa);
+    FD_STAMP(7);
     const bool tail = T0 + 32 > ctx;
     uint32_t vm[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
     int new_e = -1;  // which of this lane's 8 tokens is the new one
@@ -513,6 +546,7 @@ __global__ __launch_bounds__(PA_THREADS) void decode_attn_fused_kernel(const Fus
       DT::mfma(o[t], pfrag, __builtin_bit_cast(s16x8, vv));
     }
   }
+  FD_STAMP(8);
   VRA_MFMA_DRAIN();
   l_run += __shfl_xor(l_run, 16, 64);
   l_run += __shfl_xor(l_run, 32, 64);
@@ -524,16 +558,18 @@ __global__ __launch_bounds__(PA_THREADS) void decode_attn_fused_kernel(const Fus
     lds_ml[wave][rq][0] = m_run;
     lds_ml[wave][rq][1] = l_run;
   }
+  FD_STAMP(9);
   __syncthreads();
-  for (int idx = tid; idx < G * D; idx += PA_THREADS) {
+  FD_STAMP(10);
+  for (int idx = tid; idx < G * D; idx += FD_THREADS) {
     const int row = idx / D, d = idx % D;
     float M = -INFINITY;
 #pragma unroll
-    for (int w = 0; w < PA_WAVES; w++) M = fmaxf(M, lds_ml[w][row][0]);
+    for (int w = 0; w < FD_WAVES; w++) M = fmaxf(M, lds_ml[w][row][0]);
     const float Ms = M == -INFINITY ? 0.f : M;
     float L = 0.f, acc = 0.f;
 #pragma unroll
-    for (int w = 0; w < PA_WAVES; w++) {
+    for (int w = 0; w < FD_WAVES; w++) {
       const float f = exp2f(lds_ml[w][row][0] - Ms);
       L += lds_ml[w][row][1] * f;
       acc += lds_o[w][row][d] * f;
@@ -549,6 +585,7 @@ __global__ __launch_bounds__(PA_THREADS) void decode_attn_fused_kernel(const Fus
       static_cast<uint16_t*>(a.out)[((size_t)b * a.Hq + head) * D + d] = DT::from_f32(L > 0.f ? acc / L : 0.f);
     }
   }
+  FD_STAMP(11);
 }
 
 // second pass for split-KV decode: merge nsplit partials per (b, head)
@@ -713,13 +750,16 @@ extern "C" void vra_rope_cache_attention_decode(void* out, const void* q, const 
   a.BS = block_size;
   a.max_blocks = max_blocks_per_seq;
   a.bs_shift = (block_size & (block_size - 1)) == 0 ? 31 - __builtin_clz((unsigned)block_size) : -1;
+#ifdef VRA_ATTN_TS
+  a.ts = attn_ts_buf();
+#endif
   a.scale_log2e = scale * 1.44269504088896f;
   a.nsplit = workspace ? decode_nsplit(batch, kv_heads, max_context_len) : 1;
   a.ws_o = static_cast<float*>(workspace);
   a.ws_ml = a.ws_o ? a.ws_o + (size_t)batch * q_heads * a.nsplit * head_dim : nullptr;
   dim3 grid(a.nsplit, kv_heads, batch);
   hipStream_t st = as_stream(stream);
-#define VRA_FD(DT, DD) decode_attn_fused_kernel<DT, DD><<<grid, PA_THREADS, 0, st>>>(a)
+#define VRA_FD(DT, DD) decode_attn_fused_kernel<DT, DD><<<grid, FD_THREADS, 0, st>>>(a)
   if (dtype == VRA_BF16) {
     if (head_dim == 128) VRA_FD(BF16, 128);
     else VRA_FD(BF16, 64);
