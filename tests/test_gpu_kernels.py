@@ -456,6 +456,31 @@ def test_argument_errors_are_reported():
     L.vra_clear_error()
 
 
+def test_rccl_all_reduce_single_rank():
+    """the RCCL boundary (AllReduce::cuda_fwd, distributed.rs:438-455; id bootstrap runner/mod.rs:25-121) on the one GPU
+    a test box has: unique id -> communicator of world size 1 -> all-reduce(sum) in the storage dtype, in place and out
+    of place (identity at one rank; the 2-rank arithmetic is covered on CPU by tests/test_dist_gloo.py)"""
+    L = ops.lib()
+    uid = (C.c_uint8 * 128)()
+    assert L.vra_comm_unique_id(uid) == 0
+    comm = L.vra_comm_create(uid, 0, 1, 0)
+    assert comm, "vra_comm_create failed: " + (L.vra_last_error() or b"").decode()
+    try:
+        assert L.vra_comm_rank(comm) == 0 and L.vra_comm_world_size(comm) == 1
+        r = rng(77)
+        for dt in (BF16, F16):
+            x = rand_dt(r, (3, 4096), dt)
+            src, dst = ops.dev(x), ops.DevBuf(x.nbytes)
+            L.vra_all_reduce(comm, src.ptr, dst.ptr, x.size, dt, 0)
+            ops.check_error()
+            assert np.array_equal(dst.numpy(np.uint16, x.shape), x)
+            L.vra_all_reduce(comm, src.ptr, src.ptr, x.size, dt, 0)
+            ops.check_error()
+            assert np.array_equal(src.numpy(np.uint16, x.shape), x)
+    finally:
+        L.vra_comm_destroy(comm)
+
+
 def test_no_device_side_timeouts():
     """runs last in this file: none of the split-K exchanges above gave up waiting for a slice"""
     assert ops.lib().vra_take_device_error() == 0
