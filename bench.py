@@ -164,7 +164,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    cfg = dict(E.LLAMA3_8B) if a.model == "llama3-8b-gptq" else dict(E.QWEN2_7B)
+    cfg = dict({"llama3-8b-gptq": E.LLAMA3_8B, "qwen2-7b-awq": E.QWEN2_7B, "llama3-70b-tp8-rank": E.LLAMA3_70B_TP8_RANK}[a.model])
     max_bs = max(32, a.batch)
     eng = E.Engine(cfg, max_num_seqs=max_bs, max_model_len=8192, num_gpu_blocks=a.blocks, use_graph=not a.no_graph, device=local_rank,
                    seed=1234 + rank).init_synthetic()

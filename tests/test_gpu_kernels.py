@@ -47,7 +47,7 @@ def test_dequant_bit_exact(dt, awq, gs, layout):
 
 
 # ---------------------------------------------------------------- dequant-fused GEMM
-GEMM_SHAPES = [(512, 256), (4096, 1024), (1024, 4096), (3584, 512)]
+GEMM_SHAPES = [(512, 256), (4096, 1024), (1024, 4096), (3584, 512), (8192, 1024), (1024, 8192)]  # the last two: a Llama-3-70B TP=8 rank
 
 
 @pytest.mark.parametrize("M", [1, 2, 5, 8, 9, 16, 32, 33, 64, 100])

@@ -40,6 +40,11 @@ QWEN2_7B = dict(arch="qwen2", hidden_size=3584, intermediate_size=18944, num_lay
 LLAMA3_70B = dict(arch="llama", hidden_size=8192, intermediate_size=28672, num_layers=80, num_heads=64, num_kv_heads=8,
                   head_dim=128, vocab_size=128256, max_position_embeddings=8192, rms_norm_eps=1e-5, rope_theta=500000.0,
                   quant_method="gptq", group_size=128, dtype=BF16)
+# what ONE rank of Llama-3-70B TP=8 computes (column-parallel q/k/v/gate/up, row-parallel o/down, replicated lm_head:
+# SURVEY §8e), as a stand-alone single-GPU shape: the per-rank compute of BASELINE config 4 without the all-reduces
+LLAMA3_70B_TP8_RANK = dict(arch="llama", hidden_size=8192, intermediate_size=28672 // 8, num_layers=80, num_heads=64 // 8,
+                           num_kv_heads=1, head_dim=128, vocab_size=128256, max_position_embeddings=8192, rms_norm_eps=1e-5,
+                           rope_theta=500000.0, quant_method="gptq", group_size=128, dtype=BF16)
 TINYLLAMA = dict(arch="llama", hidden_size=2048, intermediate_size=5632, num_layers=22, num_heads=32, num_kv_heads=4,
                  head_dim=64, vocab_size=32000, max_position_embeddings=2048, rms_norm_eps=1e-5, rope_theta=10000.0,
                  quant_method=None, dtype=BF16)
