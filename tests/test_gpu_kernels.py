@@ -120,9 +120,10 @@ def test_gate_up_silu(M):
 
 # ---------------------------------------------------------------- kernel D (many rows: prefill)
 # shapes that the default dispatch routes to gemm_q4_big_kernel: M >= 256 and >= 192 workgroup tiles (256 columns x 128 rows)
+@pytest.mark.parametrize("N", [16384, 12288])   # 64 column tiles x 3 row tiles of 128 (4 m-tiles per wave) / 48 x 5 row tiles of 64 (2)
 @pytest.mark.parametrize("dt,awq,gs", [(BF16, False, 128), (F16, False, 128), (BF16, True, 128), (BF16, False, -1), (F16, True, 256)])
-def test_wna16_gemm_many_rows(dt, awq, gs):
-    M, K, N = 300, 512, 16384            # 3 row tiles (the last one ragged: 44 rows) x 64 column tiles
+def test_wna16_gemm_many_rows(dt, awq, gs, N):
+    M, K = 300, 512                      # the last row tile is ragged (44 rows)
     r = rng(11 + dt + awq + gs)
     q = make_quant(r, K, N, gs, dt, awq)
     x, bias, res = rand_dt(r, (M, K), dt), rand_dt(r, (N,), dt), rand_dt(r, (M, N), dt)

@@ -392,6 +392,9 @@ int vra_gemm_q4_big_fits(bool dual, int M, int cols, int K, int group_size, cons
   // measured (Llama-3-8B shapes, TFLOP/s, kernel B -> D): M = 4096 gate/up 526 -> 692, o 410 -> 671, down 446 -> 705;
   // M = 128 gate/up 401 -> 330 (kernel B slices K and keeps every CU busy; D has 112 workgroups there)
   if (M >= 256 && gx * ((M + 127) / 128) >= cus * 3 / 4) return 4;
+  // narrow GEMMs at 768..1535 rows: 64-row tiles fill the chip where 128-row tiles do not (M = 1024: o 92 -> 64 us, down
+  // 301 -> 205 us against kernel B; at M = 512 kernel B still wins)
+  if (M >= 256 && gx * ((M + 63) / 64) >= cus * 3 / 4) return 2;
   return 0;
 }
 template <class DT, bool DUAL, int MB>
