@@ -37,6 +37,8 @@ struct GemmCArgs {
   int silu_dual, out_f32;
   int n_blocks;  // n-blocks (or gate/up pairs) in total
   int ks;        // k-split inside the workgroup: 1, 2, 4, 8
+  int ks_shift, ktz, n_items;  // log2(ks), K/128/kz and ceil(n_blocks / (8/ks)): quotients the launcher precomputes (an
+                               // integer division is ~25 VALU instructions; one of them sat in the compute waves' inner loop)
   int kc;        // k per staged chunk: 512 or 1024 ((K/kz) % kc == 0, (kc/128) % ks == 0)
   int kz;        // K slices across workgroups (grid.z): 1 = none.  Slice partials go to fp32 slabs and the last-arriving
                  // workgroup of an (item, m-chunk) reduces them in slice order (deterministic) and runs the epilogue
@@ -73,15 +75,15 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
   const int nn = lane & 15, oct = lane >> 4;
   const int K = a.K, M = a.M, KT = K >> 7;
   const int KZ = (NBW == 1 && a.kz > 1) ? a.kz : 1, zi = (int)blockIdx.z;  // K slices across workgroups: narrow GEMMs only
-  const int KTZ = KT / KZ, kt0 = zi * KTZ;          // this workgroup's K slice, in tiles
-  const int KC = a.kc, TPC = KC >> 7, NC = KTZ / TPC, OPC = KC >> 3;  // tiles, chunks, octets per chunk
-  const int KS = a.ks, CGN = GC_CW / KS;
-  const int SC = TPC / KS;        // steps of one compute wave per chunk
-  const int T = KTZ / KS;         // steps per item
+  const int KTZ = a.ktz, kt0 = zi * KTZ;             // this workgroup's K slice, in tiles (= KT / KZ)
+  const int KC = a.kc, TPC = KC >> 7, tpc_sh = KC == 1024 ? 3 : 2, NC = KTZ >> tpc_sh, OPC = KC >> 3;  // tiles, chunks, octets per chunk
+  const int KS = a.ks, ks_sh = a.ks_shift, CGN = GC_CW >> ks_sh;
+  const int SC = TPC >> ks_sh, sc_sh = tpc_sh - ks_sh;  // steps of one compute wave per chunk
+  const int T = KTZ >> ks_sh;     // steps per item
   const bool grouped = a.group_size > 0 && a.group_size < K;
   const int gsh = grouped ? 31 - __builtin_clz(a.group_size) : 31;
   const int m0 = (int)blockIdx.y * ROWS;
-  const int n_items = (a.n_blocks + CGN - 1) / CGN;
+  const int n_items = a.n_items;  // = ceil(n_blocks / CGN)
 
   // ---- LDS
   // x buffer: row-major with one octet of padding per row — the producers write 64 consecutive octets of a row per wave
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
   }
 
   // ============================== compute waves
-  const int cg = wave / KS, ksi = wave - cg * KS;
+  const int cg = wave >> ks_sh, ksi = wave & (KS - 1);
   const int zsh = 4 * awq_rev(nn & 7);
   const bool shalf = nn & 1;
   constexpr float CB = Magic<DT>::bias;
@@ -395,14 +397,14 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
 #pragma unroll
       for (int r = 0; r < D; r++) {
         const int i = i0 + r;
-        if (i < T && (i % SC) == 0) {
-          GC_STAMP(2 + 2 * ((i / SC) < 5 ? (i / SC) : 5));
+        if (i < T && (i & (SC - 1)) == 0) {
+          GC_STAMP(2 + 2 * ((i >> sc_sh) < 5 ? (i >> sc_sh) : 5));
           __syncthreads();  // chunk i/SC is staged (and chunk i/SC - 2's buffer is free)
-          GC_STAMP(3 + 2 * ((i / SC) < 5 ? (i / SC) : 5));
+          GC_STAMP(3 + 2 * ((i >> sc_sh) < 5 ? (i >> sc_sh) : 5));
         }
         if (i < T) {
           const int ktl = ksi + KS * i;  // tile within this workgroup's K slice
-          const int c = ktl / TPC, tl = ktl - c * TPC;
+          const int c = ktl >> tpc_sh, tl = ktl & (TPC - 1);
           const uint32_t* xb = xs + (size_t)(c & 1) * XS_U32;
           f32x4 ag[NBW][MT];
 #pragma unroll

@@ -506,6 +506,9 @@ void vra_launch_gemm_q4(GemmCArgs a, bool awq, int dtype, int64_t stream) {
   }
   a.ks = ks;
   a.kz = kz;
+  a.ks_shift = ks == 8 ? 3 : ks == 4 ? 2 : ks == 2 ? 1 : 0;
+  a.ktz = KT / kz;
+  a.n_items = items;
   a.slabs = kz > 1 ? vra_scratch_slabs() : nullptr;
   a.counters = kz > 1 ? vra_scratch_counters() : nullptr;
   a.err = vra_scratch_error_word();
