@@ -144,7 +144,10 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
   u32x2 csc[TPC][NW][SPT], nsc[TPC][NW][SPT];
   uint32_t czp[TPC][NW][SPT], nzp[TPC][NW][SPT];
   const int n4 = min(nbc * 16 + oct * 4, N - 4);
-  const int G = grouped ? K / g : 1;
+  // k / g as a shift for power-of-two groups (every real checkpoint): the division sat in the main loop, once per tile,
+  // tensor and scale group (~25 VALU instructions each, in a kernel that is VALU / LDS bound)
+  const int gsh = (g & (g - 1)) == 0 ? 31 - __builtin_clz((unsigned)g) : -1;
+  const int G = grouped ? (gsh >= 0 ? K >> gsh : K / g) : 1;
   const bool awq = a.is_awq != 0 && qz0p != nullptr;
   auto load_chunk = [&](int c, u32x4 (&dst)[TPC][NW][LPT], u32x2 (&dsc)[TPC][NW][SPT], uint32_t (&dzp)[TPC][NW][SPT]) {
 #pragma unroll
@@ -160,7 +163,8 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_skinny_kernel(const GemmBArgs
         if (INT4) {
 #pragma unroll
           for (int q = 0; q < SPT; q++) {
-            const int grp = min(grouped ? (kt * 128 + q * (128 / SPT)) / g : 0, G - 1);
+            const int k0 = kt * 128 + q * (128 / SPT);
+            const int grp = min(grouped ? (gsh >= 0 ? k0 >> gsh : k0 / g) : 0, G - 1);
             const uint16_t* sp = static_cast<const uint16_t*>(w ? a.sc1 : sc0p);
             dsc[t][w][q] = *reinterpret_cast<const u32x2*>(sp + (size_t)grp * N + n4);
             if (SPT > 0 && awq) dzp[t][w][q] = (w ? a.qz1 : qz0p)[(size_t)grp * (N >> 3) + (n4 >> 3)];
