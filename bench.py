@@ -179,9 +179,10 @@ def main():
         "value": tokens / dt, "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"Llama-3-8B GPTQ int4 g128 TP=1 greedy decode, batch {a.batch} per GPU, prompt {a.prompt_len}, "
-                               f"{a.steps} generated tokens, KV block 64, hipGraph replay; N>1 = independent replicas",
-                   "model_shape": "H4096 L32 Hq32 Hkv8 D128 I14336 V128256", "batch_per_gpu": a.batch},
+        "config": {"workload": f"{a.model} shape (H{cfg['hidden_size']} L{cfg['num_layers']} Hq{cfg['num_heads']} Hkv{cfg['num_kv_heads']} "
+                               f"D{cfg['head_dim']} I{cfg['intermediate_size']} V{cfg['vocab_size']}), int4 g128, TP=1 greedy decode, batch {a.batch} per GPU, "
+                               f"prompt {a.prompt_len}, {a.steps} generated tokens, KV block 64, hipGraph replay; N>1 = independent replicas",
+                   "batch_per_gpu": a.batch},
         "gpu_ms_per_step_events": ms_events / a.steps,
     }
 
