@@ -78,9 +78,15 @@ def check_logits(got, ref, name, dt=BF16):
     return worst
 
 
-@pytest.mark.parametrize("variant", ["llama_gptq", "qwen2_awq", "dense_bf16", "gptq_f16", "llama3_rope"])
+@pytest.mark.parametrize("variant", ["llama_gptq", "qwen2_awq", "dense_bf16", "gptq_f16", "llama3_rope", "tinyllama_shape", "qwen2_7b_shape"])
 def test_forward_prefill_then_decode(variant):
     cfg = {
+        # BASELINE.json configs 1 and 3 at their real widths (fewer layers, smaller vocabulary for the AWQ one): TinyLlama-1.1B
+        # dense bf16 (D = 64, 32 heads / 4 kv heads), Qwen2-7B AWQ (K = 3584 and 18944: neither a multiple of 1024)
+        "tinyllama_shape": small_cfg(hidden_size=2048, intermediate_size=5632, num_layers=2, num_heads=32, num_kv_heads=4, head_dim=64,
+                                     vocab_size=32000, quant_method=None, max_position_embeddings=2048),
+        "qwen2_7b_shape": small_cfg(arch="qwen2", attention_bias=True, hidden_size=3584, intermediate_size=18944, num_layers=1, num_heads=28,
+                                    num_kv_heads=4, head_dim=128, vocab_size=2048, quant_method="awq", rope_theta=1e6, rms_norm_eps=1e-6),
         "llama_gptq": small_cfg(),
         "qwen2_awq": small_cfg(arch="qwen2", quant_method="awq", attention_bias=True, num_heads=8, num_kv_heads=2, head_dim=32 * 2, hidden_size=512),
         "dense_bf16": small_cfg(quant_method=None, tie_word_embeddings=True),
