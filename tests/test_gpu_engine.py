@@ -78,11 +78,13 @@ def check_logits(got, ref, name, dt=BF16):
     return worst
 
 
-@pytest.mark.parametrize("variant", ["llama_gptq", "qwen2_awq", "dense_bf16", "gptq_f16", "llama3_rope", "tinyllama_shape", "qwen2_7b_shape"])
+@pytest.mark.parametrize("variant", ["llama_gptq", "qwen2_awq", "dense_bf16", "gptq_f16", "llama3_rope", "tinyllama_shape", "qwen2_7b_shape", "llama3_8b_shape"])
 def test_forward_prefill_then_decode(variant):
     cfg = {
         # BASELINE.json configs 1 and 3 at their real widths (fewer layers, smaller vocabulary for the AWQ one): TinyLlama-1.1B
         # dense bf16 (D = 64, 32 heads / 4 kv heads), Qwen2-7B AWQ (K = 3584 and 18944: neither a multiple of 1024)
+        "llama3_8b_shape": small_cfg(hidden_size=4096, intermediate_size=14336, num_layers=1, num_heads=32, num_kv_heads=8, head_dim=128,
+                                     vocab_size=2048, rope_theta=500000.0, max_position_embeddings=2048),   # the headline config's widths
         "tinyllama_shape": small_cfg(hidden_size=2048, intermediate_size=5632, num_layers=2, num_heads=32, num_kv_heads=4, head_dim=64,
                                      vocab_size=32000, quant_method=None, max_position_embeddings=2048),
         "qwen2_7b_shape": small_cfg(arch="qwen2", attention_bias=True, hidden_size=3584, intermediate_size=18944, num_layers=1, num_heads=28,
@@ -136,10 +138,11 @@ def test_forward_long_prefill_wide_projections(arch, qm):
     eng.close()
 
 
-@pytest.mark.parametrize("B", [9, 16, 32])
-def test_forward_decode_large_batch(B):
-    """batches > 8 take the split-K skinny GEMM path (kernel B) for every projection"""
-    cfg = small_cfg()
+@pytest.mark.parametrize("B,wide", [(9, False), (16, False), (32, False), (6, True)])  # (32, True) passes too: 2 min of CPU oracle
+def test_forward_decode_large_batch(B, wide):
+    """decode batches of 5..32 rows: kernel C (kernel B at the small widths); `wide` = the Llama-3-8B widths, one layer"""
+    cfg = small_cfg(hidden_size=4096, intermediate_size=14336, num_layers=1, num_heads=32, num_kv_heads=8, head_dim=128, vocab_size=2048,
+                    rope_theta=500000.0) if wide else small_cfg()
     eng, oracle = build(cfg, seed=5, num_gpu_blocks=128, max_num_seqs=32)
     r = np.random.default_rng(B)
     prompts = [r.integers(0, cfg["vocab_size"], size=int(n)).tolist() for n in r.integers(1, 100, size=B)]
