@@ -380,3 +380,84 @@ def test_marlin_permute_scales(grouped):
     want = s.reshape(-1, len(perm))[:, perm].reshape(rows, n)
     assert (out == want).all()
     assert (orc.marlin_permute_scales(s, grouped) == want).all()
+
+
+# ------------------------------------------------------------------------------------------------ randomized stress
+@pytest.mark.parametrize("seed,prefix_cache", [(s, bool(s & 1)) for s in range(1, 13)])
+def test_engine_random_streams_keep_the_kv_invariants(seed, prefix_cache):
+    """random request streams (shared prefixes, long prompts that need chunking, block pressure, early EOS) on the
+    host-only engine: every step's metadata must be self-consistent — the properties the kernels rely on
+    (runner.rs:978-1388, block_manager.rs:113-442) — and everything must drain."""
+    r = np.random.default_rng(seed)
+    BS, NB, CHUNK = 16, 96, 64
+    cfg = dict(E.TINYLLAMA)
+    h = E.HostEngine(cfg, num_gpu_blocks=NB, block_size=BS, max_num_seqs=8, max_model_len=512, prefill_chunk=CHUNK, enable_prefix_cache=prefix_cache)
+    shared = [r.integers(5, 1000, size=int(n)).tolist() for n in (40, 70, 17)]
+    pending, live, outputs, step_no = 40, {}, {}, 0
+    def submit():
+        base = shared[int(r.integers(0, len(shared)))] if r.random() < 0.6 else []
+        tail = r.integers(5, 1000, size=int(r.integers(1, 150))).tolist()
+        prompt = (base + tail)[:300]
+        rid = h.add_request(prompt, max_tokens=int(r.integers(1, 24)), eos=(3,))
+        live[rid] = dict(prompt=prompt, seen=0)
+    while pending > 0 or h.has_unfinished():
+        while pending > 0 and r.random() < 0.5:
+            submit()
+            pending -= 1
+        st = h.schedule()
+        if st is None:
+            if pending == 0 and not h.has_unfinished():
+                break
+            if pending > 0:
+                submit()
+                pending -= 1
+            continue
+        step_no += 1
+        assert step_no < 20000, "the engine does not drain"
+        T, B = st["n_tokens"], st["n_seqs"]
+        assert 1 <= B <= 8 and T >= B
+        slots, bt, ctx = st["slots"], st["block_tables"], st["context_lens"]
+        # every written slot is written once per step and lies in a block of the writing sequence's table
+        live_slots = slots[slots >= 0]
+        assert len(set(live_slots.tolist())) == len(live_slots), "two tokens of one step share a KV slot"
+        assert (live_slots < NB * BS).all()
+        if st["is_prefill"]:
+            cu = st["cu_q"]
+            assert cu[0] == 0 and cu[-1] == T and (np.diff(cu) >= 1).all() and T <= CHUNK * B
+            for b in range(B):
+                q0, q1 = int(cu[b]), int(cu[b + 1])
+                pos = st["positions"][q0:q1]
+                assert (np.diff(pos) == 1).all() and pos[-1] == ctx[b] - 1          # a contiguous span ending at the context
+                for j in range(q0, q1):                                            # slot = table[pos / BS] * BS + pos % BS
+                    p = int(st["positions"][j])
+                    assert slots[j] == int(bt[b, p // BS]) * BS + p % BS
+        else:
+            assert T == B
+            for b in range(B):
+                p = int(st["positions"][b])
+                assert p == ctx[b] - 1 and slots[b] == int(bt[b, p // BS]) * BS + p % BS
+        # no block is shared by two sequences of the step except through the prefix cache (whole cached blocks only)
+        used = {}
+        for b in range(B):
+            nblk = (int(ctx[b]) + BS - 1) // BS
+            for i, blk in enumerate(bt[b, :nblk].tolist()):
+                assert 0 <= blk < NB
+                if blk in used and used[blk] != b:
+                    assert prefix_cache and (i + 1) * BS <= int(ctx[b]), "a partially filled block is shared"
+                used.setdefault(blk, b)
+        h.commit([3 if r.random() < 0.05 else int(v) for v in r.integers(5, 1000, size=B)])
+    for rid, info in live.items():
+        assert h.finished(rid)
+        outputs[rid] = h.output(rid)
+        assert len(outputs[rid]) <= 24
+    # drained: a fresh maximal request is admitted again (no leaked blocks)
+    rid = h.add_request(r.integers(5, 1000, size=300).tolist(), max_tokens=2)
+    n = 0
+    while h.has_unfinished():
+        st = h.schedule()
+        assert st is not None
+        h.commit([7] * st["n_seqs"])
+        n += 1
+        assert n < 100
+    assert h.finished(rid)
+    h.close()
