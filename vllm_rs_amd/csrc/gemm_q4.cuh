@@ -13,7 +13,7 @@
 //   K.  Compute wave w = (cg, ks) owns n-block cg of the item and the k-tiles kt ≡ ks (mod KS): a flat stream of T =
 //   KT/KS tile-steps with an 8 KiB register ring, branch-free, exact vmcnt (see gemv_q4.cuh for why that matters).
 //   MT m-tiles (16 rows each) share every dequantised B fragment: 4*MT MFMAs per tile and tensor.
-//   x reaches the MFMAs through LDS in K-chunks of KC = 512 or 1024 (double buffered, XOR-swizzled like kernel B), staged
+//   x reaches the MFMAs through LDS in K-chunks of KC = 512 or 1024 (double buffered, row-major with one octet of padding per row), staged
 //   by the producer waves — which have no weight loads, so their waits never touch the compute waves' ring — together
 //   with the per-tile row sums Σx of the zero-point fix-up.  One barrier per chunk.
 //   At the end of an item the KS partial tiles of every n-block meet in LDS and the producer waves run the fused epilogue
@@ -40,7 +40,7 @@ struct GemmCArgs {
   int ks_shift, ktz, n_items;  // log2(ks), K/128/kz and ceil(n_blocks / (8/ks)): quotients the launcher precomputes (an
                                // integer division is ~25 VALU instructions; one of them sat in the compute waves' inner loop)
   int kc;        // k per staged chunk: 512 or 1024 ((K/kz) % kc == 0, (kc/128) % ks == 0)
-  int kz;        // K slices across workgroups (grid.z): 1 = none.  Slice partials go to fp32 slabs and the last-arriving
+  int kz;        // K slices across workgroups (grid.z): 1 = none.  Slice partials go to fp32 slabs and the LAST slice's
                  // workgroup of an (item, m-chunk) reduces them in slice order (deterministic) and runs the epilogue
   float* slabs;        // [kz][row tile][item][NBW][half][unit][4] f32 partial tiles of the K slices
   uint32_t* counters;  // arrival flags, 16 words apart, one per (item, row tile, slice): zero on entry, zero on exit
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
 
   // ---- CGN n-blocks x ROWS rows x 16 columns, handled as 8-column vectors (16 B stores; a scalar loop over single
   // outputs exposed one global round trip per output: ~35 us).  Sum the KS partial tiles; with K slices publish to the
-  // slab and let the last-arriving workgroup finish.
+  // slab and let the last slice's workgroup (the owner) finish.
   const int nunits = CGN * ROWS * 2;
   const float* rf = reinterpret_cast<const float*>(red);
   auto unit_geom = [&](int u, int& cgi, int& mrow, int& nl0) {

@@ -1,6 +1,8 @@
 // gemm_skinny.cuh — "kernel B": skinny/medium-M GEMM (any M, processed in 16*MT-row chunks).
 //
-// Used for decode batches 9..64 and (round 1) for prefill.  Roofline: HBM for M <= ~128, MFMA above.
+// Used wherever kernels A / C / D do not apply: 33..255 rows (short prefills), fine scale groups, narrow GEMMs below 768
+// rows, the dense lm_head above 8 rows.  Roofline: HBM for M <= ~128; above that it is LDS-bandwidth bound (one x fragment
+// read per MFMA), which is what kernel D (gemm_q4_big.cuh) removes for large M.
 // Workgroup = 512 threads = 8 waves; wave w owns n-block (blockIdx.x*8 + w) = 16 output columns
 // (DUAL: the same block of the gate AND the up tensor) and walks ALL k-tiles of its K slice, so
 // each weight byte is read once per 16*MT rows.  The x chunk (16*MT rows x 256 k) is staged through

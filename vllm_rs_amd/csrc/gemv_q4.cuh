@@ -101,7 +101,7 @@ __global__ __launch_bounds__(1024) void gemv_q4_kernel(const GemvArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches, no exec masking
   const bool is_epi = wave == NW;
   const int nn = lane & 15, oct = lane >> 4;
-  // row groups (decode batches 9..32): MG workgroup families, each running the M <= 8 algorithm on its own
+  // row groups (more than 8 rows, where kernel C does not apply): MG workgroup families, each running the M <= 8 algorithm on its own
   // rows_per_group rows of x (8, or fewer when K is long: the rows must fit LDS).  The MG workgroups that stream the same n-blocks get consecutive-by-8 ids, i.e. the
   // same XCD and the same dispatch moment, so every packed tile is fetched from HBM once and from the
   // XCD's L2 by the other MG-1.
