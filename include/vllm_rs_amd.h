@@ -85,7 +85,7 @@ const char* vra_last_error(void);
 void vra_clear_error(void);
 /* Device-side error word: 1 if a split-K exchange of the GEMM kernels gave up waiting for a slice (a lost workgroup;
  * the wait is bounded so that the device never hangs, the results of that launch are invalid).  Reads and clears the
- * word; synchronises the device.  The native engine polls it (every prefill step, every 64th decode step). */
+ * word; synchronises the device.  The native engine checks it on EVERY step (the word rides along with the token download). */
 int32_t vra_take_device_error(void);
 /* library/ABI version and the gfx target it was built for */
 const char* vra_version(void);
@@ -215,7 +215,9 @@ void vra_fill_const_u32(uint32_t* out, int64_t numel, uint32_t value, int64_t st
 
 /* AllReduce CustomOp1 (src/models/layers/distributed.rs:325-396): sum over TP ranks, bf16/f16.
  * The communicator is created from the 128-byte unique id the engine ships in MessageType::Init
- * (src/runner/mod.rs:25-27; Comm::from_rank at src/runner/runner.rs:80-89). */
+ * (src/runner/mod.rs:25-27; Comm::from_rank at src/runner/runner.rs:80-89).  world_size 1 creates a
+ * real one-rank RCCL communicator.  Communicators are caller-owned (vra_engine_set_comm does not
+ * take ownership). */
 int32_t vra_comm_unique_id(uint8_t h_id_out[128]);
 void* vra_comm_create(const uint8_t h_id[128], int32_t rank, int32_t world_size, int32_t device);
 void vra_comm_destroy(void* comm);
@@ -223,6 +225,30 @@ int32_t vra_comm_rank(const void* comm);
 int32_t vra_comm_world_size(const void* comm);
 void vra_all_reduce(void* comm, const void* src, void* dst, int64_t numel, int32_t dtype,
                     int64_t stream);
+/* One-shot transport for decode-sized messages (also the only transport between
+ * ranks that are processes sharing one GPU): (1) vra_comm_ipc_begin allocates this rank's exchange
+ * region and exports its 64-byte hipIpcMemHandle — `comm` is an RCCL communicator from
+ * vra_comm_create (hybrid) or NULL (one-shot only; a new communicator is returned); (2) the
+ * launcher gathers the world_size handles exactly as it ships the unique id; (3)
+ * vra_comm_ipc_connect maps the peers.  Messages of up to `oneshot_max_bytes` (0 = 1 MiB) take the
+ * one-shot path when RCCL is also present; without RCCL every message does (in 8 MiB launches).
+ * All ranks sum in rank order in f32: results are bit-identical on every rank. */
+void* vra_comm_ipc_begin(void* comm, int32_t rank, int32_t world_size, int32_t device,
+                         uint8_t h_handle_out[64]);
+int32_t vra_comm_ipc_connect(void* comm, const uint8_t* h_all_handles /* [world_size][64] */,
+                             int64_t oneshot_max_bytes);
+/* TensorParallelRowLinear::forward + the decoder layer's residual add in ONE call
+ * (distributed.rs:438-455, llama.rs:126,130): dst = all_reduce_sum(partial); dst = round(dst +
+ * bias) (bias [cols] or NULL); dst = dst + residual (NULL, or [rows, cols]; may alias dst).
+ * `partial` is clobbered when the RCCL transport runs with an epilogue. bf16/f16. */
+void vra_all_reduce_fused(void* comm, void* partial, void* dst, const void* bias,
+                          const void* residual, int64_t rows, int32_t cols, int32_t dtype,
+                          int64_t stream);
+/* 1 if a one-shot exchange gave up waiting for a peer (bounded wait: the device never hangs; the
+ * results of that launch are invalid).  Reads and clears; synchronises.  vra_comm_error_word is the
+ * device word behind it (NULL without the one-shot transport) for callers that poll it themselves. */
+int32_t vra_comm_take_error(void* comm);
+uint32_t* vra_comm_error_word(void* comm);
 
 /* device plumbing for hosts that have no HIP binding of their own (tests, bench, the runtime) */
 int32_t vra_device_count(void);
@@ -335,6 +361,13 @@ int32_t vra_engine_load_tensor(void* eng, const char* name, const void* h_data, 
                                int32_t ndim, int32_t elem_bytes);
 int32_t vra_engine_finalize_weights(void* eng); /* repack + scale layout + KV cache + graphs */
 int32_t vra_engine_num_gpu_blocks(const void* eng);
+/* KVCacheAllocator plan of this rank before the cache exists (kvcache_allocator.rs:564-707): the
+ * block count finalize would derive from free memory x kv_fraction.  Under tensor parallelism the
+ * launcher calls it on every rank, takes the minimum (the reference's engine process does this via
+ * MessageType::UsableMemoryLeft, runner/mod.rs:277) and sets it with vra_engine_set_num_gpu_blocks
+ * before vra_engine_finalize_weights — finalize refuses tp_world_size > 1 without an explicit count. */
+int64_t vra_engine_plan_kv_blocks(void* eng);
+int32_t vra_engine_set_num_gpu_blocks(void* eng, int32_t num_gpu_blocks);
 /* request API: token ids in, token ids out (tokenizer-free) */
 int64_t vra_engine_add_request(void* eng, const uint32_t* h_prompt, int32_t n_prompt,
                                int32_t max_tokens, int32_t ignore_eos, const uint32_t* h_eos,
@@ -378,7 +411,8 @@ int32_t vra_engine_forward_raw(void* eng, const uint32_t* h_ids, const int64_t* 
  * running batch back to back (graph replay when enabled) and returns elapsed ms measured with HIP
  * events on the engine stream; tokens are sampled and appended exactly as in vra_engine_step. */
 double vra_engine_timed_decode(void* eng, int32_t steps);
-/* tensor parallel: attach a communicator created with vra_comm_create before finalize */
+/* tensor parallel: attach a communicator (vra_comm_create and/or vra_comm_ipc_begin/connect) before finalize;
+ * the communicator stays caller-owned and must outlive the engine */
 int32_t vra_engine_set_comm(void* eng, void* comm);
 /* roofline leg of bench.py: average duration (ms) of ONE launch of a decode-shaped GEMM kernel
  * family at m rows, rotating over all layers' weights so nothing is cache resident, measured with

@@ -38,6 +38,18 @@ class Linear:
             self.quant = False
             self.w = w[prefix + ".weight"]  # [N, K]
 
+    def partial(self, x, k0, k1):
+        """row-parallel shard (TensorParallelRowLinear, distributed.rs:438-455): x[:, k0:k1] against rows k0..k1 of the
+        weight, no bias, rounded to the model dtype — what ONE rank hands to the all-reduce"""
+        x = np.ascontiguousarray(x[:, k0:k1])
+        if self.quant:
+            g = self.gs if self.gs > 0 else self.idx.shape[0]
+            assert k0 % g == 0 and k1 % g == 0
+            z = None if self.zeros is None else np.ascontiguousarray(self.zeros[k0 // g:k1 // g])
+            return orc.wna16_gemm(x, np.ascontiguousarray(self.idx[k0:k1]), z, np.ascontiguousarray(self.scales[k0 // g:k1 // g]),
+                                  self.gs, self.dt, None, None)
+        return orc.dense_gemm(x, np.ascontiguousarray(self.w[:, k0:k1]), None, self.dt, self.dt)
+
     def __call__(self, x, residual=None):
         if self.quant:
             return orc.wna16_gemm(x, self.idx, self.zeros, self.scales, self.gs, self.dt, self.bias, residual)
@@ -46,8 +58,14 @@ class Linear:
 
 
 class OracleModel:
-    def __init__(self, cfg, weights, num_blocks, block_size=64):
+    """tp_world > 1 restates the tensor-parallel arithmetic of the reference in ONE process: column-parallel layers
+    produce exact slices of the unsharded result (nothing to simulate); the row-parallel o_proj / down_proj produce
+    per-rank partial sums rounded to the model dtype, which the all-reduce adds (here: in rank order, f32, one
+    rounding — NCCL's order is unspecified), then bias, then the residual (distributed.rs:438-455, llama.rs:126,130)."""
+
+    def __init__(self, cfg, weights, num_blocks, block_size=64, tp_world=1):
         self.cfg, self.w, self.BS = cfg, weights, block_size
+        self.tp = tp_world
         dt = cfg["dtype"]
         self.dt = dt
         L, Hkv, D = cfg["num_layers"], cfg["num_kv_heads"], cfg["head_dim"]
@@ -72,6 +90,18 @@ class OracleModel:
         self.final_norm = weights["model.norm.weight"]
         self.lm_head = weights.get("lm_head.weight", self.embed)
 
+    def _row_parallel(self, lin, x, residual):
+        if self.tp == 1:
+            return lin(x, residual=residual)
+        K = x.shape[1]
+        acc = np.zeros((x.shape[0], residual.shape[1]), np.float32)
+        for r in range(self.tp):
+            acc += orc.from_dt(lin.partial(x, r * K // self.tp, (r + 1) * K // self.tp), self.dt)
+        out = orc.to_dt(acc, self.dt)
+        if lin.bias is not None:
+            out = orc.add(out, np.broadcast_to(lin.bias, out.shape).copy(), self.dt)
+        return orc.add(out, residual, self.dt)
+
     def forward(self, ids, positions, slot_mapping, block_tables, context_lens, cu_q=None):
         """returns f32 logits [n_seqs, vocab]; cu_q None => decode (one token per sequence)."""
         cfg, dt = self.cfg, self.dt
@@ -88,10 +118,10 @@ class OracleModel:
             k = orc.rope(k, self.cos, self.sin, positions, False, dt, dt)
             orc.reshape_and_cache(k, v, self.kc[li], self.vc[li], slot_mapping, self.BS, dt)
             a = orc.paged_attention(q, self.kc[li], self.vc[li], block_tables, context_lens, cu_q, Hkv, self.BS, D ** -0.5, dt)
-            h = L["o"](a.reshape(T, Hq * D), residual=h)                      # attn_output + residual
+            h = self._row_parallel(L["o"], a.reshape(T, Hq * D), h)           # attn_output + residual
             x = orc.rms_norm(h, L["ffn_norm"], eps, dt)
             act = orc.silu_mul(L["gate"](x), L["up"](x), dt)
-            h = L["down"](act, residual=h)                                    # residual + mlp_output
+            h = self._row_parallel(L["down"], act, h)                         # residual + mlp_output
         if cu_q is not None:  # last token of each sequence (llama.rs:306-310)
             rows = np.asarray(cu_q[1:], np.int64) - 1
             h = np.ascontiguousarray(h[rows])

@@ -289,29 +289,46 @@ void orc_gemm_wdense(const void* x, const void* w, const void* bias, const void*
 void orc_wna16_gemm(const void* x, const uint8_t* idx, const uint8_t* zeros, const void* scales,
                     const void* bias, const void* residual, int M, int K, int N, int group_size,
                     int dt, void* out) {
+  /* Blocked for the caches (32 columns x 64 rows of accumulators per thread, k outermost inside a block, weights
+   * dequantised once per (k, column) and row block); every output is still the SEQUENTIAL sum over k = 0..K-1 in double,
+   * i.e. bit-identical to the plain triple loop. */
+  enum { NB = 32, MB = 64 };
   int g = group_size > 0 ? group_size : K;
   float* xf = (float*)malloc((size_t)M * K * sizeof(float));
   for (int64_t i = 0; i < (int64_t)M * K; i++) xf[i] = ld(x, i, dt);
+  int nblk = (N + NB - 1) / NB, mblk = (M + MB - 1) / MB;
 #pragma omp parallel
   {
-    double* acc = (double*)malloc((size_t)M * sizeof(double));
-#pragma omp for schedule(static)
-    for (int n = 0; n < N; n++) {
-      for (int m = 0; m < M; m++) acc[m] = 0.0;
-      for (int k = 0; k < K; k++) {
-        int grp = k / g;
-        int z = zeros ? zeros[(int64_t)grp * N + n] : 8;
-        double wv = (double)((int)idx[(int64_t)k * N + n] - z) * (double)ld(scales, (int64_t)grp * N + n, dt);
-        for (int m = 0; m < M; m++) acc[m] += (double)xf[(int64_t)m * K + k] * wv;
+    double acc[MB][NB];
+    double wv[NB];
+#pragma omp for collapse(2) schedule(dynamic)
+    for (int nb = 0; nb < nblk; nb++)
+      for (int mb = 0; mb < mblk; mb++) {
+        int n0 = nb * NB, nc = N - n0 < NB ? N - n0 : NB;
+        int m0 = mb * MB, mc = M - m0 < MB ? M - m0 : MB;
+        for (int m = 0; m < mc; m++)
+          for (int c = 0; c < nc; c++) acc[m][c] = 0.0;
+        for (int k = 0; k < K; k++) {
+          int grp = k / g;
+          for (int c = 0; c < nc; c++) {
+            int n = n0 + c;
+            int z = zeros ? zeros[(int64_t)grp * N + n] : 8;
+            wv[c] = (double)((int)idx[(int64_t)k * N + n] - z) * (double)ld(scales, (int64_t)grp * N + n, dt);
+          }
+          for (int m = 0; m < mc; m++) {
+            double xv = (double)xf[(int64_t)(m0 + m) * K + k];
+            for (int c = 0; c < nc; c++) acc[m][c] += xv * wv[c];
+          }
+        }
+        for (int m = 0; m < mc; m++)
+          for (int c = 0; c < nc; c++) {
+            int n = n0 + c;
+            float v = rnd((float)acc[m][c], dt);
+            if (bias) v = rnd(v + ld(bias, n, dt), dt);
+            if (residual) v = rnd(v + ld(residual, (int64_t)(m0 + m) * N + n, dt), dt);
+            st(out, (int64_t)(m0 + m) * N + n, v, dt);
+          }
       }
-      for (int m = 0; m < M; m++) {
-        float v = rnd((float)acc[m], dt);
-        if (bias) v = rnd(v + ld(bias, n, dt), dt);
-        if (residual) v = rnd(v + ld(residual, (int64_t)m * N + n, dt), dt);
-        st(out, (int64_t)m * N + n, v, dt);
-      }
-    }
-    free(acc);
   }
   free(xf);
 }
@@ -489,44 +506,69 @@ void orc_paged_attention(void* out, const void* q, const void* kc, const void* v
                          const uint32_t* block_tables, const uint32_t* context_lens,
                          const uint32_t* cu_q, int B, int Hq, int Hkv, int D, int BS, int max_blocks,
                          float scale, float softcap, int dt) {
+  /* Same arithmetic as the plain loops (scores, softmax and P.V in double, keys in ascending order); the keys and values
+   * of one (sequence, kv head) are widened to double once and the (query head, query row) pairs run in parallel, so that a
+   * 32k-token context (BASELINE config 5) is a matter of seconds on the host cores. */
   int G = Hq / Hkv;
-#pragma omp parallel for collapse(2) schedule(dynamic)
-  for (int b = 0; b < B; b++)
-    for (int h = 0; h < Hq; h++) {
-      int ctx = (int)context_lens[b];
-      int q0 = cu_q ? (int)cu_q[b] : b, lq = cu_q ? (int)(cu_q[b + 1] - cu_q[b]) : 1;
-      int hk = h / G;
-      double* sc = (double*)malloc(sizeof(double) * (ctx > 0 ? ctx : 1));
-      double* acc = (double*)malloc(sizeof(double) * D);
-      for (int i = 0; i < lq; i++) {
-        int pos = ctx - lq + i; /* attends keys 0..pos */
-        int64_t qb = ((int64_t)(q0 + i) * Hq + h) * D;
-        double mx = -1e300;
-        for (int j = 0; j <= pos; j++) {
-          int64_t slot = (int64_t)block_tables[(int64_t)b * max_blocks + j / BS] * BS + j % BS;
-          int64_t o = cache_off(slot, hk, Hkv, BS, D);
-          double s = 0.0;
-          for (int d = 0; d < D; d++) s += (double)ld(q, qb + d, dt) * (double)ld(kc, o + d, dt);
-          s *= scale;
-          if (softcap > 0.0f) s = softcap * tanh(s / softcap);
-          sc[j] = s;
-          if (s > mx) mx = s;
+  for (int b = 0; b < B; b++) {
+    int ctx = (int)context_lens[b];
+    int q0 = cu_q ? (int)cu_q[b] : b, lq = cu_q ? (int)(cu_q[b + 1] - cu_q[b]) : 1;
+    if (ctx <= 0 || lq <= 0) continue;
+    for (int hk = 0; hk < Hkv; hk++) {
+      double* Kd = (double*)malloc(sizeof(double) * (size_t)ctx * D);
+      double* Vd = (double*)malloc(sizeof(double) * (size_t)ctx * D);
+#pragma omp parallel for schedule(static)
+      for (int j = 0; j < ctx; j++) {
+        int64_t slot = (int64_t)block_tables[(int64_t)b * max_blocks + j / BS] * BS + j % BS;
+        int64_t o = cache_off(slot, hk, Hkv, BS, D);
+        for (int d = 0; d < D; d++) {
+          Kd[(size_t)j * D + d] = (double)ld(kc, o + d, dt);
+          Vd[(size_t)j * D + d] = (double)ld(vc, vcache_off(slot, hk, d, Hkv, BS, D), dt);
         }
-        double den = 0.0;
-        for (int j = 0; j <= pos; j++) {
-          sc[j] = exp(sc[j] - mx);
-          den += sc[j];
-        }
-        for (int d = 0; d < D; d++) acc[d] = 0.0;
-        for (int j = 0; j <= pos; j++) {
-          int64_t slot = (int64_t)block_tables[(int64_t)b * max_blocks + j / BS] * BS + j % BS;
-          for (int d = 0; d < D; d++) acc[d] += sc[j] * (double)ld(vc, vcache_off(slot, hk, d, Hkv, BS, D), dt);
-        }
-        for (int d = 0; d < D; d++) st(out, qb + d, (float)(acc[d] / den), dt);
       }
-      free(sc);
-      free(acc);
+#pragma omp parallel
+      {
+        double* sc = (double*)malloc(sizeof(double) * (size_t)ctx);
+        double* acc = (double*)malloc(sizeof(double) * D);
+        double* qd = (double*)malloc(sizeof(double) * D);
+#pragma omp for collapse(2) schedule(dynamic, 4)
+        for (int gi = 0; gi < G; gi++)
+          for (int i = 0; i < lq; i++) {
+            int h = hk * G + gi;
+            int pos = ctx - lq + i; /* attends keys 0..pos */
+            int64_t qb = ((int64_t)(q0 + i) * Hq + h) * D;
+            for (int d = 0; d < D; d++) qd[d] = (double)ld(q, qb + d, dt);
+            double mx = -1e300;
+            for (int j = 0; j <= pos; j++) {
+              const double* kr = Kd + (size_t)j * D;
+              double sv = 0.0;
+              for (int d = 0; d < D; d++) sv += qd[d] * kr[d];
+              sv *= scale;
+              if (softcap > 0.0f) sv = softcap * tanh(sv / softcap);
+              sc[j] = sv;
+              if (sv > mx) mx = sv;
+            }
+            double den = 0.0;
+            for (int j = 0; j <= pos; j++) {
+              sc[j] = exp(sc[j] - mx);
+              den += sc[j];
+            }
+            for (int d = 0; d < D; d++) acc[d] = 0.0;
+            for (int j = 0; j <= pos; j++) {
+              const double* vr = Vd + (size_t)j * D;
+              const double pj = sc[j];
+              for (int d = 0; d < D; d++) acc[d] += pj * vr[d];
+            }
+            for (int d = 0; d < D; d++) st(out, qb + d, (float)(acc[d] / den), dt);
+          }
+        free(sc);
+        free(acc);
+        free(qd);
+      }
+      free(Kd);
+      free(Vd);
     }
+  }
 }
 /* Prefill without cache indirection: k,v [Tk,Hkv,D] with cu_k (no prefix: cu_k == cu_q). */
 void orc_varlen_attention(void* out, const void* q, const void* k, const void* v, const uint32_t* cu_q,

@@ -458,9 +458,10 @@ def test_argument_errors_are_reported():
 
 
 def test_rccl_all_reduce_single_rank():
-    """the RCCL boundary (AllReduce::cuda_fwd, distributed.rs:438-455; id bootstrap runner/mod.rs:25-121) on the one GPU
-    a test box has: unique id -> communicator of world size 1 -> all-reduce(sum) in the storage dtype, in place and out
-    of place (identity at one rank; the 2-rank arithmetic is covered on CPU by tests/test_dist_gloo.py)"""
+    """ncclGetUniqueId -> ncclCommInitRank -> ncclAllReduce at world size 1: a REAL one-rank RCCL communicator (no dummy
+    object), all-reduce(sum) in the storage dtype, in place and out of place (identity at one rank).  The two-rank product
+    path — launcher, shard loading, Model::forward's world > 1 branch, the one-shot all-reduce (and RCCL when the box has two
+    GPUs) — is tests/test_gpu_tp.py."""
     L = ops.lib()
     uid = (C.c_uint8 * 128)()
     assert L.vra_comm_unique_id(uid) == 0

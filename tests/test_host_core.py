@@ -461,3 +461,90 @@ def test_engine_random_streams_keep_the_kv_invariants(seed, prefix_cache):
         assert n < 100
     assert h.finished(rid)
     h.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE config 5: 32k-token prompts — chunked prefill (8192), paged-KV block manager, prefix-cache stress
+# (SURVEY §8d "Config 5"; scheduler.rs:203,718-785; block_manager.rs:291-299; runner.rs:978-1241)
+# ---------------------------------------------------------------------------------------------
+LONG = dict(E.LLAMA31_8B)
+
+
+def test_config5_32k_prompt_takes_four_chunks_then_hits_511_blocks():
+    h = E.HostEngine(LONG, num_gpu_blocks=1400, block_size=64, max_num_seqs=8, max_model_len=40960, enable_prefix_cache=True)
+    r = np.random.default_rng(42)
+    prompt = r.integers(1000, 127000, size=32768).tolist()
+    a = h.add_request(prompt, max_tokens=3, ignore_eos=True)
+    trace = run_to_completion(h, lambda st, i: 555)
+    pre = [t for t in trace if t["is_prefill"]]
+    assert [t["n_tokens"] for t in pre] == [8192] * 4                 # exactly four prefill steps of 8192 (scheduler.rs:203)
+    for k, t in enumerate(pre):
+        assert t["context_lens"].tolist() == [8192 * (k + 1)] and t["positions"][0] == 8192 * k
+        bt = t["block_tables"][0]
+        assert len(set(bt[:512].tolist())) == 512                   # 512 distinct blocks, table kept across chunks (A13)
+        assert t["block_tables"][0][:512].tolist() == pre[0]["block_tables"][0][:512].tolist()
+        assert t["slots"].tolist() == [int(bt[p // 64]) * 64 + p % 64 for p in range(8192 * k, 8192 * (k + 1))]
+    first_blocks = pre[0]["block_tables"][0][:512].tolist()
+    assert h.finished(a) and h.output(a) == [555] * 3
+    # ---- the same prompt again: all 512 blocks are cached, the LAST full block is recomputed (block_manager.rs:291-299)
+    b = h.add_request(prompt, max_tokens=3, ignore_eos=True)
+    trace2 = run_to_completion(h, lambda st, i: 556)
+    pre2 = [t for t in trace2 if t["is_prefill"]]
+    assert [t["n_tokens"] for t in pre2] == [64]
+    assert pre2[0]["positions"].tolist() == list(range(511 * 64, 512 * 64)) and pre2[0]["context_lens"].tolist() == [32768]
+    assert pre2[0]["block_tables"][0][:511].tolist() == first_blocks[:511]     # the 511 cached blocks are SHARED, not copied
+    assert int(pre2[0]["block_tables"][0][511]) != first_blocks[511]          # the recomputed block is a fresh one
+    assert h.finished(b)
+
+
+def test_config5_eight_prompts_share_a_16k_prefix():
+    h = E.HostEngine(LONG, num_gpu_blocks=4096, block_size=64, max_num_seqs=8, max_model_len=40960, enable_prefix_cache=True)
+    r = np.random.default_rng(7)
+    prefix = r.integers(1000, 127000, size=16384).tolist()
+    warm = h.add_request(prefix + r.integers(1000, 127000, size=100).tolist(), max_tokens=2, ignore_eos=True)
+    run_to_completion(h, lambda st, i: 9)                            # leaves the 256 prefix blocks in the cache
+    assert h.finished(warm)
+    tails = [r.integers(1000, 127000, size=1024).tolist() for _ in range(8)]
+    rids = [h.add_request(prefix + t, max_tokens=4, ignore_eos=True) for t in tails]
+    trace = run_to_completion(h, lambda st, i: 100 + i)
+    pre = [t for t in trace if t["is_prefill"]]
+    # every prompt starts behind the 256 cached blocks: only its 1024 tail tokens are prefilled
+    assert sum(t["n_tokens"] for t in pre) == 8 * 1024
+    shared = None
+    for t in pre:
+        for i in range(t["n_seqs"]):
+            assert t["cu_q"][i + 1] - t["cu_q"][i] == 1024 and t["context_lens"][i] == 16384 + 1024
+            head = t["block_tables"][i][:256].tolist()
+            shared = shared or head
+            assert head == shared                                      # all eight read the SAME physical prefix blocks
+            assert t["positions"][t["cu_q"][i]] == 16384
+    assert all(h.finished(x) for x in rids)
+
+
+def test_more_pending_requests_than_max_num_seqs_floor_of_five():
+    """the scheduler batches up to max(max_num_seqs, 5) sequences (scheduler.rs:44): every per-sequence staging region must
+    hold that many — max_num_seqs = 2 with 7 pending requests schedules 5 and corrupts nothing"""
+    h = E.HostEngine(TINY, num_gpu_blocks=64, block_size=4, max_num_seqs=2, max_model_len=64)
+    rids = [h.add_request([10 * i + 1, 10 * i + 2, 10 * i + 3], max_tokens=3) for i in range(7)]
+    st = h.schedule()
+    assert st["is_prefill"] and st["n_seqs"] == 5
+    assert st["context_lens"].tolist() == [3] * 5 and st["cu_q"].tolist() == [0, 3, 6, 9, 12, 15]
+    assert st["block_tables"].shape[0] == 5
+    h.commit([7] * 5)
+    trace = run_to_completion(h, lambda st, i: 7)
+    assert all(h.finished(r) for r in rids)
+    for t in trace:
+        assert t["n_seqs"] <= 5
+        if not t["is_prefill"]:
+            assert (t["context_lens"] >= 4).all()                    # no staging region overwrote another
+
+
+def test_prefill_chunk_above_the_staging_cap_is_clamped():
+    """prefill_chunk > 16384 (the staging / activation cap) is clamped for scheduler AND runner alike: a 40000-token prompt
+    goes through in steps of 16384 instead of overrunning the staging buffers"""
+    h = E.HostEngine(LONG, num_gpu_blocks=1400, block_size=64, max_num_seqs=4, max_model_len=65536, prefill_chunk=32768)
+    p = (np.arange(40000) % 5000 + 1).tolist()
+    a = h.add_request(p, max_tokens=2, ignore_eos=True)
+    trace = run_to_completion(h, lambda st, i: 3)
+    assert [t["n_tokens"] for t in trace if t["is_prefill"]] == [16384, 16384, 40000 - 2 * 16384]
+    assert h.finished(a)

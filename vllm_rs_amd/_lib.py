@@ -116,6 +116,11 @@ def load():
     _sig(lib, "vra_comm_rank", c_i32, P)
     _sig(lib, "vra_comm_world_size", c_i32, P)
     _sig(lib, "vra_all_reduce", None, P, P, P, c_i64, c_i32, c_i64)
+    _sig(lib, "vra_comm_ipc_begin", P, P, c_i32, c_i32, c_i32, P)
+    _sig(lib, "vra_comm_ipc_connect", c_i32, P, P, c_i64)
+    _sig(lib, "vra_all_reduce_fused", None, P, P, P, P, P, c_i64, c_i32, c_i32, c_i64)
+    _sig(lib, "vra_comm_take_error", c_i32, P)
+    _sig(lib, "vra_comm_error_word", P, P)
     _sig(lib, "vra_device_count", c_i32)
     _sig(lib, "vra_set_device", c_i32, c_i32)
     _sig(lib, "vra_malloc", P, c_sz)
@@ -169,6 +174,8 @@ def load():
     _sig(lib, "vra_engine_load_tensor", c_i32, P, C.c_char_p, P, P, c_i32, c_i32)
     _sig(lib, "vra_engine_finalize_weights", c_i32, P)
     _sig(lib, "vra_engine_num_gpu_blocks", c_i32, P)
+    _sig(lib, "vra_engine_plan_kv_blocks", c_i64, P)
+    _sig(lib, "vra_engine_set_num_gpu_blocks", c_i32, P, c_i32)
     _sig(lib, "vra_engine_add_request", c_i64, P, P, c_i32, c_i32, c_i32, P, c_i32)
     _sig(lib, "vra_engine_step", c_i32, P, P)
     _sig(lib, "vra_engine_dry_schedule", c_i32, P, P, P)

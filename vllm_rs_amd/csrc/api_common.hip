@@ -90,49 +90,71 @@ extern "C" float vra_event_elapsed_ms(void* a, void* b) {
 }
 
 // ---------------------------------------------------------------- scratch
+// One scratch set PER DEVICE (keyed by the device current at the call, like every launcher that
+// consumes it): a second engine on another device of the same process gets its own slabs, flags and
+// error word.  Within one device the reference's threading contract applies: one forward at a time
+// per process (engine.rs:844 holds `runners.write()`), so one set per device is enough; two streams
+// of ONE device running split-K GEMMs concurrently are outside that contract.
 static const size_t kSlabBytes = (size_t)192 << 20;  // fp32 split-K partials
 static const size_t kCounters = 1 << 16;
-static float* g_slabs = nullptr;
 static const size_t kScaleBytes = (size_t)8 << 20;  // per region; two regions (gate/up)
-static unsigned char* g_scales = nullptr;
-static uint32_t* g_counters = nullptr;
+static const int kMaxDevices = 64;
+struct ScratchSet {
+  float* slabs = nullptr;
+  unsigned char* scales = nullptr;
+  uint32_t* counters = nullptr;
+};
+static ScratchSet g_scratch[kMaxDevices];
 static std::mutex g_scratch_mu;
-bool vra_scratch_init() {
+static ScratchSet* scratch_for_current_device(bool create) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+  ScratchSet& s = g_scratch[dev];
+  if (s.slabs && s.counters && s.scales) return &s;
+  if (!create) return nullptr;
   std::lock_guard<std::mutex> lk(g_scratch_mu);
-  if (g_slabs && g_counters && g_scales) return true;
+  if (s.slabs && s.counters && s.scales) return &s;
   void* p = nullptr;
-  if (hipMalloc(&p, kSlabBytes) != hipSuccess) return false;
-  g_slabs = (float*)p;
-  if (hipMalloc(&p, (kCounters + 16) * sizeof(uint32_t)) != hipSuccess) return false;
-  g_counters = (uint32_t*)p;
-  if (hipMalloc(&p, 2 * kScaleBytes) != hipSuccess) return false;
-  g_scales = (unsigned char*)p;
-  if (hipMemset(g_counters, 0, (kCounters + 16) * sizeof(uint32_t)) != hipSuccess) return false;
-  return true;
+  if (!s.slabs) {
+    if (hipMalloc(&p, kSlabBytes) != hipSuccess) return nullptr;
+    s.slabs = (float*)p;
+  }
+  if (!s.counters) {
+    if (hipMalloc(&p, (kCounters + 16) * sizeof(uint32_t)) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, (kCounters + 16) * sizeof(uint32_t)) != hipSuccess) return nullptr;
+    s.counters = (uint32_t*)p;
+  }
+  if (!s.scales) {
+    if (hipMalloc(&p, 2 * kScaleBytes) != hipSuccess) return nullptr;
+    s.scales = (unsigned char*)p;
+  }
+  return &s;
 }
+bool vra_scratch_init() { return scratch_for_current_device(true) != nullptr; }
 float* vra_scratch_slabs() {
-  if (!g_slabs) vra_scratch_init();
-  return g_slabs;
+  ScratchSet* s = scratch_for_current_device(true);
+  return s ? s->slabs : nullptr;
 }
 uint32_t* vra_scratch_counters() {
-  if (!g_counters) vra_scratch_init();
-  return g_counters;
+  ScratchSet* s = scratch_for_current_device(true);
+  return s ? s->counters : nullptr;
 }
 void* vra_scratch_scales(int which) {
-  if (!g_scales) vra_scratch_init();
-  return g_scales ? g_scales + (size_t)(which & 1) * kScaleBytes : nullptr;
+  ScratchSet* s = scratch_for_current_device(true);
+  return s ? s->scales + (size_t)(which & 1) * kScaleBytes : nullptr;
 }
 size_t vra_scratch_scale_bytes() { return kScaleBytes; }
 size_t vra_scratch_slab_bytes() { return kSlabBytes; }
 size_t vra_scratch_counter_count() { return kCounters; }
 uint32_t* vra_scratch_error_word() {
-  if (!g_counters) vra_scratch_init();
-  return g_counters ? g_counters + kCounters : nullptr;
+  ScratchSet* s = scratch_for_current_device(true);
+  return s ? s->counters + kCounters : nullptr;
 }
 int vra_scratch_take_error() {
-  if (!g_counters) return 0;
+  ScratchSet* s = scratch_for_current_device(false);
+  if (!s) return 0;
   uint32_t v = 0;
-  if (hipMemcpy(&v, g_counters + kCounters, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return 0;
-  if (v) (void)hipMemset(g_counters + kCounters, 0, sizeof(v));
+  if (hipMemcpy(&v, s->counters + kCounters, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  if (v) (void)hipMemset(s->counters + kCounters, 0, sizeof(v));
   return v != 0;
 }

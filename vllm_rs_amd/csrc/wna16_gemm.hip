@@ -121,14 +121,20 @@ extern "C" void vra_wna16_dequant(const void* qweight_tiled, const void* scales,
 
 static const int kMaxDynLds = 160 * 1024;
 
+static int cur_dev() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return dev & 63;
+}
+static bool dev_seen(const uint64_t& mask) { return (mask >> cur_dev()) & 1; }
+static void dev_mark(uint64_t& mask) { mask |= (uint64_t)1 << cur_dev(); }
 static int num_cus() {
-  static int n = 0;
-  if (!n) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  static int n[64] = {0};
+  const int dev = cur_dev();
+  if (!n[dev]) {
+    if (hipDeviceGetAttribute(&n[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n[dev] <= 0) n[dev] = 256;
   }
-  return n;
+  return n[dev];
 }
 
 #ifdef VRA_GEMV_TS
@@ -146,13 +152,14 @@ struct GemvArgs;
 static void gemv_debug_args(GemvArgs& a);
 template <class DT, bool INT4, int NBW, int SPT, bool AWQ>
 static void launch_gemv_v(GemvArgs a, int nblocks, size_t lds, hipStream_t st) {
-  static bool attr_set = false;
+  static uint64_t attr_devs = 0;  // per device: function attributes belong to the device current at the call
+  const bool attr_set = dev_seen(attr_devs);
   static size_t occ_lds = ~(size_t)0;
   static int occ_val = 1;
   auto kern = gemv_kernel<DT, INT4, NBW, SPT, AWQ>;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
-    attr_set = true;
+    dev_mark(attr_devs);
   }
   // persistent grid = resident capacity (registers/LDS decide how many workgroups fit a CU), work
   // items split evenly so that there is no ragged last round
@@ -186,7 +193,8 @@ static int gemv_q4_rows_per_group(int nbw, int M, int K, int group_size);
 // twice the k-split per item)
 template <class DT, int NBW, int SPT, bool AWQ>
 static void launch_gemv_q4_v(GemvArgs a, int nblocks, hipStream_t st) {
-  static bool attr_set = false;
+  static uint64_t attr_devs = 0;  // per device: function attributes belong to the device current at the call
+  const bool attr_set = dev_seen(attr_devs);
   static int occ9 = 0;  // resident 9-wave workgroups per CU (VGPR budget of this variant)
   auto kern = gemv_q4_kernel<DT, NBW, SPT, AWQ>;
   if (!attr_set) {
@@ -194,7 +202,7 @@ static void launch_gemv_q4_v(GemvArgs a, int nblocks, hipStream_t st) {
     int occ = 0;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 9 * 64, 48 * 1024);
     occ9 = (e == hipSuccess && occ > 0) ? (occ > 2 ? 2 : occ) : 1;
-    attr_set = true;
+    dev_mark(attr_devs);
   }
   const int cus = num_cus();
   const int rpg = gemv_q4_rows_per_group(NBW, a.M, a.K, a.group_size);
@@ -310,12 +318,13 @@ static void launch_skinny_t(GemmBArgs a, hipStream_t st) {
   // fine scale groups (SPT=4) carry 4x the scale registers: (DUAL, MT>=2) and (single, MT=4) would need > 256
   // VGPRs (spills next to MFMAs) and are never instantiated — vra_launch_skinny caps MT accordingly
   constexpr bool kHasFine = INT4 && !(DUAL && MT >= 2) && !(!DUAL && MT == 4);
-  static bool attr_set = false;
+  static uint64_t attr_devs = 0;  // per device: function attributes belong to the device current at the call
+  const bool attr_set = dev_seen(attr_devs);
   if (!attr_set) {  // MT=4 needs 64 KiB + 16 B of dynamic LDS, just past the default limit
     if constexpr (kHasFine)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<DT, INT4, DUAL, MT, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<DT, INT4, DUAL, MT, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
-    attr_set = true;
+    dev_mark(attr_devs);
   }
   if constexpr (kHasFine) {
     if (fine) {
@@ -400,11 +409,12 @@ int vra_gemm_q4_big_fits(bool dual, int M, int cols, int K, int group_size, cons
 template <class DT, bool DUAL, int MB>
 static void launch_gemm_q4_big_t(const GemmDArgs& a, bool awq, dim3 grid, hipStream_t st) {
   const size_t lds = gemm_q4_big_lds_bytes(MB);
-  static bool attr_set = false;
+  static uint64_t attr_devs = 0;  // per device: function attributes belong to the device current at the call
+  const bool attr_set = dev_seen(attr_devs);
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_q4_big_kernel<DT, DUAL, false, MB>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_q4_big_kernel<DT, DUAL, true, MB>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
-    attr_set = true;
+    dev_mark(attr_devs);
   }
   if (awq) gemm_q4_big_kernel<DT, DUAL, true, MB><<<grid, GD_THREADS, lds, st>>>(a);
   else gemm_q4_big_kernel<DT, DUAL, false, MB><<<grid, GD_THREADS, lds, st>>>(a);
@@ -463,11 +473,12 @@ bool vra_gemm_q4_fits(int nbw, int M, int K, int group_size) {
 }
 template <class DT, int NBW, int MT>
 static void launch_gemm_q4_t(const GemmCArgs& a, bool awq, dim3 grid, size_t lds, hipStream_t st) {
-  static bool attr_set = false;
+  static uint64_t attr_devs = 0;  // per device: function attributes belong to the device current at the call
+  const bool attr_set = dev_seen(attr_devs);
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_q4_kernel<DT, NBW, MT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_q4_kernel<DT, NBW, MT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
-    attr_set = true;
+    dev_mark(attr_devs);
   }
   if (awq) gemm_q4_kernel<DT, NBW, MT, true><<<grid, GC_THREADS, lds, st>>>(a);
   else gemm_q4_kernel<DT, NBW, MT, false><<<grid, GC_THREADS, lds, st>>>(a);

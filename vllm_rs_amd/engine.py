@@ -37,6 +37,11 @@ LLAMA3_8B = dict(arch="llama", hidden_size=4096, intermediate_size=14336, num_la
 QWEN2_7B = dict(arch="qwen2", hidden_size=3584, intermediate_size=18944, num_layers=28, num_heads=28, num_kv_heads=4,
                 head_dim=128, vocab_size=152064, max_position_embeddings=32768, rms_norm_eps=1e-6, rope_theta=1000000.0,
                 attention_bias=True, quant_method="awq", group_size=128, dtype=BF16)
+# Llama-3.1-8B: the same widths with the llama3 rope scaling and a 128k window — the shape of BASELINE config 5
+# (32k-token prompts need max_position_embeddings >= 32768; rotary_emb.rs:208-278)
+LLAMA31_8B = dict(LLAMA3_8B, max_position_embeddings=131072,
+                  rope_scaling=dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0,
+                                    original_max_position_embeddings=8192))
 LLAMA3_70B = dict(arch="llama", hidden_size=8192, intermediate_size=28672, num_layers=80, num_heads=64, num_kv_heads=8,
                   head_dim=128, vocab_size=128256, max_position_embeddings=8192, rms_norm_eps=1e-5, rope_theta=500000.0,
                   quant_method="gptq", group_size=128, dtype=BF16)
@@ -75,18 +80,30 @@ class Engine:
             raise RuntimeError(f"{what}: {self.L.vra_engine_last_error(self.h).decode()}")
         return rc
 
-    def init_synthetic(self):
+    def init_synthetic(self, finalize=True):
         self._check(self.L.vra_engine_init_synthetic(self.h), "init_synthetic")
-        self._check(self.L.vra_engine_finalize_weights(self.h), "finalize")
-        return self
+        return self.finalize() if finalize else self
 
-    def load_weights(self, tensors):
-        """tensors: name -> numpy array in checkpoint format (16-bit floats as uint16 bit patterns in model dtype)."""
+    def load_weights(self, tensors, finalize=True):
+        """tensors: name -> numpy array in checkpoint format (16-bit floats as uint16 bit patterns in model dtype).
+        Under tensor parallelism every rank is handed the FULL tensors and keeps its shard (wna16.rs:35-40,
+        distributed.rs:498-538)."""
         for name, a in tensors.items():
             a = np.ascontiguousarray(a)
             shape = (C.c_int64 * a.ndim)(*a.shape)
             self._check(self.L.vra_engine_load_tensor(self.h, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim, a.itemsize),
                         f"load_tensor({name})")
+        return self.finalize() if finalize else self
+
+    def plan_kv_blocks(self):
+        """this rank's KV plan before the cache exists; TP launchers take the minimum over ranks (vllm_rs_amd/runner.py)"""
+        return self._check(self.L.vra_engine_plan_kv_blocks(self.h), "plan_kv_blocks")
+
+    def set_num_gpu_blocks(self, n):
+        self._check(self.L.vra_engine_set_num_gpu_blocks(self.h, int(n)), "set_num_gpu_blocks")
+        return self
+
+    def finalize(self):
         self._check(self.L.vra_engine_finalize_weights(self.h), "finalize")
         return self
 

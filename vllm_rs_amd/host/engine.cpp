@@ -28,7 +28,12 @@ class Engine {
   Engine(const vra_model_config& mc, const vra_engine_config& ec) : mc_(mc), ec_(ec), model_(mc, ec) {
     if (ec_.block_size <= 0) ec_.block_size = 64;
     if (ec_.prefill_chunk <= 0) ec_.prefill_chunk = 8192;
+    // the staging buffers and activations hold kMaxStepTokens rows: a larger chunk is clamped HERE so that the scheduler
+    // (chunking, A13) and prepare_prefill use the same value
+    if (ec_.prefill_chunk > kMaxStepTokens) ec_.prefill_chunk = kMaxStepTokens;
   }
+  static constexpr int kMaxStepTokens = 16384;
+  static constexpr int kMinScheduledReqs = 5;  // scheduler.rs:44 — the scheduler batches up to max(max_num_seqs, 5) sequences
   ~Engine() {
     if (ec_.device < 0) {  // host-only engine: nothing was allocated through HIP
       free(h_meta_);
@@ -39,8 +44,9 @@ class Engine {
     if (d_meta_) (void)hipFree(d_meta_);
     if (h_tokens_) (void)hipHostFree(h_tokens_);
     if (d_tokens_) (void)hipFree(d_tokens_);
+    if (h_err_) (void)hipHostFree(h_err_);
     if (stream_) (void)hipStreamDestroy(stream_);
-    if (comm_) vra_comm_destroy(comm_);
+    // comm_ is caller-owned (vra_engine_set_comm): like every other buffer the caller hands over, it is not destroyed here
   }
   std::string error;
   vra_model_config mc_;
@@ -60,7 +66,10 @@ class Engine {
   size_t off_ids_, off_pos_, off_slots_, off_bt_, off_ctx_, off_cuq_, off_last_;
   uint32_t* d_tokens_ = nullptr;
   uint32_t* h_tokens_ = nullptr;
+  uint32_t* h_err_ = nullptr;  // pinned copy of the device error words (split-K exchange, one-shot all-reduce), read every step
   std::map<int64_t, hipGraphExec_t> graphs_;
+  bool prepared_ = false;
+  int64_t planned_blocks_ = 0;
 
   bool fail(const std::string& m) {
     error = m;
@@ -77,9 +86,9 @@ class Engine {
     if (ec_.num_gpu_blocks < 2) return fail("dry engine needs an explicit num_gpu_blocks");
     max_model_len_ = ec_.max_model_len > 0 ? ec_.max_model_len : mc_.max_position_embeddings;
     if (max_model_len_ > mc_.max_position_embeddings) max_model_len_ = mc_.max_position_embeddings;
-    max_seqs_ = ec_.max_num_seqs > 0 ? ec_.max_num_seqs : 32;
+    max_seqs_ = std::max(ec_.max_num_seqs > 0 ? ec_.max_num_seqs : 32, kMinScheduledReqs);
     max_step_tokens_ = std::max(ec_.prefill_chunk, 2048);
-    max_step_tokens_ = std::min(max_step_tokens_, 16384);
+    max_step_tokens_ = std::min(max_step_tokens_, kMaxStepTokens);
     const int64_t nb = ec_.num_gpu_blocks;
     setup_host(nb);
     h_meta_ = (unsigned char*)calloc(1, meta_bytes_);
@@ -90,7 +99,7 @@ class Engine {
     max_blocks_per_seq_ = (max_model_len_ + ec_.block_size - 1) / ec_.block_size;
     bm_.reset(new BlockManager((int)nb, ec_.block_size, ec_.enable_prefix_cache != 0, ec_.prefix_cache_fraction));
     SchedulerConfig sc;
-    sc.max_num_seqs = max_seqs_;
+    sc.max_num_seqs = ec_.max_num_seqs > 0 ? ec_.max_num_seqs : 32;  // the scheduler applies its own floor of 5 (scheduler.rs:44)
     sc.max_num_batched_tokens = (int)std::min<int64_t>(nb * ec_.block_size, 1 << 30);
     sc.block_size = ec_.block_size;
     sc.prefill_chunk = ec_.prefill_chunk;
@@ -111,22 +120,36 @@ class Engine {
     meta_bytes_ = o;
   }
 
-  bool finalize() {
-    if (dry()) return finalize_dry();
+  // weights are in place: activation buffers, then the KV plan of THIS rank (KVCacheAllocator::plan_allocation,
+  // kvcache_allocator.rs:564-707).  Under tensor parallelism every rank must end up with the SAME block count (the
+  // schedulers run in lock step): the launcher takes the minimum over the ranks' plans and sets it before finalize —
+  // the reference's engine process does the same through MessageType::UsableMemoryLeft (runner/mod.rs:277).
+  bool prepare() {
+    if (prepared_) return true;
     if (hipSetDevice(ec_.device) != hipSuccess) return fail("hipSetDevice failed");
     if (!stream_ && hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) != hipSuccess) return fail("stream create failed");
-    // ---- KV cache sizing (KVCacheAllocator, kvcache_allocator.rs:564-707)
-    size_t free_b = 0, total_b = 0;
-    (void)hipMemGetInfo(&free_b, &total_b);
     max_model_len_ = ec_.max_model_len > 0 ? ec_.max_model_len : mc_.max_position_embeddings;
     if (max_model_len_ > mc_.max_position_embeddings) max_model_len_ = mc_.max_position_embeddings;
-    max_seqs_ = ec_.max_num_seqs > 0 ? ec_.max_num_seqs : 32;
+    // every per-sequence buffer is sized for what the scheduler may batch: max(max_num_seqs, 5)
+    max_seqs_ = std::max(ec_.max_num_seqs > 0 ? ec_.max_num_seqs : 32, kMinScheduledReqs);
     max_step_tokens_ = std::max(ec_.prefill_chunk, 2048);
-    max_step_tokens_ = std::min(max_step_tokens_, 16384);
+    max_step_tokens_ = std::min(max_step_tokens_, kMaxStepTokens);
     // reserve activations first, then give kv_fraction of what is left to the cache
     if (!model_.init_buffers(std::max(max_step_tokens_, max_seqs_), max_seqs_)) return fail("activation buffers: " + model_.error);
+    size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
-    int64_t nb = vra_kv_plan_num_blocks(&mc_, &ec_, (int64_t)free_b);
+    planned_blocks_ = vra_kv_plan_num_blocks(&mc_, &ec_, (int64_t)free_b);
+    if (planned_blocks_ > (1 << 24)) planned_blocks_ = 1 << 24;
+    prepared_ = true;
+    return true;
+  }
+  bool finalize() {
+    if (dry()) return finalize_dry();
+    if (model_.world() > 1 && !model_.has_comm()) return fail("tensor parallel world_size > 1 without a communicator (vra_engine_set_comm before finalize)");
+    if (model_.world() > 1 && ec_.num_gpu_blocks <= 0)
+      return fail("tensor parallel: num_gpu_blocks must be set explicitly and identically on every rank (vra_engine_plan_kv_blocks on each rank, take the minimum, vra_engine_set_num_gpu_blocks)");
+    if (!prepare()) return false;
+    int64_t nb = ec_.num_gpu_blocks > 0 ? ec_.num_gpu_blocks : planned_blocks_;
     if (nb < 2) return fail("not enough memory for the KV cache");
     if (nb > (1 << 24)) nb = 1 << 24;
     if (!model_.init_kv_cache((int)nb)) return fail("kv cache: " + model_.error);
@@ -136,7 +159,10 @@ class Engine {
     if (hipMalloc((void**)&d_meta_, meta_bytes_) != hipSuccess) return fail("meta alloc failed");
     if (hipMalloc((void**)&d_tokens_, B * 4) != hipSuccess) return fail("token alloc failed");
     if (hipHostMalloc((void**)&h_tokens_, B * 4, hipHostMallocDefault) != hipSuccess) return fail("pinned alloc failed");
+    if (hipHostMalloc((void**)&h_err_, 64, hipHostMallocDefault) != hipSuccess) return fail("pinned alloc failed");
     memset(h_meta_, 0, meta_bytes_);
+    memset(h_err_, 0, 64);
+    if (ec_.use_graph && !warmup_capture()) return false;
     return true;
   }
 
@@ -152,6 +178,15 @@ class Engine {
     uint32_t* h_last = (uint32_t*)(h_meta_ + off_last_);
     const int BS = ec_.block_size, CHUNK = ec_.prefill_chunk;
     int T = 0, max_q = 0, max_ctx = 0, max_bt = 0;
+    InputMetadata md;
+    {  // the token count is checked BEFORE anything is written to the staging buffers
+      int64_t total = 0;
+      for (int id : ids) total += std::min(CHUNK, run[id].len() - run[id].num_cached_tokens);
+      if (total > std::max(max_step_tokens_, max_seqs_) || (int)ids.size() > max_seqs_) {
+        md.n_tokens = -1;
+        return md;
+      }
+    }
     for (int id : ids) max_bt = std::max(max_bt, (int)run[id].block_table.size());
     h_cuq[0] = 0;
     for (size_t b = 0; b < ids.size(); b++) {
@@ -183,7 +218,6 @@ class Engine {
       max_q = std::max(max_q, n);
       max_ctx = std::max(max_ctx, s.num_cached_tokens + n);
     }
-    InputMetadata md;
     md.is_prefill = true;
     md.n_tokens = T;
     md.n_seqs = (int)ids.size();
@@ -242,8 +276,8 @@ class Engine {
   }
   bool upload_meta() { return hipMemcpyAsync(d_meta_, h_meta_, meta_bytes_, hipMemcpyHostToDevice, stream_) == hipSuccess; }
 
-  static int batch_bucket(int n) {  // graph.rs:370-377 uses {1..15,16,32}; here {1..8,16,32,64,...}
-    if (n <= 8) return n;
+  static int batch_bucket(int n) {  // planned_graph_capture_batches (graph.rs:370-377): {1..15, 16, 32}; beyond 32: powers of two
+    if (n <= 15) return n;
     int b = 16;
     while (b < n) b *= 2;
     return b;
@@ -254,13 +288,53 @@ class Engine {
     return b;
   }
 
+  // ---- GraphCapturer::capture (graph.rs:267-308, 448-560): the decode forward of `bucket` lanes with contexts up to `cb`,
+  // static buffers, relaxed mode.  Returns null (error left empty) when capture is unavailable: the caller runs eagerly.
+  hipGraphExec_t graph_for(int bucket, int cb) {
+    const int64_t key = ((int64_t)bucket << 32) | (uint32_t)cb;
+    auto it = graphs_.find(key);
+    if (it != graphs_.end()) return it->second;
+    InputMetadata cmd;
+    cmd.is_prefill = false;
+    cmd.n_tokens = cmd.n_seqs = bucket;
+    cmd.max_blocks = max_blocks_per_seq_;
+    cmd.max_seqlen_q = 1;
+    cmd.max_context_len = cb;
+    bind(cmd);
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    if (hipStreamBeginCapture(stream_, hipStreamCaptureModeRelaxed) != hipSuccess) return nullptr;
+    const bool ok = model_.forward(cmd, (int64_t)stream_);
+    if (ok) vra_argmax_f32(model_.logits(), d_tokens_, bucket, mc_.vocab_size, (int64_t)stream_);
+    const hipError_t e = hipStreamEndCapture(stream_, &g);
+    if (ok && e == hipSuccess && g && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess) graphs_[key] = ge;
+    else ge = nullptr;
+    if (g) (void)hipGraphDestroy(g);
+    if (!ok) fail("graph capture: " + model_.error);
+    return ge;
+  }
+  // warmup_capture (engine.rs:108-503 → graph.rs:448-560): all decode graphs are captured at init, so that no request
+  // pays a capture inside its TTFT.  Batch buckets as the reference plans them; one graph per context bucket (the
+  // split-KV decision of the decode attention depends on it).
+  bool warmup_capture() {
+    std::vector<int> bs;
+    for (int b = 1; b <= std::min(max_seqs_, 15); b++) bs.push_back(b);
+    for (int b = 16; b <= max_seqs_; b *= 2) bs.push_back(b);
+    for (int b : bs)
+      for (int cb = 512;; cb *= 4) {
+        if (!graph_for(b, cb) && !error.empty()) return false;
+        if (cb >= max_model_len_) break;
+      }
+    return true;
+  }
+
   // ---- ModelRunner::run (runner.rs:743-896) + sample (argmax, logits_processor.rs:67-70)
   bool run(const std::vector<int>& ids, bool is_prefill, std::vector<uint32_t>* tokens) {
     const int B = (int)ids.size();
     if (is_prefill) {
       int nb = 0;
       InputMetadata md = prepare_prefill(ids, &nb);
-      if (md.n_tokens > std::max(max_step_tokens_, max_seqs_)) return fail("prefill step exceeds max_step_tokens");
+      if (md.n_tokens < 0) return fail("prefill step exceeds max_step_tokens / max_num_seqs");
       if (!upload_meta()) return fail("metadata upload failed");
       if (!model_.forward(md, (int64_t)stream_)) return fail(model_.error);
       vra_argmax_f32(model_.logits(), d_tokens_, B, mc_.vocab_size, (int64_t)stream_);
@@ -271,29 +345,10 @@ class Engine {
       bool launched = false;
       if (ec_.use_graph) {
         const int cb = ctx_bucket(md.max_context_len);
-        const int64_t key = ((int64_t)md.n_tokens << 32) | (uint32_t)cb;
-        auto it = graphs_.find(key);
-        if (it == graphs_.end()) {
-          // capture (graph.rs:267-308): same launches, static buffers, relaxed mode
-          InputMetadata cmd = md;
-          cmd.max_context_len = cb;
-          hipGraph_t g = nullptr;
-          hipGraphExec_t ge = nullptr;
-          if (hipStreamBeginCapture(stream_, hipStreamCaptureModeRelaxed) == hipSuccess) {
-            bool ok = model_.forward(cmd, (int64_t)stream_);
-            vra_argmax_f32(model_.logits(), d_tokens_, md.n_tokens, mc_.vocab_size, (int64_t)stream_);
-            hipError_t e = hipStreamEndCapture(stream_, &g);
-            if (ok && e == hipSuccess && g && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess) {
-              graphs_[key] = ge;
-              it = graphs_.find(key);
-            } else if (!ok) {
-              return fail("graph capture: " + model_.error);
-            }
-            if (g) (void)hipGraphDestroy(g);
-          }
-        }
-        if (it != graphs_.end()) {
-          if (hipGraphLaunch(it->second, stream_) != hipSuccess) return fail("hipGraphLaunch failed");
+        hipGraphExec_t ge = graph_for(md.n_tokens, cb);  // captured at init (warmup_capture); a miss captures now
+        if (!ge && !error.empty()) return false;
+        if (ge) {
+          if (hipGraphLaunch(ge, stream_) != hipSuccess) return fail("hipGraphLaunch failed");
           launched = true;
         }
       }
@@ -303,7 +358,22 @@ class Engine {
       }
     }
     if (hipMemcpyAsync(h_tokens_, d_tokens_, (size_t)B * 4, hipMemcpyDeviceToHost, stream_) != hipSuccess) return fail("token download failed");
+    // the split-K exchange's error word rides along with the tokens: EVERY step is checked before its tokens are committed
+    uint32_t* dev_err = vra_scratch_error_word();
+    if (dev_err && hipMemcpyAsync(h_err_, dev_err, 4, hipMemcpyDeviceToHost, stream_) != hipSuccess) return fail("error-word download failed");
+    uint32_t* comm_err = comm_ ? vra_comm_error_word(comm_) : nullptr;
+    if (comm_err && hipMemcpyAsync(h_err_ + 1, comm_err, 4, hipMemcpyDeviceToHost, stream_) != hipSuccess) return fail("error-word download failed");
     if (hipStreamSynchronize(stream_) != hipSuccess) return fail(std::string("stream error: ") + hipGetErrorString(hipGetLastError()));
+    if (h_err_[1]) {
+      h_err_[1] = 0;
+      (void)hipMemsetAsync(comm_err, 0, 4, stream_);
+      return fail("one-shot all-reduce timed out waiting for a peer (results of this step are invalid)");
+    }
+    if (h_err_[0]) {
+      h_err_[0] = 0;
+      (void)hipMemsetAsync(dev_err, 0, 4, stream_);
+      return fail("split-K exchange timed out on the device (results of this step are invalid)");
+    }
     tokens->assign(h_tokens_, h_tokens_ + B);
     return true;
   }
@@ -369,16 +439,9 @@ class Engine {
     }
     std::vector<uint32_t> tokens;
     if (!run(ids, is_prefill, &tokens)) return -1;
-    // a split-K exchange whose wait timed out (a lost slice) produced wrong numbers: surface it, every prefill step and
-    // every 64th decode step (the check is a 4-byte device-to-host copy)
-    if ((is_prefill || (++steps_since_check_ & 63) == 0) && vra_scratch_take_error()) {
-      fail("split-K exchange timed out on the device (results of this step are invalid)");
-      return -1;
-    }
     finish_step(ids, is_prefill, tokens);
     return (int)ids.size();
   }
-  unsigned steps_since_check_ = 0;
   void collect() {
     for (auto& s : sched_->clear_finished()) {
       RequestResult& r = results_[s.id];
@@ -532,14 +595,33 @@ extern "C" int32_t vra_engine_set_comm(void* e, void* comm) {
 extern "C" int32_t vra_engine_finalize_weights(void* e) {
   auto* en = static_cast<Engine*>(e);
   if (en->dry()) return en->finalize() ? 0 : -1;
-  if (en->model_.weight_bytes() == 0 || true) {
-    // explicit tensors: repack now (synthetic init has already finalised; finalize is idempotent)
-    if (!en->model_.finalize_weights()) {
-      en->error = en->model_.error;
-      return -1;
-    }
+  if (!en->model_.finalize_weights()) {  // repack of explicit tensors; a no-op after synthetic init (idempotent)
+    en->error = en->model_.error;
+    return -1;
   }
   return en->finalize() ? 0 : -1;
+}
+// KVCacheAllocator plan of THIS rank before the cache is allocated (weights repacked, activation buffers reserved):
+// the block count `finalize` would choose from free memory x kv_fraction.  Tensor-parallel launchers call it on every
+// rank, take the minimum and hand it to vra_engine_set_num_gpu_blocks, so that all schedulers see the same cache.
+extern "C" int64_t vra_engine_plan_kv_blocks(void* e) {
+  auto* en = static_cast<Engine*>(e);
+  if (en->dry()) return en->ec_.num_gpu_blocks;
+  if (!en->model_.finalize_weights()) {
+    en->error = en->model_.error;
+    return -1;
+  }
+  if (!en->prepare()) return -1;
+  return en->planned_blocks_;
+}
+extern "C" int32_t vra_engine_set_num_gpu_blocks(void* e, int32_t n) {
+  auto* en = static_cast<Engine*>(e);
+  if (n < 2 || en->sched_) {
+    en->error = "vra_engine_set_num_gpu_blocks: need n >= 2, before finalize";
+    return -1;
+  }
+  en->ec_.num_gpu_blocks = n;
+  return 0;
 }
 extern "C" int32_t vra_engine_num_gpu_blocks(const void* e) { return static_cast<const Engine*>(e)->model_.num_blocks(); }
 extern "C" int64_t vra_engine_add_request(void* e, const uint32_t* h_prompt, int32_t n_prompt, int32_t max_tokens, int32_t ignore_eos,

@@ -20,6 +20,18 @@ Model::Model(const vra_model_config& mc, const vra_engine_config& ec) : mc_(mc),
   dt_ = mc.dtype;
   es_ = 2;
   layers_.resize(mc.num_layers);
+  // tensor-parallel preconditions (kv_head_shard bails, distributed.rs:513-536; shard() needs even splits; row-parallel
+  // layers shard K in whole scale groups and whole 128-row weight tiles)
+  if (world_ > 1) {
+    const int g = mc.quant_method != 0 ? (mc.group_size > 0 ? mc.group_size : 0) : 0;
+    if (mc.num_heads % world_) tp_error_ = "tensor parallel: num_heads must be divisible by world_size";
+    else if (mc.num_kv_heads >= world_ ? mc.num_kv_heads % world_ != 0 : world_ % mc.num_kv_heads != 0)
+      tp_error_ = "tensor parallel: kv heads must divide (or be divided by) world_size";
+    else if (mc.intermediate_size % world_) tp_error_ = "tensor parallel: intermediate_size must be divisible by world_size";
+    else if (rank_ < 0 || rank_ >= world_) tp_error_ = "tensor parallel: rank out of range";
+    else if (mc.quant_method != 0 && ((hq_ * mc.head_dim) % 128 || inter_ % 128 || (g > 0 && ((hq_ * mc.head_dim) % g || inter_ % g))))
+      tp_error_ = "tensor parallel: the K shard of o_proj / down_proj must be whole 128-row tiles and whole scale groups";
+  }
 }
 Model::~Model() {
   for (void* p : allocs_) (void)hipFree(p);
@@ -186,8 +198,12 @@ bool Model::load_tensor(const std::string& name, const void* host, const int64_t
       ishard = rank_ / (world_ / mc_.num_kv_heads);
     }
     const int64_t R = shape[0], Ccols = ndim > 1 ? shape[1] : 1;
-    auto shard_upload = [&](bool shard_rows, bool shard_cols, int64_t row_unit, void*& dst, int* out_r, int* out_c) {
+    auto shard_upload = [&](bool shard_rows, bool shard_cols, void*& dst, int* out_r, int* out_c) {
       int64_t r0 = 0, r1 = R, c0 = 0, c1 = Ccols;
+      if ((shard_rows && R % nshard) || (shard_cols && Ccols % nshard)) {
+        error = "tensor parallel: " + name + " does not split evenly over " + std::to_string(nshard) + " shards";
+        return false;
+      }
       if (shard_rows) {
         r0 = R / nshard * ishard;
         r1 = r0 + R / nshard;
@@ -196,7 +212,6 @@ bool Model::load_tensor(const std::string& name, const void* host, const int64_t
         c0 = Ccols / nshard * ishard;
         c1 = c0 + Ccols / nshard;
       }
-      (void)row_unit;
       auto buf = slice2d(host, Ccols, (size_t)elem_bytes, r0, r1, c0, c1);
       dst = upload(this, allocs_, buf.data(), buf.size(), error);
       if (out_r) *out_r = (int)(r1 - r0);
@@ -207,7 +222,7 @@ bool Model::load_tensor(const std::string& name, const void* host, const int64_t
     if (leaf == "weight") {  // dense [N, K]: column-parallel shards dim 0, row-parallel dim 1
       l.quant = false;
       int r, c;
-      if (!shard_upload(sharded && !t.row_parallel, sharded && t.row_parallel, 1, l.w, &r, &c)) return false;
+      if (!shard_upload(sharded && !t.row_parallel, sharded && t.row_parallel, l.w, &r, &c)) return false;
       l.N = r;
       l.K = c;
       return true;
@@ -215,7 +230,7 @@ bool Model::load_tensor(const std::string& name, const void* host, const int64_t
     if (leaf == "qweight") {  // gptq [K/8, N] / awq [K, N/8]: packed tensors are stored [in, out] (wna16.rs:35-40)
       l.quant = true;
       l.awq = mc_.quant_method == 2;
-      if (!shard_upload(sharded && t.row_parallel, sharded && !t.row_parallel, 1, l.raw_qweight, &l.raw_rows, &l.raw_cols)) return false;
+      if (!shard_upload(sharded && t.row_parallel, sharded && !t.row_parallel, l.raw_qweight, &l.raw_rows, &l.raw_cols)) return false;
       if (l.awq) {
         l.K = l.raw_rows;
         l.N = l.raw_cols * 8;
@@ -227,12 +242,12 @@ bool Model::load_tensor(const std::string& name, const void* host, const int64_t
     }
     if (leaf == "scales") {
       int r, c;
-      return shard_upload(sharded && t.row_parallel, sharded && !t.row_parallel, 1, l.scales, &r, &c);
+      return shard_upload(sharded && t.row_parallel, sharded && !t.row_parallel, l.scales, &r, &c);
     }
     if (leaf == "qzeros") {
       int r, c;
       void* p = nullptr;
-      if (!shard_upload(sharded && t.row_parallel, sharded && !t.row_parallel, 1, p, &r, &c)) return false;
+      if (!shard_upload(sharded && t.row_parallel, sharded && !t.row_parallel, p, &r, &c)) return false;
       l.qzeros = (uint32_t*)p;
       return true;
     }
@@ -258,6 +273,11 @@ bool Model::load_tensor(const std::string& name, const void* host, const int64_t
 }
 
 bool Model::finalize_weights() {
+  if (finalized_) return true;
+  if (!tp_error_.empty()) {  // constructor-time validation
+    error = tp_error_;
+    return false;
+  }
   // one-time repack of checkpoint-format qweights into the CDNA4 tile layout (MarlinRepack,
   // src/utils/gptq.rs:266-360, invoked from wna16.rs:220-224 at load time)
   auto fin = [&](QLinear& l, const char* what) {
@@ -272,6 +292,16 @@ bool Model::finalize_weights() {
         return false;
       }
       weight_bytes_ += words * 4;
+      if (hipDeviceSynchronize() != hipSuccess) {
+        error = std::string("repack ") + what + ": device error";
+        return false;
+      }
+      for (size_t i = 0; i < allocs_.size(); i++)  // the checkpoint-format copy is not needed any more
+        if (allocs_[i] == l.raw_qweight) {
+          (void)hipFree(allocs_[i]);
+          allocs_.erase(allocs_.begin() + (long)i);
+          break;
+        }
       l.raw_qweight = nullptr;
     }
     if (!l.w) {
@@ -318,7 +348,8 @@ bool Model::finalize_weights() {
     error = "scratch allocation failed";
     return false;
   }
-  return hipDeviceSynchronize() == hipSuccess;
+  finalized_ = hipDeviceSynchronize() == hipSuccess;
+  return finalized_;
 }
 
 bool Model::init_kv_cache(int num_blocks) {
@@ -365,7 +396,9 @@ static bool take_err(std::string& error, const char* where) {
   return false;
 }
 
-bool Model::linear(const QLinear& l, const void* x, void* out, int M, const void* residual, int64_t stream) {
+bool Model::linear(const QLinear& l0, const void* x, void* out, int M, const void* residual, int64_t stream, bool with_bias) {
+  QLinear l = l0;
+  if (!with_bias) l.bias = nullptr;
   if (l.quant) {
     vra_wna16_gemm(x, l.w, l.scales, l.qzeros, l.bias, residual, out, M, l.K, l.N, mc_.group_size, l.awq ? 1 : 0,
                    VRA_SCALES_ROWMAJOR, dt_, stream);
@@ -518,6 +551,10 @@ bool Model::gate_up(const LayerWeights& L, const void* x, const void* norm_w, vo
 // ---------------------------------------------------------------------------------------------
 bool Model::forward(const InputMetadata& md, int64_t stream) {
   const int T = md.n_tokens, B = md.n_seqs, H = mc_.hidden_size, D = mc_.head_dim;
+  if (world_ > 1 && !comm_) {
+    error = "forward: tensor parallel world_size " + std::to_string(world_) + " without a communicator (vra_engine_set_comm)";
+    return false;
+  }
   if (T <= 0 || T > max_tokens_ || B <= 0 || B > max_seqs_) {
     error = "forward: batch out of range (tokens " + std::to_string(T) + ", seqs " + std::to_string(B) + ")";
     return false;
@@ -543,19 +580,21 @@ bool Model::forward(const InputMetadata& md, int64_t stream) {
                                       attn_ws_, dt_, stream);
     }
     if (take_err(error, "attention")) return false;
-    if (world_ > 1) {  // TensorParallelRowLinear: partial GEMM -> all_reduce -> + residual (distributed.rs:438-455)
-      if (!linear(L.o, attn_, tmp_, T, nullptr, stream)) return false;
-      vra_all_reduce(comm_, tmp_, tmp_, (int64_t)T * H, dt_, stream);
-      vra_add(tmp_, h_, h_, (int64_t)T * H, dt_, stream);
+    if (world_ > 1) {
+      // TensorParallelRowLinear::forward (distributed.rs:438-455): partial GEMM -> all_reduce -> + bias; then the layer's
+      // residual add (llama.rs:126) — the last two fused behind the reduction
+      if (!linear(L.o, attn_, tmp_, T, nullptr, stream, false)) return false;
+      vra_all_reduce_fused(comm_, tmp_, h_, L.o.bias, h_, T, H, dt_, stream);
+      if (take_err(error, "all_reduce(o_proj)")) return false;
     } else if (!linear(L.o, attn_, h_, T, h_, stream)) {
       return false;
     }
     // ---- MLP block (llama.rs:127-130)
     if (!gate_up(L, h_, L.ffn_norm, act_, T, stream)) return false;
     if (world_ > 1) {
-      if (!linear(L.down, act_, tmp_, T, nullptr, stream)) return false;
-      vra_all_reduce(comm_, tmp_, tmp_, (int64_t)T * H, dt_, stream);
-      vra_add(tmp_, h_, h_, (int64_t)T * H, dt_, stream);
+      if (!linear(L.down, act_, tmp_, T, nullptr, stream, false)) return false;
+      vra_all_reduce_fused(comm_, tmp_, h_, L.down.bias, h_, T, H, dt_, stream);
+      if (take_err(error, "all_reduce(down_proj)")) return false;
     } else if (!linear(L.down, act_, h_, T, h_, stream)) {
       return false;
     }

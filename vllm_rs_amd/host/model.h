@@ -67,6 +67,8 @@ class Model {
   // activations are sized for max_tokens rows
   bool init_buffers(int max_tokens, int max_seqs);
   void set_comm(void* comm) { comm_ = comm; }
+  bool has_comm() const { return comm_ != nullptr; }
+  int world() const { return world_; }
   // forward → logits (device, f32 [n_seqs, vocab]) ; returns false on argument error
   bool forward(const InputMetadata& md, int64_t stream);
   float* logits() const { return logits_; }
@@ -82,11 +84,13 @@ class Model {
  private:
   void* dalloc(size_t bytes);
   bool qlinear_synth(QLinear& l, int K, int N, bool bias, uint64_t seed);
-  bool linear(const QLinear& l, const void* x, void* out, int M, const void* residual, int64_t stream);
+  bool linear(const QLinear& l, const void* x, void* out, int M, const void* residual, int64_t stream, bool with_bias = true);
   bool linear_fused_norm(const QLinear* ls, int nl, void* const* outs, const void* x, const void* norm_w, int M, int64_t stream);
   bool gate_up(const LayerWeights& L, const void* x, const void* norm_w, void* act, int M, int64_t stream);
   vra_model_config mc_;
   vra_engine_config ec_;
+  bool finalized_ = false;
+  std::string tp_error_;  // tensor-parallel preconditions that failed at construction
   int rank_, world_;
   int hq_, hkv_, inter_;  // local sizes
   int dt_;
