@@ -63,7 +63,7 @@ def prefill_inputs(prompts, bt, BS=64, cached=None):
     return np.array(ids, np.uint32), np.array(pos, np.int64), np.array(slots, np.int64), np.array(ctx, np.uint32), np.array(cu, np.uint32)
 
 
-def check_logits(got, ref, name, dt=BF16):
+def check_logits(got, ref, name, dt=BF16, max_ulps=None):
     """logits are storage-dtype values widened to f32 (llama.rs:317-319), so the natural unit is the
     storage ulp: bf16 has 8 significant bits => 1 ulp = 2^-7 * 2^floor(log2|x|) (0.0078 at 1, 0.0156 at 2)."""
     d = np.abs(got - ref)
@@ -73,7 +73,7 @@ def check_logits(got, ref, name, dt=BF16):
     # rounding noise of the O(max) hidden state it is a cancellation of, not by its own magnitude
     ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(ref).max(axis=-1, keepdims=True), 1.0))) - (bits - 1))
     worst = float((d / ulp).max())
-    assert worst <= LOGIT_ULPS, f"{name}: max deviation {worst:.2f} ulp (|dlogit| {d.max():.4f}, ref magnitude {np.abs(ref).max():.2f})"
+    assert worst <= (max_ulps or LOGIT_ULPS), f"{name}: max deviation {worst:.2f} ulp (|dlogit| {d.max():.4f}, ref magnitude {np.abs(ref).max():.2f})"
     print(f"[parity] {name}: max {worst:.2f} ulp, mean |d| {d.mean():.5f}, exact {100.0 * (d == 0).mean():.1f}%")
     return worst
 

@@ -14,7 +14,7 @@ import pytest
 
 from oracle import model as om
 from oracle import oracle as orc
-from tests.test_gpu_engine import check_logits, prefill_inputs, simple_tables, small_cfg
+from tests.test_gpu_engine import LOGIT_ULPS, check_logits, prefill_inputs, simple_tables, small_cfg
 from vllm_rs_amd import _lib
 from vllm_rs_amd.runner import TPEngine
 
@@ -73,7 +73,9 @@ def test_tp2_forward_matches_oracle(quant, kv_heads, dt, transport):
     for i, (g, rt, r1) in enumerate(zip(got, ref_tp, ref_1)):
         assert (g[0] == g[1]).all(), f"step {i}: the two ranks disagree (A21)"
         check_logits(g[0], rt, f"tp2/{transport} {quant} kv{kv_heads} step {i} vs TP oracle", dt)
-        check_logits(g[0], r1, f"tp2/{transport} {quant} kv{kv_heads} step {i} vs unsharded oracle", dt)
+        # against the UNSHARDED arithmetic the per-rank roundings of the partial sums reorder (row a11: <= ~2 ulp per reduction,
+        # four reductions in this model): twice the single-GPU bound
+        check_logits(g[0], r1, f"tp2/{transport} {quant} kv{kv_heads} step {i} vs unsharded oracle", dt, max_ulps=2 * LOGIT_ULPS)
 
 
 @pytest.mark.parametrize("transport", _transports())

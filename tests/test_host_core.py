@@ -508,8 +508,9 @@ def test_config5_eight_prompts_share_a_16k_prefix():
     rids = [h.add_request(prefix + t, max_tokens=4, ignore_eos=True) for t in tails]
     trace = run_to_completion(h, lambda st, i: 100 + i)
     pre = [t for t in trace if t["is_prefill"]]
-    # every prompt starts behind the 256 cached blocks: only its 1024 tail tokens are prefilled
-    assert sum(t["n_tokens"] for t in pre) == 8 * 1024
+    # every prompt starts behind the 256 cached blocks: only its 1024 tail tokens are prefilled — all eight in ONE step
+    # (the per-step token cap counts tokens after the prefix match, core.cpp Scheduler::schedule)
+    assert [t["n_tokens"] for t in pre] == [8 * 1024]
     shared = None
     for t in pre:
         for i in range(t["n_seqs"]):

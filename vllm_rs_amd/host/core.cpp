@@ -321,12 +321,12 @@ std::vector<int> Scheduler::schedule(bool* is_prefill) {
   const int CHUNK = cfg_.prefill_chunk;
   const int pre_existing_running = (int)running_.size();
   const int max_seqs_limit = std::max(cfg_.max_num_seqs, kMinScheduledReqs);
+  int step_tokens = 0;  // tokens this step really carries (prefix-cache hits known): what the activation buffers must hold
   while (!waiting_.empty()) {
     Sequence& seq = waiting_.front();
     const int effective = std::min(CHUNK, seq.len() - seq.num_cached_tokens);
     if ((int)running_.size() >= max_seqs_limit || (int)scheduled.size() >= max_seqs_limit ||
         num_tokens + effective >= cfg_.max_num_batched_tokens - 1 ||
-        (num_tokens > 0 && num_tokens + effective > cfg_.max_step_tokens) ||
         (seq.block_table.empty() && !bm_->can_allocate(seq)) ||
         (is_last_prefill_ && pre_existing_running > 0)) {  // interleave prefill/decode (:262-264)
       break;
@@ -339,8 +339,18 @@ std::vector<int> Scheduler::schedule(bool* is_prefill) {
         break;
       }
     }
+    // NOT in the reference: one step carries at most max_step_tokens tokens (the activation buffers are sized for that,
+    // the reference's only bound is max_num_batched_tokens = blocks x block_size).  Counted AFTER allocation, when the
+    // prefix-cache hit is known: eight prompts behind a cached 16k prefix are 8 x 1024 tokens, not 8 x 8192.  A sequence
+    // that does not fit waits at the front of the queue keeping its blocks, like an unfinished chunked prefill (A13).
+    const int actual = std::min(CHUNK, s.len() - s.num_cached_tokens);
+    if (step_tokens > 0 && step_tokens + actual > cfg_.max_step_tokens) {
+      waiting_.push_front(std::move(s));
+      break;
+    }
     s.status = SeqStatus::Running;
     num_tokens += effective;
+    step_tokens += actual;
     running_.push_back(std::move(s));
     scheduled.push_back((int)running_.size() - 1);
   }

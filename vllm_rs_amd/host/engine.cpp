@@ -63,7 +63,7 @@ class Engine {
   uint8_t* h_meta_ = nullptr;
   uint8_t* d_meta_ = nullptr;
   size_t meta_bytes_ = 0;
-  size_t off_ids_, off_pos_, off_slots_, off_bt_, off_ctx_, off_cuq_, off_last_;
+  size_t off_ids_, off_pos_, off_slots_, off_bt_, off_ctx_, off_cuq_, off_last_, off_dids_, off_dpos_, off_dslots_;
   uint32_t* d_tokens_ = nullptr;
   uint32_t* h_tokens_ = nullptr;
   uint32_t* h_err_ = nullptr;  // pinned copy of the device error words (split-K exchange, one-shot all-reduce), read every step
@@ -87,8 +87,7 @@ class Engine {
     max_model_len_ = ec_.max_model_len > 0 ? ec_.max_model_len : mc_.max_position_embeddings;
     if (max_model_len_ > mc_.max_position_embeddings) max_model_len_ = mc_.max_position_embeddings;
     max_seqs_ = std::max(ec_.max_num_seqs > 0 ? ec_.max_num_seqs : 32, kMinScheduledReqs);
-    max_step_tokens_ = std::max(ec_.prefill_chunk, 2048);
-    max_step_tokens_ = std::min(max_step_tokens_, kMaxStepTokens);
+    max_step_tokens_ = kMaxStepTokens;
     const int64_t nb = ec_.num_gpu_blocks;
     setup_host(nb);
     h_meta_ = (unsigned char*)calloc(1, meta_bytes_);
@@ -106,17 +105,21 @@ class Engine {
     sc.max_step_tokens = max_step_tokens_;
     sc.max_model_len = max_model_len_;
     sched_.reset(new Scheduler(bm_.get(), sc));
-    // ---- metadata staging
+    // ---- metadata staging: the per-sequence arrays and the block tables come first, so that a decode step uploads only
+    // [0, off_bt_ + n_seqs * stride * 4); the token-sized arrays of prefill steps follow
     const size_t T = std::max(max_step_tokens_, max_seqs_), B = max_seqs_;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t o = 0;
-    off_ids_ = o, o += al(T * 4);
-    off_pos_ = o, o += al(T * 8);
-    off_slots_ = o, o += al(T * 8);
-    off_bt_ = o, o += al(B * (size_t)max_blocks_per_seq_ * 4);
     off_ctx_ = o, o += al(B * 4);
     off_cuq_ = o, o += al((B + 1) * 4);
     off_last_ = o, o += al(B * 4);
+    off_dids_ = o, o += al(B * 4);
+    off_dpos_ = o, o += al(B * 8);
+    off_dslots_ = o, o += al(B * 8);
+    off_bt_ = o, o += al(B * (size_t)max_blocks_per_seq_ * 4);
+    off_ids_ = o, o += al(T * 4);
+    off_pos_ = o, o += al(T * 8);
+    off_slots_ = o, o += al(T * 8);
     meta_bytes_ = o;
   }
 
@@ -132,8 +135,7 @@ class Engine {
     if (max_model_len_ > mc_.max_position_embeddings) max_model_len_ = mc_.max_position_embeddings;
     // every per-sequence buffer is sized for what the scheduler may batch: max(max_num_seqs, 5)
     max_seqs_ = std::max(ec_.max_num_seqs > 0 ? ec_.max_num_seqs : 32, kMinScheduledReqs);
-    max_step_tokens_ = std::max(ec_.prefill_chunk, 2048);
-    max_step_tokens_ = std::min(max_step_tokens_, kMaxStepTokens);
+    max_step_tokens_ = kMaxStepTokens;  // a prefill step batches prompts up to this many tokens (1.2 GB of activations for Llama-3-8B)
     // reserve activations first, then give kv_fraction of what is left to the cache
     if (!model_.init_buffers(std::max(max_step_tokens_, max_seqs_), max_seqs_)) return fail("activation buffers: " + model_.error);
     size_t free_b = 0, total_b = 0;
@@ -231,9 +233,9 @@ class Engine {
   // ---- ModelRunner::prepare_decode (runner.rs:1243-1388); `bucket` >= batch pads the static buffers
   InputMetadata prepare_decode(const std::vector<int>& ids, int bucket) {
     auto& run = sched_->running();
-    uint32_t* h_ids = (uint32_t*)(h_meta_ + off_ids_);
-    int64_t* h_pos = (int64_t*)(h_meta_ + off_pos_);
-    int64_t* h_slots = (int64_t*)(h_meta_ + off_slots_);
+    uint32_t* h_ids = (uint32_t*)(h_meta_ + off_dids_);
+    int64_t* h_pos = (int64_t*)(h_meta_ + off_dpos_);
+    int64_t* h_slots = (int64_t*)(h_meta_ + off_dslots_);
     uint32_t* h_bt = (uint32_t*)(h_meta_ + off_bt_);
     uint32_t* h_ctx = (uint32_t*)(h_meta_ + off_ctx_);
     const int BS = ec_.block_size, stride = max_blocks_per_seq_;
@@ -265,16 +267,23 @@ class Engine {
     bind(md);
     return md;
   }
-  void bind(InputMetadata& md) {
-    md.input_ids = (const uint32_t*)(d_meta_ + off_ids_);
-    md.positions = (const int64_t*)(d_meta_ + off_pos_);
-    md.slot_mapping = (const int64_t*)(d_meta_ + off_slots_);
+  void bind(InputMetadata& md) {  // decode steps read the compact per-sequence arrays, prefill steps the token-sized ones
+    md.input_ids = (const uint32_t*)(d_meta_ + (md.is_prefill ? off_ids_ : off_dids_));
+    md.positions = (const int64_t*)(d_meta_ + (md.is_prefill ? off_pos_ : off_dpos_));
+    md.slot_mapping = (const int64_t*)(d_meta_ + (md.is_prefill ? off_slots_ : off_dslots_));
     md.block_tables = (const uint32_t*)(d_meta_ + off_bt_);
     md.context_lens = (const uint32_t*)(d_meta_ + off_ctx_);
     md.cu_seqlens_q = (const uint32_t*)(d_meta_ + off_cuq_);
     md.last_token_rows = (const uint32_t*)(d_meta_ + off_last_);
   }
-  bool upload_meta() { return hipMemcpyAsync(d_meta_, h_meta_, meta_bytes_, hipMemcpyHostToDevice, stream_) == hipSuccess; }
+  // one H2D copy per step (the reference does five, runner.rs:1222-1238): a decode step only needs the head of the staging
+  // buffer (per-sequence arrays + the block-table rows in use), a prefill step everything up to its last token
+  bool upload_meta(const InputMetadata& md) {
+    size_t bytes = off_bt_ + (size_t)md.n_seqs * (md.is_prefill ? md.max_blocks : max_blocks_per_seq_) * 4;
+    if (md.is_prefill) bytes = off_slots_ + (size_t)md.n_tokens * 8;
+    bytes = std::min(meta_bytes_, (bytes + 255) & ~(size_t)255);
+    return hipMemcpyAsync(d_meta_, h_meta_, bytes, hipMemcpyHostToDevice, stream_) == hipSuccess;
+  }
 
   static int batch_bucket(int n) {  // planned_graph_capture_batches (graph.rs:370-377): {1..15, 16, 32}; beyond 32: powers of two
     if (n <= 15) return n;
@@ -335,13 +344,13 @@ class Engine {
       int nb = 0;
       InputMetadata md = prepare_prefill(ids, &nb);
       if (md.n_tokens < 0) return fail("prefill step exceeds max_step_tokens / max_num_seqs");
-      if (!upload_meta()) return fail("metadata upload failed");
+      if (!upload_meta(md)) return fail("metadata upload failed");
       if (!model_.forward(md, (int64_t)stream_)) return fail(model_.error);
       vra_argmax_f32(model_.logits(), d_tokens_, B, mc_.vocab_size, (int64_t)stream_);
     } else {
       const int bucket = std::min(batch_bucket(B), max_seqs_);
       InputMetadata md = prepare_decode(ids, std::max(bucket, B));
-      if (!upload_meta()) return fail("metadata upload failed");
+      if (!upload_meta(md)) return fail("metadata upload failed");
       bool launched = false;
       if (ec_.use_graph) {
         const int cb = ctx_bucket(md.max_context_len);
@@ -721,9 +730,13 @@ extern "C" int32_t vra_engine_forward_raw(void* e, const uint32_t* h_ids, const 
     en->error = "forward_raw: batch exceeds engine limits";
     return -1;
   }
-  memcpy(en->h_meta_ + en->off_ids_, h_ids, (size_t)n_tokens * 4);
-  memcpy(en->h_meta_ + en->off_pos_, h_positions, (size_t)n_tokens * 8);
-  memcpy(en->h_meta_ + en->off_slots_, h_slot_mapping, (size_t)n_tokens * 8);
+  if (!is_prefill && n_tokens != n_seqs) {
+    en->error = "forward_raw: a decode step carries one token per sequence";
+    return -1;
+  }
+  memcpy(en->h_meta_ + (is_prefill ? en->off_ids_ : en->off_dids_), h_ids, (size_t)n_tokens * 4);
+  memcpy(en->h_meta_ + (is_prefill ? en->off_pos_ : en->off_dpos_), h_positions, (size_t)n_tokens * 8);
+  memcpy(en->h_meta_ + (is_prefill ? en->off_slots_ : en->off_dslots_), h_slot_mapping, (size_t)n_tokens * 8);
   memcpy(en->h_meta_ + en->off_bt_, h_block_tables, (size_t)n_seqs * max_blocks * 4);
   memcpy(en->h_meta_ + en->off_ctx_, h_context_lens, (size_t)n_seqs * 4);
   uint32_t* h_last = (uint32_t*)(en->h_meta_ + en->off_last_);
@@ -743,7 +756,7 @@ extern "C" int32_t vra_engine_forward_raw(void* e, const uint32_t* h_ids, const 
     }
   }
   en->bind(md);
-  if (!en->upload_meta()) return -1;
+  if (!en->upload_meta(md)) return -1;
   if (!en->model_.forward(md, (int64_t)en->stream_)) {
     en->error = en->model_.error;
     return -1;

@@ -146,6 +146,10 @@ static std::vector<uint8_t> slice2d(const void* src, int64_t cols, size_t es, in
 }
 
 bool Model::load_tensor(const std::string& name, const void* host, const int64_t* shape, int ndim, int elem_bytes) {
+  if (!tp_error_.empty()) {
+    error = tp_error_;
+    return false;
+  }
   const int H = mc_.hidden_size;
   auto up1 = [&](void*& dst, size_t n_elems) {
     dst = upload(this, allocs_, host, n_elems * (size_t)elem_bytes, error);
