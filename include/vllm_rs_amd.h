@@ -105,6 +105,23 @@ void vra_wna16_gate_up_silu(const void* in, const void* qw_gate, const void* sc_
                             const void* qz_up, void* out, int32_t m, int32_t k, int32_t n,
                             int32_t group_size, int32_t is_awq, int32_t scales_layout,
                             int32_t dtype, int64_t stream);
+/* NormX::forward + QLinear::forward in one call (others.rs:11-29 in front of wna16.rs:263-306):
+ * out = rmsnorm(in, norm_weight, eps)·W (+ bias).  Decode batches of 1..4 rows run fused (the
+ * normalised activations never reach HBM); other shapes write rmsnorm(in) to `xn_workspace`
+ * [m, k] (may be NULL only for the fused shapes) and run the general GEMM.  Rounding points are
+ * those of the two separate calls. */
+void vra_rms_norm_wna16_gemm(const void* in, const void* norm_weight, float eps,
+                             const void* qweight_tiled, const void* scales, const void* qzeros,
+                             const void* bias, void* out, void* xn_workspace, int32_t m, int32_t k,
+                             int32_t n, int32_t group_size, int32_t is_awq, int32_t scales_layout,
+                             int32_t dtype, int64_t stream);
+/* NormX + MLP gate/up + SiLU·mul (llama.rs:127-129, mlp.rs:451-469) in one call. */
+void vra_rms_norm_wna16_gate_up_silu(const void* in, const void* norm_weight, float eps,
+                                     const void* qw_gate, const void* sc_gate, const void* qz_gate,
+                                     const void* qw_up, const void* sc_up, const void* qz_up,
+                                     void* out, void* xn_workspace, int32_t m, int32_t k, int32_t n,
+                                     int32_t group_size, int32_t is_awq, int32_t scales_layout,
+                                     int32_t dtype, int64_t stream);
 /* debug/parity: expand a tiled qweight back to nibble indices idx[k,n] u8 (bit-exact check) */
 void vra_wna16_unpack_indices(const void* qweight_tiled, uint8_t* idx, int32_t k, int32_t n,
                               int64_t stream);

@@ -1,0 +1,138 @@
+"""GPU parity tests of kernel E (csrc/gemv_q4s.cuh): the int4 GEMV of decode batches of 1..4 rows — the kernel behind the
+bs = 1 headline and the one `roofline` is quoted on — through the C ABI, against the CPU oracle (exact W4A16 product, one
+rounding: <= 1 storage ulp) at the REAL widths of the BASELINE configs:
+  Llama-3-8B   o_proj 4096x4096, q/k/v 4096x6144, gate/up 4096x14336 (pair), down 14336x4096 (7 k-tiles per wave)
+  Qwen2-7B     K = 3584 (28 k-tiles: waves 12..15 have one tile fewer), AWQ zero points
+  Llama-3-70B  TP=8 rank: K = 1024 (8 k-tiles: half of the waves idle) x 8192, K = 8192 (4 tiles per wave)
+and across scale layouts (row-major checkpoint tensors, the Marlin-permuted scales of the reference's FFI), group sizes
+(128, 256, channel-wise), dtypes, fused bias / residual / RMSNorm / SiLU*mul."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from tests.util import BF16, F16, assert_close_dt, make_quant, rand_dt, rng
+from vllm_rs_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _tiled(q, awq=False):
+    return ops.marlin_weight_repack(ops.dev(q["qweight"]), q["qweight"].shape, 4, awq)
+
+
+@pytest.mark.parametrize("M", [1, 2, 3, 4])
+@pytest.mark.parametrize("K,N", [(4096, 4096), (4096, 6144), (14336, 4096), (3584, 4608), (1024, 8192), (8192, 2304), (4096, 2064)])
+def test_gemv_s_gptq_real_widths(M, K, N):
+    r = rng(M * 7 + K + N)
+    q = make_quant(r, K, N, 128, BF16, False)
+    x = rand_dt(r, (M, K), BF16)
+    out = ops.wna16_gemm(ops.dev(x), _tiled(q), ops.dev(q["scales"]), None, M, K, N, 128)
+    ref = orc.wna16_gemm(x, q["idx"], None, q["scales"], 128, BF16)
+    assert_close_dt(out.numpy(np.uint16, (M, N)), ref, BF16, name=f"gemv_s M={M} K={K} N={N}", abs_floor=2e-3)
+
+
+@pytest.mark.parametrize("M", [1, 4])
+@pytest.mark.parametrize("dt,awq,gs,layout", [(BF16, True, 128, 0), (F16, True, 128, 0), (F16, False, 128, 0), (BF16, False, 128, 1), (F16, True, 128, 1),
+                                              (BF16, False, 256, 0), (BF16, True, 512, 1), (BF16, False, -1, 0), (F16, True, -1, 0)])
+def test_gemv_s_formats(M, dt, awq, gs, layout):
+    K, N = 3584, 4608
+    r = rng(M + gs + layout * 3 + awq)
+    q = make_quant(r, K, N, gs, dt, awq)
+    x = rand_dt(r, (M, K), dt)
+    sc = orc.marlin_permute_scales(q["scales"], grouped=True) if layout == 1 else q["scales"]
+    out = ops.wna16_gemm(ops.dev(x), _tiled(q, awq), ops.dev(sc), ops.dev(q["qzeros"]) if awq else None, M, K, N, gs, awq, layout, dtype=dt)
+    ref = orc.wna16_gemm(x, q["idx"], q["zeros"], q["scales"], gs, dt)
+    assert_close_dt(out.numpy(np.uint16, (M, N)), ref, dt, name=f"gemv_s formats dt={dt} awq={awq} gs={gs} layout={layout}", abs_floor=2e-3)
+
+
+@pytest.mark.parametrize("M", [1, 3])
+@pytest.mark.parametrize("awq", [False, True])
+def test_gemv_s_marlin_ffi_symbols(M, awq):
+    """through the reference's own symbols (gptq.rs:118-178): Marlin-permuted scales are read in place — no conversion
+    launch, no scratch copy — and the workspace stays zero"""
+    K, N, gs, dt = 4096, 4096, 128, BF16
+    r = rng(M + 17 * awq)
+    q = make_quant(r, K, N, gs, dt, awq)
+    x = rand_dt(r, (M, K), dt)
+    sc = orc.marlin_permute_scales(q["scales"], grouped=True)
+    ws = ops.DevBuf(N * 4).zero()
+    out = ops.gptq_matmul(ops.dev(x), _tiled(q, awq), ops.dev(sc), ops.dev(q["qzeros"]), None, ws, 4, gs, awq, M, K, N, dt)
+    ref = orc.wna16_gemm(x, q["idx"], q["zeros"], q["scales"], gs, dt)
+    assert_close_dt(out.numpy(np.uint16, (M, N)), ref, dt, name="marlin ffi (kernel E)", abs_floor=2e-3)
+    assert not ws.numpy(np.uint32, (N,)).any()
+
+
+@pytest.mark.parametrize("M", [1, 2, 4])
+def test_gemv_s_bias_residual(M):
+    K, N = 4096, 4096
+    r = rng(M + 5)
+    q = make_quant(r, K, N, 128, BF16, True)
+    x, bias, res = rand_dt(r, (M, K), BF16), rand_dt(r, (N,), BF16), rand_dt(r, (M, N), BF16)
+    out = ops.wna16_gemm(ops.dev(x), _tiled(q, True), ops.dev(q["scales"]), ops.dev(q["qzeros"]), M, K, N, 128, True, 0, ops.dev(bias), ops.dev(res))
+    ref = orc.wna16_gemm(x, q["idx"], q["zeros"], q["scales"], 128, BF16, bias, res)
+    g0 = orc.from_dt(orc.wna16_gemm(x, q["idx"], q["zeros"], q["scales"], 128, BF16), BF16)
+    mag = np.maximum(np.abs(g0), np.abs(g0 + orc.from_dt(bias, BF16)[None, :]))
+    assert_close_dt(out.numpy(np.uint16, (M, N)), ref, BF16, max_ulp=1.0, name="gemv_s bias+residual", mag=mag)
+
+
+@pytest.mark.parametrize("M", [1, 2, 4])
+@pytest.mark.parametrize("K,N,awq", [(4096, 14336, False), (3584, 18944, True), (8192, 3584, False)])
+def test_gemv_s_gate_up_pair(M, K, N, awq):
+    r = rng(M + K)
+    qg, qu = make_quant(r, K, N, 128, BF16, awq), make_quant(r, K, N, 128, BF16, awq)
+    x = rand_dt(r, (M, K), BF16)
+    z = (lambda q: ops.dev(q["qzeros"])) if awq else (lambda q: None)
+    out = ops.wna16_gate_up_silu(ops.dev(x), _tiled(qg, awq), ops.dev(qg["scales"]), z(qg), _tiled(qu, awq), ops.dev(qu["scales"]), z(qu), M, K, N, 128, awq)
+    g = orc.wna16_gemm(x, qg["idx"], qg["zeros"], qg["scales"], 128, BF16)
+    u = orc.wna16_gemm(x, qu["idx"], qu["zeros"], qu["scales"], 128, BF16)
+    assert_close_dt(out.numpy(np.uint16, (M, N)), orc.silu_mul(g, u, BF16), BF16, max_ulp=3.0, max_mismatch_frac=0.04, name="gemv_s gate/up", abs_floor=4e-3)
+
+
+@pytest.mark.parametrize("M", [1, 2, 4])
+@pytest.mark.parametrize("dt", [BF16, F16])
+def test_gemv_s_fused_rms_norm(M, dt):
+    """RMSNorm fused into the prologue (every wave normalises its own x slices; the only cross-wave step is the 16 x 4 table
+    of partial sums of squares) against the oracle's norm -> GEMM, and against the two separate device calls"""
+    K, N = 4096, 6144
+    r = rng(M + dt)
+    q = make_quant(r, K, N, 128, dt, False)
+    x, nw = rand_dt(r, (M, K), dt, 2.0), orc.to_dt((1.0 + 0.1 * r.standard_normal(K)).astype(np.float32), dt)
+    bias = rand_dt(r, (N,), dt)
+    t = _tiled(q)
+    out = ops.rms_norm_wna16_gemm(ops.dev(x), ops.dev(nw), 1e-5, t, ops.dev(q["scales"]), None, M, K, N, 128, bias=ops.dev(bias), dtype=dt)
+    got = out.numpy(np.uint16, (M, N))
+    xn = orc.rms_norm(x, nw, 1e-5, dt)
+    ref = orc.wna16_gemm(xn, q["idx"], None, q["scales"], 128, dt, bias)
+    g0 = np.abs(orc.from_dt(orc.wna16_gemm(xn, q["idx"], None, q["scales"], 128, dt), dt))
+    # a 1-ulp flip of one normalised activation (f32 vs f64 sum of squares) moves an output by far less than an output ulp
+    assert_close_dt(got, ref, dt, max_ulp=1.0, max_mismatch_frac=0.03, name="fused norm gemv", mag=g0)
+    sep = ops.wna16_gemm(ops.rms_norm(ops.dev(x), ops.dev(nw), M, K, 1e-5, dt), t, ops.dev(q["scales"]), None, M, K, N, 128, bias=ops.dev(bias), dtype=dt)
+    frac = float((got != sep.numpy(np.uint16, (M, N))).mean())
+    print(f"[fused norm] M={M} dt={dt}: {100 * frac:.3f}% of outputs differ from rms_norm + gemm as separate launches")
+    assert frac < 0.01
+
+
+@pytest.mark.parametrize("M", [1, 4])
+def test_gemv_s_fused_rms_norm_gate_up(M):
+    K, N = 4096, 14336
+    r = rng(M + 31)
+    qg, qu = make_quant(r, K, N, 128, BF16), make_quant(r, K, N, 128, BF16)
+    x, nw = rand_dt(r, (M, K), BF16, 2.0), orc.to_dt((1.0 + 0.1 * r.standard_normal(K)).astype(np.float32), BF16)
+    out = ops.rms_norm_wna16_gate_up_silu(ops.dev(x), ops.dev(nw), 1e-5, _tiled(qg), ops.dev(qg["scales"]), None, _tiled(qu), ops.dev(qu["scales"]), None,
+                                          M, K, N, 128)
+    xn = orc.rms_norm(x, nw, 1e-5, BF16)
+    g = orc.wna16_gemm(xn, qg["idx"], None, qg["scales"], 128, BF16)
+    u = orc.wna16_gemm(xn, qu["idx"], None, qu["scales"], 128, BF16)
+    assert_close_dt(out.numpy(np.uint16, (M, N)), orc.silu_mul(g, u, BF16), BF16, max_ulp=3.0, max_mismatch_frac=0.05, name="fused norm gate/up", abs_floor=4e-3)
+
+
+def test_gemv_s_repeated_launches_are_bitwise_stable():
+    """fixed summation order (no atomics): the same launch twice gives the same bits, also with the tail prefetch active"""
+    K, N, M = 4096, 4096, 2
+    r = rng(3)
+    q = make_quant(r, K, N, 128, BF16, False)
+    x = rand_dt(r, (M, K), BF16)
+    t, sc, xd = _tiled(q), ops.dev(q["scales"]), ops.dev(x)
+    a = ops.wna16_gemm(xd, t, sc, None, M, K, N, 128).numpy(np.uint16, (M, N))
+    for _ in range(5):
+        assert np.array_equal(a, ops.wna16_gemm(xd, t, sc, None, M, K, N, 128).numpy(np.uint16, (M, N)))

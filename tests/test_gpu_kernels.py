@@ -53,8 +53,6 @@ GEMM_SHAPES = [(512, 256), (4096, 1024), (1024, 4096), (3584, 512), (8192, 1024)
 @pytest.mark.parametrize("M", [1, 2, 5, 8, 9, 16, 32, 33, 64, 100])
 @pytest.mark.parametrize("K,N", GEMM_SHAPES)
 def test_wna16_gemm_gptq(M, K, N):
-    if M > 33 and K * N > 2 ** 21:
-        pytest.skip("oracle time")
     r = rng(M * 131 + K + N)
     q = make_quant(r, K, N, 128, BF16, False)
     x = rand_dt(r, (M, K), BF16)
@@ -204,12 +202,6 @@ def test_rms_norm(dt, T, H):
     href = orc.add(x, res, dt)
     assert np.array_equal(h.numpy(np.uint16, (T, H)), href)
     assert_close_dt(o.numpy(np.uint16, (T, H)), orc.rms_norm(href, w, 1e-5, dt), dt, name="add_rms_norm")
-
-
-def test_fused_norm_gemv():
-    """RMSNorm fused into the GEMV prologue == separate norm + GEMM (rounding points preserved)."""
-    pytest.importorskip("ctypes")
-    # exercised through the engine tests; here only the standalone ops are available
 
 
 @pytest.mark.parametrize("dt", [BF16, F16])

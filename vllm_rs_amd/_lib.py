@@ -84,6 +84,8 @@ def load():
     _sig(lib, "vra_version", C.c_char_p)
     _sig(lib, "vra_wna16_gemm", None, P, P, P, P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64)
     _sig(lib, "vra_wna16_gate_up_silu", None, P, P, P, P, P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64)
+    _sig(lib, "vra_rms_norm_wna16_gemm", None, P, P, c_f32, P, P, P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64)
+    _sig(lib, "vra_rms_norm_wna16_gate_up_silu", None, P, P, c_f32, P, P, P, P, P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64)
     _sig(lib, "vra_wna16_unpack_indices", None, P, P, c_i32, c_i32, c_i64)
     _sig(lib, "vra_wna16_dequant", None, P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64)
     _sig(lib, "vra_rms_norm", None, P, P, P, c_i32, c_i32, c_f32, c_i32, c_i64)

@@ -4,6 +4,7 @@
 #include "gemv.cuh"
 #include "gemm_q4.cuh"
 #include "gemm_q4_big.cuh"
+#include "gemv_q4s.cuh"
 bool vra_gemv_fits(bool int4, int nbw, int M, int K, int group_size);
 void vra_launch_gemv(const GemvArgs& a, bool int4, int dtype, int64_t stream);
 void vra_launch_skinny(GemmBArgs a, bool int4, bool dual, int dtype, int64_t stream);
@@ -14,3 +15,10 @@ void vra_launch_gemm_q4(GemmCArgs a, bool awq, int dtype, int64_t stream);
 // (DUAL: of one tensor).  Returns the m-tiles per wave to launch with (2 or 4), or 0 when the shape belongs to kernel B.
 int vra_gemm_q4_big_fits(bool dual, int M, int cols, int K, int group_size, const GemmDArgs* segs);
 void vra_launch_gemm_q4_big(const GemmDArgs& a, bool dual, bool awq, int mb, int dtype, int64_t stream);
+// kernel E (gemv_q4s.cuh): int4, 1..4 rows, scale groups >= 128 (or channel-wise), n_units = 16-column blocks (pairs count once).
+// ns = 1 | 2 (gate/up pair with SiLU*mul).  The launcher fills KT / TPW / the unit distribution / gsh.
+bool vra_gemv_s_fits(int ns, int M, int K, int group_size, int n_units, bool norm);
+void vra_gemv_s_plan(int n_units, int* grid, int* q, int* r);
+void vra_launch_gemv_s(GemvSArgs a, int ns, int group_size, bool awq, int dtype, int64_t stream);
+void vra_scales_to_unit_major(const void* scales, void* out, int G, int N, int unit0, int64_t stream);
+void vra_zeros_to_unit_major(const uint32_t* zeros, uint32_t* out, int G, int N, int unit0, int64_t stream);

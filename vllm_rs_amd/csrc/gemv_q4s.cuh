@@ -1,0 +1,323 @@
+// gemv_q4s.cuh — "kernel E": int4 GEMV for decode batches of 1..4 rows (the bs = 1 headline), built around what the
+// round-1 timelines of kernel A showed: at these sizes a launch is dominated by its fixed costs (three workgroup barriers
+// and two passes over LDS before the first MFMA, a barrier per work item, an epilogue wave that meets the compute waves
+// per item), not by streaming.
+//
+// Roofline: HBM.  Algorithmic bytes per call: K*N/2 (packed int4) + (K/g)*N*2 (scales) [+ (K/g)*N/2 AWQ zeros]
+// + M*K*2 + M*N*2.
+//
+// Shape of the launch:
+//   * ONE workgroup of 16 waves per CU (grid <= #CUs), no persistence loop.  The unit of work is one 16-column n-block
+//     over the full K ("unit"; NS = 2: the same n-block of the gate and of the up tensor).  Workgroup b owns a contiguous
+//     range of units — a contiguous run of the packed weights, (units x K/128) KiB — and every wave w takes the k-tiles
+//     w, w+16, ... of each unit: 1 KiB coalesced per tile-step, 2 KiB in flight per wave (the depth that measured best on
+//     this memory system), branch-free issue so that hipcc's s_waitcnt stays at vmcnt(ring-1).
+//   * x never crosses waves: a wave needs only the x slices of ITS k-tiles.  It loads them itself (one 16-byte load per lane
+//     covers 4 rows x 128 columns), parks them in a wave-private LDS region (row-major, one octet of padding per row: the
+//     MFMA A-fragment reads of 4 rows are 4 banks apart) together with the per-tile sums Σx of the zero-point fix-up.  With
+//     a fused RMSNorm the ONLY cross-wave step of the prologue is the 16 x 4 table of partial Σx² (one barrier); every wave
+//     then normalises its own slices in place.
+//   * partial tiles of all units meet in LDS ONCE, behind the single barrier at the end of the stream; the first
+//     units*64 threads then add the 16 wave partials in fixed order and run the fused epilogue (bias, SiLU·mul, residual);
+//     bias / residual were requested before the weight stream started.
+//   * tail prefetch: after its last tile-step a wave requests the first tile-steps its twin (same workgroup id => same XCD,
+//     same wave) will need in the NEXT launch of the decode chain.  They land in that XCD's L2 while this launch drains,
+//     the launch boundary passes and the next prologue runs: the next launch's first ring fill is an L2 hit instead of
+//     the HBM round trip that otherwise sits between its prologue and its first MFMA.
+//   * scales / AWQ zeros are addressed as  grp*grp_stride + unit*unit_stride + column: row-major checkpoint tensors
+//     ([K/g, N]: strides N, 16), the unit-major copies the native runtime makes at load ([N/16][K/g][16]: strides 16,
+//     16*K/g — the scales of a workgroup's stream are then one contiguous run, like its weights) and the Marlin-permuted
+//     scales the reference passes (wna16.rs:180-218: a permutation inside 64 columns, i.e. a per-lane index) all work.
+#pragma once
+#include <type_traits>
+
+#include "gemv.cuh"
+
+#define GS_WAVES 16
+#define GS_THREADS (GS_WAVES * 64)
+#define GS_MAX_UNITS 8   // units (pairs) per workgroup at most
+#define GS_MAX_TPW 8     // k-tiles per wave and unit at most (K <= 16384)
+#define GS_NORM_TPW 4    // ... with a fused RMSNorm (the norm weights of a wave's tiles stay in registers)
+#define GS_MAX_SEG 3
+#ifndef GS_RING_KIB
+#define GS_RING_KIB 2
+#endif
+#define GS_TILE_LDS 1104  // bytes of a wave's LDS per k-tile: 4 rows x (256 + 16) + 16 (Σx of the 4 rows)
+
+struct GemvSSeg {  // output segment (q / k / v of one launch): epilogue only
+  void* out;
+  const void* bias;  // [columns of the segment] or null
+  int out_ld;
+  int unit_start;  // first unit of the segment
+};
+struct GemvSArgs {
+  const void* w[2];          // tiled weights of stream 0 (and 1: the up tensor of a gate/up pair), unit-major
+  const void* scales[2];     // 16-bit
+  const uint32_t* zeros[2];  // AWQ: packed zero points (8 columns per word), else null
+  int s_grp_stride, s_unit_stride;  // scale element index = grp*s_grp_stride + unit*s_unit_stride + column (both even)
+  int z_grp_stride, z_unit_stride;  // zero word index   = grp*z_grp_stride + unit*z_unit_stride + column/8
+  int marlin;                       // scales in the reference's marlin_permute_scales order (grouped form), N % 64 == 0
+  const void* x;                    // [M, K] (ld = x_ld)
+  int x_ld;
+  const void* norm_w;  // non-null: x <- rmsnorm(x) * norm_w
+  float eps;
+  const void* residual;  // [M, res_ld] added after bias
+  int res_ld;
+  GemvSSeg seg[GS_MAX_SEG];
+  int nseg;
+  int M, K, KT, TPW, gsh;  // KT = K/128, TPW = ceil(KT/16), k >> gsh = scale group
+  int n_units, units_q, units_r;  // workgroup b owns units_q (+1 if b < units_r) units starting at b*units_q + min(b, units_r)
+  // tail prefetch: the next launch's streams, its tiles per unit and its unit distribution (next_grid = 0: none)
+  const void* next_w[2];
+  int next_kt, next_units_q, next_units_r, next_grid;
+  int dbg;
+  unsigned long long* ts;
+};
+
+static inline size_t gemv_q4s_lds_bytes(int ns, int tpw, int max_units) {
+  return (size_t)GS_WAVES * tpw * GS_TILE_LDS + 256 + (size_t)max_units * ns * GS_WAVES * 256;
+}
+
+template <class DT, int NS, bool AWQ>
+__global__ __launch_bounds__(GS_THREADS) void gemv_q4s_kernel(const GemvSArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int D = GS_RING_KIB / NS < 1 ? 1 : GS_RING_KIB / NS;  // ring depth in tile-steps
+  // every kernel argument the way to the first load needs, requested in ONE batch of scalar loads
+  asm volatile("" ::"s"(a.x), "s"(a.x_ld), "s"(a.norm_w), "s"(a.K), "s"(a.M), "s"(a.KT), "s"(a.TPW), "s"(a.gsh), "s"(a.units_q), "s"(a.units_r),
+               "s"(a.w[0]), "s"(a.scales[0]), "s"(a.s_grp_stride), "s"(a.s_unit_stride), "s"(a.marlin), "s"(a.residual), "s"(a.res_ld),
+               "s"(a.nseg), "s"(a.seg[0].out), "s"(a.seg[0].bias), "s"(a.seg[0].out_ld), "s"(a.seg[1].unit_start), "s"(a.seg[2].unit_start));
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nn = lane & 15, oct = lane >> 4;
+  const int M = a.M, KT = a.KT, TPW = a.TPW;
+  const int wg = (int)blockIdx.x;
+  const int u0 = wg * a.units_q + min(wg, a.units_r);
+  const int nu = a.units_q + (wg < a.units_r ? 1 : 0);
+  const int S = (a.dbg & 1) ? 0 : nu * TPW;  // tile-steps of this wave
+  GEMV_STAMP(0);
+
+  // ---- LDS carve-up
+  unsigned char* xw = smem + (size_t)wave * TPW * GS_TILE_LDS;  // this wave's x slices
+  float* part = reinterpret_cast<float*>(smem + (size_t)GS_WAVES * TPW * GS_TILE_LDS);  // [16 waves][4 rows] Σx²
+  f32x4* red = reinterpret_cast<f32x4*>(smem + (size_t)GS_WAVES * TPW * GS_TILE_LDS + 256);  // [unit][NS][wave][16 lanes]
+
+  // ---- epilogue operands of the threads that will finish the outputs (requested before the weight stream starts):
+  // thread -> (unit ui, row m, column nl) for tid < nu*64
+  // (one unit per wave: everything about the unit is wave-uniform and comes from SGPRs — selects, no indexed kernarg reads)
+  const int e_ui = wave, e_m = oct, e_nl = nn;
+  const bool e_act = e_ui < nu && e_m < M;
+  const int e_unit = u0 + min(e_ui, nu - 1);
+  const bool e_s1 = a.nseg > 1 && e_unit >= a.seg[1].unit_start, e_s2 = a.nseg > 2 && e_unit >= a.seg[2].unit_start;
+  void* const e_out = e_s2 ? a.seg[2].out : (e_s1 ? a.seg[1].out : a.seg[0].out);
+  const void* const e_biasp = e_s2 ? a.seg[2].bias : (e_s1 ? a.seg[1].bias : a.seg[0].bias);
+  const int e_ld = e_s2 ? a.seg[2].out_ld : (e_s1 ? a.seg[1].out_ld : a.seg[0].out_ld);
+  const int e_col = (e_unit - (e_s2 ? a.seg[2].unit_start : (e_s1 ? a.seg[1].unit_start : a.seg[0].unit_start))) * 16 + e_nl;
+  const void* const e_bias2p = NS == 2 ? a.seg[1].bias : nullptr;  // pair: seg[1].bias is the up tensor's bias
+  // (the 32-bit word holding the value: a 16-bit load gets its zero extension — i.e. a wait — right behind the issue)
+  uint32_t e_bias_w = 0u, e_bias2_w = 0u, e_res_w = 0u;
+  const size_t e_res_idx = (size_t)e_m * a.res_ld + e_col;
+  if (e_act) {
+    if (e_biasp) e_bias_w = static_cast<const uint32_t*>(e_biasp)[e_col >> 1];
+    if (NS == 2 && e_bias2p) e_bias2_w = static_cast<const uint32_t*>(e_bias2p)[e_col >> 1];
+    if (a.residual) e_res_w = static_cast<const uint32_t*>(a.residual)[e_res_idx >> 1];
+  }
+
+  // ---- prologue: this wave's x slices.  Staging lane = (row group oct, octet nn): region `oct` of a tile holds row
+  // min(oct, M-1), so rows >= M alias the last row (their outputs are never stored).
+  const bool norm = a.norm_w != nullptr;
+  const uint16_t* xrow = static_cast<const uint16_t*>(a.x) + (size_t)min(oct, M - 1) * a.x_ld + nn * 8;
+  const uint16_t* nwp = static_cast<const uint16_t*>(a.norm_w) + nn * 8;
+  u32x4 nr[GS_NORM_TPW];
+  float ss = 0.f;
+  for (int t0 = 0; t0 < TPW; t0 += 4) {
+    u32x4 xv[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int kt = min(wave + 16 * min(t0 + i, TPW - 1), KT - 1);
+      xv[i] = *reinterpret_cast<const u32x4*>(xrow + (size_t)kt * 128);
+      if (norm && t0 == 0) nr[i] = *reinterpret_cast<const u32x4*>(nwp + (size_t)kt * 128);  // (norm => TPW <= 4)
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int ti = t0 + i;
+      if (ti < TPW) {
+        const bool valid = wave + 16 * ti < KT;
+        if (!valid) xv[i] = u32x4{0u, 0u, 0u, 0u};  // a wave without this k-tile: zero slice (and zeroed scales below)
+        unsigned char* tp = xw + (size_t)ti * GS_TILE_LDS;
+        *reinterpret_cast<u32x4*>(tp + oct * 272 + nn * 16) = xv[i];
+        if (norm) {
+          float f[8];
+          unpack8<DT>(xv[i], f);
+#pragma unroll
+          for (int e = 0; e < 8; e++) ss += f[e] * f[e];
+        } else {
+          const float s8 = row16_sum(octet_sum<DT>(xv[i]));
+          if (nn == 0) reinterpret_cast<float*>(tp + 1088)[oct] = s8;
+        }
+      }
+    }
+  }
+  GEMV_STAMP(16);
+
+  // ---- the weight stream of this wave: step s = (unit ui, tile ti); everything on the issue path is branch free
+  u32x4 wb[D][NS];
+  uint32_t sb[D][NS];
+  uint32_t zb[D][AWQ ? NS : 1];
+  const int gsh = a.gsh;
+  const int mperm = ((nn & 7) << 3) + (nn >> 3);  // marlin: column r = (unit&3)*16 + nn sits at (r&7)*8 + (r>>3) of its 64
+  auto issue = [&](int ui, int ti, u32x4 (&w)[NS], uint32_t (&sc)[NS], uint32_t (&zp)[AWQ ? NS : 1]) {
+    const int unit = u0 + ui;
+    const int kt = min(wave + 16 * ti, KT - 1);
+    const int grp = (kt * 128) >> gsh;
+    const int col = a.marlin ? ((unit >> 2) << 6) + ((unit & 3) << 1) + mperm : unit * a.s_unit_stride + nn;
+    const int64_t si = (int64_t)grp * a.s_grp_stride + col;
+    const int64_t zi = (int64_t)grp * a.z_grp_stride + unit * a.z_unit_stride + (nn >> 3);
+#pragma unroll
+    for (int b = 0; b < NS; b++) {
+      w[b] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.w[b]) + ((size_t)unit * KT + kt) * 64 + lane);
+      sc[b] = reinterpret_cast<const uint32_t*>(a.scales[b])[si >> 1];  // the word holding the scale; its half is a per-lane constant
+      if (AWQ) zp[AWQ ? b : 0] = a.zeros[b][zi];
+    }
+  };
+  int iu = 0, it = 0;  // issue cursor, clamped to the last step
+  auto advance_issue = [&]() {
+    const bool last = iu == nu - 1 && it == TPW - 1;
+    const bool wrap = it == TPW - 1;
+    it = last ? it : (wrap ? 0 : it + 1);
+    iu = last ? iu : (wrap ? iu + 1 : iu);
+  };
+
+  // x and the epilogue operands have arrived (L2) before the first HBM load is queued: loads return in order per wave
+  // and an L2 hit queued behind the CU's streaming loads comes back microseconds late
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+#pragma unroll
+  for (int r = 0; r < D; r++) {
+    issue(iu, it, wb[r], sb[r], zb[r]);
+    advance_issue();
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  GEMV_STAMP(1);
+
+  if (norm) {
+    // Σx² of the rows: every wave contributes the partial sums of its slices, fixed order
+    const float rsum = row16_sum(ss);
+    if (nn == 0) part[wave * 4 + oct] = rsum;
+    __syncthreads();
+    GEMV_STAMP(18);
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < GS_WAVES; w++) tot += part[w * 4 + oct];
+    const float rstd = 1.0f / sqrtf(tot / (float)a.K + a.eps);
+#pragma unroll
+    for (int ti = 0; ti < GS_NORM_TPW; ti++) {
+      if (ti < TPW) {
+        unsigned char* tp = xw + (size_t)ti * GS_TILE_LDS;
+        const u32x4 raw = *reinterpret_cast<const u32x4*>(tp + oct * 272 + nn * 16);
+        float f[8], g[8];
+        unpack8<DT>(raw, f);
+        unpack8<DT>(nr[ti], g);
+#pragma unroll
+        for (int e = 0; e < 8; e++) f[e] = f[e] * rstd * g[e];
+        const u32x4 v = pack8<DT>(f);
+        *reinterpret_cast<u32x4*>(tp + oct * 272 + nn * 16) = v;
+        const float s8 = row16_sum(octet_sum<DT>(v));  // over the ROUNDED values the MFMA will see
+        if (nn == 0) reinterpret_cast<float*>(tp + 1088)[oct] = s8;
+      }
+    }
+  }
+  GEMV_STAMP(2);
+
+  // ---- main loop
+  // A fragment: lane (oct, nn) reads row min(nn, 3) (region r holds row min(r, M-1)), columns j*32 + oct*8 ..
+  const unsigned char* xfrag = xw + min(nn, 3) * 272 + oct * 16;
+  const int zsh = 4 * awq_rev(nn & 7);
+  const bool shalf = a.marlin ? (nn >> 3) & 1 : nn & 1;  // which half of the loaded word is this lane's scale
+  constexpr float CB = Magic<DT>::bias;
+  f32x4 acc[NS];
+#pragma unroll
+  for (int b = 0; b < NS; b++) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int cu = 0, ct = 0;  // consume cursor
+  const int S_pad = (S + D - 1) / D * D;  // the only loop exit is the back edge (see gemv_q4.cuh)
+  for (int s0 = 0; s0 < S_pad; s0 += D) {
+#pragma unroll
+    for (int r = 0; r < D; r++) {
+      if (s0 + r < S) {
+        const bool valid = wave + 16 * ct < KT;
+        const unsigned char* xp = xfrag + (size_t)ct * GS_TILE_LDS;
+        f32x4 ag[NS];
+#pragma unroll
+        for (int b = 0; b < NS; b++) ag[b] = vra_zero_acc();
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const s16x8 xf = __builtin_bit_cast(s16x8, *reinterpret_cast<const u32x4*>(xp + j * 64));
+#pragma unroll
+          for (int b = 0; b < NS; b++) DT::mfma(ag[b], xf, magic_word<DT>(wb[r][b][j]));
+        }
+        VRA_MFMA_DRAIN();
+        const f32x4 sx = *reinterpret_cast<const f32x4*>(xw + (size_t)ct * GS_TILE_LDS + 1088);  // Σx of rows 0..3 over this tile
+#pragma unroll
+        for (int b = 0; b < NS; b++) {
+          float s = DT::to_f32((uint16_t)(shalf ? sb[r][b] >> 16 : sb[r][b]));
+          s = valid ? s : 0.f;
+          const float zc = AWQ ? CB + (float)((zb[r][AWQ ? b : 0] >> zsh) & 0xFu) : CB + 8.f;
+#pragma unroll
+          for (int e = 0; e < 4; e++) acc[b][e] = fmaf(s, fmaf(-zc, sx[e], ag[b][e]), acc[b][e]);
+        }
+        GEMV_STAMP(3 + 2 * (s0 + r < 5 ? s0 + r : 5));
+        if (++ct == TPW) {  // end of a unit: park the partial tile (rows 0..3 live in lanes 0..15)
+          ct = 0;
+          if (oct == 0) {
+#pragma unroll
+            for (int b = 0; b < NS; b++) red[((cu * NS + b) * GS_WAVES + wave) * 16 + nn] = acc[b];
+          }
+#pragma unroll
+          for (int b = 0; b < NS; b++) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+          ++cu;
+        }
+      }
+      issue(iu, it, wb[r], sb[r], zb[r]);  // refill this ring slot with the step D ahead (unconditionally)
+      advance_issue();
+    }
+  }
+  GEMV_STAMP(15);
+
+  // ---- tail prefetch: the first tile-steps of this (workgroup, wave) in the next launch, into this XCD's L2
+  // (two 1 KiB requests per wave = the next launch's first ring fill: (stream 0, tile 0) and (stream 1, tile 0) of a pair,
+  // or tiles 0 and 1 of a single stream)
+  u32x4 pf0 = u32x4{0u, 0u, 0u, 0u}, pf1 = pf0;
+  const bool have_next = a.next_grid > 0 && wg < a.next_grid && !(a.dbg & 2);
+  if (have_next) {
+    const int nu0 = wg * a.next_units_q + min(wg, a.next_units_r);
+    const int k0 = min(wave, a.next_kt - 1), k1 = a.next_w[1] ? k0 : min(wave + 16, a.next_kt - 1);
+    const void* w1 = a.next_w[1] ? a.next_w[1] : a.next_w[0];
+    pf0 = *(reinterpret_cast<const u32x4*>(a.next_w[0]) + ((size_t)nu0 * a.next_kt + k0) * 64 + lane);
+    pf1 = *(reinterpret_cast<const u32x4*>(w1) + ((size_t)nu0 * a.next_kt + k1) * 64 + lane);
+  }
+
+  // ---- all partial tiles of the workgroup meet once; units*64 threads finish the outputs
+  __syncthreads();
+  if (e_act) {
+    const float* rf = reinterpret_cast<const float*>(red);
+    float v = 0.f, v2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < GS_WAVES; w++) {
+      v += rf[(((e_ui * NS + 0) * GS_WAVES + w) * 16 + e_nl) * 4 + e_m];
+      if (NS == 2) v2 += rf[(((e_ui * NS + 1) * GS_WAVES + w) * 16 + e_nl) * 4 + e_m];
+    }
+    const float e_bias = DT::to_f32((uint16_t)((e_col & 1) ? e_bias_w >> 16 : e_bias_w));
+    const float e_bias2 = DT::to_f32((uint16_t)((e_col & 1) ? e_bias2_w >> 16 : e_bias2_w));
+    const float e_res = DT::to_f32((uint16_t)((e_res_idx & 1) ? e_res_w >> 16 : e_res_w));
+    v = rnd_dt<DT>(v);
+    if (e_biasp) v = rnd_dt<DT>(v + e_bias);
+    if (NS == 2) {
+      v2 = rnd_dt<DT>(v2);
+      if (e_bias2p) v2 = rnd_dt<DT>(v2 + e_bias2);
+      const float sl = rnd_dt<DT>(v / (1.0f + expf(-v)));
+      v = sl * v2;
+    }
+    if (a.residual) v = rnd_dt<DT>(v) + e_res;
+    static_cast<uint16_t*>(e_out)[(size_t)e_m * e_ld + e_col] = DT::from_f32(v);
+  }
+  if (have_next) asm volatile("" ::"v"(pf0), "v"(pf1));  // keep the prefetch loads alive until they have landed
+  GEMV_STAMP(14);
+}

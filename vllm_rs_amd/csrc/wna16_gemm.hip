@@ -5,6 +5,7 @@
 #include "gemm_skinny.cuh"
 #include "gemv.cuh"
 #include "gemv_q4.cuh"
+#include "gemv_q4s.cuh"
 #include "scratch.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -308,6 +309,103 @@ void vra_launch_gemv(const GemvArgs& a, bool int4, int dtype, int64_t stream) {
   }
 }
 
+// ---- kernel E (gemv_q4s.cuh): decode batches of 1..4 rows
+// distribution of `n_units` units over the workgroups of one launch: grid <= #CUs, the first `r` workgroups own q+1 units.
+// A grid that divides the units evenly is preferred when it keeps at least 3/4 of the CUs busy (Llama-3-8B: 384 q/k/v
+// units -> 192 x 2, 896 gate/up pairs -> 224 x 4): equal streams end together, which a ragged last unit does not.
+void vra_gemv_s_plan(int n_units, int* grid, int* q, int* r) {
+  const int cus = num_cus();
+  int g = n_units < cus ? n_units : cus;
+  static const char* mode = getenv("VRA_GS_GRID");  // tuning aid: "all" = always every CU, ragged
+  if (!(mode && mode[0] == 'a')) {
+    for (int c = g; c >= (cus * 3) / 4 && c >= 1; c--)
+      if (n_units % c == 0) {
+        g = c;
+        break;
+      }
+  }
+  *grid = g;
+  *q = n_units / g;
+  *r = n_units % g;
+}
+bool vra_gemv_s_fits(int ns, int M, int K, int group_size, int n_units, bool norm) {
+  static const char* off = getenv("VRA_NO_GEMV_S");
+  if (off && off[0] == '1') return false;
+  if (M < 1 || M > 4 || K % 128 || K > 128 * 16 * GS_MAX_TPW) return false;
+  const int g = group_size > 0 && group_size < K ? group_size : K;
+  if (g < K && (g < 128 || (g & (g - 1)))) return false;  // power-of-two groups of >= one k-tile, or channel-wise
+  const int KT = K / 128, tpw = (KT + 15) / 16;
+  if (norm && tpw > GS_NORM_TPW) return false;
+  if (n_units < num_cus() / 2) return false;  // too few n-blocks to spread over the chip without slicing K: kernel A / B
+  int grid, q, r;
+  vra_gemv_s_plan(n_units, &grid, &q, &r);
+  const int mu = q + (r ? 1 : 0);
+  return mu <= GS_MAX_UNITS && gemv_q4s_lds_bytes(ns, tpw, mu) <= (size_t)kMaxDynLds;
+}
+template <class DT, int NS, bool AWQ>
+static void launch_gemv_s_v(GemvSArgs a, hipStream_t st) {
+  static uint64_t attr_devs = 0;
+  auto kern = gemv_q4s_kernel<DT, NS, AWQ>;
+  if (!dev_seen(attr_devs)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+    dev_mark(attr_devs);
+  }
+  const int g = a.K / 128;
+  a.KT = g;
+  a.TPW = (a.KT + 15) / 16;
+  int grid;
+  vra_gemv_s_plan(a.n_units, &grid, &a.units_q, &a.units_r);
+  const size_t lds = gemv_q4s_lds_bytes(NS, a.TPW, a.units_q + (a.units_r ? 1 : 0));
+  static const char* exp_env = getenv("VRA_EXP");
+  a.dbg = exp_env ? atoi(exp_env) : 0;
+#ifdef VRA_GEMV_TS
+  a.ts = vra_gemv_ts_buf();
+#else
+  a.ts = nullptr;
+#endif
+  kern<<<grid, GS_THREADS, lds, st>>>(a);
+}
+// a.{KT, TPW, units_q, units_r} are filled here; a.gsh from group_size
+void vra_launch_gemv_s(GemvSArgs a, int ns, int group_size, bool awq, int dtype, int64_t stream) {
+  hipStream_t st = as_stream(stream);
+  const bool grouped = group_size > 0 && group_size < a.K;
+  a.gsh = grouped ? 31 - __builtin_clz((unsigned)group_size) : 31;
+  if ((a.s_grp_stride | a.s_unit_stride) & 1) {
+    vra_set_error("gemv_s: scale strides must be even");
+    return;
+  }
+  const bool bf = dtype == VRA_BF16;
+  if (ns == 2) {
+    if (awq) bf ? launch_gemv_s_v<BF16, 2, true>(a, st) : launch_gemv_s_v<F16, 2, true>(a, st);
+    else bf ? launch_gemv_s_v<BF16, 2, false>(a, st) : launch_gemv_s_v<F16, 2, false>(a, st);
+  } else {
+    if (awq) bf ? launch_gemv_s_v<BF16, 1, true>(a, st) : launch_gemv_s_v<F16, 1, true>(a, st);
+    else bf ? launch_gemv_s_v<BF16, 1, false>(a, st) : launch_gemv_s_v<F16, 1, false>(a, st);
+  }
+}
+// one-time copies for kernel E: scales [G, N] row-major -> unit-major [N/16][G][16] at unit offset `unit0` of `out`
+// (G groups per unit in the destination), AWQ zeros [G, N/8] -> [N/16][G][2]
+__global__ void scales_unit_major_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int G, int N, int unit0) {
+  const size_t total = (size_t)G * N;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int g = (int)(i / N), n = (int)(i % N);
+    out[((size_t)(unit0 + (n >> 4)) * G + g) * 16 + (n & 15)] = in[i];
+  }
+}
+__global__ void zeros_unit_major_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int G, int N8, int unit0) {
+  const size_t total = (size_t)G * N8;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int g = (int)(i / N8), w = (int)(i % N8);
+    out[((size_t)(unit0 + (w >> 1)) * G + g) * 2 + (w & 1)] = in[i];
+  }
+}
+void vra_scales_to_unit_major(const void* scales, void* out, int G, int N, int unit0, int64_t stream) {
+  scales_unit_major_kernel<<<grid_for((size_t)G * N, 256), 256, 0, as_stream(stream)>>>((const uint16_t*)scales, (uint16_t*)out, G, N, unit0);
+}
+void vra_zeros_to_unit_major(const uint32_t* zeros, uint32_t* out, int G, int N, int unit0, int64_t stream) {
+  zeros_unit_major_kernel<<<grid_for((size_t)G * (N / 8), 256), 256, 0, as_stream(stream)>>>(zeros, out, G, N / 8, unit0);
+}
+
 // columns of the flattened n-block space (all segments)
 static inline int skinny_cols(const GemmBArgs& a) { return a.nseg > 1 ? a.xseg[a.nseg - 2].blk_start * 16 + a.xseg[a.nseg - 2].n : a.N; }
 template <class DT, bool INT4, bool DUAL, int MT>
@@ -589,6 +687,32 @@ static bool check_gemm_shape(const char* who, int m, int k, int n, int group_siz
   return true;
 }
 
+// decode batches of 1..4 rows on kernel E straight from the caller's tensors: row-major scales / zeros as in the
+// checkpoint, or the Marlin-permuted scales the reference passes (grouped form: a per-lane index inside 64 columns, no copy)
+static bool gemv_s_direct(int ns, const void* in, const void* w0, const void* sc0, const void* qz0, const void* w1, const void* sc1, const void* qz1,
+                          const void* bias, const void* residual, void* out, int m, int k, int n, int group_size, int is_awq, int scales_layout,
+                          int dtype, int64_t stream, const void* norm_w = nullptr, float eps = 0.f) {
+  if (n % 16 || !vra_gemv_s_fits(ns, m, k, group_size, n / 16, norm_w != nullptr)) return false;
+  const bool grouped = group_size > 0 && group_size < k;
+  if (scales_layout == VRA_SCALES_MARLIN && (!grouped || n % 64)) return false;  // channel-wise permutation: converted copy (rowmajor_scales)
+  const bool awq = is_awq != 0 && qz0 != nullptr;
+  GemvSArgs a = {};
+  a.w[0] = w0, a.scales[0] = sc0, a.zeros[0] = awq ? (const uint32_t*)qz0 : nullptr;
+  a.w[1] = w1, a.scales[1] = sc1, a.zeros[1] = awq ? (const uint32_t*)qz1 : nullptr;
+  a.s_grp_stride = n, a.s_unit_stride = 16;
+  a.z_grp_stride = n / 8, a.z_unit_stride = 2;
+  a.marlin = scales_layout == VRA_SCALES_MARLIN ? 1 : 0;
+  a.x = in, a.x_ld = k;
+  a.norm_w = norm_w, a.eps = eps;
+  a.residual = residual, a.res_ld = n;
+  a.nseg = ns;
+  a.seg[0] = GemvSSeg{out, bias, n, 0};
+  a.seg[1] = GemvSSeg{out, nullptr, n, 0x7fffffff};
+  a.M = m, a.K = k, a.n_units = n / 16;
+  vra_launch_gemv_s(a, ns, group_size, awq, dtype, stream);
+  return true;
+}
+
 extern "C" void vra_wna16_gemm(const void* in, const void* qweight_tiled, const void* scales, const void* qzeros,
                                const void* bias, const void* residual, void* out, int32_t m, int32_t k, int32_t n,
                                int32_t group_size, int32_t is_awq, int32_t scales_layout, int32_t dtype,
@@ -596,6 +720,9 @@ extern "C" void vra_wna16_gemm(const void* in, const void* qweight_tiled, const 
   VRA_CHECK_ARG(in && qweight_tiled && scales && out, "vra_wna16_gemm: null pointer");
   VRA_CHECK_ARG(dtype == VRA_BF16 || dtype == VRA_F16, "vra_wna16_gemm: dtype must be bf16/f16");
   if (!check_gemm_shape("vra_wna16_gemm", m, k, n, group_size)) return;
+  if (gemv_s_direct(1, in, qweight_tiled, scales, qzeros, nullptr, nullptr, nullptr, bias, residual, out, m, k, n, group_size, is_awq, scales_layout,
+                    dtype, stream))
+    return;
   {
     const void* rs = rowmajor_scales(scales, scales_layout, k, n, group_size, 0, stream);
     if (!rs) return;
@@ -664,6 +791,9 @@ extern "C" void vra_wna16_gate_up_silu(const void* in, const void* qw_gate, cons
   VRA_CHECK_ARG(in && qw_gate && sc_gate && qw_up && sc_up && out, "vra_wna16_gate_up_silu: null pointer");
   VRA_CHECK_ARG(dtype == VRA_BF16 || dtype == VRA_F16, "vra_wna16_gate_up_silu: dtype must be bf16/f16");
   if (!check_gemm_shape("vra_wna16_gate_up_silu", m, k, n, group_size)) return;
+  if (gemv_s_direct(2, in, qw_gate, sc_gate, qz_gate, qw_up, sc_up, qz_up, nullptr, nullptr, out, m, k, n, group_size, is_awq, scales_layout, dtype,
+                    stream))
+    return;
   {
     int32_t l0 = scales_layout, l1 = scales_layout;
     const void* g0 = rowmajor_scales(sc_gate, l0, k, n, group_size, 0, stream);
@@ -842,4 +972,36 @@ extern "C" void gemm_half_q_half_alt(const void* in, const uint32_t* qweight, co
   // so g_idx == NULL means group_size 128 (the only non-g_idx configuration wna16.rs routes here).
   dim3 grid((n + 63) / 64, m);
   gptq_alt_kernel<<<grid, 256, 0, as_stream(stream)>>>((const uint16_t*)in, qweight, qzeros, (const uint16_t*)scales, g_idx, (uint16_t*)out, m, n, k, 128);
+}
+
+// NormX::forward + QLinear::forward in one call (others.rs:11-29 in front of wna16.rs:263-306): out = rmsnorm(in)·W (+ bias).
+// 1..4 rows run fused on kernel E (the normalised activations never reach HBM); otherwise `xn_workspace` [m, k] receives
+// rmsnorm(in) and the general GEMM follows — same rounding points either way (the normalised x is rounded to `dtype`).
+extern "C" void vra_rms_norm_wna16_gemm(const void* in, const void* norm_weight, float eps, const void* qweight_tiled, const void* scales,
+                                        const void* qzeros, const void* bias, void* out, void* xn_workspace, int32_t m, int32_t k, int32_t n,
+                                        int32_t group_size, int32_t is_awq, int32_t scales_layout, int32_t dtype, int64_t stream) {
+  VRA_CHECK_ARG(in && norm_weight && qweight_tiled && scales && out, "vra_rms_norm_wna16_gemm: null pointer");
+  VRA_CHECK_ARG(dtype == VRA_BF16 || dtype == VRA_F16, "vra_rms_norm_wna16_gemm: dtype must be bf16/f16");
+  if (!check_gemm_shape("vra_rms_norm_wna16_gemm", m, k, n, group_size)) return;
+  if (gemv_s_direct(1, in, qweight_tiled, scales, qzeros, nullptr, nullptr, nullptr, bias, nullptr, out, m, k, n, group_size, is_awq, scales_layout, dtype,
+                    stream, norm_weight, eps))
+    return;
+  VRA_CHECK_ARG(xn_workspace != nullptr, "vra_rms_norm_wna16_gemm: this shape needs xn_workspace [m, k]");
+  vra_rms_norm(in, norm_weight, xn_workspace, m, k, eps, dtype, stream);
+  vra_wna16_gemm(xn_workspace, qweight_tiled, scales, qzeros, bias, nullptr, out, m, k, n, group_size, is_awq, scales_layout, dtype, stream);
+}
+// NormX + MLP gate/up + SiLU·mul (llama.rs:127-129, mlp.rs:451-469): out = silu(rmsnorm(in)·Wg) * (rmsnorm(in)·Wu)
+extern "C" void vra_rms_norm_wna16_gate_up_silu(const void* in, const void* norm_weight, float eps, const void* qw_gate, const void* sc_gate,
+                                                const void* qz_gate, const void* qw_up, const void* sc_up, const void* qz_up, void* out,
+                                                void* xn_workspace, int32_t m, int32_t k, int32_t n, int32_t group_size, int32_t is_awq,
+                                                int32_t scales_layout, int32_t dtype, int64_t stream) {
+  VRA_CHECK_ARG(in && norm_weight && qw_gate && sc_gate && qw_up && sc_up && out, "vra_rms_norm_wna16_gate_up_silu: null pointer");
+  VRA_CHECK_ARG(dtype == VRA_BF16 || dtype == VRA_F16, "vra_rms_norm_wna16_gate_up_silu: dtype must be bf16/f16");
+  if (!check_gemm_shape("vra_rms_norm_wna16_gate_up_silu", m, k, n, group_size)) return;
+  if (gemv_s_direct(2, in, qw_gate, sc_gate, qz_gate, qw_up, sc_up, qz_up, nullptr, nullptr, out, m, k, n, group_size, is_awq, scales_layout, dtype,
+                    stream, norm_weight, eps))
+    return;
+  VRA_CHECK_ARG(xn_workspace != nullptr, "vra_rms_norm_wna16_gate_up_silu: this shape needs xn_workspace [m, k]");
+  vra_rms_norm(in, norm_weight, xn_workspace, m, k, eps, dtype, stream);
+  vra_wna16_gate_up_silu(xn_workspace, qw_gate, sc_gate, qz_gate, qw_up, sc_up, qz_up, out, m, k, n, group_size, is_awq, scales_layout, dtype, stream);
 }

@@ -59,7 +59,7 @@ bool Model::qlinear_synth(QLinear& l, int K, int N, bool bias, uint64_t seed) {
   if (l.quant) {
     const int g = mc_.group_size > 0 ? mc_.group_size : K;
     const size_t words = (size_t)(K / 8) * N;
-    if (!(l.w = dalloc(words * 4))) return false;
+    if (!l.w && !(l.w = dalloc(words * 4))) return false;  // (q/k/v: carved out of the layer's fused block)
     vra_fill_hash_u32((uint32_t*)l.w, (int64_t)words, seed, 0);  // tiled layout directly (codes are iid)
     const size_t ns = (size_t)(K / g) * N;
     if (!(l.scales = dalloc(ns * es_))) return false;
@@ -124,6 +124,13 @@ bool Model::init_synthetic(uint64_t seed) {
     vra_fill_normal(L.attn_norm, H, seed + 100 + l * 2, 1.f, 0.02f, dt_, 0);
     vra_fill_normal(L.ffn_norm, H, seed + 101 + l * 2, 1.f, 0.02f, dt_, 0);
     const bool qb = mc_.attention_bias != 0;
+    if (mc_.quant_method != 0) {  // q | k | v tiles contiguous
+      const size_t wq = (size_t)(H / 8) * hq_ * D * 4, wk = (size_t)(H / 8) * hkv_ * D * 4;
+      if (!(L.qkv_w = dalloc(wq + 2 * wk))) return false;
+      L.q.w = L.qkv_w;
+      L.k.w = (char*)L.qkv_w + wq;
+      L.v.w = (char*)L.qkv_w + wq + wk;
+    }
     if (!qlinear_synth(L.q, H, hq_ * D, qb, s + 0) || !qlinear_synth(L.k, H, hkv_ * D, qb, s + 4) ||
         !qlinear_synth(L.v, H, hkv_ * D, qb, s + 8) || !qlinear_synth(L.o, hq_ * D, H, false, s + 12) ||
         !qlinear_synth(L.gate, H, inter_, false, s + 16) || !qlinear_synth(L.up, H, inter_, false, s + 20) ||
@@ -287,7 +294,7 @@ bool Model::finalize_weights() {
   auto fin = [&](QLinear& l, const char* what) {
     if (l.raw_qweight) {
       const size_t words = (size_t)l.raw_rows * l.raw_cols;
-      if (!(l.w = dalloc(words * 4))) return false;
+      if (!l.w && !(l.w = dalloc(words * 4))) return false;
       if (l.awq) awq_repack(l.raw_qweight, l.w, l.raw_rows, l.raw_cols, 4, 0);
       else gptq_repack(l.raw_qweight, l.w, l.raw_rows, l.raw_cols, 0);
       const char* e = vra_last_error();
@@ -327,6 +334,14 @@ bool Model::finalize_weights() {
       error = "missing layer norm weights";
       return false;
     }
+    if (L.q.raw_qweight && L.k.raw_qweight && L.v.raw_qweight && !L.qkv_w) {  // q | k | v tiles contiguous
+      const size_t wq = (size_t)L.q.raw_rows * L.q.raw_cols * 4, wk = (size_t)L.k.raw_rows * L.k.raw_cols * 4,
+                   wv = (size_t)L.v.raw_rows * L.v.raw_cols * 4;
+      if (!(L.qkv_w = dalloc(wq + wk + wv))) return false;
+      L.q.w = L.qkv_w;
+      L.k.w = (char*)L.qkv_w + wq;
+      L.v.w = (char*)L.qkv_w + wq + wk;
+    }
     if (!fin(L.q, "q_proj") || !fin(L.k, "k_proj") || !fin(L.v, "v_proj") || !fin(L.o, "o_proj") || !fin(L.gate, "gate_proj") ||
         !fin(L.up, "up_proj") || !fin(L.down, "down_proj"))
       return false;
@@ -352,6 +367,7 @@ bool Model::finalize_weights() {
     error = "scratch allocation failed";
     return false;
   }
+  if (!build_decode_streams()) return false;
   finalized_ = hipDeviceSynchronize() == hipSuccess;
   return finalized_;
 }
@@ -551,6 +567,123 @@ bool Model::gate_up(const LayerWeights& L, const void* x, const void* norm_w, vo
 }
 
 // ---------------------------------------------------------------------------------------------
+// decode streams of kernel E (gemv_q4s.cuh)
+// ---------------------------------------------------------------------------------------------
+bool Model::build_decode_streams() {
+  if (mc_.quant_method == 0) return true;
+  auto one = [&](QLinear& l) {
+    if (!l.quant || l.s_um) return true;
+    const int g = mc_.group_size > 0 && mc_.group_size < l.K ? mc_.group_size : l.K;
+    const int G = l.K / g;
+    if (!(l.s_um = dalloc((size_t)G * l.N * es_))) return false;
+    vra_scales_to_unit_major(l.scales, l.s_um, G, l.N, 0, 0);
+    if (l.awq) {
+      if (!(l.z_um = (uint32_t*)dalloc((size_t)G * (l.N / 8) * 4))) return false;
+      vra_zeros_to_unit_major(l.qzeros, l.z_um, G, l.N, 0, 0);
+    }
+    return true;
+  };
+  for (auto& L : layers_) {
+    if (!one(L.o) || !one(L.gate) || !one(L.up) || !one(L.down)) return false;
+    if (L.qkv_w && !L.qkv_s_um && L.q.K == L.k.K && L.q.K == L.v.K) {
+      const int K = L.q.K, g = mc_.group_size > 0 && mc_.group_size < K ? mc_.group_size : K, G = K / g;
+      const int Nt = L.q.N + L.k.N + L.v.N;
+      if (!(L.qkv_s_um = dalloc((size_t)G * Nt * es_))) return false;
+      vra_scales_to_unit_major(L.q.scales, L.qkv_s_um, G, L.q.N, 0, 0);
+      vra_scales_to_unit_major(L.k.scales, L.qkv_s_um, G, L.k.N, L.q.N / 16, 0);
+      vra_scales_to_unit_major(L.v.scales, L.qkv_s_um, G, L.v.N, (L.q.N + L.k.N) / 16, 0);
+      if (L.q.awq) {
+        if (!(L.qkv_z_um = (uint32_t*)dalloc((size_t)G * (Nt / 8) * 4))) return false;
+        vra_zeros_to_unit_major(L.q.qzeros, L.qkv_z_um, G, L.q.N, 0, 0);
+        vra_zeros_to_unit_major(L.k.qzeros, L.qkv_z_um, G, L.k.N, L.q.N / 16, 0);
+        vra_zeros_to_unit_major(L.v.qzeros, L.qkv_z_um, G, L.v.N, (L.q.N + L.k.N) / 16, 0);
+      }
+    }
+  }
+  return true;
+}
+
+// (K, n_units, ns, fused norm) of decode GEMV `which`
+static void gemv_s_shape(const LayerWeights& L, int which, int* K, int* units, int* ns, bool* norm) {
+  switch (which) {
+    case 0: *K = L.q.K, *units = (L.q.N + L.k.N + L.v.N) / 16, *ns = 1, *norm = true; break;
+    case 1: *K = L.o.K, *units = L.o.N / 16, *ns = 1, *norm = false; break;
+    case 2: *K = L.gate.K, *units = L.gate.N / 16, *ns = 2, *norm = true; break;
+    default: *K = L.down.K, *units = L.down.N / 16, *ns = 1, *norm = false; break;
+  }
+}
+bool Model::gemv_s_ok(int which, int M) const {
+  const LayerWeights& L = layers_[0];
+  if (!L.q.quant || !L.qkv_s_um || !L.o.s_um || !L.gate.s_um || !L.up.s_um || !L.down.s_um) return false;
+  if ((L.q.N | L.k.N | L.v.N | L.o.N | L.gate.N | L.down.N) % 16) return false;
+  int K, units, ns;
+  bool norm;
+  gemv_s_shape(L, which, &K, &units, &ns, &norm);
+  return vra_gemv_s_fits(ns, M, K, mc_.group_size, units, norm);
+}
+bool Model::gemv_s(int l, int which, int M, void* out, const void* residual, int64_t stream) {
+  if (!gemv_s_ok(which, M)) return false;
+  const LayerWeights& L = layers_[l];
+  const int H = mc_.hidden_size;
+  GemvSArgs a = {};
+  int K, units, ns;
+  bool norm;
+  gemv_s_shape(L, which, &K, &units, &ns, &norm);
+  const int g = mc_.group_size > 0 && mc_.group_size < K ? mc_.group_size : K, G = K / g;
+  a.s_grp_stride = 16, a.s_unit_stride = 16 * G;  // unit-major copies
+  a.z_grp_stride = 2, a.z_unit_stride = 2 * G;
+  a.M = M, a.K = K, a.n_units = units;
+  a.eps = mc_.rms_norm_eps;
+  a.nseg = 1;
+  switch (which) {
+    case 0:
+      a.w[0] = L.qkv_w, a.scales[0] = L.qkv_s_um, a.zeros[0] = L.qkv_z_um;
+      a.x = h_, a.x_ld = H, a.norm_w = L.attn_norm;
+      a.nseg = 3;
+      a.seg[0] = GemvSSeg{q_, L.q.bias, L.q.N, 0};
+      a.seg[1] = GemvSSeg{k_, L.k.bias, L.k.N, L.q.N / 16};
+      a.seg[2] = GemvSSeg{v_, L.v.bias, L.v.N, (L.q.N + L.k.N) / 16};
+      break;
+    case 1:
+      a.w[0] = L.o.w, a.scales[0] = L.o.s_um, a.zeros[0] = L.o.z_um;
+      a.x = attn_, a.x_ld = L.o.K;
+      a.seg[0] = GemvSSeg{out, world_ > 1 ? nullptr : L.o.bias, L.o.N, 0};
+      a.residual = residual, a.res_ld = L.o.N;
+      break;
+    case 2:
+      a.w[0] = L.gate.w, a.scales[0] = L.gate.s_um, a.zeros[0] = L.gate.z_um;
+      a.w[1] = L.up.w, a.scales[1] = L.up.s_um, a.zeros[1] = L.up.z_um;
+      a.x = h_, a.x_ld = H, a.norm_w = L.ffn_norm;
+      a.nseg = 2;  // pair: seg[0] carries the output and the gate bias, seg[1].bias the up bias
+      a.seg[0] = GemvSSeg{act_, L.gate.bias, L.gate.N, 0};
+      a.seg[1] = GemvSSeg{act_, L.up.bias, L.gate.N, 0x7fffffff};
+      break;
+    default:
+      a.w[0] = L.down.w, a.scales[0] = L.down.s_um, a.zeros[0] = L.down.z_um;
+      a.x = act_, a.x_ld = L.down.K;
+      a.seg[0] = GemvSSeg{out, world_ > 1 ? nullptr : L.down.bias, L.down.N, 0};
+      a.residual = residual, a.res_ld = L.down.N;
+      break;
+  }
+  // tail prefetch: the next decode GEMV in program order (the attention launch between q/k/v and o_proj streams little)
+  {
+    const int nw = which == 3 ? 0 : which + 1, nl = which == 3 ? l + 1 : l;
+    if (nl < mc_.num_layers && gemv_s_ok(nw, M)) {
+      const LayerWeights& N2 = layers_[nl];
+      int nK, nunits, nns;
+      bool nnorm;
+      gemv_s_shape(N2, nw, &nK, &nunits, &nns, &nnorm);
+      a.next_w[0] = nw == 0 ? N2.qkv_w : (nw == 1 ? N2.o.w : (nw == 2 ? N2.gate.w : N2.down.w));
+      a.next_w[1] = nw == 2 ? N2.up.w : nullptr;
+      a.next_kt = nK / 128;
+      vra_gemv_s_plan(nunits, &a.next_grid, &a.next_units_q, &a.next_units_r);
+    }
+  }
+  vra_launch_gemv_s(a, ns, mc_.group_size, L.q.awq, dt_, stream);
+  return !take_err(error, "gemv_s");
+}
+
+// ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
 bool Model::forward(const InputMetadata& md, int64_t stream) {
@@ -564,6 +697,7 @@ bool Model::forward(const InputMetadata& md, int64_t stream) {
     return false;
   }
   const float scale = 1.0f / sqrtf((float)D);
+  error.clear();
   // embed_forward (llama.rs:260-267)
   vra_embedding(md.input_ids, embed_, h_, T, H, mc_.vocab_size, dt_, stream);
   for (int l = 0; l < mc_.num_layers; l++) {
@@ -571,7 +705,10 @@ bool Model::forward(const InputMetadata& md, int64_t stream) {
     // ---- attention block (llama.rs:115-126): norm -> q,k,v -> rope -> cache + attention -> o_proj (+ residual)
     const QLinear qkv[3] = {L.q, L.k, L.v};
     void* outs[3] = {q_, k_, v_};
-    if (!linear_fused_norm(qkv, 3, outs, h_, L.attn_norm, T, stream)) return false;
+    if (!gemv_s(l, 0, T, nullptr, nullptr, stream)) {
+      if (!error.empty()) return false;
+      if (!linear_fused_norm(qkv, 3, outs, h_, L.attn_norm, T, stream)) return false;
+    }
     if (md.is_prefill) {
       vra_fused_rope(q_, k_, cos_, sin_, md.positions, T, hq_, hkv_, D, D, 0, dt_, dt_, stream);
       vra_reshape_and_cache(k_, v_, kc_[l], vc_[l], md.slot_mapping, T, hkv_, D, ec_.block_size, dt_, stream);
@@ -587,19 +724,19 @@ bool Model::forward(const InputMetadata& md, int64_t stream) {
     if (world_ > 1) {
       // TensorParallelRowLinear::forward (distributed.rs:438-455): partial GEMM -> all_reduce -> + bias; then the layer's
       // residual add (llama.rs:126) — the last two fused behind the reduction
-      if (!linear(L.o, attn_, tmp_, T, nullptr, stream, false)) return false;
+      if (!gemv_s(l, 1, T, tmp_, nullptr, stream) && (!error.empty() || !linear(L.o, attn_, tmp_, T, nullptr, stream, false))) return false;
       vra_all_reduce_fused(comm_, tmp_, h_, L.o.bias, h_, T, H, dt_, stream);
       if (take_err(error, "all_reduce(o_proj)")) return false;
-    } else if (!linear(L.o, attn_, h_, T, h_, stream)) {
+    } else if (!gemv_s(l, 1, T, h_, h_, stream) && (!error.empty() || !linear(L.o, attn_, h_, T, h_, stream))) {
       return false;
     }
     // ---- MLP block (llama.rs:127-130)
-    if (!gate_up(L, h_, L.ffn_norm, act_, T, stream)) return false;
+    if (!gemv_s(l, 2, T, nullptr, nullptr, stream) && (!error.empty() || !gate_up(L, h_, L.ffn_norm, act_, T, stream))) return false;
     if (world_ > 1) {
-      if (!linear(L.down, act_, tmp_, T, nullptr, stream, false)) return false;
+      if (!gemv_s(l, 3, T, tmp_, nullptr, stream) && (!error.empty() || !linear(L.down, act_, tmp_, T, nullptr, stream, false))) return false;
       vra_all_reduce_fused(comm_, tmp_, h_, L.down.bias, h_, T, H, dt_, stream);
       if (take_err(error, "all_reduce(down_proj)")) return false;
-    } else if (!linear(L.down, act_, h_, T, h_, stream)) {
+    } else if (!gemv_s(l, 3, T, h_, h_, stream) && (!error.empty() || !linear(L.down, act_, h_, T, h_, stream))) {
       return false;
     }
   }
@@ -637,6 +774,8 @@ bool Model::forward(const InputMetadata& md, int64_t stream) {
 bool Model::launch_gemm(int which, int layer, int M, int64_t stream) {
   if (layer < 0 || layer >= mc_.num_layers || M < 1 || M > max_tokens_) return false;
   const LayerWeights& L = layers_[layer];
+  if (gemv_s(layer, which, M, which == 1 || which == 3 ? tmp_ : nullptr, which == 1 || which == 3 ? h_ : nullptr, stream)) return true;
+  if (!error.empty()) return false;
   switch (which) {
     case 0: {
       const QLinear qkv[3] = {L.q, L.k, L.v};

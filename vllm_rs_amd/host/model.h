@@ -22,6 +22,9 @@ struct QLinear {
   void* scales = nullptr;        // [K/g, N] model dtype, row-major
   uint32_t* qzeros = nullptr;    // awq raw [K/g, N/8]
   void* bias = nullptr;          // [N] or null
+  // decode streams of kernel E (gemv_q4s.cuh): unit-major copies made at load — [N/16][K/g][16] scales, [N/16][K/g][2] zeros
+  void* s_um = nullptr;
+  uint32_t* z_um = nullptr;
   // staging of checkpoint-format pieces until finalize()
   void* raw_qweight = nullptr;
   int raw_rows = 0, raw_cols = 0;
@@ -31,6 +34,11 @@ struct LayerWeights {
   void* attn_norm = nullptr;
   void* ffn_norm = nullptr;
   QLinear q, k, v, o, gate, up, down;
+  // q | k | v tiles in ONE allocation (q.w, k.w, v.w point into it): the fused q/k/v launch of kernel E walks one
+  // contiguous run of units; their unit-major scales / zeros are fused the same way
+  void* qkv_w = nullptr;
+  void* qkv_s_um = nullptr;
+  uint32_t* qkv_z_um = nullptr;
 };
 
 // The data contract between runner and kernels (InputMetadata, runner.rs:1222-1238,1369-1385);
@@ -87,6 +95,11 @@ class Model {
   bool linear(const QLinear& l, const void* x, void* out, int M, const void* residual, int64_t stream, bool with_bias = true);
   bool linear_fused_norm(const QLinear* ls, int nl, void* const* outs, const void* x, const void* norm_w, int M, int64_t stream);
   bool gate_up(const LayerWeights& L, const void* x, const void* norm_w, void* act, int M, int64_t stream);
+  bool build_decode_streams();
+  // kernel E launch of one decode GEMV of layer `l` (which: 0 norm+q/k/v, 1 o_proj, 2 norm+gate/up+SiLU*mul, 3 down);
+  // false = shape not covered (the caller takes the general path).  `out`/`residual` as for linear().
+  bool gemv_s(int l, int which, int M, void* out, const void* residual, int64_t stream);
+  bool gemv_s_ok(int which, int M) const;
   vra_model_config mc_;
   vra_engine_config ec_;
   bool finalized_ = false;

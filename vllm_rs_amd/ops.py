@@ -126,6 +126,24 @@ def wna16_gate_up_silu(x, qw_g, sc_g, qz_g, qw_u, sc_u, qz_u, m, k, n, group_siz
     return out
 
 
+def rms_norm_wna16_gemm(x, norm_w, eps, qweight_tiled, scales, qzeros, m, k, n, group_size, is_awq=False,
+                        scales_layout=SCALES_ROWMAJOR, bias=None, dtype=BF16):
+    out, ws = DevBuf(m * n * 2), DevBuf(m * k * 2)
+    lib().vra_rms_norm_wna16_gemm(_ptr(x), _ptr(norm_w), eps, _ptr(qweight_tiled), _ptr(scales), _ptr(qzeros), _ptr(bias), out.ptr,
+                                  ws.ptr, m, k, n, group_size, int(is_awq), scales_layout, dtype, 0)
+    check_error()
+    return out
+
+
+def rms_norm_wna16_gate_up_silu(x, norm_w, eps, qw_g, sc_g, qz_g, qw_u, sc_u, qz_u, m, k, n, group_size, is_awq=False,
+                                scales_layout=SCALES_ROWMAJOR, dtype=BF16):
+    out, ws = DevBuf(m * n * 2), DevBuf(m * k * 2)
+    lib().vra_rms_norm_wna16_gate_up_silu(_ptr(x), _ptr(norm_w), eps, _ptr(qw_g), _ptr(sc_g), _ptr(qz_g), _ptr(qw_u), _ptr(sc_u),
+                                          _ptr(qz_u), out.ptr, ws.ptr, m, k, n, group_size, int(is_awq), scales_layout, dtype, 0)
+    check_error()
+    return out
+
+
 def unpack_indices(qweight_tiled, k, n):
     out = DevBuf(k * n)
     lib().vra_wna16_unpack_indices(_ptr(qweight_tiled), out.ptr, k, n, 0)
