@@ -1,17 +1,21 @@
 #!/usr/bin/env python3
-"""bench.py — decode tokens/s (+ p50 TTFT) of Llama-3-8B GPTQ-int4 (BASELINE.json configs[1]) on N
-MI355X GPUs of one node, synthetic weights/prompts of that shape (SURVEY.md §8d recipe).
+"""bench.py — decode tokens/s (+ p50 TTFT) of Llama-3-8B GPTQ-int4 (BASELINE.json configs[1]) on N MI355X GPUs of one
+node, synthetic weights/prompts of that shape (SURVEY.md §8d recipe).
 
-A "step" = one decode step of the running batch through the whole engine (scheduler, metadata upload,
-hipGraph replay of the forward, argmax, token download).  Weights and KV cache are resident in HBM when
-the timed region starts.  At N > 1 every rank is an independent replica (the 8B model fits one GPU:
-north_star asks for TP only "where the model is too large") — no data-path collective, scaling "weak".
+A "step" = one decode step of the running batch through the whole engine (scheduler, metadata upload, hipGraph replay of
+the forward, argmax, token download).  Weights and KV cache are resident in HBM when the timed region starts.  At N > 1
+every rank is an independent replica (the 8B model fits one GPU: north_star asks for TP only "where the model is too
+large") — no data-path collective, scaling "weak".  `--tp N` instead runs ONE tensor-parallel engine over N ranks
+(BASELINE config 4's mechanics: RCCL + one-shot all-reduce, vllm_rs_amd/runner.py) and reports its tokens/s.
 
-Prints ONE JSON line on rank 0.  Extra legs (not in the timed region): bs=32 throughput, p50 TTFT,
-the per-kernel roofline of the dequant-GEMM family (HIP-event timed launches, rotating layers), and the
-CPU oracle timed on the host cores (rank 0, N == 1 only).
+Prints ONE JSON line on rank 0.  Extra legs (not in the timed region): the roofline of the dequant-GEMM family (HIP-event
+timed launches, rotating layers), bs=32 throughput, long-context decode, p50 TTFT (128 / 2048 / 32768-token prompts, the
+last one cold and with a prefix-cache hit: config 5), the reference-binding path (`ffi_path`: the GEMMs of a layer through
+marlin_4bit_bf16 + vra_rms_norm + vra_silu_mul as the Rust layers would issue them), a Qwen2-7B-AWQ decode line (config 3)
+and the CPU oracle timed on the host cores (rank 0, N == 1 only).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -20,7 +24,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300-6900 GB/s is the measured streaming ceiling
+FAMILY = {0: "norm+qkv", 1: "o_proj+res", 2: "norm+gate_up+silu", 3: "down+res"}
+KERNEL_OF = {"norm+qkv": "gemv_q4s_kernel<BF16,1,false>", "o_proj+res": "gemv_q4s_kernel<BF16,1,false>",
+             "norm+gate_up+silu": "gemv_q4s_kernel<BF16,2,false>", "down+res": "gemv_q4s_kernel<BF16,1,false>"}
 
 
 def parse():
@@ -31,10 +38,11 @@ def parse():
     ap.add_argument("--batch", type=int, default=1, help="decode batch of the timed region (headline: 1)")
     ap.add_argument("--prompt-len", type=int, default=128)
     ap.add_argument("--model", default="llama3-8b-gptq")
-    ap.add_argument("--no-extras", action="store_true", help="skip bs=32 / TTFT / roofline / cpu legs")
+    ap.add_argument("--no-extras", action="store_true", help="skip the roofline / bs=32 / TTFT / ffi / qwen / cpu legs")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches (rocprofv3 kernel tracing crashes on hipGraph replay)")
     ap.add_argument("--blocks", type=int, default=8192, help="KV blocks (64 tokens each); 0 = kv_fraction of free HBM")
+    ap.add_argument("--tp", type=int, default=0, help="run ONE tensor-parallel engine over this many ranks (spawns its own runner processes)")
     return ap.parse_args()
 
 
@@ -48,7 +56,7 @@ def run_decode(eng, prompts, warmup, steps, sync):
     """prefill the prompts (untimed), `warmup` decode steps (untimed), then time exactly `steps` steps."""
     rids = [eng.add_request(p, max_tokens=warmup + steps + 8, ignore_eos=True) for p in prompts]
     # all prompts through prefill: the scheduler alternates prefill and decode steps once something is running (A14),
-    # so "the first decode step" is not enough for batches whose prompts exceed one 8192-token prefill step
+    # so "the first decode step" is not enough for batches whose prompts exceed one prefill step
     while True:
         n, is_prefill = eng.step()
         if not is_prefill and n == len(prompts):
@@ -68,12 +76,12 @@ def run_decode(eng, prompts, warmup, steps, sync):
     return dt, ms_events, outs
 
 
-def ttft_p50(eng, prompt_len, vocab, batch, reps=5):
+def ttft_p50(eng, prompt_len, vocab, batch, reps=5, seed0=100):
     """TTFT = first-token time - creation time (engine.rs:1004-1012), `batch` requests submitted together"""
     import numpy as np
     vals = []
     for i in range(reps):
-        prompts = make_prompts(batch, prompt_len, vocab, seed=100 + i)
+        prompts = make_prompts(batch, prompt_len, vocab, seed=seed0 + i)
         rids = [eng.add_request(p, max_tokens=2, ignore_eos=True) for p in prompts]
         while eng.has_unfinished():
             eng.step()
@@ -83,36 +91,149 @@ def ttft_p50(eng, prompt_len, vocab, batch, reps=5):
     return float(np.median(vals))
 
 
-def cpu_baseline(cfg):
-    """the CPU oracle (kind "port": the reference has no int4 CPU path, src/utils/gptq.rs:212-222) timed
-    on the host cores: one decode token through 2 of the 32 layers' seven int4 GEMMs, extrapolated."""
+def lib_sha16():
+    from vllm_rs_amd import _lib
+    return hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16]
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc FETCH_SIZE pass — ONLY if that pass was taken
+    with this very library (the .so hash is stored next to the counters): a kernel change can never leave a stale number."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
+        if pmc.get("lib_sha16") != lib_sha16():
+            return None
+        return pmc["kernels"][kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
+def ffi_path(L, cfg, iters=6):
+    """the reference's own binding path: what the Rust layers issue for ONE decode token through the seven
+    symbols of src/utils/gptq.rs:3-6 — per layer NormX, marlin_4bit_bf16 x (q, k, v, o), +residual, NormX, marlin x (gate, up),
+    silu*mul, marlin (down), +residual; Marlin-permuted scales, caller-owned workspace, no fusion across calls.  Attention
+    is not on this path's GEMM count and is left out.  Distinct weights per layer (8 layer sets rotate: nothing is cache
+    resident).  Returns ms per token (32 layers) measured with HIP events on one stream."""
+    import ctypes as C
+    H, I, D, Hq, Hkv, g = cfg["hidden_size"], cfg["intermediate_size"], cfg["head_dim"], cfg["num_heads"], cfg["num_kv_heads"], cfg["group_size"]
+    P = C.c_void_p
+    shapes = dict(q=(H, Hq * D), k=(H, Hkv * D), v=(H, Hkv * D), o=(Hq * D, H), gate=(H, I), up=(H, I), down=(I, H))
+    nset = 8
+    sets, allocs = [], []
+
+    def dalloc(nbytes):
+        p = L.vra_malloc(nbytes)
+        allocs.append(p)
+        return p
+    for s in range(nset):
+        lw = {}
+        for i, (name, (K, N)) in enumerate(shapes.items()):
+            w, sc = dalloc(K * N // 2), dalloc(K // g * N * 2)
+            L.vra_fill_hash_u32(w, K * N // 8, 1000 + s * 16 + i, 0)
+            L.vra_fill_uniform(sc, K // g * N, 2000 + s * 16 + i, 0.002, 0.02, 0, 0)
+            lw[name] = (w, sc, K, N)
+        lw["n1"], lw["n2"] = dalloc(H * 2), dalloc(H * 2)
+        L.vra_fill_normal(lw["n1"], H, 7 + s, 1.0, 0.02, 0, 0)
+        L.vra_fill_normal(lw["n2"], H, 9 + s, 1.0, 0.02, 0, 0)
+        sets.append(lw)
+    h, xn, q, k, v, att, t1, gt, up, act = (dalloc(n * 2) for n in (H, H, Hq * D, Hkv * D, Hkv * D, Hq * D, H, I, I, I))
+    ws = dalloc(I * 4)
+    L.vra_memset(ws, 0, I * 4, 0)
+    L.vra_fill_normal(h, H, 3, 0.0, 1.0, 0, 0)
+    L.vra_fill_normal(att, Hq * D, 4, 0.0, 1.0, 0, 0)
+
+    def mm(x, lwt, out):
+        w, sc, K, N = lwt
+        L.marlin_4bit_bf16(x, w, sc, None, None, out, 1, K, N, ws, g, 0)
+
+    def layer(lw):
+        L.vra_rms_norm(h, lw["n1"], xn, 1, H, 1e-5, 0, 0)
+        mm(xn, lw["q"], q), mm(xn, lw["k"], k), mm(xn, lw["v"], v)
+        mm(att, lw["o"], t1)
+        L.vra_add(t1, h, h, H, 0, 0)
+        L.vra_rms_norm(h, lw["n2"], xn, 1, H, 1e-5, 0, 0)
+        mm(xn, lw["gate"], gt), mm(xn, lw["up"], up)
+        L.vra_silu_mul(gt, up, act, I, 0, 0)
+        mm(act, lw["down"], t1)
+        L.vra_add(t1, h, h, H, 0, 0)
+    for lw in sets:
+        layer(lw)
+    L.vra_device_sync()
+    e0, e1 = L.vra_event_create(), L.vra_event_create()
+    L.vra_event_record(e0, 0)
+    for _ in range(iters):
+        for lw in sets:
+            layer(lw)
+    L.vra_event_record(e1, 0)
+    ms = L.vra_event_elapsed_ms(e0, e1)
+    err = L.vra_last_error().decode()
+    for p in allocs:
+        L.vra_free(p)
+    L.vra_event_destroy(e0), L.vra_event_destroy(e1)
+    if err:
+        return {"error": err}
+    per_layer = ms / (iters * nset)
+    return {"ms_per_token_gemm_path": per_layer * cfg["num_layers"], "us_per_layer": per_layer * 1e3, "launches_per_layer": 12,
+            "note": "7 marlin_4bit_bf16 + 2 vra_rms_norm + vra_silu_mul + 2 vra_add per layer, Marlin-permuted scales read in place (no conversion "
+                    "launch), eager launches on the null stream; attention excluded"}
+
+
+def oracle_decode_tokens_per_s(cfg, layers_sample, n_tokens, prompt_len, label):
+    """CPU baseline: a REAL greedy decode through oracle/model.py (all ops: norm, GEMMs, rope, paged attention, lm_head,
+    argmax) on a model of the named shape with `layers_sample` of its layers; the per-layer time comes from the difference to
+    the same run with 0 layers and is scaled to the full depth."""
     import numpy as np
+    from oracle import model as om
     from oracle import oracle as orc
-    H, I, D = cfg["hidden_size"], cfg["intermediate_size"], cfg["head_dim"]
-    Hq, Hkv, g = cfg["num_heads"], cfg["num_kv_heads"], cfg["group_size"]
-    shapes = [(H, Hq * D), (H, Hkv * D), (H, Hkv * D), (Hq * D, H), (H, I), (H, I), (I, H)]
-    n_layers_sample = 2
-    mats = []
-    for li in range(n_layers_sample):
-        for si, (K, N) in enumerate(shapes):
-            qw = orc.fill_hash_u32((K // 8) * N, 7 + li * 16 + si).reshape(K // 8, N)
-            sc = orc.fill_uniform((K // g, N), 99 + si, 0.002, 0.02, 0)
-            mats.append((K, N, qw, sc))
-    xs = {K: orc.fill_normal((1, K), K, 0.0, 1.0, 0) for K in {s[0] for s in shapes}}
-    orc.gptq_gemv_fast(xs[H], mats[0][2], mats[0][3], g, 0)  # warm the thread pool
+    H, I, V, D = cfg["hidden_size"], cfg["intermediate_size"], cfg["vocab_size"], cfg["head_dim"]
+    Hq, Hkv, g, dt = cfg["num_heads"], cfg["num_kv_heads"], cfg.get("group_size", 128), cfg["dtype"]
+    quant = cfg.get("quant_method") == "gptq"
+    w = {"model.embed_tokens.weight": orc.fill_normal((V, H), 1, 0.0, 0.02, dt), "model.norm.weight": orc.fill_normal((H,), 2, 1.0, 0.02, dt),
+         "lm_head.weight": orc.fill_normal((V, H), 3, 0.0, 0.02, dt)}
+    for i in range(layers_sample):
+        p = f"model.layers.{i}."
+        w[p + "input_layernorm.weight"] = orc.fill_normal((H,), 10 + i, 1.0, 0.02, dt)
+        w[p + "post_attention_layernorm.weight"] = orc.fill_normal((H,), 20 + i, 1.0, 0.02, dt)
+        for j, (name, K, N) in enumerate((("self_attn.q_proj", H, Hq * D), ("self_attn.k_proj", H, Hkv * D), ("self_attn.v_proj", H, Hkv * D),
+                                          ("self_attn.o_proj", Hq * D, H), ("mlp.gate_proj", H, I), ("mlp.up_proj", H, I), ("mlp.down_proj", I, H))):
+            if quant:
+                w[p + name + ".qweight"] = orc.fill_hash_u32((K // 8) * N, 100 + i * 16 + j).reshape(K // 8, N)
+                w[p + name + ".scales"] = orc.fill_uniform((K // g, N), 300 + i * 16 + j, 0.0005, 0.002, dt)
+            else:
+                w[p + name + ".weight"] = orc.fill_normal((N, K), 100 + i * 16 + j, 0.0, 1.0 / np.sqrt(K), dt)
+
+    def run(nl):
+        c = dict(cfg, num_layers=nl, max_position_embeddings=min(cfg["max_position_embeddings"], 2048))
+        m = om.OracleModel(c, w, num_blocks=8)
+        ids = np.arange(1000, 1000 + prompt_len, dtype=np.uint32)
+        pos = np.arange(prompt_len, dtype=np.int64)
+        bt = np.arange(8, dtype=np.uint32)[None]
+        logits = m.forward(ids, pos, pos.copy(), bt, [prompt_len], [0, prompt_len])  # prefill (untimed)
+        t0 = time.perf_counter()
+        n = prompt_len
+        for _ in range(n_tokens):
+            tok = orc.argmax_f32(logits).astype(np.uint32)
+            logits = m.forward(tok, np.array([n], np.int64), np.array([n], np.int64), bt, [n + 1])
+            n += 1
+        return (time.perf_counter() - t0) / n_tokens
     t0 = time.perf_counter()
-    reps = 0
-    while time.perf_counter() - t0 < 10.0 or reps < 1:
-        for K, N, qw, sc in mats:
-            orc.gptq_gemv_fast(xs[K], qw, sc, g, 0)
-        reps += 1
-    per_layer = (time.perf_counter() - t0) / reps / n_layers_sample
-    # lm_head (bf16 dense, 1 GB) is not in the sample; scale by its share of the per-token bytes
-    quant_bytes = sum(K * N // 2 for K, N in shapes) * cfg["num_layers"]
-    total = per_layer * cfg["num_layers"] * (1.0 + (cfg["vocab_size"] * H * 2) / quant_bytes)
+    t_head = run(0)
+    t_part = run(layers_sample)
+    per_layer = max(t_part - t_head, 0.0) / layers_sample
+    total = t_head + per_layer * cfg["num_layers"]
     return dict(value=1.0 / total, unit="tokens/s", cores=int(os.environ.get("OMP_NUM_THREADS", "1")), kind="port",
-                sample=f"bs=1 decode: {reps}x the 7 int4 GEMMs of {n_layers_sample}/32 Llama-3-8B layers via oracle/vra_oracle.c "
-                       f"orc_gptq_gemv_fast (~{time.perf_counter() - t0:.0f}s), extrapolated to 32 layers + lm_head bytes")
+                sample=f"{label}: {n_tokens} greedy tokens through oracle/model.py + vra_oracle.c (double-precision accumulation, OpenMP) with "
+                       f"{layers_sample}/{cfg['num_layers']} layers + embedding/lm_head, prompt {prompt_len}; per-layer time scaled to "
+                       f"{cfg['num_layers']} layers ({time.perf_counter() - t0:.0f} s of CPU work incl. weight generation)")
+
+
+def cpu_baseline(cfg_int4, cfg_tiny):
+    """`cpu_baseline` of the JSON line = the workload of the headline metric (Llama-3-8B int4 decode, bs 1; kind "port": the
+    reference has no int4 CPU path, src/utils/gptq.rs:212-222, and cannot be built here); `cpu_baseline_config1` = BASELINE
+    config 1, the shape the reference COULD run on its CPU backend (TinyLlama-1.1B bf16 greedy decode)."""
+    b = oracle_decode_tokens_per_s(cfg_int4, 2, 12, 32, "Llama-3-8B-shape GPTQ int4 g128 bs=1 decode")
+    a = oracle_decode_tokens_per_s(cfg_tiny, 4, 16, 32, "TinyLlama-1.1B-shape bf16 bs=1 decode (BASELINE config 1)")
+    return b, a
 
 
 def dist_init(world, local_rank, backend="nccl"):
@@ -140,8 +261,29 @@ def max_over_ranks(dist, seconds):
     return float(t.item())
 
 
+def tp_main(a):
+    """ONE tensor-parallel engine over a.tp ranks (runner processes; shared GPU => one-shot IPC transport, own GPUs => RCCL +
+    one-shot): decode tokens/s of the TP engine on the Llama-3-70B shape scaled to the rank count, or of --model."""
+    from vllm_rs_amd import engine as E
+    from vllm_rs_amd.runner import TPEngine
+    cfg = dict({"llama3-8b-gptq": E.LLAMA3_8B, "qwen2-7b-awq": E.QWEN2_7B, "llama3-70b": E.LLAMA3_70B}[a.model])
+    t0 = time.perf_counter()
+    with TPEngine(cfg, a.tp, tensors=None, num_gpu_blocks=a.blocks // a.tp, max_num_seqs=max(32, a.batch), max_model_len=8192,
+                  use_graph=not a.no_graph, seed=1234) as tp:
+        load_s = time.perf_counter() - t0
+        res = tp.timed_decode(make_prompts(a.batch, a.prompt_len, cfg["vocab_size"]), a.warmup, a.steps)
+    ms = max(r[0] for r in res)
+    print(json.dumps({"metric": f"decode tokens/sec, {a.model} TP={a.tp}", "value": a.batch * a.steps / (ms / 1e3), "unit": "tokens/s", "n_gpus": a.tp,
+                      "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms / a.steps, "higher_is_better": True, "scaling": "strong",
+                      "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                      "config": {"workload": f"{a.model} shape, int4 g128, tensor parallel over {a.tp} ranks ({tp.transport} transport), batch {a.batch}, "
+                                             f"prompt {a.prompt_len}, {a.steps} generated tokens", "load_s": load_s}}))
+
+
 def main():
     a = parse()
+    if a.tp > 1:
+        return tp_main(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -164,7 +306,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    cfg = dict({"llama3-8b-gptq": E.LLAMA3_8B, "qwen2-7b-awq": E.QWEN2_7B, "llama3-70b-tp8-rank": E.LLAMA3_70B_TP8_RANK}[a.model])
+    models = {"llama3-8b-gptq": E.LLAMA3_8B, "qwen2-7b-awq": E.QWEN2_7B, "llama3-70b-tp8-rank": E.LLAMA3_70B_TP8_RANK}
+    cfg = dict(models[a.model])
     max_bs = max(32, a.batch)
     eng = E.Engine(cfg, max_num_seqs=max_bs, max_model_len=8192, num_gpu_blocks=a.blocks, use_graph=not a.no_graph, device=local_rank,
                    seed=1234 + rank).init_synthetic()
@@ -187,29 +330,27 @@ def main():
     }
 
     if rank == 0 and not a.no_extras:
-        # ---------------- roofline of the dequant-GEMM family (bs = headline batch)
-        fam = {0: "norm+qkv", 1: "o_proj+res", 2: "norm+gate_up+silu", 3: "down+res"}
+        # ---------------- roofline of the dequant-GEMM family at the headline batch: every launch of the four GEMV shapes of a
+        # layer timed with HIP events on the engine stream (320 launches each, rotating over all layers' weights).  `roofline`
+        # is quoted on the TIME-DOMINANT launch (the largest share of the family's time per token); the family figure is the
+        # quantity north_star grades (3 625 975 808 algorithmic bytes per token / the family's time per token).
         per = {}
         tot_b = tot_ms = 0.0
-        for w, name in fam.items():
+        for w, name in FAMILY.items():
             ms = eng.bench_gemm(w, a.batch, 320)
             b = eng.gemm_bytes(w, a.batch)
-            per[name] = {"ms": ms, "bytes": b, "GBps": b / ms / 1e6}
+            per[name] = {"ms": ms, "bytes": b, "GBps": b / ms / 1e6, "kernel": KERNEL_OF[name]}
             tot_b += b
             tot_ms += ms
-        dom = per["norm+gate_up+silu"]
-        traffic = None  # HBM bytes per launch from the PMC pass (rocprofv3 --pmc FETCH_SIZE, corrected per the microarch guide)
-        try:
-            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc.json")))
-            traffic = pmc["kernels"]["gemv_q4_kernel<BF16,2,1,false>"]["hbm_bytes_per_launch"] if a.batch == 1 else None
-        except Exception:
-            pass
-        line["roofline"] = {"bound": "hbm", "kernel": "gemv_q4_kernel<BF16,NBW=2,SPT=1,AWQ=false> (RMSNorm + gate/up int4 GEMV + SiLU*mul)", "achieved": dom["GBps"],
-                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
+        dom_name = max(per, key=lambda k: per[k]["ms"])
+        dom = per[dom_name]
+        line["roofline"] = {"bound": "hbm", "kernel": f"{dom['kernel']} ({dom_name}: the launch with the largest share of the family's time)",
+                            "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS,
+                            "traffic": pmc_traffic(dom["kernel"]) if a.batch == 1 else None,
                             "algorithmic_bytes_per_launch": dom["bytes"], "avg_launch_ms": dom["ms"],
                             "family": per, "family_GBps": tot_b / tot_ms / 1e6, "family_frac": tot_b / tot_ms / 1e6 / HBM_PEAK_GBS,
-                            "family_ms_per_token": tot_ms * cfg["num_layers"]}
-        # ---------------- bs=32 decode + TTFT
+                            "family_ms_per_token": tot_ms * cfg["num_layers"], "lib_sha16": lib_sha16()}
+        # ---------------- bs=32 decode
         if a.batch != 32:
             dt32, _, _ = run_decode(eng, make_prompts(32, a.prompt_len, V, seed=43), 8, 64, lambda: L.vra_device_sync())
             line["bs32_tokens_per_s_per_gpu"] = 32 * 64 / dt32
@@ -225,9 +366,40 @@ def main():
                                "bs1_prompt2048": ttft_p50(eng, 2048, V, 1, reps=3)}
         line["step_bytes_roofline"] = {"algorithmic_bytes_per_step": 3625975808 + 1050673152 + 532480,
                                        "frac_of_8TBps": (3625975808 + 1050673152 + 532480) / (dt / a.steps) / 8e12 if a.batch == 1 else None}
+        eng.close()
+        eng = None
+        if a.model == "llama3-8b-gptq":
+            # ---------------- config 5: 32 768-token prompt (4 chunks of 8192), then the same prompt again (511-block prefix hit)
+            e5 = E.Engine(E.LLAMA31_8B, max_num_seqs=8, max_model_len=40960, num_gpu_blocks=2048, enable_prefix_cache=True,
+                          use_graph=not a.no_graph, device=local_rank, seed=1234).init_synthetic()
+            p32 = make_prompts(1, 32768, V, seed=5)[0]
+            res = []
+            for _ in range(2):
+                rid = e5.add_request(p32, max_tokens=2, ignore_eos=True)
+                while e5.has_unfinished():
+                    e5.step()
+                t = e5.times(rid)
+                res.append(t["first_token_ms"] - t["created_ms"])
+            line["ttft_p50_ms"]["bs1_prompt32768"] = res[0]
+            line["ttft_p50_ms"]["bs1_prompt32768_prefix_hit_511_blocks"] = res[1]
+            e5.close()
+            # ---------------- the reference's binding path
+            line["ffi_path"] = ffi_path(L, cfg)
+            line["ffi_path"]["native_family_ms_per_token"] = line["roofline"]["family_ms_per_token"]
+            # ---------------- config 3: Qwen2-7B AWQ
+            eq = E.Engine(E.QWEN2_7B, max_num_seqs=32, max_model_len=8192, num_gpu_blocks=2048, use_graph=not a.no_graph, device=local_rank,
+                          seed=99).init_synthetic()
+            Vq = E.QWEN2_7B["vocab_size"]
+            d1, _, _ = run_decode(eq, make_prompts(1, a.prompt_len, Vq, seed=11), 8, 64, lambda: L.vra_device_sync())
+            d32, _, _ = run_decode(eq, make_prompts(32, a.prompt_len, Vq, seed=12), 8, 32, lambda: L.vra_device_sync())
+            line["qwen2_7b_awq"] = {"bs1_tokens_per_s": 64 / d1, "bs1_ms_per_step": d1 * 1e3 / 64, "bs32_tokens_per_s": 32 * 32 / d32,
+                                    "bs32_ms_per_step": d32 * 1e3 / 32, "algorithmic_bytes_per_step": 3390091264 + 1089994752,
+                                    "frac_of_8TBps_bs1": (3390091264 + 1089994752) / (d1 / 64) / 8e12}
+            eq.close()
         if world == 1 and not a.no_cpu:
-            line["cpu_baseline"] = cpu_baseline(cfg)
-    eng.close()
+            line["cpu_baseline"], line["cpu_baseline_config1"] = cpu_baseline(E.LLAMA3_8B, E.TINYLLAMA)
+    if eng is not None:
+        eng.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

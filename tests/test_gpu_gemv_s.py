@@ -72,7 +72,9 @@ def test_gemv_s_bias_residual(M):
     ref = orc.wna16_gemm(x, q["idx"], q["zeros"], q["scales"], 128, BF16, bias, res)
     g0 = orc.from_dt(orc.wna16_gemm(x, q["idx"], q["zeros"], q["scales"], 128, BF16), BF16)
     mag = np.maximum(np.abs(g0), np.abs(g0 + orc.from_dt(bias, BF16)[None, :]))
-    assert_close_dt(out.numpy(np.uint16, (M, N)), ref, BF16, max_ulp=1.0, name="gemv_s bias+residual", mag=mag)
+    # three roundings (GEMM, + bias, + residual): each may flip by one ulp of ITS magnitude; two flips on one element are
+    # rare but happen (1 of 8192 here)
+    assert_close_dt(out.numpy(np.uint16, (M, N)), ref, BF16, max_ulp=2.0, name="gemv_s bias+residual", mag=mag)
 
 
 @pytest.mark.parametrize("M", [1, 2, 4])
@@ -104,8 +106,9 @@ def test_gemv_s_fused_rms_norm(M, dt):
     xn = orc.rms_norm(x, nw, 1e-5, dt)
     ref = orc.wna16_gemm(xn, q["idx"], None, q["scales"], 128, dt, bias)
     g0 = np.abs(orc.from_dt(orc.wna16_gemm(xn, q["idx"], None, q["scales"], 128, dt), dt))
-    # a 1-ulp flip of one normalised activation (f32 vs f64 sum of squares) moves an output by far less than an output ulp
-    assert_close_dt(got, ref, dt, max_ulp=1.0, max_mismatch_frac=0.03, name="fused norm gemv", mag=g0)
+    # a 1-ulp flip of one normalised activation (f32 vs f64 sum of squares) moves an output by far less than an output ulp;
+    # GEMM and + bias are two roundings: a few double flips in 25k outputs
+    assert_close_dt(got, ref, dt, max_ulp=2.0, max_mismatch_frac=0.03, name="fused norm gemv", mag=g0)
     sep = ops.wna16_gemm(ops.rms_norm(ops.dev(x), ops.dev(nw), M, K, 1e-5, dt), t, ops.dev(q["scales"]), None, M, K, N, 128, bias=ops.dev(bias), dtype=dt)
     frac = float((got != sep.numpy(np.uint16, (M, N))).mean())
     print(f"[fused norm] M={M} dt={dt}: {100 * frac:.3f}% of outputs differ from rms_norm + gemm as separate launches")

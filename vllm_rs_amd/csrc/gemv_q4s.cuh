@@ -78,10 +78,18 @@ static inline size_t gemv_q4s_lds_bytes(int ns, int tpw, int max_units) {
   return (size_t)GS_WAVES * tpw * GS_TILE_LDS + 256 + (size_t)max_units * ns * GS_WAVES * 256;
 }
 
+#ifdef GS_OCC2
+#define GS_MIN_WAVES_PER_SIMD 8  // two 16-wave workgroups per CU: at most 64 VGPRs
+#else
+#define GS_MIN_WAVES_PER_SIMD 4
+#endif
+#ifndef GS_RING_PAIR
+#define GS_RING_PAIR 2  // ring depth (tile-steps of 2 KiB) of the gate/up pair stream (measured: 2 beats 1 by 2 % of the decode step)
+#endif
 template <class DT, int NS, bool AWQ>
-__global__ __launch_bounds__(GS_THREADS) void gemv_q4s_kernel(const GemvSArgs a) {
+__global__ __launch_bounds__(GS_THREADS, GS_MIN_WAVES_PER_SIMD) void gemv_q4s_kernel(const GemvSArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int D = GS_RING_KIB / NS < 1 ? 1 : GS_RING_KIB / NS;  // ring depth in tile-steps
+  constexpr int D = NS == 2 ? GS_RING_PAIR : GS_RING_KIB;  // ring depth in tile-steps (1 KiB per stream and step)
   // every kernel argument the way to the first load needs, requested in ONE batch of scalar loads
   asm volatile("" ::"s"(a.x), "s"(a.x_ld), "s"(a.norm_w), "s"(a.K), "s"(a.M), "s"(a.KT), "s"(a.TPW), "s"(a.gsh), "s"(a.units_q), "s"(a.units_r),
                "s"(a.w[0]), "s"(a.scales[0]), "s"(a.s_grp_stride), "s"(a.s_unit_stride), "s"(a.marlin), "s"(a.residual), "s"(a.res_ld),
@@ -122,6 +130,43 @@ __global__ __launch_bounds__(GS_THREADS) void gemv_q4s_kernel(const GemvSArgs a)
     if (a.residual) e_res_w = static_cast<const uint32_t*>(a.residual)[e_res_idx >> 1];
   }
 
+  // ---- the weight stream of this wave: step s = (unit ui, tile ti); everything on the issue path is branch free
+  u32x4 wb[D][NS];
+  uint32_t sb[D][NS];
+  uint32_t zb[D][AWQ ? NS : 1];
+  const int gsh = a.gsh;
+  const int mperm = ((nn & 7) << 3) + (nn >> 3);  // marlin: column r = (unit&3)*16 + nn sits at (r&7)*8 + (r>>3) of its 64
+  auto issue = [&](int ui, int ti, u32x4 (&w)[NS], uint32_t (&sc)[NS], uint32_t (&zp)[AWQ ? NS : 1]) {
+    const int unit = u0 + ui;
+    const int kt = min(wave + 16 * ti, KT - 1);
+    const int grp = (kt * 128) >> gsh;
+    const int col = a.marlin ? ((unit >> 2) << 6) + ((unit & 3) << 1) + mperm : unit * a.s_unit_stride + nn;
+    const int64_t si = (int64_t)grp * a.s_grp_stride + col;
+    const int64_t zi = (int64_t)grp * a.z_grp_stride + unit * a.z_unit_stride + (nn >> 3);
+#pragma unroll
+    for (int b = 0; b < NS; b++) {
+      w[b] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.w[b]) + ((size_t)unit * KT + kt) * 64 + lane);
+      sc[b] = reinterpret_cast<const uint32_t*>(a.scales[b])[si >> 1];  // the word holding the scale; its half is a per-lane constant
+      if (AWQ) zp[AWQ ? b : 0] = a.zeros[b][zi];
+    }
+  };
+  int iu = 0, it = 0;  // issue cursor, clamped to the last step
+  auto advance_issue = [&]() {
+    const bool last = iu == nu - 1 && it == TPW - 1;
+    const bool wrap = it == TPW - 1;
+    it = last ? it : (wrap ? 0 : it + 1);
+    iu = last ? iu : (wrap ? iu + 1 : iu);
+  };
+
+#ifdef GS_RING_FIRST
+  // variant: the ring is filled BEFORE the x loads (x then returns behind the first weight tiles)
+#pragma unroll
+  for (int r = 0; r < D; r++) {
+    issue(iu, it, wb[r], sb[r], zb[r]);
+    advance_issue();
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#endif
   // ---- prologue: this wave's x slices.  Staging lane = (row group oct, octet nn): region `oct` of a tile holds row
   // min(oct, M-1), so rows >= M alias the last row (their outputs are never stored).
   const bool norm = a.norm_w != nullptr;
@@ -159,43 +204,18 @@ __global__ __launch_bounds__(GS_THREADS) void gemv_q4s_kernel(const GemvSArgs a)
   }
   GEMV_STAMP(16);
 
-  // ---- the weight stream of this wave: step s = (unit ui, tile ti); everything on the issue path is branch free
-  u32x4 wb[D][NS];
-  uint32_t sb[D][NS];
-  uint32_t zb[D][AWQ ? NS : 1];
-  const int gsh = a.gsh;
-  const int mperm = ((nn & 7) << 3) + (nn >> 3);  // marlin: column r = (unit&3)*16 + nn sits at (r&7)*8 + (r>>3) of its 64
-  auto issue = [&](int ui, int ti, u32x4 (&w)[NS], uint32_t (&sc)[NS], uint32_t (&zp)[AWQ ? NS : 1]) {
-    const int unit = u0 + ui;
-    const int kt = min(wave + 16 * ti, KT - 1);
-    const int grp = (kt * 128) >> gsh;
-    const int col = a.marlin ? ((unit >> 2) << 6) + ((unit & 3) << 1) + mperm : unit * a.s_unit_stride + nn;
-    const int64_t si = (int64_t)grp * a.s_grp_stride + col;
-    const int64_t zi = (int64_t)grp * a.z_grp_stride + unit * a.z_unit_stride + (nn >> 3);
-#pragma unroll
-    for (int b = 0; b < NS; b++) {
-      w[b] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.w[b]) + ((size_t)unit * KT + kt) * 64 + lane);
-      sc[b] = reinterpret_cast<const uint32_t*>(a.scales[b])[si >> 1];  // the word holding the scale; its half is a per-lane constant
-      if (AWQ) zp[AWQ ? b : 0] = a.zeros[b][zi];
-    }
-  };
-  int iu = 0, it = 0;  // issue cursor, clamped to the last step
-  auto advance_issue = [&]() {
-    const bool last = iu == nu - 1 && it == TPW - 1;
-    const bool wrap = it == TPW - 1;
-    it = last ? it : (wrap ? 0 : it + 1);
-    iu = last ? iu : (wrap ? iu + 1 : iu);
-  };
-
-  // x and the epilogue operands have arrived (L2) before the first HBM load is queued: loads return in order per wave
-  // and an L2 hit queued behind the CU's streaming loads comes back microseconds late
+  // the ring is filled right behind the x loads (in order per wave: x first); the staging below overlaps the first HBM round trip
+#ifndef GS_RING_FIRST
+#ifdef GS_XWAIT  // variant: x (L2) complete before the first HBM load is queued — measured equal to not waiting
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+#endif
 #pragma unroll
   for (int r = 0; r < D; r++) {
     issue(iu, it, wb[r], sb[r], zb[r]);
     advance_issue();
   }
   __builtin_amdgcn_sched_barrier(0);
+#endif
   GEMV_STAMP(1);
 
   if (norm) {
@@ -285,7 +305,7 @@ __global__ __launch_bounds__(GS_THREADS) void gemv_q4s_kernel(const GemvSArgs a)
   // (two 1 KiB requests per wave = the next launch's first ring fill: (stream 0, tile 0) and (stream 1, tile 0) of a pair,
   // or tiles 0 and 1 of a single stream)
   u32x4 pf0 = u32x4{0u, 0u, 0u, 0u}, pf1 = pf0;
-  const bool have_next = a.next_grid > 0 && wg < a.next_grid && !(a.dbg & 2);
+  const bool have_next = a.next_grid > 0 && wg < a.next_grid && (a.dbg & 2);  // measured: a net loss as built (VRA_EXP=2 turns it on)
   if (have_next) {
     const int nu0 = wg * a.next_units_q + min(wg, a.next_units_r);
     const int k0 = min(wave, a.next_kt - 1), k1 = a.next_w[1] ? k0 : min(wave + 16, a.next_kt - 1);

@@ -314,7 +314,11 @@ void vra_launch_gemv(const GemvArgs& a, bool int4, int dtype, int64_t stream) {
 // A grid that divides the units evenly is preferred when it keeps at least 3/4 of the CUs busy (Llama-3-8B: 384 q/k/v
 // units -> 192 x 2, 896 gate/up pairs -> 224 x 4): equal streams end together, which a ragged last unit does not.
 void vra_gemv_s_plan(int n_units, int* grid, int* q, int* r) {
+#ifdef GS_OCC2
+  const int cus = 2 * num_cus();  // two resident workgroups per CU
+#else
   const int cus = num_cus();
+#endif
   int g = n_units < cus ? n_units : cus;
   static const char* mode = getenv("VRA_GS_GRID");  // tuning aid: "all" = always every CU, ragged
   if (!(mode && mode[0] == 'a')) {
