@@ -219,6 +219,23 @@ void vra_dense_gemm(const void* x, const void* w, const void* bias, void* out, i
                     int32_t n, int32_t dtype, int32_t out_dtype, int64_t stream);
 /* logits.argmax(-1) (logits_processor.rs:67-70): first maximal index per row. */
 void vra_argmax_f32(const float* logits, uint32_t* out, int32_t rows, int32_t cols, int64_t stream);
+/* Stochastic sampling on the device — LogitsProcessor::sample_with_strategy for Sampling::{All, TopK, TopP,
+ * TopKThenTopP} (logits_processor.rs:199-271; the reference's own device path is `sampler.sample_cuda(logits,
+ * k, p, t, seed)` with k <= 256, and k = 256 standing in for "top-p only"): probabilities = softmax(logits /
+ * temperature) over the whole row; the top_k most probable tokens in descending order (ties: lower id first);
+ * top-p keeps a candidate while the mass accumulated before it is < top_p; one draw u in [0, kept mass) picks
+ * the first candidate whose running sum exceeds u.  top_k <= 0: unset; top_p outside (0,1): unset; both unset:
+ * the whole distribution.  The uniform of row r is the counter hash of (seed, r).  `dbg_idx`/`dbg_prob`
+ * [rows, 256] (nullable) receive the ordered candidates and their probabilities (0 = dropped by top-p). */
+void vra_sample(const float* logits, uint32_t* out, int32_t rows, int32_t vocab, int32_t top_k,
+                float top_p, float temperature, uint64_t seed, uint32_t* dbg_idx, float* dbg_prob,
+                int64_t stream);
+/* LogitsProcessor::apply_batch_repeat_penalty (logits_processor.rs:288-345), in place on f32 logits [rows, vocab]:
+ * logit -= count*frequency_penalty + (count > 0)*presence_penalty with counts over context[row, :context_lens[row]]
+ * (u32 token ids, row stride max_context <= 1024); rows with <= 1 context token or penalties in {0, 1} are untouched. */
+void vra_apply_penalties(float* logits, const uint32_t* context, const int32_t* context_lens, int32_t rows,
+                         int32_t max_context, int32_t vocab, const float* frequency_penalties,
+                         const float* presence_penalties, int64_t stream);
 /* Tensor::to_dtype between bf16/f16/f32 */
 void vra_cast(const void* in, void* out, int64_t numel, int32_t in_dtype, int32_t out_dtype,
               int64_t stream);
@@ -389,6 +406,22 @@ int32_t vra_engine_set_num_gpu_blocks(void* eng, int32_t num_gpu_blocks);
 int64_t vra_engine_add_request(void* eng, const uint32_t* h_prompt, int32_t n_prompt,
                                int32_t max_tokens, int32_t ignore_eos, const uint32_t* h_eos,
                                int32_t n_eos);
+/* SamplingParams as ModelRunner::sample reads them (config.rs:476-520, runner.rs:1405-1497).  Unset ("None") values:
+ * temperature < 0, top_k <= 0, top_p < 0, has_*_penalty = 0.  temperature == 0 is greedy.  With nothing set the
+ * reference's default applies: top-k 32, top-p 0.95, temperature 0.7 (Appendix A4).  As in the reference the strategy
+ * and penalties of a batch are those of its FIRST sequence at prefill, cached for the decode steps (Appendix A3);
+ * penalties act on decode steps once a sequence has sampled more than 128 tokens, over the last 128 (runner.rs:1519-1534). */
+typedef struct vra_sampling_params {
+  float temperature;
+  int32_t top_k;
+  float top_p;
+  int32_t has_frequency_penalty, has_presence_penalty;
+  float frequency_penalty, presence_penalty;
+} vra_sampling_params;
+/* vra_engine_add_request with sampling params (NULL = greedy, as vra_engine_add_request) */
+int64_t vra_engine_add_request_ex(void* eng, const uint32_t* h_prompt, int32_t n_prompt,
+                                  int32_t max_tokens, int32_t ignore_eos, const uint32_t* h_eos,
+                                  int32_t n_eos, const vra_sampling_params* sampling);
 /* one engine step (engine.rs:1693-1757): schedule → forward → postprocess.
  * returns number of sequences run (0 = idle), *h_is_prefill set. */
 int32_t vra_engine_step(void* eng, int32_t* h_is_prefill);

@@ -326,3 +326,65 @@ def argmax_f32(logits):
     out = np.empty(logits.shape[0], np.uint32)
     lib().orc_argmax_f32(_p(logits), logits.shape[0], logits.shape[1], _p(out))
     return out
+
+
+# ---------------------------------------------------------------- sampling (LogitsProcessor, src/utils/logits_processor.rs:72-345)
+def hash_unit(seed, rows):
+    """the uniforms of csrc/common.cuh vra_hash_unit(seed, row): (hash32 >> 8) / 2^24, float32"""
+    out = np.empty(rows, np.float32)
+    M = (1 << 64) - 1
+    for r in range(rows):
+        z = (seed * 0x9E3779B97F4A7C15 + r * 0xD1B54A32D192ED03 + 0x8CB92BA72F3D8DD7) & M
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        z = z ^ (z >> 31)
+        out[r] = np.float32((z >> 32) >> 8) * np.float32(1.0 / 16777216.0)
+    return out
+
+
+def sample_candidates(logits_row, top_k, top_p, temperature):
+    """sample_topk_topp / sample_topk / sample_topp restated (logits_processor.rs:72-197): probabilities of the full softmax,
+    the top_k most probable in descending order (stable: ties keep token order), top-p clamp.  Returns (ids, probs after the
+    clamp) — top_k <= 0 with a top_p means k = 256 (the reference's device-sampler convention, :206-213)."""
+    x = logits_row.astype(np.float32) * np.float32(1.0 / temperature)
+    e = np.exp(x - x.max(), dtype=np.float32)
+    prs = e / e.sum(dtype=np.float32)
+    has_p = 0.0 < top_p < 1.0
+    k = top_k if top_k > 0 else (256 if has_p else 0)
+    if k == 0:
+        return np.arange(len(prs), dtype=np.uint32), prs
+    k = min(k, len(prs), 256)
+    order = np.argsort(-x, kind="stable")[:k]            # descending value, ascending token id among ties
+    p = prs[order].copy()
+    sum_p = p.sum(dtype=np.float32)
+    if has_p and top_p < sum_p:
+        cumsum = np.float32(0.0)
+        for i in range(k):
+            if cumsum >= top_p:
+                p[i] = 0.0
+            else:
+                cumsum += p[i]
+    return order.astype(np.uint32), p
+
+
+def sample_draw(ids, probs, u01):
+    """WeightedIndex: u in [0, total), first index whose running sum exceeds u"""
+    run = np.cumsum(probs.astype(np.float64))
+    u = float(u01) * float(run[-1])
+    i = int(np.searchsorted(run, u, side="right"))
+    i = min(i, len(ids) - 1)
+    while probs[i] == 0.0 and i > 0:
+        i -= 1
+    return int(ids[i]), u, run
+
+
+def apply_penalties(logits, context, frequency_penalty, presence_penalty):
+    """apply_penalties + the guard of apply_batch_repeat_penalty (logits_processor.rs:288-345); one row"""
+    out = logits.astype(np.float32).copy()
+    if len(context) <= 1 or not ((frequency_penalty not in (0.0, 1.0)) or (presence_penalty not in (0.0, 1.0))):
+        return out
+    counts = np.zeros(len(out), np.float32)
+    for t in context:
+        if t < len(out):
+            counts[t] += 1.0
+    return (out - counts * np.float32(frequency_penalty) - (counts > 0).astype(np.float32) * np.float32(presence_penalty)).astype(np.float32)

@@ -38,6 +38,12 @@ class EngineConfig(C.Structure):
     ]
 
 
+class SamplingParams(C.Structure):
+    """vra_sampling_params (config.rs:476-520): unset = temperature < 0, top_k <= 0, top_p < 0, has_* = 0"""
+    _fields_ = [("temperature", c_f32), ("top_k", c_i32), ("top_p", c_f32), ("has_frequency_penalty", c_i32),
+                ("has_presence_penalty", c_i32), ("frequency_penalty", c_f32), ("presence_penalty", c_f32)]
+
+
 MISSING = []
 
 
@@ -108,6 +114,8 @@ def load():
     _sig(lib, "vra_dense_gemm", None, P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64)
     _sig(lib, "vra_argmax_f32", None, P, P, c_i32, c_i32, c_i64)
     _sig(lib, "vra_cast", None, P, P, c_i64, c_i32, c_i32, c_i64)
+    _sig(lib, "vra_sample", None, P, P, c_i32, c_i32, c_i32, c_f32, c_f32, c_u64, P, P, c_i64)
+    _sig(lib, "vra_apply_penalties", None, P, P, P, c_i32, c_i32, c_i32, P, P, c_i64)
     _sig(lib, "vra_fill_hash_u32", None, P, c_i64, c_u64, c_i64)
     _sig(lib, "vra_fill_uniform", None, P, c_i64, c_u64, c_f32, c_f32, c_i32, c_i64)
     _sig(lib, "vra_fill_normal", None, P, c_i64, c_u64, c_f32, c_f32, c_i32, c_i64)
@@ -179,6 +187,7 @@ def load():
     _sig(lib, "vra_engine_plan_kv_blocks", c_i64, P)
     _sig(lib, "vra_engine_set_num_gpu_blocks", c_i32, P, c_i32)
     _sig(lib, "vra_engine_add_request", c_i64, P, P, c_i32, c_i32, c_i32, P, c_i32)
+    _sig(lib, "vra_engine_add_request_ex", c_i64, P, P, c_i32, c_i32, c_i32, P, c_i32, P)
     _sig(lib, "vra_engine_step", c_i32, P, P)
     _sig(lib, "vra_engine_dry_schedule", c_i32, P, P, P)
     _sig(lib, "vra_engine_dry_commit", c_i32, P, P, c_i32)

@@ -341,3 +341,4 @@ __global__ __launch_bounds__(GS_THREADS, GS_MIN_WAVES_PER_SIMD) void gemv_q4s_ke
   if (have_next) asm volatile("" ::"v"(pf0), "v"(pf1));  // keep the prefetch loads alive until they have landed
   GEMV_STAMP(14);
 }
+

@@ -125,11 +125,22 @@ class Engine:
     def num_gpu_blocks(self):
         return self.L.vra_engine_num_gpu_blocks(self.h)
 
-    def add_request(self, prompt, max_tokens=16, ignore_eos=False, eos=()):
+    def add_request(self, prompt, max_tokens=16, ignore_eos=False, eos=(), sampling=None):
+        """sampling: None = greedy; dict(temperature=, top_k=, top_p=, frequency_penalty=, presence_penalty=) with missing
+        keys unset (an EMPTY dict is the reference's default: top-k 32, top-p 0.95, temperature 0.7 — Appendix A4)"""
         p = np.ascontiguousarray(prompt, np.uint32)
         e = np.ascontiguousarray(list(eos), np.uint32)
-        rid = self.L.vra_engine_add_request(self.h, p.ctypes.data_as(C.c_void_p), len(p), max_tokens, int(ignore_eos),
-                                            e.ctypes.data_as(C.c_void_p) if len(e) else None, len(e))
+        ep = e.ctypes.data_as(C.c_void_p) if len(e) else None
+        if sampling is None:
+            rid = self.L.vra_engine_add_request(self.h, p.ctypes.data_as(C.c_void_p), len(p), max_tokens, int(ignore_eos), ep, len(e))
+        else:
+            sp = _lib.SamplingParams(temperature=sampling.get("temperature", -1.0), top_k=sampling.get("top_k", 0) or 0,
+                                     top_p=sampling.get("top_p", -1.0), has_frequency_penalty=int("frequency_penalty" in sampling),
+                                     has_presence_penalty=int("presence_penalty" in sampling),
+                                     frequency_penalty=sampling.get("frequency_penalty", 0.0),
+                                     presence_penalty=sampling.get("presence_penalty", 0.0))
+            rid = self.L.vra_engine_add_request_ex(self.h, p.ctypes.data_as(C.c_void_p), len(p), max_tokens, int(ignore_eos), ep, len(e),
+                                                   C.byref(sp))
         return self._check(rid, "add_request")
 
     def step(self):
@@ -154,9 +165,9 @@ class Engine:
         self.L.vra_engine_request_times(self.h, rid, t)
         return dict(created_ms=t[0], first_token_ms=t[1], finished_ms=t[2])
 
-    def generate(self, prompts, max_tokens=16, ignore_eos=False, eos=()):
+    def generate(self, prompts, max_tokens=16, ignore_eos=False, eos=(), sampling=None):
         """LLMEngine::generate_sync (engine.rs:1291): run to completion, return outputs in request order."""
-        rids = [self.add_request(p, max_tokens, ignore_eos, eos) for p in prompts]
+        rids = [self.add_request(p, max_tokens, ignore_eos, eos, sampling) for p in prompts]
         while self.has_unfinished():
             self.step()
         return [self.output(r) for r in rids]

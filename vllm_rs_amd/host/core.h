@@ -36,7 +36,14 @@ struct Sequence {
   int block_size = 64;
   uint32_t last_token = 0;
   int prompt_len = 0;
-  // sampling params the path needs (greedy only; logits_processor.rs:67-70)
+  // SamplingParams (config.rs:476-520) as ModelRunner::sample reads them (runner.rs:1405-1497); "None" = unset:
+  // temperature < 0, top_k <= 0, top_p < 0, penalties not set
+  float temperature = 0.f;  // the plain request API is greedy (parity runs pass temperature = 0 explicitly, Appendix A4)
+  int top_k = 0;
+  float top_p = -1.f;
+  bool has_freq_penalty = false, has_pres_penalty = false;
+  float freq_penalty = 0.f, pres_penalty = 0.f;
+  std::vector<uint32_t> sampled;  // tokens sampled for this sequence so far (runner.rs:1549-1563 `seq_tokens`): penalty context
   int max_tokens = 16384;  // scheduler.rs:598 default
   bool ignore_eos = false;
   std::vector<uint32_t> eos;

@@ -17,6 +17,14 @@
 
 namespace vra {
 
+static inline uint32_t vra_hash32_host(uint64_t seed, uint64_t idx) {  // == vra_hash32 of csrc/common.cuh
+  uint64_t z = seed * 0x9E3779B97F4A7C15ull + idx * 0xD1B54A32D192ED03ull + 0x8CB92BA72F3D8DD7ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)(z >> 32);
+}
+
 struct RequestResult {
   std::vector<uint32_t> output;
   double created_ms = 0, first_token_ms = 0, finished_ms = 0;
@@ -45,6 +53,8 @@ class Engine {
     if (h_tokens_) (void)hipHostFree(h_tokens_);
     if (d_tokens_) (void)hipFree(d_tokens_);
     if (h_err_) (void)hipHostFree(h_err_);
+    if (h_pen_ctx_) (void)hipHostFree(h_pen_ctx_);
+    if (d_pen_) (void)hipFree(d_pen_);
     if (stream_) (void)hipStreamDestroy(stream_);
     // comm_ is caller-owned (vra_engine_set_comm): like every other buffer the caller hands over, it is not destroyed here
   }
@@ -70,6 +80,18 @@ class Engine {
   std::map<int64_t, hipGraphExec_t> graphs_;
   bool prepared_ = false;
   int64_t planned_blocks_ = 0;
+  // ---- sampling (ModelRunner::sample, runner.rs:1390-1570): strategy cached at prefill from the first sequence (A3)
+  struct CachedSampling {
+    int kind = 0;  // 0 ArgMax, 1 stochastic (All / TopK / TopP / TopKThenTopP by k and p)
+    int k = 0;
+    float p = -1.f, temperature = 1.f;
+    bool has_freq = false, has_pres = false;
+    float freq = 0.f, pres = 0.f;
+  } cached_sampling_;
+  uint64_t sample_calls_ = 0;
+  uint32_t* h_pen_ctx_ = nullptr;  // pinned [max_seqs, 128] tokens + [max_seqs] lengths + 2 x [max_seqs] penalties
+  uint8_t* d_pen_ = nullptr;
+  static constexpr int kPenaltyWindow = 128;
 
   bool fail(const std::string& m) {
     error = m;
@@ -162,6 +184,9 @@ class Engine {
     if (hipMalloc((void**)&d_tokens_, B * 4) != hipSuccess) return fail("token alloc failed");
     if (hipHostMalloc((void**)&h_tokens_, B * 4, hipHostMallocDefault) != hipSuccess) return fail("pinned alloc failed");
     if (hipHostMalloc((void**)&h_err_, 64, hipHostMallocDefault) != hipSuccess) return fail("pinned alloc failed");
+    const size_t pen_bytes = B * (kPenaltyWindow * 4 + 4 + 4 + 4);
+    if (hipHostMalloc((void**)&h_pen_ctx_, pen_bytes, hipHostMallocDefault) != hipSuccess) return fail("pinned alloc failed");
+    if (hipMalloc((void**)&d_pen_, pen_bytes) != hipSuccess) return fail("penalty staging alloc failed");
     memset(h_meta_, 0, meta_bytes_);
     memset(h_err_, 0, 64);
     if (ec_.use_graph && !warmup_capture()) return false;
@@ -366,6 +391,7 @@ class Engine {
         vra_argmax_f32(model_.logits(), d_tokens_, md.n_tokens, mc_.vocab_size, (int64_t)stream_);
       }
     }
+    if (!sample_stochastic(ids, is_prefill)) return false;
     if (hipMemcpyAsync(h_tokens_, d_tokens_, (size_t)B * 4, hipMemcpyDeviceToHost, stream_) != hipSuccess) return fail("token download failed");
     // the split-K exchange's error word rides along with the tokens: EVERY step is checked before its tokens are committed
     uint32_t* dev_err = vra_scratch_error_word();
@@ -384,6 +410,70 @@ class Engine {
       return fail("split-K exchange timed out on the device (results of this step are invalid)");
     }
     tokens->assign(h_tokens_, h_tokens_ + B);
+    return true;
+  }
+
+  // ---- ModelRunner::sample beyond argmax (runner.rs:1390-1570).  The forward (or its graph) has left f32 logits
+  // [B, V] and the argmax tokens; a stochastic strategy overwrites the tokens.
+  bool sample_stochastic(const std::vector<int>& ids, bool is_prefill) {
+    auto& run = sched_->running();
+    const int B = (int)ids.size();
+    if (is_prefill) {  // strategy and penalties of the batch = those of its first sequence, cached for decode (A3)
+      const Sequence& s0 = run[ids[0]];
+      CachedSampling c;
+      const bool has_t = s0.temperature >= 0.f;
+      const bool greedy = has_t && s0.temperature == 0.f;
+      const bool has_user = has_t || s0.top_k > 0 || (s0.top_p > 0.f && s0.top_p < 1.f);
+      if (greedy) {
+        c.kind = 0;
+      } else if (has_user) {  // LogitsProcessor::get_strategy (logits_processor.rs:48-65)
+        const bool t_ok = has_t && s0.temperature >= 1e-7f;
+        c.kind = t_ok ? 1 : 0;
+        c.temperature = t_ok ? s0.temperature : 1.f;
+        c.k = s0.top_k > 0 ? s0.top_k : 0;
+        c.p = s0.top_p >= 0.f ? s0.top_p : -1.f;
+      } else {  // no user config and no generation_config: top-k 32, top-p 0.95, temperature 0.7 (runner.rs:1475-1486, A4)
+        c.kind = 1, c.k = 32, c.p = 0.95f, c.temperature = 0.7f;
+      }
+      c.has_freq = s0.has_freq_penalty, c.freq = s0.freq_penalty;
+      c.has_pres = s0.has_pres_penalty, c.pres = s0.pres_penalty;
+      cached_sampling_ = c;
+    }
+    const CachedSampling& c = cached_sampling_;
+    const bool any_pen = c.has_freq || c.has_pres;
+    if (c.kind == 0 && !any_pen) return true;  // the argmax tokens stand
+    if (c.k > 256) return fail("top_k > 256 is not supported by the device sampler");
+    if (!is_prefill && any_pen) {  // runner.rs:1519-1541: last 128 sampled tokens once more than 128 were sampled
+      int32_t* h_len = (int32_t*)(h_pen_ctx_ + (size_t)max_seqs_ * kPenaltyWindow);
+      float* h_f = (float*)(h_len + max_seqs_);
+      float* h_p = h_f + max_seqs_;
+      bool any = false;
+      for (int b = 0; b < B; b++) {
+        const std::vector<uint32_t>& t = run[ids[b]].sampled;
+        const int n = (int)t.size() > kPenaltyWindow ? kPenaltyWindow : 0;
+        for (int i = 0; i < n; i++) h_pen_ctx_[(size_t)b * kPenaltyWindow + i] = t[t.size() - n + i];
+        h_len[b] = n;
+        h_f[b] = c.has_freq ? c.freq : 0.f;
+        h_p[b] = c.has_pres ? c.pres : 0.f;
+        any = any || n > 0;
+      }
+      if (any) {
+        const size_t bytes = (size_t)max_seqs_ * (kPenaltyWindow * 4 + 12);
+        if (hipMemcpyAsync(d_pen_, h_pen_ctx_, bytes, hipMemcpyHostToDevice, stream_) != hipSuccess) return fail("penalty upload failed");
+        const uint8_t* d_len = d_pen_ + (size_t)max_seqs_ * kPenaltyWindow * 4;
+        vra_apply_penalties(model_.logits(), (const uint32_t*)d_pen_, (const int32_t*)d_len, B, kPenaltyWindow, mc_.vocab_size,
+                            (const float*)(d_len + (size_t)max_seqs_ * 4), (const float*)(d_len + (size_t)max_seqs_ * 8), (int64_t)stream_);
+      }
+    }
+    if (c.kind == 0) {  // greedy with penalties
+      vra_argmax_f32(model_.logits(), d_tokens_, B, mc_.vocab_size, (int64_t)stream_);
+    } else {
+      // one fresh seed per call, as `self.rng.lock().next_u64()` (logits_processor.rs:223-226)
+      const uint64_t seed = (uint64_t)vra_hash32_host(ec_.seed ? ec_.seed : 1234, ++sample_calls_) << 32 | vra_hash32_host(ec_.seed + 1, sample_calls_);
+      vra_sample(model_.logits(), d_tokens_, B, mc_.vocab_size, c.k, c.p, c.temperature, seed, nullptr, nullptr, (int64_t)stream_);
+    }
+    const char* e = vra_last_error();
+    if (e && e[0]) return fail(std::string("sampler: ") + e);
     return true;
   }
 
@@ -418,6 +508,11 @@ class Engine {
   }
   void finish_step(const std::vector<int>& ids, bool is_prefill, const std::vector<uint32_t>& tokens) {
     const double now = now_ms();
+    if (cached_sampling_.has_freq || cached_sampling_.has_pres) {  // runner.rs:1549-1563: every sampled token is tracked
+      auto& run = sched_->running();
+      for (size_t i = 0; i < ids.size() && i < tokens.size(); i++)
+        if (ids[i] >= 0 && ids[i] < (int)run.size()) run[ids[i]].sampled.push_back(tokens[i]);
+    }
     if (is_prefill) {
       std::vector<int> keep, ridx;
       sched_->filter_prefill_finished(ids, &keep, &ridx);  // only fully-prefilled prompts keep their token (engine.rs:906-916)
@@ -645,6 +740,29 @@ extern "C" int64_t vra_engine_add_request(void* e, const uint32_t* h_prompt, int
   s.max_tokens = max_tokens > 0 ? max_tokens : 16384;
   s.ignore_eos = ignore_eos != 0;
   if (h_eos) s.eos.assign(h_eos, h_eos + n_eos);
+  int64_t id = en->sched_->add(std::move(s));
+  if (id < 0) en->error = en->sched_->last_error;
+  return id;
+}
+extern "C" int64_t vra_engine_add_request_ex(void* e, const uint32_t* h_prompt, int32_t n_prompt, int32_t max_tokens, int32_t ignore_eos,
+                                             const uint32_t* h_eos, int32_t n_eos, const vra_sampling_params* sp) {
+  auto* en = static_cast<Engine*>(e);
+  if (!en->sched_) {
+    en->error = "engine not finalised";
+    return -1;
+  }
+  vra::Sequence s;
+  s.token_ids.assign(h_prompt, h_prompt + n_prompt);
+  s.max_tokens = max_tokens > 0 ? max_tokens : 16384;
+  s.ignore_eos = ignore_eos != 0;
+  if (h_eos) s.eos.assign(h_eos, h_eos + n_eos);
+  if (sp) {
+    s.temperature = sp->temperature;
+    s.top_k = sp->top_k;
+    s.top_p = sp->top_p;
+    s.has_freq_penalty = sp->has_frequency_penalty != 0, s.freq_penalty = sp->frequency_penalty;
+    s.has_pres_penalty = sp->has_presence_penalty != 0, s.pres_penalty = sp->presence_penalty;
+  }
   int64_t id = en->sched_->add(std::move(s));
   if (id < 0) en->error = en->sched_->last_error;
   return id;
