@@ -33,6 +33,9 @@ extern "C" {
 #define VRA_BF16 0
 #define VRA_F16 1
 #define VRA_F32 2
+/* KV-cache storage format of the `kv_dtype` parameters: the activation dtype (16-bit cache) or one OCP FP8 E4M3 byte
+ * per element with scale 1.0 — the reference's `fp8_kvcache` option (kvcache_allocator.rs:188-193,776) */
+#define VRA_FP8_E4M3 3
 
 /* scale-tensor layouts accepted by vra_wna16_gemm */
 #define VRA_SCALES_ROWMAJOR 0 /* [K/g, N] as stored in the checkpoint                           */
@@ -165,7 +168,8 @@ void vra_fused_rope(void* q, void* k, const void* cos, const void* sin, const in
  * to slot_mapping[T] (i64, slot = block*BS + offset; negative slot = skip, Appendix A6). */
 void vra_reshape_and_cache(const void* k, const void* v, void* k_cache, void* v_cache,
                            const int64_t* slot_mapping, int32_t tokens, int32_t kv_heads,
-                           int32_t head_dim, int32_t block_size, int32_t dtype, int64_t stream);
+                           int32_t head_dim, int32_t block_size, int32_t dtype, int32_t kv_dtype,
+                           int64_t stream);
 /* decode half of PagedAttention::forward: one query token per sequence.
  * q/out [B,Hq,D]; block_tables [B,max_blocks] u32 (right-padded with 0, Appendix A5);
  * context_lens [B] u32 (includes the token just written). `workspace` must hold
@@ -177,7 +181,7 @@ void vra_paged_attention_decode(void* out, const void* q, const void* k_cache, c
                                 int32_t batch, int32_t q_heads, int32_t kv_heads, int32_t head_dim,
                                 int32_t block_size, int32_t max_blocks_per_seq,
                                 int32_t max_context_len, float scale, float softcap,
-                                void* workspace, int32_t dtype, int64_t stream);
+                                void* workspace, int32_t dtype, int32_t kv_dtype, int64_t stream);
 /* prefill half: causal varlen attention. q [T,Hq,D] with cu_seqlens_q [B+1] u32.
  * If block_tables != NULL keys/values are read from the paged cache (context_lens[b] tokens,
  * query i of sequence b sits at position context_lens[b]-len_q(b)+i) — this covers chunked prefill
@@ -190,7 +194,7 @@ void vra_paged_attention_prefill(void* out, const void* q, const void* k, const 
                                  int32_t batch, int32_t total_q, int32_t max_seqlen_q,
                                  int32_t q_heads, int32_t kv_heads, int32_t head_dim,
                                  int32_t block_size, int32_t max_blocks_per_seq, float scale,
-                                 float softcap, int32_t dtype, int64_t stream);
+                                 float softcap, int32_t dtype, int32_t kv_dtype, int64_t stream);
 /* Fused decode step of one layer's attention front half, ONE launch for what the reference issues as
  * FusedRope::apply_inplace + reshape_and_cache + PagedAttention::forward (attention.rs:745-820): rotary on q
  * and k (NeoX pairing, tables [n_pos, head_dim/2] in the model dtype), scatter of the rotated k and of v
@@ -204,7 +208,8 @@ void vra_rope_cache_attention_decode(void* out, const void* q, const void* k, co
                                      int32_t batch, int32_t q_heads, int32_t kv_heads,
                                      int32_t head_dim, int32_t block_size,
                                      int32_t max_blocks_per_seq, int32_t max_context_len,
-                                     float scale, void* workspace, int32_t dtype, int64_t stream);
+                                     float scale, void* workspace, int32_t dtype, int32_t kv_dtype,
+                                     int64_t stream);
 /* attention_rs::mask::causal_mask (src/models/layers/mask.rs:24-27): additive [L,L] mask,
  * 0 on/below the diagonal (and within sliding_window if >0), -inf above. */
 void vra_causal_mask(void* mask, int32_t len, int32_t sliding_window, int32_t dtype, int64_t stream);
@@ -341,6 +346,8 @@ typedef struct vra_engine_config {
   int32_t tp_rank, tp_world_size; /* tensor parallel */
   int32_t device;
   uint64_t seed;                  /* synthetic-weight seed */
+  int32_t fp8_kvcache;            /* EngineConfig.fp8_kvcache (config.rs:316): KV cache in FP8 E4M3, 1 byte per element */
+  int32_t reserved_;
 } vra_engine_config;
 
 /* Pure-host helpers (no GPU needed; also exported by libvra_host.so for CPU tests) */

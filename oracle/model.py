@@ -63,14 +63,17 @@ class OracleModel:
     per-rank partial sums rounded to the model dtype, which the all-reduce adds (here: in rank order, f32, one
     rounding — NCCL's order is unspecified), then bias, then the residual (distributed.rs:438-455, llama.rs:126,130)."""
 
-    def __init__(self, cfg, weights, num_blocks, block_size=64, tp_world=1):
+    def __init__(self, cfg, weights, num_blocks, block_size=64, tp_world=1, fp8_kvcache=False):
         self.cfg, self.w, self.BS = cfg, weights, block_size
         self.tp = tp_world
         dt = cfg["dtype"]
         self.dt = dt
+        # fp8 KV cache (EngineConfig.fp8_kvcache, kvcache_allocator.rs:188-193,776): one E4M3 byte per element, scale 1.0
+        self.kv_dt = orc.FP8 if fp8_kvcache else dt
         L, Hkv, D = cfg["num_layers"], cfg["num_kv_heads"], cfg["head_dim"]
-        self.kc = [np.zeros((num_blocks, Hkv, block_size, D), np.uint16) for _ in range(L)]
-        self.vc = [np.zeros((num_blocks, Hkv, D, block_size), np.uint16) for _ in range(L)]
+        cdt = np.uint8 if fp8_kvcache else np.uint16
+        self.kc = [np.zeros((num_blocks, Hkv, block_size, D), cdt) for _ in range(L)]
+        self.vc = [np.zeros((num_blocks, Hkv, D, block_size), cdt) for _ in range(L)]
         rs = cfg.get("rope_scaling") or {}
         st = {"": 0, "default": 0, "linear": 1, "llama3": 2}[rs.get("rope_type", "")]
         cos, sin = orc.rope_tables(D, cfg["rope_theta"], cfg["max_position_embeddings"], st, rs.get("factor", 1.0),
@@ -116,8 +119,8 @@ class OracleModel:
             v = L["v"](x).reshape(T, Hkv, D)
             q = orc.rope(q, self.cos, self.sin, positions, False, dt, dt)
             k = orc.rope(k, self.cos, self.sin, positions, False, dt, dt)
-            orc.reshape_and_cache(k, v, self.kc[li], self.vc[li], slot_mapping, self.BS, dt)
-            a = orc.paged_attention(q, self.kc[li], self.vc[li], block_tables, context_lens, cu_q, Hkv, self.BS, D ** -0.5, dt)
+            orc.reshape_and_cache(k, v, self.kc[li], self.vc[li], slot_mapping, self.BS, dt, self.kv_dt)
+            a = orc.paged_attention(q, self.kc[li], self.vc[li], block_tables, context_lens, cu_q, Hkv, self.BS, D ** -0.5, dt, kv_dt=self.kv_dt)
             h = self._row_parallel(L["o"], a.reshape(T, Hq * D), h)           # attn_output + residual
             x = orc.rms_norm(h, L["ffn_norm"], eps, dt)
             act = orc.silu_mul(L["gate"](x), L["up"](x), dt)

@@ -284,14 +284,31 @@ def rope(x, cos, sin, positions, is_interleaved, dt, table_dt, rot_dim=None):
 
 
 # ---------------------------------------------------------------- paged attention
-def reshape_and_cache(k, v, kc, vc, slots, BS, dt):
+FP8 = 3  # cache dtype id: one OCP E4M3 byte per element (uint8 arrays)
+
+
+def to_e4m3(x):
+    x = _c(x, np.float32)
+    out = np.empty(x.shape, np.uint8)
+    lib().orc_f32_to_e4m3(_p(x), _p(out), x.size)
+    return out
+
+
+def from_e4m3(x):
+    x = _c(x, np.uint8)
+    out = np.empty(x.shape, np.float32)
+    lib().orc_e4m3_to_f32(_p(x), _p(out), x.size)
+    return out
+
+
+def reshape_and_cache(k, v, kc, vc, slots, BS, dt, kv_dt=None):
     k, v = _c(k), _c(v)
     T, Hkv, D = k.shape
     slots = _c(slots, np.int64)
-    lib().orc_reshape_and_cache(_p(k), _p(v), _p(kc), _p(vc), _p(slots), T, Hkv, D, BS, dt)
+    lib().orc_reshape_and_cache_kv(_p(k), _p(v), _p(kc), _p(vc), _p(slots), T, Hkv, D, BS, dt, dt if kv_dt is None else kv_dt)
 
 
-def paged_attention(q, kc, vc, block_tables, context_lens, cu_q, Hkv, BS, scale, dt, softcap=0.0):
+def paged_attention(q, kc, vc, block_tables, context_lens, cu_q, Hkv, BS, scale, dt, softcap=0.0, kv_dt=None):
     q = _c(q)
     Tq, Hq, D = q.shape
     block_tables = _c(block_tables, np.uint32)
@@ -299,8 +316,8 @@ def paged_attention(q, kc, vc, block_tables, context_lens, cu_q, Hkv, BS, scale,
     cu_q = _c(cu_q, np.uint32)
     B, max_blocks = block_tables.shape
     out = np.empty(q.shape, np_dt(dt))
-    lib().orc_paged_attention(_p(out), _p(q), _p(kc), _p(vc), _p(block_tables), _p(context_lens), _p(cu_q), B, Hq, Hkv,
-                              D, BS, max_blocks, C.c_float(scale), C.c_float(softcap), dt)
+    lib().orc_paged_attention_kv(_p(out), _p(q), _p(kc), _p(vc), _p(block_tables), _p(context_lens), _p(cu_q), B, Hq, Hkv,
+                                 D, BS, max_blocks, C.c_float(scale), C.c_float(softcap), dt, dt if kv_dt is None else kv_dt)
     return out
 
 

@@ -79,7 +79,53 @@ static inline uint16_t f32_to_f16(float f) { /* RNE */
   if (r >= 0x7c00u) return (uint16_t)(s | 0x7c00u);
   return (uint16_t)(s | r);
 }
+/* OCP FP8 E4M3 ("e4m3fn": 4 exponent bits, bias 7, 3 mantissa bits, no infinities, 0x7f/0xff = NaN, max 448) — the storage
+ * format of the reference's fp8 KV cache (kvcache_allocator.rs:188-193,776: dtype_size 1, cache dtype U8), scale 1.0.
+ * Round to nearest even, saturating at +-448. */
+#define DT_FP8 3
+static inline uint8_t f32_to_e4m3(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  uint8_t s = (uint8_t)((u >> 24) & 0x80u);
+  uint32_t a = u & 0x7fffffffu;
+  if (a > 0x7f800000u) return (uint8_t)(s | 0x7f);
+  float af = fabsf(f);
+  if (af >= 448.0f) return (uint8_t)(s | 0x7e);
+  int e32 = (int)(a >> 23) - 127;
+  if (e32 >= -6) { /* normal in e4m3 */
+    uint32_t m = a & 0x7fffffu, r = m >> 20, rem = m & 0xfffffu;
+    if (rem > 0x80000u || (rem == 0x80000u && (r & 1))) r++;
+    int e = e32 + 7;
+    if (r == 8) {
+      r = 0;
+      e++;
+    }
+    if (e > 15 || (e == 15 && r == 7)) return (uint8_t)(s | 0x7e);
+    return (uint8_t)(s | (e << 3) | r);
+  }
+  /* subnormal: multiples of 2^-9; k = RNE(af * 512) in 0..8 (8 = the smallest normal, 0x08) */
+  float sc = af * 512.0f;
+  int k = (int)sc;
+  float frac = sc - (float)k;
+  if (frac > 0.5f || (frac == 0.5f && (k & 1))) k++;
+  return (uint8_t)(s | k);
+}
+static inline float e4m3_to_f32(uint8_t b) {
+  int e = (b >> 3) & 15, m = b & 7;
+  float v;
+  if ((b & 0x7f) == 0x7f) return NAN;
+  if (e == 0) v = (float)m * (1.0f / 512.0f);
+  else v = (1.0f + (float)m / 8.0f) * ldexpf(1.0f, e - 7);
+  return (b & 0x80) ? -v : v;
+}
+void orc_f32_to_e4m3(const float* in, uint8_t* out, int64_t n) {
+  for (int64_t i = 0; i < n; i++) out[i] = f32_to_e4m3(in[i]);
+}
+void orc_e4m3_to_f32(const uint8_t* in, float* out, int64_t n) {
+  for (int64_t i = 0; i < n; i++) out[i] = e4m3_to_f32(in[i]);
+}
 static inline float ld(const void* p, int64_t i, int dt) {
+  if (dt == DT_FP8) return e4m3_to_f32(((const uint8_t*)p)[i]);
   if (dt == DT_BF16) return bf16_to_f32(((const uint16_t*)p)[i]);
   if (dt == DT_F16) return f16_to_f32(((const uint16_t*)p)[i]);
   return ((const float*)p)[i];
@@ -90,7 +136,8 @@ static inline float rnd(float v, int dt) { /* round to storage dtype, return as 
   return v;
 }
 static inline void st(void* p, int64_t i, float v, int dt) {
-  if (dt == DT_BF16) ((uint16_t*)p)[i] = f32_to_bf16(v);
+  if (dt == DT_FP8) ((uint8_t*)p)[i] = f32_to_e4m3(v);
+  else if (dt == DT_BF16) ((uint16_t*)p)[i] = f32_to_bf16(v);
   else if (dt == DT_F16) ((uint16_t*)p)[i] = f32_to_f16(v);
   else ((float*)p)[i] = v;
 }
@@ -484,28 +531,41 @@ static inline int64_t vcache_off(int64_t slot, int h, int d, int Hkv, int BS, in
 }
 /* reshape_and_cache half of PagedAttention::forward (attention.rs:808-820), slots from
  * ModelRunner::prepare_* (runner.rs:1020-1038,1259-1262). Negative slot = skip (Appendix A6). */
-void orc_reshape_and_cache(const void* k, const void* v, void* kc, void* vc, const int64_t* slots,
-                           int T, int Hkv, int D, int BS, int dt) {
-  size_t es = dt == DT_F32 ? 4 : 2;
+void orc_reshape_and_cache_kv(const void* k, const void* v, void* kc, void* vc, const int64_t* slots,
+                              int T, int Hkv, int D, int BS, int dt, int kv_dt) {
   for (int t = 0; t < T; t++) {
     if (slots[t] < 0) continue;
-    for (int h = 0; h < Hkv; h++) {
-      int64_t o = cache_off(slots[t], h, Hkv, BS, D);
-      memcpy((char*)kc + o * es, (const char*)k + ((int64_t)t * Hkv + h) * D * es, D * es);
-      for (int d = 0; d < D; d++)
-        memcpy((char*)vc + vcache_off(slots[t], h, d, Hkv, BS, D) * es, (const char*)v + (((int64_t)t * Hkv + h) * D + d) * es, es);
-    }
+    for (int h = 0; h < Hkv; h++)
+      for (int d = 0; d < D; d++) {
+        int64_t src = ((int64_t)t * Hkv + h) * D + d;
+        st(kc, cache_off(slots[t], h, Hkv, BS, D) + d, ld(k, src, dt), kv_dt);  /* 16-bit -> 16-bit is the identity */
+        st(vc, vcache_off(slots[t], h, d, Hkv, BS, D), ld(v, src, dt), kv_dt);
+      }
   }
+}
+void orc_reshape_and_cache(const void* k, const void* v, void* kc, void* vc, const int64_t* slots,
+                           int T, int Hkv, int D, int BS, int dt) {
+  orc_reshape_and_cache_kv(k, v, kc, vc, slots, T, Hkv, D, BS, dt, dt);
 }
 /* Attention over the paged cache, covering both halves of PagedAttention::forward:
  *   decode  (runner.rs:1243-1388): cu_q == NULL, one query per sequence at position ctx-1;
  *   prefill (runner.rs:978-1241):  query i of sequence b at position ctx_b - len_q_b + i, causal.
  * scores = (q·k)*scale in f32-equivalent (double acc), optional softcap tanh, softmax, P·V, one
  * rounding of the output.  out/q [Tq,Hq,D].  block_tables [B,max_blocks] zero padded (A5). */
+void orc_paged_attention_kv(void* out, const void* q, const void* kc, const void* vc,
+                            const uint32_t* block_tables, const uint32_t* context_lens,
+                            const uint32_t* cu_q, int B, int Hq, int Hkv, int D, int BS, int max_blocks,
+                            float scale, float softcap, int dt, int kv_dt);
 void orc_paged_attention(void* out, const void* q, const void* kc, const void* vc,
                          const uint32_t* block_tables, const uint32_t* context_lens,
                          const uint32_t* cu_q, int B, int Hq, int Hkv, int D, int BS, int max_blocks,
                          float scale, float softcap, int dt) {
+  orc_paged_attention_kv(out, q, kc, vc, block_tables, context_lens, cu_q, B, Hq, Hkv, D, BS, max_blocks, scale, softcap, dt, dt);
+}
+void orc_paged_attention_kv(void* out, const void* q, const void* kc, const void* vc,
+                            const uint32_t* block_tables, const uint32_t* context_lens,
+                            const uint32_t* cu_q, int B, int Hq, int Hkv, int D, int BS, int max_blocks,
+                            float scale, float softcap, int dt, int kv_dt) {
   /* Same arithmetic as the plain loops (scores, softmax and P.V in double, keys in ascending order); the keys and values
    * of one (sequence, kv head) are widened to double once and the (query head, query row) pairs run in parallel, so that a
    * 32k-token context (BASELINE config 5) is a matter of seconds on the host cores. */
@@ -522,8 +582,8 @@ void orc_paged_attention(void* out, const void* q, const void* kc, const void* v
         int64_t slot = (int64_t)block_tables[(int64_t)b * max_blocks + j / BS] * BS + j % BS;
         int64_t o = cache_off(slot, hk, Hkv, BS, D);
         for (int d = 0; d < D; d++) {
-          Kd[(size_t)j * D + d] = (double)ld(kc, o + d, dt);
-          Vd[(size_t)j * D + d] = (double)ld(vc, vcache_off(slot, hk, d, Hkv, BS, D), dt);
+          Kd[(size_t)j * D + d] = (double)ld(kc, o + d, kv_dt);
+          Vd[(size_t)j * D + d] = (double)ld(vc, vcache_off(slot, hk, d, Hkv, BS, D), kv_dt);
         }
       }
 #pragma omp parallel

@@ -34,7 +34,7 @@ class EngineConfig(C.Structure):
         ("block_size", c_i32), ("max_num_seqs", c_i32), ("max_model_len", c_i32), ("num_gpu_blocks", c_i32),
         ("kv_fraction", c_f32), ("prefill_chunk", c_i32), ("enable_prefix_cache", c_i32),
         ("prefix_cache_fraction", c_f32), ("use_graph", c_i32), ("tp_rank", c_i32), ("tp_world_size", c_i32),
-        ("device", c_i32), ("seed", c_u64),
+        ("device", c_i32), ("seed", c_u64), ("fp8_kvcache", c_i32), ("reserved_", c_i32),
     ]
 
 
@@ -101,14 +101,14 @@ def load():
     _sig(lib, "vra_index_select_rows", None, P, P, P, c_i32, c_i32, c_i32, c_i64)
     _sig(lib, "vra_silu_mul", None, P, P, P, c_i64, c_i32, c_i64)
     _sig(lib, "vra_fused_rope", None, P, P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64)
-    _sig(lib, "vra_reshape_and_cache", None, P, P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64)
+    _sig(lib, "vra_reshape_and_cache", None, P, P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64)
     _sig(lib, "vra_paged_attention_decode_workspace_bytes", c_sz, c_i32, c_i32, c_i32, c_i32)
     _sig(lib, "vra_paged_attention_decode", None, P, P, P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
-         c_f32, c_f32, P, c_i32, c_i64)
+         c_f32, c_f32, P, c_i32, c_i32, c_i64)
     _sig(lib, "vra_paged_attention_prefill", None, P, P, P, P, P, P, P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32,
-         c_i32, c_i32, c_i32, c_f32, c_f32, c_i32, c_i64)
+         c_i32, c_i32, c_i32, c_f32, c_f32, c_i32, c_i32, c_i64)
     _sig(lib, "vra_rope_cache_attention_decode", None, P, P, P, P, P, P, P, P, P, P, P, P, c_i32, c_i32, c_i32, c_i32,
-         c_i32, c_i32, c_i32, c_f32, P, c_i32, c_i64)
+         c_i32, c_i32, c_i32, c_f32, P, c_i32, c_i32, c_i64)
     _sig(lib, "vra_causal_mask", None, P, c_i32, c_i32, c_i32, c_i64)
     _sig(lib, "vra_swap_blocks", None, P, P, P, c_i32, c_i64, c_i32, c_i64)
     _sig(lib, "vra_dense_gemm", None, P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64)

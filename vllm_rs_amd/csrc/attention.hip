@@ -13,6 +13,7 @@
 //        from the transposed V cache with two 8-byte loads.
 // Roofline: HBM (KV bytes) for decode; MFMA for long prefill.
 #include "common.cuh"
+#include "kvcache.cuh"
 
 #define PA_THREADS 256
 #define PA_WAVES 4
@@ -44,8 +45,9 @@ struct PagedAttnArgs {
   float* ws_ml;  // [B, Hq, nsplit, 2]
 };
 
-template <class DT, int D>
+template <class DT, int D, bool KV8>
 __global__ __launch_bounds__(PA_THREADS) void paged_attn_kernel(const PagedAttnArgs a) {
+  typedef typename KVT<KV8>::elem kv_t;  // cache element: 16-bit model dtype, or one E4M3 byte (paged mode only)
   constexpr int DJ = D / 32;  // k-steps of QK^T
   constexpr int DT16 = D / 16;  // output channel tiles
   __shared__ __attribute__((aligned(16))) float lds_o[PA_WAVES][16][D + 4];
@@ -119,19 +121,20 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_kernel(const PagedAttnA
   for (int t = 0; t < DT16; t++) o[t] = vra_zero_acc();
   float m_run = -INFINITY, l_run = 0.f;  // per lane: row rq; l_run is this lane's partial sum
 
-  const uint16_t* kcache = static_cast<const uint16_t*>(a.kc);
-  const uint16_t* vcache = static_cast<const uint16_t*>(a.vc);
+  const kv_t* kcache = static_cast<const kv_t*>(a.kc);
+  const kv_t* vcache = static_cast<const kv_t*>(a.vc);
   for (int tile = kv_w0; tile < kv_w1; tile++) {
     const int T0 = tile << 5;
     // ---- Sᵀ for the two 16-token halves
     f32x4 s0 = vra_zero_acc(), s1 = vra_zero_acc();
-    const uint16_t *krow0, *krow1;
+    const uint16_t *krow0 = nullptr, *krow1 = nullptr;  // contiguous (non-paged) k rows
+    const kv_t *kc0 = nullptr, *kc1 = nullptr;          // paged cache rows
     size_t vbase = 0;
     if (a.block_tables) {
       const uint32_t blk = a.block_tables[(size_t)b * a.max_blocks + T0 / a.BS];
       const int off = T0 % a.BS;
-      krow0 = kcache + (((size_t)blk * a.Hkv + hk) * a.BS + off + rq) * D;
-      krow1 = krow0 + 16 * D;
+      kc0 = kcache + (((size_t)blk * a.Hkv + hk) * a.BS + off + rq) * D;
+      kc1 = kc0 + 16 * D;
       vbase = (((size_t)blk * a.Hkv + hk) * D) * a.BS + off;
     } else {
       // fallback: rows beyond ctx are clamped (their scores are masked below)
@@ -142,8 +145,14 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_kernel(const PagedAttnA
     }
 #pragma unroll
     for (int j = 0; j < DJ; j++) {
-      const u32x4 k0 = *reinterpret_cast<const u32x4*>(krow0 + j * 32 + oct * 8);
-      const u32x4 k1 = *reinterpret_cast<const u32x4*>(krow1 + j * 32 + oct * 8);
+      u32x4 k0, k1;
+      if (a.block_tables) {
+        k0 = kv_load8<DT, KV8>(kc0 + j * 32 + oct * 8);
+        k1 = kv_load8<DT, KV8>(kc1 + j * 32 + oct * 8);
+      } else {
+        k0 = *reinterpret_cast<const u32x4*>(krow0 + j * 32 + oct * 8);
+        k1 = *reinterpret_cast<const u32x4*>(krow1 + j * 32 + oct * 8);
+      }
       DT::mfma(s0, __builtin_bit_cast(s16x8, k0), qf[j]);
       DT::mfma(s1, __builtin_bit_cast(s16x8, k1), qf[j]);
     }
@@ -199,9 +208,9 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_kernel(const PagedAttnA
     for (int t = 0; t < DT16; t++) {
       u32x4 vv;
       if (a.block_tables) {
-        const uint16_t* vp = vcache + vbase + (size_t)(t * 16 + rq) * a.BS + oct * 4;
-        const u32x2 lo = *reinterpret_cast<const u32x2*>(vp);
-        const u32x2 hi = *reinterpret_cast<const u32x2*>(vp + 16);
+        const kv_t* vp = vcache + vbase + (size_t)(t * 16 + rq) * a.BS + oct * 4;
+        const u32x2 lo = kv_load4<DT, KV8>(vp);
+        const u32x2 hi = kv_load4<DT, KV8>(vp + 16);
         vv = u32x4{lo[0], lo[1], hi[0], hi[1]};
       } else {
         const size_t kb = a.cu_k[b];
@@ -331,13 +340,14 @@ struct FusedDecodeArgs {
   unsigned long long* ts;  // VRA_ATTN_TS builds: per-workgroup wall-clock stamps
 };
 
-template <class DT, int D>
+template <class DT, int D, bool KV8>
 __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const FusedDecodeArgs a) {
+  typedef typename KVT<KV8>::elem kv_t;
   constexpr int DJ = D / 32, DT16 = D / 16, HALF = D / 2;
   __shared__ __attribute__((aligned(16))) float lds_o[FD_WAVES][16][D + 4];
   __shared__ float lds_ml[FD_WAVES][16][2];
-  __shared__ __attribute__((aligned(16))) uint16_t knew[D];
-  __shared__ __attribute__((aligned(16))) uint16_t vnew[D];
+  __shared__ __attribute__((aligned(16))) kv_t knew[D];       // the new token's K row in CACHE format (read like a cache row)
+  __shared__ __attribute__((aligned(16))) uint16_t vnew[D];   // its V column as the model-dtype values a cache read returns
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rq = lane & 15, oct = lane >> 4;
@@ -384,23 +394,29 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
       y2[e] = x2[e] * cs[e] + x1[e] * sn[e];
     }
     const u32x4 r1 = pack8<DT>(y1), r2 = pack8<DT>(y2);
-    *reinterpret_cast<u32x4*>(knew + tid * 8) = r1;
-    *reinterpret_cast<u32x4*>(knew + HALF + tid * 8) = r2;
+    kv_store8<DT, KV8>(knew + tid * 8, r1);
+    kv_store8<DT, KV8>(knew + HALF + tid * 8, r2);
     if (split == 0 && slot >= 0) {
-      uint16_t* kcp = static_cast<uint16_t*>(a.kc) + ((((size_t)slot_blk) * a.Hkv + hk) * a.BS + slot_off) * D;
-      *reinterpret_cast<u32x4*>(kcp + tid * 8) = r1;
-      *reinterpret_cast<u32x4*>(kcp + HALF + tid * 8) = r2;
+      kv_t* kcp = static_cast<kv_t*>(a.kc) + ((((size_t)slot_blk) * a.Hkv + hk) * a.BS + slot_off) * D;
+      kv_store8<DT, KV8>(kcp + tid * 8, r1);
+      kv_store8<DT, KV8>(kcp + HALF + tid * 8, r2);
     }
   } else if (tid >= 64 && tid < 64 + D / 8) {
     const int c = tid - 64;
     const u32x4 vv = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.v) + ((size_t)b * a.Hkv + hk) * D + c * 8);
-    *reinterpret_cast<u32x4*>(vnew + c * 8) = vv;
+    *reinterpret_cast<u32x4*>(vnew + c * 8) = kv_roundtrip8<DT, KV8>(vv);
     if (split == 0 && slot >= 0) {
-      uint16_t* vcp = static_cast<uint16_t*>(a.vc) + (((size_t)slot_blk) * a.Hkv + hk) * D * a.BS + slot_off;
+      kv_t* vcp = static_cast<kv_t*>(a.vc) + (((size_t)slot_blk) * a.Hkv + hk) * D * a.BS + slot_off;
+      if constexpr (KV8) {
+        const u32x2 q8 = vra_pack_e4m3x8<DT>(vv);
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
-        vcp[(size_t)(c * 8 + 2 * e) * a.BS] = (uint16_t)(vv[e] & 0xffffu);
-        vcp[(size_t)(c * 8 + 2 * e + 1) * a.BS] = (uint16_t)(vv[e] >> 16);
+        for (int e = 0; e < 8; e++) vcp[(size_t)(c * 8 + e) * a.BS] = (uint8_t)(q8[e >> 2] >> (8 * (e & 3)));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          vcp[(size_t)(c * 8 + 2 * e) * a.BS] = (uint16_t)(vv[e] & 0xffffu);
+          vcp[(size_t)(c * 8 + 2 * e + 1) * a.BS] = (uint16_t)(vv[e] >> 16);
+        }
       }
     }
   }
@@ -445,15 +461,15 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
 #pragma unroll
   for (int t = 0; t < DT16; t++) o[t] = vra_zero_acc();
   float m_run = -INFINITY, l_run = 0.f;
-  const uint16_t* kcache = static_cast<const uint16_t*>(a.kc);
-  const uint16_t* vcache = static_cast<const uint16_t*>(a.vc);
+  const kv_t* kcache = static_cast<const kv_t*>(a.kc);
+  const kv_t* vcache = static_cast<const kv_t*>(a.vc);
   for (int tile = kv_w0; tile < kv_w1; tile++) {
     const int T0 = tile << 5;
     const uint32_t blk = blk_cur;
     const int off = a.bs_shift >= 0 ? T0 & (a.BS - 1) : T0 % a.BS;
     blk_cur = a.block_tables[tile_blk_index(min(tile + 1, ntiles - 1))];  // next tile's block id, in flight during this tile
-    const uint16_t* krow0 = kcache + (((size_t)blk * a.Hkv + hk) * a.BS + off + rq) * D;
-    const uint16_t* krow1 = krow0 + 16 * D;
+    const kv_t* krow0 = kcache + (((size_t)blk * a.Hkv + hk) * a.BS + off + rq) * D;
+    const kv_t* krow1 = krow0 + 16 * D;
     const size_t vbase = (((size_t)blk * a.Hkv + hk) * D) * a.BS + off;
     const bool has_new = last >= T0 && last < T0 + 32;  // wave-uniform: the tile that holds the new token
     if (has_new) {  // its K row comes from LDS (the cache write of split 0 may not be visible yet)
@@ -463,16 +479,16 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
     u32x4 k0[DJ], k1[DJ];
 #pragma unroll
     for (int j = 0; j < DJ; j++) {
-      k0[j] = *reinterpret_cast<const u32x4*>(krow0 + j * 32 + oct * 8);
-      k1[j] = *reinterpret_cast<const u32x4*>(krow1 + j * 32 + oct * 8);
+      k0[j] = kv_load8<DT, KV8>(krow0 + j * 32 + oct * 8);
+      k1[j] = kv_load8<DT, KV8>(krow1 + j * 32 + oct * 8);
     }
     // V: issue the loads now (they only depend on the block table), consume after the softmax
     u32x2 vlo[DT16], vhi[DT16];
 #pragma unroll
     for (int t = 0; t < DT16; t++) {
-      const uint16_t* vp = vcache + vbase + (size_t)(t * 16 + rq) * a.BS + oct * 4;
-      vlo[t] = *reinterpret_cast<const u32x2*>(vp);
-      vhi[t] = *reinterpret_cast<const u32x2*>(vp + 16);
+      const kv_t* vp = vcache + vbase + (size_t)(t * 16 + rq) * a.BS + oct * 4;
+      vlo[t] = kv_load4<DT, KV8>(vp);
+      vhi[t] = kv_load4<DT, KV8>(vp + 16);
     }
     FD_STAMP(5);
     f32x4 s0 = vra_zero_acc(), s1 = vra_zero_acc();
@@ -621,18 +637,31 @@ extern "C" size_t vra_paged_attention_decode_workspace_bytes(int32_t max_batch, 
 }
 
 template <class DT>
-static void launch_attn(const PagedAttnArgs& a, int D, dim3 grid, hipStream_t st) {
-  if (D == 128) paged_attn_kernel<DT, 128><<<grid, PA_THREADS, 0, st>>>(a);
-  else if (D == 64) paged_attn_kernel<DT, 64><<<grid, PA_THREADS, 0, st>>>(a);
-  else vra_set_error("paged attention: head_dim %d not supported (64, 128)", D);
+static void launch_attn(const PagedAttnArgs& a, int D, bool kv8, dim3 grid, hipStream_t st) {
+  if (D == 128) {
+    if (kv8) paged_attn_kernel<DT, 128, true><<<grid, PA_THREADS, 0, st>>>(a);
+    else paged_attn_kernel<DT, 128, false><<<grid, PA_THREADS, 0, st>>>(a);
+  } else if (D == 64) {
+    if (kv8) paged_attn_kernel<DT, 64, true><<<grid, PA_THREADS, 0, st>>>(a);
+    else paged_attn_kernel<DT, 64, false><<<grid, PA_THREADS, 0, st>>>(a);
+  } else {
+    vra_set_error("paged attention: head_dim %d not supported (64, 128)", D);
+  }
+}
+// kv_dtype: the activation dtype (16-bit cache) or VRA_FP8_E4M3
+static bool kv_dtype_ok(const char* who, int dtype, int kv_dtype) {
+  if (kv_dtype == dtype || kv_dtype == VRA_FP8_E4M3) return true;
+  vra_set_error("%s: kv_dtype must be the activation dtype or VRA_FP8_E4M3", who);
+  return false;
 }
 
 extern "C" void vra_paged_attention_decode(void* out, const void* q, const void* k_cache, const void* v_cache,
                                            const uint32_t* block_tables, const uint32_t* context_lens, int32_t batch,
                                            int32_t q_heads, int32_t kv_heads, int32_t head_dim, int32_t block_size,
                                            int32_t max_blocks_per_seq, int32_t max_context_len, float scale, float softcap,
-                                           void* workspace, int32_t dtype, int64_t stream) {
+                                           void* workspace, int32_t dtype, int32_t kv_dtype, int64_t stream) {
   VRA_CHECK_ARG(dtype == VRA_BF16 || dtype == VRA_F16, "vra_paged_attention_decode: dtype must be bf16/f16");
+  if (!kv_dtype_ok("vra_paged_attention_decode", dtype, kv_dtype)) return;
   VRA_CHECK_ARG(block_size % 32 == 0, "vra_paged_attention_decode: block_size must be a multiple of 32");
   VRA_CHECK_ARG(q_heads % kv_heads == 0 && q_heads / kv_heads <= 16, "vra_paged_attention_decode: need Hq %% Hkv == 0 and group <= 16");
   VRA_CHECK_ARG(out && q && k_cache && v_cache && block_tables && context_lens, "vra_paged_attention_decode: null pointer");
@@ -658,8 +687,8 @@ extern "C" void vra_paged_attention_decode(void* out, const void* q, const void*
   a.ws_ml = a.ws_o ? a.ws_o + (size_t)batch * q_heads * a.nsplit * head_dim : nullptr;
   dim3 grid(a.nsplit, kv_heads, batch);
   hipStream_t st = as_stream(stream);
-  if (dtype == VRA_BF16) launch_attn<BF16>(a, head_dim, grid, st);
-  else launch_attn<F16>(a, head_dim, grid, st);
+  if (dtype == VRA_BF16) launch_attn<BF16>(a, head_dim, kv_dtype == VRA_FP8_E4M3, grid, st);
+  else launch_attn<F16>(a, head_dim, kv_dtype == VRA_FP8_E4M3, grid, st);
   if (a.nsplit > 1) {
     dim3 mg(q_heads, batch);
 #define VRA_MERGE(DT, DD) paged_attn_merge_kernel<DT, DD><<<mg, DD, 0, st>>>((uint16_t*)out, a.ws_o, a.ws_ml, q_heads, a.nsplit)
@@ -679,9 +708,11 @@ extern "C" void vra_paged_attention_prefill(void* out, const void* q, const void
                                             const uint32_t* cu_seqlens_q, const uint32_t* cu_seqlens_k, int32_t batch,
                                             int32_t total_q, int32_t max_seqlen_q, int32_t q_heads, int32_t kv_heads,
                                             int32_t head_dim, int32_t block_size, int32_t max_blocks_per_seq, float scale,
-                                            float softcap, int32_t dtype, int64_t stream) {
+                                            float softcap, int32_t dtype, int32_t kv_dtype, int64_t stream) {
   (void)total_q;
   VRA_CHECK_ARG(dtype == VRA_BF16 || dtype == VRA_F16, "vra_paged_attention_prefill: dtype must be bf16/f16");
+  if (!kv_dtype_ok("vra_paged_attention_prefill", dtype, kv_dtype)) return;
+  VRA_CHECK_ARG(block_tables || kv_dtype == dtype, "vra_paged_attention_prefill: contiguous k/v are in the activation dtype");
   VRA_CHECK_ARG(out && q && cu_seqlens_q, "vra_paged_attention_prefill: null pointer");
   VRA_CHECK_ARG(q_heads % kv_heads == 0, "vra_paged_attention_prefill: need Hq %% Hkv == 0");
   if (block_tables) {
@@ -713,8 +744,8 @@ extern "C" void vra_paged_attention_prefill(void* out, const void* q, const void
   a.decode = 0;
   a.nsplit = 1;
   dim3 grid((max_seqlen_q + 63) / 64, q_heads, batch);
-  if (dtype == VRA_BF16) launch_attn<BF16>(a, head_dim, grid, as_stream(stream));
-  else launch_attn<F16>(a, head_dim, grid, as_stream(stream));
+  if (dtype == VRA_BF16) launch_attn<BF16>(a, head_dim, kv_dtype == VRA_FP8_E4M3, grid, as_stream(stream));
+  else launch_attn<F16>(a, head_dim, kv_dtype == VRA_FP8_E4M3, grid, as_stream(stream));
 }
 
 extern "C" void vra_rope_cache_attention_decode(void* out, const void* q, const void* k, const void* v, void* k_cache, void* v_cache,
@@ -723,8 +754,9 @@ extern "C" void vra_rope_cache_attention_decode(void* out, const void* q, const 
                                                 const uint32_t* context_lens, int32_t batch, int32_t q_heads,
                                                 int32_t kv_heads, int32_t head_dim, int32_t block_size,
                                                 int32_t max_blocks_per_seq, int32_t max_context_len, float scale,
-                                                void* workspace, int32_t dtype, int64_t stream) {
+                                                void* workspace, int32_t dtype, int32_t kv_dtype, int64_t stream) {
   VRA_CHECK_ARG(dtype == VRA_BF16 || dtype == VRA_F16, "vra_rope_cache_attention_decode: dtype must be bf16/f16");
+  if (!kv_dtype_ok("vra_rope_cache_attention_decode", dtype, kv_dtype)) return;
   VRA_CHECK_ARG(out && q && k && v && k_cache && v_cache && cos && sin && positions && slot_mapping && block_tables && context_lens,
                 "vra_rope_cache_attention_decode: null pointer");
   VRA_CHECK_ARG(block_size % 32 == 0, "vra_rope_cache_attention_decode: block_size must be a multiple of 32");
@@ -759,7 +791,12 @@ extern "C" void vra_rope_cache_attention_decode(void* out, const void* q, const 
   a.ws_ml = a.ws_o ? a.ws_o + (size_t)batch * q_heads * a.nsplit * head_dim : nullptr;
   dim3 grid(a.nsplit, kv_heads, batch);
   hipStream_t st = as_stream(stream);
-#define VRA_FD(DT, DD) decode_attn_fused_kernel<DT, DD><<<grid, FD_THREADS, 0, st>>>(a)
+  const bool kv8 = kv_dtype == VRA_FP8_E4M3;
+#define VRA_FD(DT, DD)                                                                   \
+  do {                                                                                   \
+    if (kv8) decode_attn_fused_kernel<DT, DD, true><<<grid, FD_THREADS, 0, st>>>(a);     \
+    else decode_attn_fused_kernel<DT, DD, false><<<grid, FD_THREADS, 0, st>>>(a);        \
+  } while (0)
   if (dtype == VRA_BF16) {
     if (head_dim == 128) VRA_FD(BF16, 128);
     else VRA_FD(BF16, 64);

@@ -2,6 +2,7 @@
 // casts, block swap and the synthetic fills.  All HBM-bound streaming kernels: 16 B per lane,
 // f32 math, one rounding per reference op (include/vllm_rs_amd.h §B).
 #include "common.cuh"
+#include "kvcache.cuh"
 
 // ---------------------------------------------------------------- RMSNorm (+ residual add)
 // one workgroup (256 threads) per token row; row cached in registers between the two passes.
@@ -233,6 +234,31 @@ extern "C" void vra_fused_rope(void* q, void* k, const void* cos, const void* si
 // K cache [NB, Hkv, BS, D] (token rows contiguous), V cache [NB, Hkv, D, BS] (token-minor, so the
 // attention kernel reads 4/8 consecutive tokens of one channel with one load — the same choice the
 // reference makes for its non-flash V cache, kvcache_allocator.rs:170-173,844).
+// FP8 (E4M3) cache: same geometry with one byte per element (kvcache.cuh)
+template <class DT>
+__global__ __launch_bounds__(256) void reshape_and_cache_fp8_kernel(const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
+                                                                    uint8_t* __restrict__ kc, uint8_t* __restrict__ vc,
+                                                                    const int64_t* __restrict__ slots, int Hkv, int D, int BS) {
+  const int t = blockIdx.x;
+  const int64_t slot = slots[t];
+  if (slot < 0) return;
+  const int64_t blk = slot / BS;
+  const int off = (int)(slot % BS);
+  const int n = Hkv * D;
+  for (int i = threadIdx.x * 4; i < n; i += blockDim.x * 4) {  // D % 4 == 0: four channels of one head per thread
+    const int h = i / D, d = i - h * D;
+    float fk[4], fv[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      fk[e] = DT::to_f32(k[(size_t)t * n + i + e]);
+      fv[e] = DT::to_f32(v[(size_t)t * n + i + e]);
+    }
+    *reinterpret_cast<uint32_t*>(kc + ((blk * Hkv + h) * BS + off) * D + d) = vra_f32x4_to_e4m3(fk[0], fk[1], fk[2], fk[3]);
+    const uint32_t q = vra_f32x4_to_e4m3(fv[0], fv[1], fv[2], fv[3]);
+#pragma unroll
+    for (int e = 0; e < 4; e++) vc[((blk * Hkv + h) * D + d + e) * BS + off] = (uint8_t)(q >> (8 * e));
+  }
+}
 __global__ __launch_bounds__(256) void reshape_and_cache_kernel(const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
                                                                 uint16_t* __restrict__ kc, uint16_t* __restrict__ vc,
                                                                 const int64_t* __restrict__ slots, int Hkv, int D, int BS) {
@@ -250,9 +276,18 @@ __global__ __launch_bounds__(256) void reshape_and_cache_kernel(const uint16_t* 
 }
 extern "C" void vra_reshape_and_cache(const void* k, const void* v, void* k_cache, void* v_cache, const int64_t* slot_mapping,
                                       int32_t tokens, int32_t kv_heads, int32_t head_dim, int32_t block_size, int32_t dtype,
-                                      int64_t stream) {
+                                      int32_t kv_dtype, int64_t stream) {
   VRA_CHECK_ARG(dtype == VRA_BF16 || dtype == VRA_F16, "vra_reshape_and_cache: dtype must be bf16/f16");
+  VRA_CHECK_ARG(kv_dtype == dtype || kv_dtype == VRA_FP8_E4M3, "vra_reshape_and_cache: kv_dtype must be the activation dtype or VRA_FP8_E4M3");
   if (tokens <= 0) return;
+  if (kv_dtype == VRA_FP8_E4M3) {
+    VRA_CHECK_ARG(head_dim % 4 == 0, "vra_reshape_and_cache: head_dim %% 4 != 0");
+    if (dtype == VRA_BF16)
+      reshape_and_cache_fp8_kernel<BF16><<<tokens, 256, 0, as_stream(stream)>>>((const uint16_t*)k, (const uint16_t*)v, (uint8_t*)k_cache, (uint8_t*)v_cache, slot_mapping, kv_heads, head_dim, block_size);
+    else
+      reshape_and_cache_fp8_kernel<F16><<<tokens, 256, 0, as_stream(stream)>>>((const uint16_t*)k, (const uint16_t*)v, (uint8_t*)k_cache, (uint8_t*)v_cache, slot_mapping, kv_heads, head_dim, block_size);
+    return;
+  }
   reshape_and_cache_kernel<<<tokens, 256, 0, as_stream(stream)>>>((const uint16_t*)k, (const uint16_t*)v, (uint16_t*)k_cache, (uint16_t*)v_cache, slot_mapping, kv_heads, head_dim, block_size);
 }
 

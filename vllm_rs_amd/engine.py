@@ -58,7 +58,7 @@ TINYLLAMA = dict(arch="llama", hidden_size=2048, intermediate_size=5632, num_lay
 class Engine:
     def __init__(self, cfg, *, block_size=64, max_num_seqs=32, max_model_len=0, num_gpu_blocks=0, kv_fraction=0.0,
                  prefill_chunk=8192, enable_prefix_cache=False, use_graph=True, tp_rank=0, tp_world_size=1, device=0,
-                 seed=1234, comm=None):
+                 seed=1234, comm=None, fp8_kvcache=False):
         self.L = _lib.load()
         if self.L.vra_device_count() <= 0:
             raise RuntimeError("vllm_rs_amd.Engine needs a GPU: no HIP device visible (there is no CPU fallback)")
@@ -68,7 +68,7 @@ class Engine:
                                num_gpu_blocks=num_gpu_blocks, kv_fraction=kv_fraction, prefill_chunk=prefill_chunk,
                                enable_prefix_cache=int(enable_prefix_cache), prefix_cache_fraction=0.65,
                                use_graph=int(use_graph), tp_rank=tp_rank, tp_world_size=tp_world_size, device=device,
-                               seed=seed)
+                               seed=seed, fp8_kvcache=int(fp8_kvcache))
         self.h = self.L.vra_engine_create(C.byref(self.mc), C.byref(self.ec))
         if not self.h:
             raise RuntimeError("vra_engine_create failed")

@@ -14,7 +14,8 @@ extern "C" int64_t vra_kv_per_block_bytes(const vra_model_config* mc, const vra_
   const int world = ec->tp_world_size > 1 ? ec->tp_world_size : 1;
   const int hkv = mc->num_kv_heads >= world ? mc->num_kv_heads / world : 1;  // :127-141
   const int bs = ec->block_size > 0 ? ec->block_size : 64;
-  return (int64_t)bs * hkv * mc->head_dim * 2 /*dtype bytes*/ * 2 * mc->num_layers;
+  const int dtype_size = ec->fp8_kvcache ? 1 : 2;  // kvcache_allocator.rs:188-193
+  return (int64_t)bs * hkv * mc->head_dim * dtype_size * 2 * mc->num_layers;
 }
 // plan_allocation (:616-707): num_gpu_blocks = floor(free * kv_fraction / per_block_bytes);
 // kv_fraction default 0.5, 0.95 when max_model_len is given (:196-202,311-315).

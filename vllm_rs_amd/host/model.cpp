@@ -375,7 +375,7 @@ bool Model::finalize_weights() {
 bool Model::init_kv_cache(int num_blocks) {
   // per layer: K [NB, Hkv, BS, D], V [NB, Hkv, D, BS] (kvcache_allocator.rs:737-932 shapes, re-laid)
   num_blocks_ = num_blocks;
-  const size_t per = (size_t)num_blocks * hkv_ * ec_.block_size * mc_.head_dim * es_;
+  const size_t per = (size_t)num_blocks * hkv_ * ec_.block_size * mc_.head_dim * (ec_.fp8_kvcache ? 1 : es_);
   kc_.resize(mc_.num_layers);
   vc_.resize(mc_.num_layers);
   for (int l = 0; l < mc_.num_layers; l++) {
@@ -697,6 +697,7 @@ bool Model::forward(const InputMetadata& md, int64_t stream) {
     return false;
   }
   const float scale = 1.0f / sqrtf((float)D);
+  const int kv_dt = ec_.fp8_kvcache ? VRA_FP8_E4M3 : dt_;
   error.clear();
   // embed_forward (llama.rs:260-267)
   vra_embedding(md.input_ids, embed_, h_, T, H, mc_.vocab_size, dt_, stream);
@@ -711,14 +712,14 @@ bool Model::forward(const InputMetadata& md, int64_t stream) {
     }
     if (md.is_prefill) {
       vra_fused_rope(q_, k_, cos_, sin_, md.positions, T, hq_, hkv_, D, D, 0, dt_, dt_, stream);
-      vra_reshape_and_cache(k_, v_, kc_[l], vc_[l], md.slot_mapping, T, hkv_, D, ec_.block_size, dt_, stream);
+      vra_reshape_and_cache(k_, v_, kc_[l], vc_[l], md.slot_mapping, T, hkv_, D, ec_.block_size, dt_, kv_dt, stream);
       vra_paged_attention_prefill(attn_, q_, nullptr, nullptr, kc_[l], vc_[l], md.block_tables, md.context_lens, md.cu_seqlens_q,
-                                  nullptr, B, T, md.max_seqlen_q, hq_, hkv_, D, ec_.block_size, md.max_blocks, scale, 0.f, dt_, stream);
+                                  nullptr, B, T, md.max_seqlen_q, hq_, hkv_, D, ec_.block_size, md.max_blocks, scale, 0.f, dt_, kv_dt, stream);
     } else {
       // decode: RoPE + KV write + paged attention in ONE launch (three in the reference, attention.rs:745-820)
       vra_rope_cache_attention_decode(attn_, q_, k_, v_, kc_[l], vc_[l], cos_, sin_, md.positions, md.slot_mapping, md.block_tables,
                                       md.context_lens, B, hq_, hkv_, D, ec_.block_size, md.max_blocks, md.max_context_len, scale,
-                                      attn_ws_, dt_, stream);
+                                      attn_ws_, dt_, kv_dt, stream);
     }
     if (take_err(error, "attention")) return false;
     if (world_ > 1) {

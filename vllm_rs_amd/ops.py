@@ -225,12 +225,13 @@ class FusedRope:
 class PagedAttention:
     """attention_rs::PagedAttention (attention.rs:607-616,808-820): new(heads, D, scale, kv_heads, …)."""
 
-    def __init__(self, num_heads, head_dim, scale, num_kv_heads, block_size=64, dtype=BF16, softcap=0.0):
+    def __init__(self, num_heads, head_dim, scale, num_kv_heads, block_size=64, dtype=BF16, softcap=0.0, fp8_kvcache=False):
         self.Hq, self.D, self.scale, self.Hkv, self.BS, self.dtype, self.softcap = num_heads, head_dim, scale, num_kv_heads, block_size, dtype, softcap
+        self.kv_dtype = 3 if fp8_kvcache else dtype   # VRA_FP8_E4M3 (PagedAttention::new(.., fp8_kvcache), attention.rs:607-616)
 
     def reshape_and_cache(self, k, v, k_cache, v_cache, slot_mapping, tokens):
         lib().vra_reshape_and_cache(_ptr(k), _ptr(v), _ptr(k_cache), _ptr(v_cache), _ptr(slot_mapping), tokens, self.Hkv,
-                                    self.D, self.BS, self.dtype, 0)
+                                    self.D, self.BS, self.dtype, self.kv_dtype, 0)
         check_error()
 
     def forward_decode(self, q, k_cache, v_cache, block_tables, context_lens, batch, max_blocks, max_context_len,
@@ -238,7 +239,7 @@ class PagedAttention:
         out = DevBuf(batch * self.Hq * self.D * 2)
         lib().vra_paged_attention_decode(out.ptr, _ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(block_tables),
                                          _ptr(context_lens), batch, self.Hq, self.Hkv, self.D, self.BS, max_blocks,
-                                         max_context_len, self.scale, self.softcap, _ptr(workspace), self.dtype, 0)
+                                         max_context_len, self.scale, self.softcap, _ptr(workspace), self.dtype, self.kv_dtype, 0)
         check_error()
         return out
 
@@ -249,7 +250,7 @@ class PagedAttention:
         lib().vra_rope_cache_attention_decode(out.ptr, _ptr(q), _ptr(k), _ptr(v), _ptr(k_cache), _ptr(v_cache), _ptr(cos), _ptr(sin),
                                               _ptr(positions), _ptr(slot_mapping), _ptr(block_tables), _ptr(context_lens), batch,
                                               self.Hq, self.Hkv, self.D, self.BS, max_blocks, max_context_len, self.scale,
-                                              _ptr(workspace), self.dtype, 0)
+                                              _ptr(workspace), self.dtype, self.kv_dtype, 0)
         check_error()
         return out
 
@@ -259,6 +260,6 @@ class PagedAttention:
         lib().vra_paged_attention_prefill(out.ptr, _ptr(q), _ptr(k), _ptr(v), _ptr(k_cache), _ptr(v_cache),
                                           _ptr(block_tables), _ptr(context_lens), _ptr(cu_q), _ptr(cu_k), batch, total_q,
                                           max_seqlen_q, self.Hq, self.Hkv, self.D, self.BS, max_blocks, self.scale,
-                                          self.softcap, self.dtype, 0)
+                                          self.softcap, self.dtype, self.kv_dtype, 0)
         check_error()
         return out
