@@ -140,3 +140,66 @@ def test_gemv_s_repeated_launches_are_bitwise_stable():
     a = ops.wna16_gemm(xd, t, sc, None, M, K, N, 128).numpy(np.uint16, (M, N))
     for _ in range(5):
         assert np.array_equal(a, ops.wna16_gemm(xd, t, sc, None, M, K, N, 128).numpy(np.uint16, (M, N)))
+
+
+# ---------------------------------------------------------------------------------------------
+# kernel W (csrc/gemv_q4w.cuh): 5..32 rows, K <= 4096 — x fragments in registers, weights dequantised once for all rows
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M", [5, 8, 16, 17, 31, 32])
+@pytest.mark.parametrize("K,N", [(4096, 4096), (4096, 6144), (3584, 4608), (1024, 8192), (2048, 2064)])
+def test_gemv_w_gptq_real_widths(M, K, N):
+    r = rng(M * 11 + K + N)
+    q = make_quant(r, K, N, 128, BF16, False)
+    x = rand_dt(r, (M, K), BF16)
+    out = ops.wna16_gemm(ops.dev(x), _tiled(q), ops.dev(q["scales"]), None, M, K, N, 128)
+    ref = orc.wna16_gemm(x, q["idx"], None, q["scales"], 128, BF16)
+    assert_close_dt(out.numpy(np.uint16, (M, N)), ref, BF16, name=f"gemv_w M={M} K={K} N={N}", abs_floor=2e-3)
+
+
+@pytest.mark.parametrize("M", [7, 32])
+@pytest.mark.parametrize("dt,awq,gs,layout", [(BF16, True, 128, 0), (F16, True, 128, 1), (F16, False, 128, 0), (BF16, False, 128, 1), (BF16, False, 256, 0),
+                                              (BF16, True, -1, 0)])
+def test_gemv_w_formats_bias_residual(M, dt, awq, gs, layout):
+    K, N = 3584, 4608
+    r = rng(M + gs + layout * 3 + awq + 100)
+    q = make_quant(r, K, N, gs, dt, awq)
+    x, bias, res = rand_dt(r, (M, K), dt), rand_dt(r, (N,), dt), rand_dt(r, (M, N), dt)
+    sc = orc.marlin_permute_scales(q["scales"], grouped=True) if layout == 1 else q["scales"]
+    out = ops.wna16_gemm(ops.dev(x), _tiled(q, awq), ops.dev(sc), ops.dev(q["qzeros"]) if awq else None, M, K, N, gs, awq, layout, ops.dev(bias), ops.dev(res),
+                         dtype=dt)
+    ref = orc.wna16_gemm(x, q["idx"], q["zeros"], q["scales"], gs, dt, bias, res)
+    g0 = orc.from_dt(orc.wna16_gemm(x, q["idx"], q["zeros"], q["scales"], gs, dt), dt)
+    mag = np.maximum(np.abs(g0), np.abs(g0 + orc.from_dt(bias, dt)[None, :]))
+    assert_close_dt(out.numpy(np.uint16, (M, N)), ref, dt, max_ulp=2.0, name=f"gemv_w formats dt={dt} awq={awq} gs={gs} layout={layout}", mag=mag)
+
+
+@pytest.mark.parametrize("M", [6, 16, 32])
+def test_gemv_w_fused_rms_norm_qkv_shape(M):
+    K, N, dt = 4096, 6144, BF16
+    r = rng(M + 55)
+    q = make_quant(r, K, N, 128, dt, False)
+    x, nw = rand_dt(r, (M, K), dt, 2.0), orc.to_dt((1.0 + 0.1 * r.standard_normal(K)).astype(np.float32), dt)
+    bias = rand_dt(r, (N,), dt)
+    out = ops.rms_norm_wna16_gemm(ops.dev(x), ops.dev(nw), 1e-5, _tiled(q), ops.dev(q["scales"]), None, M, K, N, 128, bias=ops.dev(bias), dtype=dt)
+    xn = orc.rms_norm(x, nw, 1e-5, dt)
+    ref = orc.wna16_gemm(xn, q["idx"], None, q["scales"], 128, dt, bias)
+    g0 = np.abs(orc.from_dt(orc.wna16_gemm(xn, q["idx"], None, q["scales"], 128, dt), dt))
+    assert_close_dt(out.numpy(np.uint16, (M, N)), ref, dt, max_ulp=2.0, max_mismatch_frac=0.03, name="gemv_w fused norm", mag=g0, abs_floor=2e-3)
+
+
+@pytest.mark.parametrize("M", [5, 12, 16])
+@pytest.mark.parametrize("awq", [False, True])
+def test_gemv_w_gate_up_pair(M, awq):
+    K, N = 4096, 14336
+    r = rng(M + K + awq)
+    qg, qu = make_quant(r, K, N, 128, BF16, awq), make_quant(r, K, N, 128, BF16, awq)
+    x, nw = rand_dt(r, (M, K), BF16, 2.0), orc.to_dt((1.0 + 0.1 * r.standard_normal(K)).astype(np.float32), BF16)
+    z = (lambda q: ops.dev(q["qzeros"])) if awq else (lambda q: None)
+    out = ops.rms_norm_wna16_gate_up_silu(ops.dev(x), ops.dev(nw), 1e-5, _tiled(qg, awq), ops.dev(qg["scales"]), z(qg), _tiled(qu, awq), ops.dev(qu["scales"]), z(qu),
+                                          M, K, N, 128, awq)
+    xn = orc.rms_norm(x, nw, 1e-5, BF16)
+    g = orc.wna16_gemm(xn, qg["idx"], qg["zeros"], qg["scales"], 128, BF16)
+    u = orc.wna16_gemm(xn, qu["idx"], qu["zeros"], qu["scales"], 128, BF16)
+    # gate and up each carry a possible 1-ulp flip (f32 vs f64 accumulation, one flipped normalised activation): their product moves
+    # by up to the sum of both relative errors, silu's slope adds a little: 4 ulps over 230k outputs
+    assert_close_dt(out.numpy(np.uint16, (M, N)), orc.silu_mul(g, u, BF16), BF16, max_ulp=4.0, max_mismatch_frac=0.05, name="gemv_w gate/up", abs_floor=8e-3)

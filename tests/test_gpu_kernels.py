@@ -156,19 +156,22 @@ def test_gate_up_silu_many_rows(awq):
     assert_close_dt(out.numpy(np.uint16, (M, N)), ref, BF16, max_ulp=3.0, max_mismatch_frac=0.04, name="kernel D gate_up_silu", abs_floor=4e-3)
 
 
-def test_gemm_half_q_half_alt():
+@pytest.mark.parametrize("gs,with_g_idx", [(128, True), (64, True), (64, False), (32, False), (128, False)])
+def test_gemm_half_q_half_alt(gs, with_g_idx):
+    """the non-Marlin GPTQ path (gptq.rs:181-198): asymmetric zeros (stored z-1), groups from g_idx — or, without it, from the
+    extent of the scales allocation (the reference's signature carries no group size)"""
     M, K, N = 3, 256, 128
-    r = rng(5)
-    q = make_quant(r, K, N, 128, F16, False)
+    r = rng(5 + gs)
+    q = make_quant(r, K, N, gs, F16, False)
     zeros = r.integers(0, 15, size=(q["G"], N), dtype=np.uint8)  # stored value (z-1)
     qz = np.zeros((q["G"], N // 8), np.uint32)
     for n in range(N):
         qz[:, n // 8] |= zeros[:, n].astype(np.uint32) << (4 * (n % 8))
     x = rand_dt(r, (M, K), F16)
-    g_idx = (np.arange(K) // 128).astype(np.int32)
-    out = ops.gptq_matmul(ops.dev(x), ops.dev(q["qweight"]), ops.dev(q["scales"]), ops.dev(qz), ops.dev(g_idx), None, 4, 128, False, M, K, N, F16)
+    g_idx = ops.dev((np.arange(K) // gs).astype(np.int32)) if with_g_idx else None
+    out = ops.gptq_matmul(ops.dev(x), ops.dev(q["qweight"]), ops.dev(q["scales"]), ops.dev(qz), g_idx, None, 4, gs, False, M, K, N, F16)
     got = out.numpy(np.uint16, (M, N))
-    ref = orc.wna16_gemm(x, q["idx"], orc.gptq_unpack_zeros(qz, q["G"], N), q["scales"], 128, F16)
+    ref = orc.wna16_gemm(x, q["idx"], orc.gptq_unpack_zeros(qz, q["G"], N), q["scales"], gs, F16)
     assert_close_dt(got, ref, F16, name="gptq alt", abs_floor=2e-3)
 
 

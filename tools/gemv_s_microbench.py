@@ -9,7 +9,7 @@ from vllm_rs_amd import engine as E
 cfg = dict(E.LLAMA3_8B)
 cfg["num_layers"] = 8
 eng = E.Engine(cfg, max_num_seqs=8, max_model_len=2048, num_gpu_blocks=64, use_graph=False).init_synthetic()
-tag = " ".join(f"{k}={os.environ[k]}" for k in ("VRA_LIB", "VRA_EXP", "VRA_GS_GRID", "VRA_NO_GEMV_S") if k in os.environ) or "default"
+tag = " ".join(f"{k}={os.environ[k]}" for k in ("VRA_LIB", "VRA_EXP", "VRA_GS_GRID", "VRA_NO_GEMV_S", "VRA_NO_GEMV_W") if k in os.environ) or "default"
 for M in [int(a) for a in sys.argv[1:]] or [1]:
     tot_ms = tot_b = 0
     parts = []

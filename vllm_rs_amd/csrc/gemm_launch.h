@@ -5,6 +5,7 @@
 #include "gemm_q4.cuh"
 #include "gemm_q4_big.cuh"
 #include "gemv_q4s.cuh"
+#include "gemv_q4w.cuh"
 bool vra_gemv_fits(bool int4, int nbw, int M, int K, int group_size);
 void vra_launch_gemv(const GemvArgs& a, bool int4, int dtype, int64_t stream);
 void vra_launch_skinny(GemmBArgs a, bool int4, bool dual, int dtype, int64_t stream);
@@ -22,3 +23,6 @@ void vra_gemv_s_plan(int n_units, int* grid, int* q, int* r);
 void vra_launch_gemv_s(GemvSArgs a, int ns, int group_size, bool awq, int dtype, int64_t stream);
 void vra_scales_to_unit_major(const void* scales, void* out, int G, int N, int unit0, int64_t stream);
 void vra_zeros_to_unit_major(const uint32_t* zeros, uint32_t* out, int G, int N, int unit0, int64_t stream);
+// kernel W (gemv_q4w.cuh): int4, 5..32 rows, K <= 4096, same argument block and unit distribution as kernel E
+bool vra_gemv_w_fits(int ns, int M, int K, int group_size, int n_units, bool has_res);
+void vra_launch_gemv_w(GemvSArgs a, int ns, int group_size, bool awq, int dtype, int64_t stream);

@@ -1,0 +1,313 @@
+// gemv_q4w.cuh — "kernel W": int4 GEMM for decode batches of 5..32 rows and K <= 4096 (q/k/v, o_proj, gate/up of the 7-8B
+// shapes), on the unit distribution of kernel E (gemv_q4s.cuh): one workgroup per CU, a contiguous run of units (16-column
+// n-blocks, or gate/up pairs) per workgroup.  EIGHT waves here (two per SIMD: 256 VGPRs each), every wave streaming the
+// k-tiles w, w+8, w+16, w+24 of each unit through a 4-deep register ring (4 KiB per wave, 32 KiB per CU in flight as in E).
+// What changes with the rows:
+//   * x lives in REGISTERS: a wave only ever needs the 32 rows x 512 columns of its own four k-tiles, as MFMA A fragments
+//     (lane (oct, nn): row mt*16 + nn, 8 columns) — 4 tiles x 4 k-steps x MT m-tiles x 4 VGPRs (128 at 32 rows; with 16 waves
+//     of 128 VGPRs the fragments of two tiles already pushed hipcc into spilling them right behind their loads).  Nothing is
+//     staged through LDS, no workgroup ever holds the 256 KiB of a 32-row x (kernel C stages it in K-chunks with a barrier per
+//     chunk), and the fused RMSNorm costs ONE barrier (the 8 x 32 table of partial Σx²), like kernel E.
+//   * every dequantised weight fragment feeds MT MFMAs (one per 16-row m-tile): the int4 -> bf16 work is done once for all rows.
+//   * the partial tiles of a unit (8 waves x NS x MT KiB) meet in a double-buffered LDS slab behind one barrier per unit; the
+//     first 16*MT*16 threads sum them in fixed order, run the epilogue from LDS-resident bias / residual and park the results in
+//     LDS — the main loop contains no global access besides the weight ring (a load or a store there would turn hipcc's ring
+//     waits into vmcnt(0), gemv_q4.cuh) — and everything is stored after the stream has ended.
+// Roofline: HBM (weights once; x is re-read by every workgroup from L2: M*K*2 bytes x grid).  Same arithmetic contract as the
+// other int4 kernels (wna16.cuh): exact product, one rounding.
+#pragma once
+#include "gemv_q4s.cuh"
+
+#define GW_MAX_UNITS 8
+#define GW_WAVES 8
+#define GW_THREADS (GW_WAVES * 64)
+#define GW_TPW 4  // k-tiles per wave and unit: w + 8*ti (K <= 4096)
+
+static inline size_t gemv_q4w_lds_bytes(int ns, int mt, int max_units, bool has_res) {
+  size_t b = (size_t)2 * GW_WAVES * ns * mt * 1024;           // double-buffered partial tiles
+  b += (size_t)GW_WAVES * 32 * 4;                              // Σx² partials [wave][32 rows]
+  b += (size_t)GW_WAVES * GW_TPW * 32 * 4;                     // Σx per (wave, tile, row)
+  b += (size_t)max_units * mt * 16 * 16 * 2;                   // finished outputs (16-bit), stored after the stream
+  if (has_res) b += (size_t)max_units * mt * 16 * 16 * 2;      // residual tiles
+  b += (size_t)max_units * ns * 16 * 2 + 64;                   // bias values
+  return b;
+}
+
+// NS = streams (2: gate/up pair with SiLU*mul), MT = 16-row m-tiles (1: up to 16 rows, 2: up to 32), NORM = fused RMSNorm
+// (compile time: a run-time branch around code that rewrites 128 fragment registers ends in spills at its merge point)
+template <class DT, int NS, int MT, bool AWQ, bool NORM>
+__global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int D = GW_TPW;  // ring slot = the wave's tile index within a unit (w + 8*ti)
+  asm volatile("" ::"s"(a.x), "s"(a.x_ld), "s"(a.norm_w), "s"(a.K), "s"(a.M), "s"(a.KT), "s"(a.gsh), "s"(a.units_q), "s"(a.units_r), "s"(a.w[0]),
+               "s"(a.scales[0]), "s"(a.s_grp_stride), "s"(a.s_unit_stride), "s"(a.marlin), "s"(a.residual), "s"(a.res_ld), "s"(a.nseg),
+               "s"(a.seg[0].out), "s"(a.seg[0].bias), "s"(a.seg[0].out_ld), "s"(a.seg[1].unit_start), "s"(a.seg[2].unit_start));
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nn = lane & 15, oct = lane >> 4;
+  const int M = a.M, KT = a.KT;
+  const int wg = (int)blockIdx.x;
+  const int u0 = wg * a.units_q + min(wg, a.units_r);
+  const int nu = a.units_q + (wg < a.units_r ? 1 : 0);
+  const int max_u = a.units_q + (a.units_r ? 1 : 0);
+  const bool has_res = a.residual != nullptr;
+
+  // ---- LDS carve-up
+  f32x4* red = reinterpret_cast<f32x4*>(smem);  // [2][wave][NS][MT][64 lanes]
+  size_t off = (size_t)2 * GW_WAVES * NS * MT * 1024;
+  float* part = reinterpret_cast<float*>(smem + off);  // [wave][32]
+  off += (size_t)GW_WAVES * 32 * 4;
+  float* xsum = reinterpret_cast<float*>(smem + off) + (size_t)wave * GW_TPW * 32;  // this wave's [4 tiles][32 rows]
+  off += (size_t)GW_WAVES * GW_TPW * 32 * 4;
+  uint16_t* outs = reinterpret_cast<uint16_t*>(smem + off);  // [unit][MT*16 rows][16 cols]
+  off += (size_t)max_u * MT * 256 * 2;
+  uint16_t* ress = reinterpret_cast<uint16_t*>(smem + off);
+  if (has_res) off += (size_t)max_u * MT * 256 * 2;
+  uint16_t* biass = reinterpret_cast<uint16_t*>(smem + off);  // [unit][NS][16]
+
+  // ---- epilogue operands of all units of this workgroup -> LDS (nothing but the weight ring touches memory in the main loop)
+  // thread t: (unit t >> 9 for MT = 2, row, column) covers 16*MT rows x 16 columns per unit
+  constexpr int OPU = MT * 256;  // outputs per unit
+  auto seg_of = [&](int unit, void*& out, const void*& bias, int& ld, int& col0) {
+    const bool s1 = a.nseg > 1 && NS == 1 && unit >= a.seg[1].unit_start, s2 = a.nseg > 2 && NS == 1 && unit >= a.seg[2].unit_start;
+    out = s2 ? a.seg[2].out : (s1 ? a.seg[1].out : a.seg[0].out);
+    bias = s2 ? a.seg[2].bias : (s1 ? a.seg[1].bias : a.seg[0].bias);
+    ld = s2 ? a.seg[2].out_ld : (s1 ? a.seg[1].out_ld : a.seg[0].out_ld);
+    col0 = (unit - (s2 ? a.seg[2].unit_start : (s1 ? a.seg[1].unit_start : a.seg[0].unit_start))) * 16;
+  };
+  // (requested and written BEFORE the x fragments are loaded: their registers are gone by then — at 32 rows the fragments
+  // alone take half of the wave's 128 VGPRs; skipped entirely when the launch has neither bias nor residual)
+  const bool any_bias = a.seg[0].bias || (a.nseg > 1 && a.seg[1].bias) || (a.nseg > 2 && a.seg[2].bias);
+  if (has_res || any_bias) {
+    constexpr int EPI_IT = GW_MAX_UNITS * OPU / GW_THREADS;
+    uint16_t e_res[EPI_IT], e_b0[EPI_IT], e_b1[EPI_IT];
+#pragma unroll
+    for (int it = 0; it < EPI_IT; it++) {
+      const int idx = tid + it * GW_THREADS;
+      e_res[it] = e_b0[it] = e_b1[it] = 0;
+      if (idx < nu * OPU) {
+        const int ui = idx / OPU, rem = idx - ui * OPU, row = rem >> 4, col = rem & 15;
+        void* o_;
+        const void* b_;
+        int ld_, c0;
+        seg_of(u0 + ui, o_, b_, ld_, c0);
+        if (has_res && row < M) e_res[it] = static_cast<const uint16_t*>(a.residual)[(size_t)row * a.res_ld + c0 + col];
+        if (row == 0) {
+          if (b_) e_b0[it] = static_cast<const uint16_t*>(b_)[c0 + col];
+          if (NS == 2 && a.seg[1].bias) e_b1[it] = static_cast<const uint16_t*>(a.seg[1].bias)[c0 + col];
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < EPI_IT; it++) {
+      const int idx = tid + it * GW_THREADS;
+      if (idx < nu * OPU) {
+        const int ui = idx / OPU, rem = idx - ui * OPU, row = rem >> 4, col = rem & 15;
+        if (has_res) ress[idx] = e_res[it];
+        if (row == 0) {
+          biass[(ui * NS + 0) * 16 + col] = e_b0[it];
+          if (NS == 2) biass[(ui * NS + 1) * 16 + col] = e_b1[it];
+        }
+      }
+    }
+  }
+
+  __builtin_amdgcn_sched_barrier(0);  // (phase boundaries are scheduling barriers: hipcc otherwise interleaves the phases for
+                                      // ILP and the prologue, not the main loop, sets the register peak)
+  // ---- x fragments of this wave's two k-tiles: lane (oct, nn) holds row mt*16 + nn, columns kt*128 + j*32 + oct*8 ..
+  constexpr bool norm = NORM;
+  u32x4 xf[GW_TPW][4][MT];
+  float ss[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++) ss[mt] = 0.f;
+#pragma unroll
+  for (int ti = 0; ti < GW_TPW; ti++) {
+    // (a wave without this k-tile re-reads the last one: its scale is zeroed in the main loop and its Σx² share below — a
+    // select on the loaded fragments would double their registers)
+    const int kt = min(wave + GW_WAVES * ti, KT - 1);
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+      const uint16_t* xr = static_cast<const uint16_t*>(a.x) + (size_t)min(mt * 16 + nn, M - 1) * a.x_ld + kt * 128 + oct * 8;
+#pragma unroll
+      for (int j = 0; j < 4; j++) xf[ti][j][mt] = *reinterpret_cast<const u32x4*>(xr + j * 32);
+    }
+  }
+
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- the weight stream: step = (unit ui, tile ti); branch-free issue
+  u32x4 wb[D][NS];
+  uint32_t sb[D][NS];
+  uint32_t zb[D][AWQ ? NS : 1];
+  const int gsh = a.gsh;
+  const int mperm = ((nn & 7) << 3) + (nn >> 3);
+  auto issue = [&](int ui, int ti, u32x4 (&w)[NS], uint32_t (&sc)[NS], uint32_t (&zp)[AWQ ? NS : 1]) {
+    const int unit = u0 + min(ui, nu - 1);
+    const int kt = min(wave + GW_WAVES * ti, KT - 1);
+    const int grp = (kt * 128) >> gsh;
+    const int col = a.marlin ? ((unit >> 2) << 6) + ((unit & 3) << 1) + mperm : unit * a.s_unit_stride + nn;
+    const int64_t si = (int64_t)grp * a.s_grp_stride + col;
+    const int64_t zi = (int64_t)grp * a.z_grp_stride + unit * a.z_unit_stride + (nn >> 3);
+#pragma unroll
+    for (int b = 0; b < NS; b++) {
+      w[b] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.w[b]) + ((size_t)unit * KT + kt) * 64 + lane);
+      sc[b] = reinterpret_cast<const uint32_t*>(a.scales[b])[si >> 1];
+      if (AWQ) zp[AWQ ? b : 0] = a.zeros[b][zi];
+    }
+  };
+#pragma unroll
+  for (int ti = 0; ti < GW_TPW; ti++) issue(0, ti, wb[ti], sb[ti], zb[ti]);
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- fused RMSNorm + Σx per (tile, row)
+  if (norm) {
+#pragma unroll
+    for (int ti = 0; ti < GW_TPW; ti++) {
+      const float tmask = wave + GW_WAVES * ti < KT ? 1.0f : 0.0f;
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+          float f[8], t8 = 0.f;
+          unpack8<DT>(xf[ti][j][mt], f);
+#pragma unroll
+          for (int e = 0; e < 8; e++) t8 += f[e] * f[e];
+          ss[mt] += t8 * tmask;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {  // sum over the 4 column groups (lanes nn, nn+16, nn+32, nn+48)
+      float v = ss[mt];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (oct == 0) part[wave * 32 + mt * 16 + nn] = v;
+    }
+    __syncthreads();
+    // (opaque to the optimiser: without this hipcc keeps the UNPACKED f32 copies of all fragments alive from the Σx² pass to
+    // the normalisation below — 8 floats per fragment, more than the whole register file)
+#pragma unroll
+    for (int ti = 0; ti < GW_TPW; ti++)
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) asm volatile("" : "+v"(xf[ti][j][mt]));
+    float rstd[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+      float tot = 0.f;
+#pragma unroll
+      for (int w = 0; w < GW_WAVES; w++) tot += part[w * 32 + mt * 16 + nn];
+      rstd[mt] = 1.0f / sqrtf(tot / (float)a.K + a.eps);
+    }
+#pragma unroll
+    for (int ti = 0; ti < GW_TPW; ti++) {
+      const int kt = min(wave + GW_WAVES * ti, KT - 1);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        float g[8];
+        unpack8<DT>(*reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.norm_w) + kt * 128 + j * 32 + oct * 8), g);
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+          float f[8];
+          unpack8<DT>(xf[ti][j][mt], f);
+#pragma unroll
+          for (int e = 0; e < 8; e++) f[e] = f[e] * rstd[mt] * g[e];
+          xf[ti][j][mt] = pack8<DT>(f);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+#pragma unroll
+  for (int ti = 0; ti < GW_TPW; ti++)
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {  // Σx of row (mt, nn) over tile ti, over the ROUNDED values the MFMA will see
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; j++) s += octet_sum<DT>(xf[ti][j][mt]);
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      if (oct == 0) xsum[ti * 32 + mt * 16 + nn] = s;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  __syncthreads();  // epilogue operands staged (and, without a norm, the first barrier of the kernel)
+
+  // ---- main loop: one unit = four tile-steps (ring slots 0..3)
+  const int zsh = 4 * awq_rev(nn & 7);
+  const bool shalf = a.marlin ? (nn >> 3) & 1 : nn & 1;
+  constexpr float CB = Magic<DT>::bias;
+  f32x4 acc[NS][MT];
+  for (int ui = 0; ui < nu; ui++) {
+#pragma unroll
+    for (int b = 0; b < NS; b++)
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++) acc[b][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ti = 0; ti < GW_TPW; ti++) {
+      const bool valid = wave + GW_WAVES * ti < KT;
+#pragma unroll
+      for (int b = 0; b < NS; b++) {  // stream by stream: only the MT accumulators of one stream's tile are live at a time
+        f32x4 ag[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) ag[mt] = vra_zero_acc();
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const s16x8 bf = magic_word<DT>(wb[ti][b][j]);  // dequantised ONCE for all m-tiles
+#pragma unroll
+          for (int mt = 0; mt < MT; mt++) DT::mfma(ag[mt], __builtin_bit_cast(s16x8, xf[ti][j][mt]), bf);
+        }
+        VRA_MFMA_DRAIN();
+        float s = DT::to_f32((uint16_t)(shalf ? sb[ti][b] >> 16 : sb[ti][b]));
+        s = valid ? s : 0.f;
+        const float zc = AWQ ? CB + (float)((zb[ti][AWQ ? b : 0] >> zsh) & 0xFu) : CB + 8.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+          const f32x4 sx = *reinterpret_cast<const f32x4*>(xsum + ti * 32 + mt * 16 + oct * 4);  // rows mt*16 + oct*4 .. +3
+#pragma unroll
+          for (int e = 0; e < 4; e++) acc[b][mt][e] = fmaf(s, fmaf(-zc, sx[e], ag[mt][e]), acc[b][mt][e]);
+        }
+      }
+      issue(ui + 1, ti, wb[ti], sb[ti], zb[ti]);  // the same tile of the next unit (clamped: re-reads the last unit, never consumed)
+    }
+    // ---- the unit's partial tiles meet in LDS (double-buffered by unit parity: one barrier per unit)
+    f32x4* rbuf = red + (size_t)(ui & 1) * GW_WAVES * NS * MT * 64;
+#pragma unroll
+    for (int b = 0; b < NS; b++)
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++) rbuf[((wave * NS + b) * MT + mt) * 64 + lane] = acc[b][mt];
+    __syncthreads();
+    if (tid < OPU) {
+      const int row = tid >> 4, col = tid & 15, mt = row >> 4;
+      const int dl = (((row & 15) >> 2) << 4) + col, r = row & 3;  // D layout: lane = (row/4)*16 + column, register = row % 4
+      const float* rf = reinterpret_cast<const float*>(rbuf);
+      float v = 0.f, v2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < GW_WAVES; w++) {
+        v += rf[((((w * NS + 0) * MT + mt) * 64) + dl) * 4 + r];
+        if (NS == 2) v2 += rf[((((w * NS + 1) * MT + mt) * 64) + dl) * 4 + r];
+      }
+      const float bias = DT::to_f32(biass[(ui * NS + 0) * 16 + col]);
+      v = rnd_dt<DT>(v);
+      if (any_bias) v = rnd_dt<DT>(v + bias);  // (a segment without a bias was staged as +0: adding it changes nothing but the sign of -0)
+      if (NS == 2) {
+        v2 = rnd_dt<DT>(v2);
+        if (a.seg[1].bias) v2 = rnd_dt<DT>(v2 + DT::to_f32(biass[(ui * NS + 1) * 16 + col]));
+        const float sl = rnd_dt<DT>(v / (1.0f + expf(-v)));
+        v = sl * v2;
+      }
+      if (has_res) v = rnd_dt<DT>(v) + DT::to_f32(ress[ui * OPU + tid]);
+      outs[ui * OPU + tid] = DT::from_f32(v);
+    }
+  }
+  __syncthreads();
+  // ---- everything is stored after the stream has ended
+  for (int idx = tid; idx < nu * OPU; idx += GW_THREADS) {
+    const int ui = idx / OPU, rem = idx - ui * OPU, row = rem >> 4, col = rem & 15;
+    if (row >= M) continue;
+    void* o_;
+    const void* b_;
+    int ld_, c0;
+    seg_of(u0 + ui, o_, b_, ld_, c0);
+    static_cast<uint16_t*>(o_)[(size_t)row * ld_ + c0 + col] = outs[idx];
+  }
+}

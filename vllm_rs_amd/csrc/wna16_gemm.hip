@@ -6,6 +6,7 @@
 #include "gemv.cuh"
 #include "gemv_q4.cuh"
 #include "gemv_q4s.cuh"
+#include "gemv_q4w.cuh"
 #include "scratch.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -387,6 +388,65 @@ void vra_launch_gemv_s(GemvSArgs a, int ns, int group_size, bool awq, int dtype,
     else bf ? launch_gemv_s_v<BF16, 1, false>(a, st) : launch_gemv_s_v<F16, 1, false>(a, st);
   }
 }
+// ---- kernel W (gemv_q4w.cuh): 5..32 rows, K <= 4096
+bool vra_gemv_w_fits(int ns, int M, int K, int group_size, int n_units, bool has_res) {
+  static const char* off = getenv("VRA_NO_GEMV_W");
+  if (off && off[0] == '1') return false;
+  if (M < 5 || M > 32 || K % 128 || K > 4096) return false;
+  if (ns == 2 && M > 16) return false;  // pair x two m-tiles: 8 accumulator tiles + a 4-slot pair ring beside 128 fragment registers spill inside the loop: kernel C
+  const int g = group_size > 0 && group_size < K ? group_size : K;
+  if (g < K && (g < 128 || (g & (g - 1)))) return false;
+  if (n_units < num_cus() / 2) return false;
+  int grid, q, r;
+  vra_gemv_s_plan(n_units, &grid, &q, &r);
+  const int mu = q + (r ? 1 : 0);
+  return mu <= GW_MAX_UNITS && gemv_q4w_lds_bytes(ns, M > 16 ? 2 : 1, mu, has_res) <= (size_t)kMaxDynLds;
+}
+template <class DT, int NS, int MT, bool AWQ, bool NORM>
+static void launch_gemv_w_n(GemvSArgs a, hipStream_t st) {
+  static uint64_t attr_devs = 0;
+  auto kern = gemv_q4w_kernel<DT, NS, MT, AWQ, NORM>;
+  if (!dev_seen(attr_devs)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+    dev_mark(attr_devs);
+  }
+  a.KT = a.K / 128;
+  a.TPW = GW_TPW;
+  int grid;
+  vra_gemv_s_plan(a.n_units, &grid, &a.units_q, &a.units_r);
+  const size_t lds = gemv_q4w_lds_bytes(NS, MT, a.units_q + (a.units_r ? 1 : 0), a.residual != nullptr);
+  a.dbg = 0;
+  a.ts = nullptr;
+  kern<<<grid, GW_THREADS, lds, st>>>(a);
+}
+template <class DT, int NS, int MT, bool AWQ>
+static void launch_gemv_w_v(const GemvSArgs& a, hipStream_t st) {
+  if (a.norm_w) launch_gemv_w_n<DT, NS, MT, AWQ, true>(a, st);
+  else launch_gemv_w_n<DT, NS, MT, AWQ, false>(a, st);
+}
+void vra_launch_gemv_w(GemvSArgs a, int ns, int group_size, bool awq, int dtype, int64_t stream) {
+  hipStream_t st = as_stream(stream);
+  const bool grouped = group_size > 0 && group_size < a.K;
+  a.gsh = grouped ? 31 - __builtin_clz((unsigned)group_size) : 31;
+  if ((a.s_grp_stride | a.s_unit_stride) & 1) {
+    vra_set_error("gemv_w: scale strides must be even");
+    return;
+  }
+  const bool bf = dtype == VRA_BF16, two = a.M > 16;
+#define VRA_W(NS_, AWQ_)                                                                                   \
+  do {                                                                                                     \
+    if (bf) two ? launch_gemv_w_v<BF16, NS_, 2, AWQ_>(a, st) : launch_gemv_w_v<BF16, NS_, 1, AWQ_>(a, st);  \
+    else two ? launch_gemv_w_v<F16, NS_, 2, AWQ_>(a, st) : launch_gemv_w_v<F16, NS_, 1, AWQ_>(a, st);       \
+  } while (0)
+  if (ns == 2) {
+    if (awq) VRA_W(2, true);
+    else VRA_W(2, false);
+  } else {
+    if (awq) VRA_W(1, true);
+    else VRA_W(1, false);
+  }
+#undef VRA_W
+}
 // one-time copies for kernel E: scales [G, N] row-major -> unit-major [N/16][G][16] at unit offset `unit0` of `out`
 // (G groups per unit in the destination), AWQ zeros [G, N/8] -> [N/16][G][2]
 __global__ void scales_unit_major_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int G, int N, int unit0) {
@@ -696,7 +756,8 @@ static bool check_gemm_shape(const char* who, int m, int k, int n, int group_siz
 static bool gemv_s_direct(int ns, const void* in, const void* w0, const void* sc0, const void* qz0, const void* w1, const void* sc1, const void* qz1,
                           const void* bias, const void* residual, void* out, int m, int k, int n, int group_size, int is_awq, int scales_layout,
                           int dtype, int64_t stream, const void* norm_w = nullptr, float eps = 0.f) {
-  if (n % 16 || !vra_gemv_s_fits(ns, m, k, group_size, n / 16, norm_w != nullptr)) return false;
+  const bool use_w = n % 16 == 0 && vra_gemv_w_fits(ns, m, k, group_size, n / 16, residual != nullptr);
+  if (n % 16 || !(use_w || vra_gemv_s_fits(ns, m, k, group_size, n / 16, norm_w != nullptr))) return false;
   const bool grouped = group_size > 0 && group_size < k;
   if (scales_layout == VRA_SCALES_MARLIN && (!grouped || n % 64)) return false;  // channel-wise permutation: converted copy (rowmajor_scales)
   const bool awq = is_awq != 0 && qz0 != nullptr;
@@ -713,7 +774,8 @@ static bool gemv_s_direct(int ns, const void* in, const void* w0, const void* sc
   a.seg[0] = GemvSSeg{out, bias, n, 0};
   a.seg[1] = GemvSSeg{out, nullptr, n, 0x7fffffff};
   a.M = m, a.K = k, a.n_units = n / 16;
-  vra_launch_gemv_s(a, ns, group_size, awq, dtype, stream);
+  if (use_w) vra_launch_gemv_w(a, ns, group_size, awq, dtype, stream);
+  else vra_launch_gemv_s(a, ns, group_size, awq, dtype, stream);
   return true;
 }
 
@@ -972,10 +1034,23 @@ extern "C" void gemm_half_q_half_alt(const void* in, const uint32_t* qweight, co
   VRA_CHECK_ARG(in && qweight && qzeros && scales && out, "gemm_half_q_half_alt: null pointer");
   VRA_CHECK_ARG(bits == 4, "gemm_half_q_half_alt: only 4-bit supported (bits=%d)", bits);
   VRA_CHECK_ARG(k % 8 == 0 && n % 8 == 0, "gemm_half_q_half_alt: k,n must be multiples of 8");
-  // group size is implied by the scales tensor in the reference; without g_idx we cannot know it,
-  // so g_idx == NULL means group_size 128 (the only non-g_idx configuration wna16.rs routes here).
+  // The reference's signature carries no group size: with g_idx (every GPTQ checkpoint has one, and wna16.rs:127-148 always
+  // passes it on this path) the group of a row is g_idx[k].  Without it the group size is read off the EXTENT of the scales
+  // allocation ([k/g, n] f16: g = k * n * 2 / bytes) when `scales` is the start of its own allocation; 128 otherwise.
+  int group = 128;
+  if (!g_idx) {
+    void* base = nullptr;
+    size_t bytes = 0;
+    if (hipMemGetAddressRange((hipDeviceptr_t*)&base, &bytes, (hipDeviceptr_t)scales) == hipSuccess && base == scales && bytes >= (size_t)n * 2 &&
+        bytes % ((size_t)n * 2) == 0) {
+      const size_t groups = bytes / ((size_t)n * 2);
+      if (groups <= (size_t)k && (size_t)k % groups == 0) group = (int)((size_t)k / groups);
+    } else {
+      (void)hipGetLastError();
+    }
+  }
   dim3 grid((n + 63) / 64, m);
-  gptq_alt_kernel<<<grid, 256, 0, as_stream(stream)>>>((const uint16_t*)in, qweight, qzeros, (const uint16_t*)scales, g_idx, (uint16_t*)out, m, n, k, 128);
+  gptq_alt_kernel<<<grid, 256, 0, as_stream(stream)>>>((const uint16_t*)in, qweight, qzeros, (const uint16_t*)scales, g_idx, (uint16_t*)out, m, n, k, group);
 }
 
 // NormX::forward + QLinear::forward in one call (others.rs:11-29 in front of wna16.rs:263-306): out = rmsnorm(in)·W (+ bias).

@@ -619,7 +619,7 @@ bool Model::gemv_s_ok(int which, int M) const {
   int K, units, ns;
   bool norm;
   gemv_s_shape(L, which, &K, &units, &ns, &norm);
-  return vra_gemv_s_fits(ns, M, K, mc_.group_size, units, norm);
+  return vra_gemv_s_fits(ns, M, K, mc_.group_size, units, norm) || vra_gemv_w_fits(ns, M, K, mc_.group_size, units, which == 1 || which == 3);
 }
 bool Model::gemv_s(int l, int which, int M, void* out, const void* residual, int64_t stream) {
   if (!gemv_s_ok(which, M)) return false;
@@ -679,7 +679,8 @@ bool Model::gemv_s(int l, int which, int M, void* out, const void* residual, int
       vra_gemv_s_plan(nunits, &a.next_grid, &a.next_units_q, &a.next_units_r);
     }
   }
-  vra_launch_gemv_s(a, ns, mc_.group_size, L.q.awq, dt_, stream);
+  if (M > 4) vra_launch_gemv_w(a, ns, mc_.group_size, L.q.awq, dt_, stream);  // kernel W: 5..32 rows, K <= 4096
+  else vra_launch_gemv_s(a, ns, mc_.group_size, L.q.awq, dt_, stream);
   return !take_err(error, "gemv_s");
 }
 
