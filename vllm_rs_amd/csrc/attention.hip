@@ -143,18 +143,33 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_kernel(const PagedAttnA
       krow0 = static_cast<const uint16_t*>(a.kflat) + ((kb + t0) * a.Hkv + hk) * D;
       krow1 = static_cast<const uint16_t*>(a.kflat) + ((kb + t1) * a.Hkv + hk) * D;
     }
+    // all K fragments of the tile, then all V fragments, are REQUESTED before the first MFMA (paged mode): the wave then pays one
+    // memory round trip per tile instead of one per fragment — with V loaded fragment by fragment inside the P·V loop a
+    // 4096-token prefill ran at 60 TFLOP/s (2.3 ms per layer), latency bound on 8 dependent L2 round trips per tile
+    u32x4 kf0[DJ], kf1[DJ];
 #pragma unroll
     for (int j = 0; j < DJ; j++) {
-      u32x4 k0, k1;
       if (a.block_tables) {
-        k0 = kv_load8<DT, KV8>(kc0 + j * 32 + oct * 8);
-        k1 = kv_load8<DT, KV8>(kc1 + j * 32 + oct * 8);
+        kf0[j] = kv_load8<DT, KV8>(kc0 + j * 32 + oct * 8);
+        kf1[j] = kv_load8<DT, KV8>(kc1 + j * 32 + oct * 8);
       } else {
-        k0 = *reinterpret_cast<const u32x4*>(krow0 + j * 32 + oct * 8);
-        k1 = *reinterpret_cast<const u32x4*>(krow1 + j * 32 + oct * 8);
+        kf0[j] = *reinterpret_cast<const u32x4*>(krow0 + j * 32 + oct * 8);
+        kf1[j] = *reinterpret_cast<const u32x4*>(krow1 + j * 32 + oct * 8);
       }
-      DT::mfma(s0, __builtin_bit_cast(s16x8, k0), qf[j]);
-      DT::mfma(s1, __builtin_bit_cast(s16x8, k1), qf[j]);
+    }
+    u32x2 vlo[DT16], vhi[DT16];
+    if (a.block_tables) {
+#pragma unroll
+      for (int t = 0; t < DT16; t++) {
+        const kv_t* vp = vcache + vbase + (size_t)(t * 16 + rq) * a.BS + oct * 4;
+        vlo[t] = kv_load4<DT, KV8>(vp);
+        vhi[t] = kv_load4<DT, KV8>(vp + 16);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < DJ; j++) {
+      DT::mfma(s0, __builtin_bit_cast(s16x8, kf0[j]), qf[j]);
+      DT::mfma(s1, __builtin_bit_cast(s16x8, kf1[j]), qf[j]);
     }
     VRA_MFMA_DRAIN();  // s0/s1 (and the previous tile's O updates) are complete past this point
     // ---- scale, softcap, causal/length mask; scores in log2 domain
@@ -208,10 +223,7 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_kernel(const PagedAttnA
     for (int t = 0; t < DT16; t++) {
       u32x4 vv;
       if (a.block_tables) {
-        const kv_t* vp = vcache + vbase + (size_t)(t * 16 + rq) * a.BS + oct * 4;
-        const u32x2 lo = kv_load4<DT, KV8>(vp);
-        const u32x2 hi = kv_load4<DT, KV8>(vp + 16);
-        vv = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        vv = u32x4{vlo[t][0], vlo[t][1], vhi[t][0], vhi[t][1]};
       } else {
         const size_t kb = a.cu_k[b];
         uint16_t tmp[8];
