@@ -14,6 +14,7 @@
 // Roofline: HBM (KV bytes) for decode; MFMA for long prefill.
 #include "common.cuh"
 #include "kvcache.cuh"
+#include "attn_prefill.cuh"
 
 #define PA_THREADS 256
 #define PA_WAVES 4
@@ -755,6 +756,41 @@ extern "C" void vra_paged_attention_prefill(void* out, const void* q, const void
   a.softcap = softcap;
   a.decode = 0;
   a.nsplit = 1;
+  if (block_tables && (head_dim == 128 || head_dim == 64) && !getenv("VRA_NO_PREFILL_TILED")) {
+    // the LDS-tiled prefill kernel (attn_prefill.cuh); 2 row tiles per wave once that still leaves >= 2 workgroups per CU
+    PrefillAttnArgs p = {};
+    p.out = out, p.q = q, p.kc = k_cache, p.vc = v_cache;
+    p.block_tables = block_tables, p.context_lens = context_lens, p.cu_q = cu_seqlens_q;
+    p.Hq = q_heads, p.Hkv = kv_heads, p.BS = block_size, p.max_blocks = max_blocks_per_seq;
+    p.scale = scale, p.scale_log2e = a.scale_log2e, p.softcap = softcap;
+    const bool kv8 = kv_dtype == VRA_FP8_E4M3;
+    const long wgs2 = (long)((max_seqlen_q + 127) / 128) * q_heads * batch;
+    const int mt = wgs2 >= 512 ? 2 : 1;
+    dim3 pg((max_seqlen_q + 64 * mt - 1) / (64 * mt), q_heads, batch);
+    hipStream_t st = as_stream(stream);
+#define VRA_PF(DT, DD, K8, MM) prefill_attn_kernel<DT, DD, K8, MM><<<pg, PF_THREADS, 0, st>>>(p)
+#define VRA_PF_MT(DT, DD, K8) \
+  do {                        \
+    if (mt == 2) VRA_PF(DT, DD, K8, 2); \
+    else VRA_PF(DT, DD, K8, 1);         \
+  } while (0)
+#define VRA_PF_KV(DT, DD)            \
+  do {                               \
+    if (kv8) VRA_PF_MT(DT, DD, true); \
+    else VRA_PF_MT(DT, DD, false);    \
+  } while (0)
+    if (dtype == VRA_BF16) {
+      if (head_dim == 128) VRA_PF_KV(BF16, 128);
+      else VRA_PF_KV(BF16, 64);
+    } else {
+      if (head_dim == 128) VRA_PF_KV(F16, 128);
+      else VRA_PF_KV(F16, 64);
+    }
+#undef VRA_PF_KV
+#undef VRA_PF_MT
+#undef VRA_PF
+    return;
+  }
   dim3 grid((max_seqlen_q + 63) / 64, q_heads, batch);
   if (dtype == VRA_BF16) launch_attn<BF16>(a, head_dim, kv_dtype == VRA_FP8_E4M3, grid, as_stream(stream));
   else launch_attn<F16>(a, head_dim, kv_dtype == VRA_FP8_E4M3, grid, as_stream(stream));
