@@ -1,4 +1,4 @@
-"""one prefill-heavy run for profiling: two 4096-token prompts through the Llama-3-8B-shape engine (eager launches)"""
+"""one prefill-heavy run for profiling: two T-token prompts (argv[1], default 4096) through the Llama-3-8B-shape engine (eager launches)"""
 import os
 import sys
 
@@ -9,8 +9,9 @@ from vllm_rs_amd import engine as E
 
 eng = E.Engine(dict(E.LLAMA3_8B), max_num_seqs=8, max_model_len=8192, num_gpu_blocks=512, use_graph=False).init_synthetic()
 r = np.random.default_rng(0)
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 for _ in range(2):
-    rid = eng.add_request(r.integers(1000, 100000, size=4096).astype(np.uint32), max_tokens=2, ignore_eos=True)
+    rid = eng.add_request(r.integers(1000, 100000, size=T).astype(np.uint32), max_tokens=2, ignore_eos=True)
     while eng.has_unfinished():
         eng.step()
     t = eng.times(rid)

@@ -5,8 +5,13 @@
 // (measured: 560 TFLOP/s at M = 4096), and its 64 x 128 workgroup tile re-reads x and the weights from L2 at 87 FLOP/B.
 // Here a wave owns GD_NB = 4 n-blocks x MB m-tiles:
 //   * every x fragment read from LDS feeds 4 MFMAs (LDS traffic per MFMA / 4);
-//   * workgroup = 8 waves as 4 (n) x 2 (m): tile 256 columns x 32*MB rows — packed weights are a quarter of the size of
-//     x per element, so the tile is wide in n: 175 FLOP per byte fetched from L2 at MB = 4;
+//   * workgroup = 4 waves side by side in n: tile 256 columns x 16*MB rows, TWO workgroups co-resident per CU (<= 256 VGPRs,
+//     52 KB of LDS each at MB = 4).  Round 1 ran 8 waves as 4 (n) x 2 (m) under one barrier per k-tile: the phase timers
+//     (tools/gemm_big_ts.py) showed the two waves of a SIMD serialised — both start their VALU phase (dequant) together after
+//     the barrier, one wins the VALU, and while the loser runs its MFMA phase the winner already idles at the barrier
+//     (1840 of 5300 cycles per k-tile).  Two independent 4-wave workgroups drift apart instead and one's MFMA phase covers
+//     the other's VALU phase: M = 4096 layer 2299 -> 2036 us, M = 2048 1206 -> 1052 us.  Each workgroup fetches its own copy
+//     of the weights from L2 (117 FLOP per L2 byte at MB = 4 instead of 175): far below the L2 rate;
 //   * the 4 x 4 weight fragments of a k-tile are dequantised ONCE per k-tile ((C + q) "magic" words, wna16.cuh: 7 VALU
 //     ops per 8 weights, amortised over MB m-tiles) and kept in registers; the exact per-group fix-up
 //     acc += s·(acc_g − (C + z)·Σx)  runs per m-tile (16 group-accumulator registers instead of 64);
@@ -15,15 +20,24 @@
 //   * every global access is a buffer instruction with a wave-uniform (SGPR) offset and ONE shared VGPR offset per
 //     stream — 64-bit per-lane addresses for 4 weight, 4 scale and MB x streams cost ~30 VGPRs the tile needs.
 // Operand roles as in kernel B: A = weights (16 columns x 32 k), B = x (16 rows x 32 k), D[column][row].
-// x chunks (32*MB rows x 128 k) are staged through LDS, double buffered, one workgroup barrier per k-tile
+// x chunks (16*MB rows x 128 k) are staged through LDS, triple buffered, one workgroup barrier per k-tile
 // (16*MB MFMAs per wave between barriers).  Scale groups of >= 128 (or per channel) only; row-major scales.
 // DUAL: a wave owns 2 gate + 2 up n-blocks of the same columns and the epilogue is silu(gate)·up (mlp.rs:451-469).
 #pragma once
 #include "gemv.cuh"  // GemvSeg
 #include "wna16.cuh"
 
-#define GD_THREADS 512
+#ifndef GD_WM
+#define GD_WM 1  // waves along m per workgroup (workgroup = 4 (n) x GD_WM (m) waves)
+#endif
+#define GD_THREADS (256 * GD_WM)
 #define GD_NB 4
+#ifndef GD_PK_FIXUP
+#define GD_PK_FIXUP 1
+#endif
+#ifndef GD_XDEPTH
+#define GD_XDEPTH 2
+#endif
 
 struct GemmDArgs {
   const void* w0;  // int4 tiled
@@ -47,9 +61,22 @@ struct GemmDArgs {
   int nseg;
   GemvSeg xseg[2];
   const float* xsum;  // [M][K/128] row sums of x per k-tile (xsum_rows_kernel), set by the launcher
+  unsigned long long* ts;  // -DVRA_GEMV_TS builds: per-workgroup phase cycle sums (tools/gemm_big_ts.py)
 };
+#ifdef VRA_GEMV_TS
+#define GD_STAMP(v)                         \
+  do {                                      \
+    __builtin_amdgcn_sched_barrier(0);      \
+    v = (long long)__builtin_readcyclecounter(); \
+    __builtin_amdgcn_sched_barrier(0);      \
+  } while (0)
+#else
+#define GD_STAMP(v) \
+  do {              \
+  } while (0)
+#endif
 
-static inline size_t gemm_q4_big_lds_bytes(int mb) { return (size_t)3 * (32 * mb) * (16 + 1) * 16; }
+static inline size_t gemm_q4_big_lds_bytes(int mb) { return (size_t)3 * (16 * GD_WM * mb) * (16 + 1) * 16; }
 
 // Σ over each (row, k-tile) of x, from the 16-bit values the MFMA sees: 16 lanes per (row, k-tile), one octet each.
 template <class DT>
@@ -66,10 +93,11 @@ __global__ __launch_bounds__(256) void xsum_rows_kernel(const void* x, int x_ld,
 }
 
 template <class DT, bool DUAL, bool AWQ, int MB>
-__global__ __launch_bounds__(GD_THREADS) void gemm_q4_big_kernel(const GemmDArgs a) {
+__global__ __launch_bounds__(GD_THREADS, 2) void gemm_q4_big_kernel(const GemmDArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NB = GD_NB;
-  constexpr int ROWS = 32 * MB;       // rows of x per workgroup
+  constexpr int ROWS = 16 * GD_WM * MB;  // rows of x per workgroup
+  constexpr int RPP = GD_THREADS / 16;   // rows one pass of the workgroup's threads stages
   constexpr int RS = (16 + 1) * 4;    // LDS row stride in u32: 16 octets + one of padding (see gemm_skinny.cuh)
   constexpr int XS_U32 = ROWS * RS;   // one x buffer
   constexpr uint32_t RSRC3 = 0x00020000u;
@@ -134,7 +162,7 @@ __global__ __launch_bounds__(GD_THREADS) void gemm_q4_big_kernel(const GemmDArgs
   // x: rows m0 + r*32 + tid/16, octet tid%16; Σx: the lane's row of every m-tile.  Rows >= M alias row M-1 (never stored).
   uint32_t vo_x[XPT], vo_sum[MB];
 #pragma unroll
-  for (int r = 0; r < XPT; r++) vo_x[r] = ((uint32_t)min(m0 + r * 32 + (tid >> 4), M - 1) * (uint32_t)a.x_ld + (uint32_t)(tid & 15) * 8u) * 2u;
+  for (int r = 0; r < XPT; r++) vo_x[r] = ((uint32_t)min(m0 + r * RPP + (tid >> 4), M - 1) * (uint32_t)a.x_ld + (uint32_t)(tid & 15) * 8u) * 2u;
 #pragma unroll
   for (int mt = 0; mt < MB; mt++) vo_sum[mt] = (uint32_t)min(m0 + wm * (MB * 16) + mt * 16 + nn, M - 1) * (uint32_t)KT * 4u;
   // x tiles go global -> registers at the START of an iteration and registers -> LDS at its END, two k-tiles ahead of
@@ -147,7 +175,7 @@ __global__ __launch_bounds__(GD_THREADS) void gemm_q4_big_kernel(const GemmDArgs
   auto x_store = [&](int buf, const u32x4 (&xr)[XPT]) {
     uint32_t* dst = xs + (size_t)buf * XS_U32 + (size_t)(tid >> 4) * RS + (tid & 15) * 4;
 #pragma unroll
-    for (int r = 0; r < XPT; r++) *reinterpret_cast<u32x4*>(dst + (size_t)(r * 32) * RS) = xr[r];
+    for (int r = 0; r < XPT; r++) *reinterpret_cast<u32x4*>(dst + (size_t)(r * RPP) * RS) = xr[r];
   };
   // weight stream: one 16-byte word per (n-block, k-tile) and lane; scales / zero points in the MFMA OUTPUT layout
   auto w_load = [&](int kt, u32x4 (&wq)[NB], u32x2 (&sc)[NB], uint32_t (&zw)[NB]) {
@@ -186,8 +214,11 @@ __global__ __launch_bounds__(GD_THREADS) void gemm_q4_big_kernel(const GemmDArgs
   }
   __syncthreads();
 
+  long long tA = 0, tB = 0, tC = 0, tD = 0, tE = 0, sB = 0, sC = 0, sD = 0, sE = 0;
+  (void)tA, (void)tB, (void)tC, (void)tD, (void)tE, (void)sB, (void)sC, (void)sD, (void)sE;
   for (int kt = 0; kt < KT; kt++) {
     const int buf = kt % 3;
+    GD_STAMP(tA);
     // ---- the k-tile's 4 x 4 weight fragments (C + q), its scales and row sums; then the loads of the next k-tile
     s16x8 af[NB][4];
     f32x2 sc2[NB][2], nzc2[NB][2];
@@ -210,19 +241,22 @@ __global__ __launch_bounds__(GD_THREADS) void gemm_q4_big_kernel(const GemmDArgs
     x_load(min(kt + 2, KT - 1), xr);
     w_load(ktn, wq, scw, zw);
     sum_load(ktn, sxn);
+    GD_STAMP(tB);
     const uint32_t* xb = xs + (size_t)buf * XS_U32 + (size_t)(wm * (MB * 16) + nn) * RS + oct * 4;
     // 4*MB steps (m-tile, j): the x fragment of step s+1 is read from LDS BEFORE the MFMAs of step s are issued (the
     // chain ds_read -> wait -> 4 MFMAs per step left the matrix pipe idle for the LDS latency: 3.4 us per k-tile)
     auto frag = [&](int s) { return *reinterpret_cast<const u32x4*>(xb + (size_t)((s >> 2) * 16) * RS + (s & 3) * 16); };
-    u32x4 xv[2];
-    xv[0] = frag(0);
+    constexpr int XD = GD_XDEPTH;  // x fragments in flight ahead of the MFMAs that consume them
+    u32x4 xv[XD + 1];
+#pragma unroll
+    for (int s = 0; s < XD; s++) xv[s] = frag(s);
     f32x4 ag[NB];
 #pragma unroll
     for (int s = 0; s < 4 * MB; s++) {
       const int mt = s >> 2, j = s & 3;
-      if (s + 1 < 4 * MB) xv[(s + 1) & 1] = frag(s + 1);
+      if (s + XD < 4 * MB) xv[(s + XD) % (XD + 1)] = frag(s + XD);
       __builtin_amdgcn_sched_barrier(0);
-      const s16x8 bfrag = __builtin_bit_cast(s16x8, xv[s & 1]);
+      const s16x8 bfrag = __builtin_bit_cast(s16x8, xv[s % (XD + 1)]);
 #pragma unroll
       for (int b = 0; b < NB; b++) {
         if (j == 0) DT::mfma0(ag[b], af[b][j], bfrag);
@@ -230,6 +264,7 @@ __global__ __launch_bounds__(GD_THREADS) void gemm_q4_big_kernel(const GemmDArgs
       }
       if (j == 3) {
         VRA_MFMA_DRAIN();
+#if GD_PK_FIXUP
         const f32x2 sx2 = {sxc[mt], sxc[mt]};
 #pragma unroll
         for (int b = 0; b < NB; b++) {
@@ -237,11 +272,34 @@ __global__ __launch_bounds__(GD_THREADS) void gemm_q4_big_kernel(const GemmDArgs
           acc[b][mt][0] = __builtin_elementwise_fma(sc2[b][0], __builtin_elementwise_fma(nzc2[b][0], sx2, g0), acc[b][mt][0]);
           acc[b][mt][1] = __builtin_elementwise_fma(sc2[b][1], __builtin_elementwise_fma(nzc2[b][1], sx2, g1), acc[b][mt][1]);
         }
+#else
+        // scalar v_fma_f32 (2 cycles each), not v_pk_fma_f32: packed f32 VALU beside MFMAs costs more than its two halves
+        // (MI355X_MICROARCH.md, per-instruction constants).  The asm keeps the SLP vectoriser from re-packing the pairs.
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            float t = __builtin_fmaf(nzc2[b][r >> 1][r & 1], sxc[mt], ag[b][r]);
+            asm volatile("" : "+v"(t));
+            acc[b][mt][r >> 1][r & 1] = __builtin_fmaf(sc2[b][r >> 1][r & 1], t, acc[b][mt][r >> 1][r & 1]);
+          }
+        }
+#endif
       }
     }
+    GD_STAMP(tC);
     x_store((kt + 2) % 3, xr);
+    GD_STAMP(tD);
     __syncthreads();
+    GD_STAMP(tE);
+    sB += tB - tA, sC += tC - tB, sD += tD - tC, sE += tE - tD;
   }
+#ifdef VRA_GEMV_TS
+  if (a.ts && lane == 0 && (int)(blockIdx.y * gridDim.x + blockIdx.x) < 4096) {
+    unsigned long long* t = a.ts + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 4;
+    t[0] = (unsigned long long)sB, t[1] = (unsigned long long)sC, t[2] = (unsigned long long)sD, t[3] = (unsigned long long)sE;
+  }
+#endif
 
   // ---- epilogue: D[column (lane>>4)*4 + r][row lane&15] of tile (b, mt)
   constexpr int NBO = DUAL ? 2 : NB;  // output n-blocks of the wave

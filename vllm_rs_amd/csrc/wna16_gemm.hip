@@ -556,16 +556,27 @@ int vra_gemm_q4_big_fits(bool dual, int M, int cols, int K, int group_size, cons
     for (int i = 0; i + 1 < segs->nseg; i++)
       if (segs->xseg[i].n % 64) return 0;
   }
-  // enough workgroups to fill the chip without slicing K (kernel B slices K and wins on narrow / short problems)
+  // Which of kernel B (slices K, every CU busy on narrow / short problems), kernel D with 64-row tiles (mb 4) or with 32-row
+  // tiles (mb 2)?  A small cost model fitted to the Llama-3-8B shapes at M = 128..4096 (tools/gemv_s_microbench.py, us):
+  //   kernel D: workgroups are co-resident in pairs (2 per CU, 4 waves each); per K = 4096 a pair of 64-row workgroups takes
+  //             82 us and a lone one 47; 32-row workgroups 46 and 28; + 15 us of launch, row-sum pass and epilogue;
+  //   kernel B: 17 us + FLOPs at 490 TFLOP/s (650 for the gate/up pair).
+  // e.g. M = 512: o 50.9 (B) / 39.8 (D, mb 2) / 58.3 (mb 4); down 143 / 117 / 180; gate/up 169 (mb 4) / 189 (mb 2).
   const int gx = dual ? (cols + 127) / 128 : (cols + 255) / 256;
   const int cus = num_cus();
   if (mb_env && (atoi(mb_env) == 2 || atoi(mb_env) == 4)) return atoi(mb_env);
-  // measured (Llama-3-8B shapes, TFLOP/s, kernel B -> D): M = 4096 gate/up 526 -> 692, o 410 -> 671, down 446 -> 705;
-  // M = 128 gate/up 401 -> 330 (kernel B slices K and keeps every CU busy; D has 112 workgroups there)
-  if (M >= 256 && gx * ((M + 127) / 128) >= cus * 3 / 4) return 4;
-  // narrow GEMMs at 768..1535 rows: 64-row tiles fill the chip where 128-row tiles do not (M = 1024: o 92 -> 64 us, down
-  // 301 -> 205 us against kernel B; at M = 512 kernel B still wins)
-  if (M >= 256 && gx * ((M + 63) / 64) >= cus * 3 / 4) return 2;
+  const double kf = (double)K / 4096.0;
+  auto est_d = [&](int mb) {
+    const long w = (long)gx * ((M + 16 * mb - 1) / (16 * mb));
+    const long q = (w + cus - 1) / cus;
+    const double pair = mb == 4 ? 82.0 : 46.0, lone = mb == 4 ? 47.0 : 28.0;
+    return 15.0 + ((double)(q / 2) * pair + (double)(q % 2) * lone) * kf;
+  };
+  const double flops = 2.0 * (double)M * (double)cols * (dual ? 2.0 : 1.0) * (double)K;
+  const double est_b = 17.0 + flops / ((dual ? 650.0 : 490.0) * 1e6);
+  const double d4 = est_d(4), d2 = est_d(2);
+  if (d4 <= d2 && d4 < est_b) return 4;
+  if (d2 < est_b) return 2;
   return 0;
 }
 template <class DT, bool DUAL, int MB>
@@ -595,8 +606,11 @@ void vra_launch_gemm_q4_big(const GemmDArgs& a0, bool dual, bool awq, int mb, in
     else xsum_rows_kernel<F16><<<(unsigned)((total + 255) / 256), 256, 0, as_stream(stream)>>>(a.x, a.x_ld, a.M, KT, tbl);
     a.xsum = tbl;
   }
+#ifdef VRA_GEMV_TS
+  a.ts = vra_gemv_ts_buf();
+#endif
   const int cols = dual ? a.N : (a.nseg > 1 ? a.xseg[a.nseg - 2].blk_start * 16 + a.xseg[a.nseg - 2].n : a.N);
-  dim3 grid(dual ? (cols + 127) / 128 : (cols + 255) / 256, (a.M + 32 * mb - 1) / (32 * mb));
+  dim3 grid(dual ? (cols + 127) / 128 : (cols + 255) / 256, (a.M + 16 * GD_WM * mb - 1) / (16 * GD_WM * mb));
   hipStream_t st = as_stream(stream);
   const bool bf = dtype == VRA_BF16;
 #define VRA_GD(DU, MBV)                                                   \
