@@ -347,7 +347,10 @@ typedef struct vra_engine_config {
   int32_t device;
   uint64_t seed;                  /* synthetic-weight seed */
   int32_t fp8_kvcache;            /* EngineConfig.fp8_kvcache (config.rs:316): KV cache in FP8 E4M3, 1 byte per element */
-  int32_t reserved_;
+  float cpu_mem_fold;             /* CPU swap space as a fraction of the GPU blocks (kvcache_allocator.rs:317,673: the
+                                     reference defaults to 0.2); 0 = no swap space, preempted sequences wait or are dropped */
+  int32_t swap_cooling_ms;        /* scheduler.rs:49 SWAP_COOLING_PERIOD; 0 = 5000, negative = none */
+  int32_t min_tokens_left_for_swap; /* scheduler.rs:50; 0 = 1000, negative = 0 */
 } vra_engine_config;
 
 /* Pure-host helpers (no GPU needed; also exported by libvra_host.so for CPU tests) */
@@ -401,6 +404,8 @@ int32_t vra_engine_init_synthetic(void* eng);
 int32_t vra_engine_load_tensor(void* eng, const char* name, const void* h_data, const int64_t* shape,
                                int32_t ndim, int32_t elem_bytes);
 int32_t vra_engine_finalize_weights(void* eng); /* repack + scale layout + KV cache + graphs */
+/* CPU swap (block_manager.rs:870-1010): out4 = {cpu blocks, free cpu blocks, blocks swapped out so far, blocks swapped in} */
+void vra_engine_swap_stats(const void* engine, int64_t* out4);
 int32_t vra_engine_num_gpu_blocks(const void* eng);
 /* KVCacheAllocator plan of this rank before the cache exists (kvcache_allocator.rs:564-707): the
  * block count finalize would derive from free memory x kv_fraction.  Under tensor parallelism the

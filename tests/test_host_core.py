@@ -383,15 +383,18 @@ def test_marlin_permute_scales(grouped):
 
 
 # ------------------------------------------------------------------------------------------------ randomized stress
-@pytest.mark.parametrize("seed,prefix_cache", [(s, bool(s & 1)) for s in range(1, 13)])
-def test_engine_random_streams_keep_the_kv_invariants(seed, prefix_cache):
+@pytest.mark.parametrize("seed,prefix_cache,swap", [(s, bool(s & 1), False) for s in range(1, 13)] + [(s, bool(s & 1), True) for s in range(13, 21)])
+def test_engine_random_streams_keep_the_kv_invariants(seed, prefix_cache, swap):
     """random request streams (shared prefixes, long prompts that need chunking, block pressure, early EOS) on the
     host-only engine: every step's metadata must be self-consistent — the properties the kernels rely on
     (runner.rs:978-1388, block_manager.rs:113-442) — and everything must drain."""
     r = np.random.default_rng(seed)
     BS, NB, CHUNK = 16, 96, 64
     cfg = dict(E.TINYLLAMA)
-    h = E.HostEngine(cfg, num_gpu_blocks=NB, block_size=BS, max_num_seqs=8, max_model_len=512, prefill_chunk=CHUNK, enable_prefix_cache=prefix_cache)
+    skw = dict(cpu_mem_fold=0.5, swap_cooling_ms=-1, min_tokens_left_for_swap=-1) if swap else {}
+    if swap:
+        NB = 56   # tighter cache: decode-time preemption (and with it swap-out / swap-in) becomes common
+    h = E.HostEngine(cfg, num_gpu_blocks=NB, block_size=BS, max_num_seqs=8, max_model_len=512, prefill_chunk=CHUNK, enable_prefix_cache=prefix_cache, **skw)
     shared = [r.integers(5, 1000, size=int(n)).tolist() for n in (40, 70, 17)]
     pending, live, outputs, step_no = 40, {}, {}, 0
     def submit():
@@ -450,6 +453,9 @@ def test_engine_random_streams_keep_the_kv_invariants(seed, prefix_cache):
         assert h.finished(rid)
         outputs[rid] = h.output(rid)
         assert len(outputs[rid]) <= 24
+    if swap:
+        cpu, free_cpu, out_blocks, in_blocks = h.swap_stats()
+        assert free_cpu == cpu and in_blocks <= out_blocks     # swap space fully returned (a dropped sequence frees its copy)
     # drained: a fresh maximal request is admitted again (no leaked blocks)
     rid = h.add_request(r.integers(5, 1000, size=300).tolist(), max_tokens=2)
     n = 0
@@ -549,3 +555,85 @@ def test_prefill_chunk_above_the_staging_cap_is_clamped():
     trace = run_to_completion(h, lambda st, i: 3)
     assert [t["n_tokens"] for t in trace if t["is_prefill"]] == [16384, 16384, 40000 - 2 * 16384]
     assert h.finished(a)
+
+
+# ------------------------------------------------------------------------------------------------ CPU swap
+def _swap_engine(**kw):
+    args = dict(num_gpu_blocks=12, block_size=4, max_num_seqs=4, max_model_len=64, cpu_mem_fold=1.0, swap_cooling_ms=-1,
+                min_tokens_left_for_swap=-1)
+    args.update(kw)
+    return E.HostEngine(TINY, **args)
+
+
+def test_preempted_sequence_is_swapped_out_and_back_in():
+    """scheduler.rs:303-338,826-955 + block_manager.rs:870-1010: when a running sequence cannot get its next slot and there is
+    no prefix cache to evict, the OLDEST preempted sequence goes to the CPU swap space (its GPU blocks return to the free
+    list at once), the others keep decoding, and it comes back — into freshly allocated blocks — once there is room."""
+    h = _swap_engine()
+    a = h.add_request(list(range(1, 13)), max_tokens=20, ignore_eos=True)
+    b = h.add_request(list(range(21, 33)), max_tokens=20, ignore_eos=True)
+    assert h.swap_stats()[:2] == (12, 12)
+    trace = run_to_completion(h, lambda st, i: 7)
+    assert h.finished(a) and h.finished(b)
+    assert len(h.output(a)) == 20 and len(h.output(b)) == 20          # nobody was dropped
+    cpu, free_cpu, out_blocks, in_blocks = h.swap_stats()
+    assert out_blocks > 0 and in_blocks == out_blocks and free_cpu == cpu
+    # the swapped-out request is the older one (min id among the preempted, scheduler.rs:326-334)
+    # (one step earlier request a may decode alone: it took the last free block of that step, scheduler.rs:353-358)
+    solo = [t["requests"] for t in trace if not t["is_prefill"] and t["n_seqs"] == 1]
+    assert solo.count([b]) >= 4 and solo[-1] == [a]                   # b runs on alone; a finishes last, after its swap-in
+    # after the swap-in request a decodes again, its context continuing where it stopped, in a table of new blocks
+    a_steps = [t for t in trace if not t["is_prefill"] and a in t["requests"]]
+    ctx = [int(t["context_lens"][t["requests"].index(a)]) for t in a_steps]
+    assert ctx == list(range(13, 13 + len(ctx)))                      # no token lost or repeated across the swap
+    for t in a_steps:                                                  # slots always derive from the table of that step
+        i = t["requests"].index(a)
+        pos = int(t["positions"][i])
+        assert int(t["slots"][i]) == int(t["block_tables"][i][pos // 4]) * 4 + pos % 4
+
+
+def test_single_running_sequence_is_never_swapped_out():
+    """scheduler.rs:315-324: with one running sequence swapping makes no sense — it waits (here: is dropped by the engine's
+    no-progress rule, engine.rs:1103-1120)."""
+    h = _swap_engine(num_gpu_blocks=6, max_model_len=64)
+    a = h.add_request(list(range(1, 13)), max_tokens=40, ignore_eos=True)
+    run_to_completion(h, lambda st, i: 7)
+    assert h.finished(a) and h.swap_stats()[2] == 0
+
+
+def test_swap_in_waits_for_the_cooling_period():
+    """scheduler.rs:49,846: a sequence swapped out less than SWAP_COOLING_PERIOD ago stays where it is."""
+    import time
+    h = _swap_engine(swap_cooling_ms=150)
+    a = h.add_request(list(range(1, 13)), max_tokens=20, ignore_eos=True)
+    b = h.add_request(list(range(21, 33)), max_tokens=20, ignore_eos=True)
+    t_out = None
+    t_back = None
+    for _ in range(100000):
+        st = h.schedule()
+        out_blocks, in_blocks = h.swap_stats()[2:]
+        if out_blocks and t_out is None:
+            t_out = time.monotonic()
+        if in_blocks and t_back is None:
+            t_back = time.monotonic()
+        if st is None:
+            if not h.has_unfinished():
+                break
+            continue
+        h.commit([7] * st["n_seqs"])
+    assert h.finished(a) and h.finished(b) and len(h.output(a)) == 20
+    assert t_out is not None and t_back is not None and t_back - t_out >= 0.14
+
+
+def test_shared_prefix_blocks_are_not_swapped():
+    """block_manager.rs:876-893: a sequence holding a block with ref_count > 1 (prefix cache) cannot be swapped out."""
+    h = _swap_engine(num_gpu_blocks=14, enable_prefix_cache=True)
+    warm = h.add_request(list(range(1, 10)), max_tokens=1)
+    run_to_completion(h, lambda st, i: 7)
+    a = h.add_request(list(range(1, 10)) + [90, 91, 92], max_tokens=24, ignore_eos=True)   # shares 2 cached blocks
+    b = h.add_request(list(range(41, 53)), max_tokens=24, ignore_eos=True)
+    run_to_completion(h, lambda st, i: 7)
+    assert h.finished(a) and h.finished(b)
+    # pressure is relieved by evicting the prefix cache first (scheduler.rs:318-321); whatever was swapped came back
+    cpu, free_cpu, out_blocks, in_blocks = h.swap_stats()
+    assert in_blocks == out_blocks and free_cpu == cpu

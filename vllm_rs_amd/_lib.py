@@ -34,7 +34,8 @@ class EngineConfig(C.Structure):
         ("block_size", c_i32), ("max_num_seqs", c_i32), ("max_model_len", c_i32), ("num_gpu_blocks", c_i32),
         ("kv_fraction", c_f32), ("prefill_chunk", c_i32), ("enable_prefix_cache", c_i32),
         ("prefix_cache_fraction", c_f32), ("use_graph", c_i32), ("tp_rank", c_i32), ("tp_world_size", c_i32),
-        ("device", c_i32), ("seed", c_u64), ("fp8_kvcache", c_i32), ("reserved_", c_i32),
+        ("device", c_i32), ("seed", c_u64), ("fp8_kvcache", c_i32), ("cpu_mem_fold", c_f32),
+        ("swap_cooling_ms", c_i32), ("min_tokens_left_for_swap", c_i32),
     ]
 
 
@@ -184,6 +185,7 @@ def load():
     _sig(lib, "vra_engine_load_tensor", c_i32, P, C.c_char_p, P, P, c_i32, c_i32)
     _sig(lib, "vra_engine_finalize_weights", c_i32, P)
     _sig(lib, "vra_engine_num_gpu_blocks", c_i32, P)
+    _sig(lib, "vra_engine_swap_stats", None, P, P)
     _sig(lib, "vra_engine_plan_kv_blocks", c_i64, P)
     _sig(lib, "vra_engine_set_num_gpu_blocks", c_i32, P, c_i32)
     _sig(lib, "vra_engine_add_request", c_i64, P, P, c_i32, c_i32, c_i32, P, c_i32)

@@ -58,7 +58,7 @@ TINYLLAMA = dict(arch="llama", hidden_size=2048, intermediate_size=5632, num_lay
 class Engine:
     def __init__(self, cfg, *, block_size=64, max_num_seqs=32, max_model_len=0, num_gpu_blocks=0, kv_fraction=0.0,
                  prefill_chunk=8192, enable_prefix_cache=False, use_graph=True, tp_rank=0, tp_world_size=1, device=0,
-                 seed=1234, comm=None, fp8_kvcache=False):
+                 seed=1234, comm=None, fp8_kvcache=False, cpu_mem_fold=0.0, swap_cooling_ms=0, min_tokens_left_for_swap=0):
         self.L = _lib.load()
         if self.L.vra_device_count() <= 0:
             raise RuntimeError("vllm_rs_amd.Engine needs a GPU: no HIP device visible (there is no CPU fallback)")
@@ -68,7 +68,8 @@ class Engine:
                                num_gpu_blocks=num_gpu_blocks, kv_fraction=kv_fraction, prefill_chunk=prefill_chunk,
                                enable_prefix_cache=int(enable_prefix_cache), prefix_cache_fraction=0.65,
                                use_graph=int(use_graph), tp_rank=tp_rank, tp_world_size=tp_world_size, device=device,
-                               seed=seed, fp8_kvcache=int(fp8_kvcache))
+                               seed=seed, fp8_kvcache=int(fp8_kvcache), cpu_mem_fold=cpu_mem_fold,
+                               swap_cooling_ms=swap_cooling_ms, min_tokens_left_for_swap=min_tokens_left_for_swap)
         self.h = self.L.vra_engine_create(C.byref(self.mc), C.byref(self.ec))
         if not self.h:
             raise RuntimeError("vra_engine_create failed")
@@ -94,6 +95,12 @@ class Engine:
             self._check(self.L.vra_engine_load_tensor(self.h, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim, a.itemsize),
                         f"load_tensor({name})")
         return self.finalize() if finalize else self
+
+    def swap_stats(self):
+        """(cpu blocks, free cpu blocks, blocks swapped out so far, blocks swapped in so far)"""
+        out = (C.c_int64 * 4)()
+        self.L.vra_engine_swap_stats(self.h, out)
+        return tuple(int(x) for x in out)
 
     def plan_kv_blocks(self):
         """this rank's KV plan before the cache exists; TP launchers take the minimum over ranks (vllm_rs_amd/runner.py)"""
@@ -217,13 +224,14 @@ class HostEngine:
     Needs no GPU; used by the CPU parity tests of scheduler.rs / block_manager.rs / runner.rs behaviour."""
 
     def __init__(self, cfg, *, num_gpu_blocks, block_size=64, max_num_seqs=32, max_model_len=0, prefill_chunk=8192,
-                 enable_prefix_cache=False):
+                 enable_prefix_cache=False, cpu_mem_fold=0.0, swap_cooling_ms=0, min_tokens_left_for_swap=0):
         self.L = _lib.load()
         self.mc = model_config(cfg)
         self.ec = EngineConfig(block_size=block_size, max_num_seqs=max_num_seqs, max_model_len=max_model_len,
                                num_gpu_blocks=num_gpu_blocks, kv_fraction=0.0, prefill_chunk=prefill_chunk,
                                enable_prefix_cache=int(enable_prefix_cache), prefix_cache_fraction=0.65, use_graph=0,
-                               tp_rank=0, tp_world_size=1, device=-1, seed=0)
+                               tp_rank=0, tp_world_size=1, device=-1, seed=0, cpu_mem_fold=cpu_mem_fold,
+                               swap_cooling_ms=swap_cooling_ms, min_tokens_left_for_swap=min_tokens_left_for_swap)
         self.h = self.L.vra_engine_create(C.byref(self.mc), C.byref(self.ec))
         if not self.h or self.L.vra_engine_finalize_weights(self.h) != 0:
             raise RuntimeError("host engine: " + (self.L.vra_engine_last_error(self.h).decode() if self.h else "create failed"))
@@ -261,6 +269,12 @@ class HostEngine:
 
     def has_unfinished(self):
         return bool(self.L.vra_engine_has_unfinished(self.h))
+
+    def swap_stats(self):
+        """(cpu blocks, free cpu blocks, blocks swapped out so far, blocks swapped in so far)"""
+        out = (C.c_int64 * 4)()
+        self.L.vra_engine_swap_stats(self.h, out)
+        return tuple(int(x) for x in out)
 
     def finished(self, rid):
         return bool(self.L.vra_engine_request_finished(self.h, rid))

@@ -156,7 +156,7 @@ void PrefixCache::compact_lru_if_needed() {
 // ---------------------------------------------------------------------------------------------
 // BlockManager (src/core/block_manager.rs)
 // ---------------------------------------------------------------------------------------------
-BlockManager::BlockManager(int num_blocks, int block_size, bool prefix_cache, float prefix_fraction)
+BlockManager::BlockManager(int num_blocks, int block_size, bool prefix_cache, float prefix_fraction, int num_cpu_blocks)
     : block_size_(block_size),
       ref_(num_blocks, 0),
       next_(num_blocks, -1),
@@ -164,6 +164,8 @@ BlockManager::BlockManager(int num_blocks, int block_size, bool prefix_cache, fl
       in_free_(num_blocks, 0),
       cache_(block_size, prefix_cache, (int)((double)num_blocks * (prefix_fraction > 0 ? prefix_fraction : 0.65f))) {
   for (int i = 0; i < num_blocks; i++) push_back(i);  // block_manager.rs:62-68 — FIFO 0..n-1
+  num_cpu_blocks_ = std::max(0, num_cpu_blocks);
+  for (int i = 0; i < num_cpu_blocks_; i++) free_cpu_.push_back(i);
 }
 void BlockManager::push_back(int id) {
   prev_[id] = tail_;
@@ -289,6 +291,63 @@ int BlockManager::evict_prefix_cache(int n) {
   return (int)ev.size();
 }
 
+// ---- CPU swap space (block_manager.rs:870-1010)
+bool BlockManager::can_swap_out(const Sequence& s) const {
+  for (uint32_t id : s.block_table)
+    if (ref_[id] > 1) return false;  // a block shared with the prefix cache or another sequence stays on the GPU
+  return (int)free_cpu_.size() > s.num_blocks();
+}
+bool BlockManager::can_swap_in(const Sequence& s) const { return free_count_ > s.num_blocks(); }
+bool BlockManager::ensure_allocate(Sequence& s) {
+  while ((int)s.block_table.size() < s.num_blocks()) {
+    const int id = pop_front();
+    if (id < 0) return false;
+    ref_[id] = 1;
+    s.block_table.push_back((uint32_t)id);
+  }
+  return true;
+}
+bool BlockManager::swap_out(const Sequence& s, std::vector<std::pair<int, int>>* gpu_to_cpu) {
+  if (free_cpu_.size() < s.block_table.size()) return false;
+  std::vector<int> cpu_ids;
+  cpu_ids.reserve(s.block_table.size());
+  for (uint32_t g : s.block_table) {
+    const int c = free_cpu_.front();
+    free_cpu_.pop_front();
+    cpu_ids.push_back(c);
+    gpu_to_cpu->push_back({(int)g, c});
+  }
+  swapped_map_[s.id] = std::move(cpu_ids);
+  return true;
+}
+bool BlockManager::swap_in(const Sequence& s, std::vector<std::pair<int, int>>* cpu_to_gpu) {
+  auto it = swapped_map_.find(s.id);
+  if (it == swapped_map_.end()) return false;
+  if (it->second.size() > s.block_table.size()) {  // :964-969: not enough GPU blocks behind the table: give the space back
+    free_cpu_swap_for_seq(s.id);
+    return false;
+  }
+  for (size_t i = 0; i < it->second.size(); i++) cpu_to_gpu->push_back({it->second[i], (int)s.block_table[i]});
+  for (int c : it->second) free_cpu_.push_back(c);
+  swapped_map_.erase(it);
+  return true;
+}
+void BlockManager::free_cpu_swap_for_seq(int64_t seq_id) {
+  auto it = swapped_map_.find(seq_id);
+  if (it == swapped_map_.end()) return;
+  for (int c : it->second) free_cpu_.push_back(c);
+  swapped_map_.erase(it);
+}
+int BlockManager::evict_prefix_cache_until_free(int required_free) {
+  int evicted = 0;
+  while (free_count_ < required_free && cache_.cached_blocks() > 0) {
+    const int n = evict_prefix_cache(std::max(1, required_free - free_count_));
+    if (n == 0) break;
+    evicted += n;
+  }
+  return evicted;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Scheduler (src/core/scheduler.rs)
 // ---------------------------------------------------------------------------------------------
@@ -361,17 +420,32 @@ std::vector<int> Scheduler::schedule(bool* is_prefill) {
   }
   // ---- decode phase (:285-379)
   std::vector<int> decode_ids;
-  bool any_preempt = false;
-  for (auto& seq : running_)
-    if (!bm_->can_append(seq)) any_preempt = true;
-  if (any_preempt || bm_->usage() > kSwapThreshold) {
+  std::vector<int> preempt_ids;  // running sequences that cannot get their next slot (:288-296)
+  for (int idx = 0; idx < (int)running_.size(); idx++)
+    if (!bm_->can_append(running_[idx])) preempt_ids.push_back(idx);
+  const double now = now_ms();
+  const bool swap_space = bm_->num_cpu_blocks() > 0;
+  // :303-338.  Swap a sequence back in while there is room; under pressure evict a tenth of the prefix cache, and only when
+  // there is nothing to evict swap the OLDEST preempted sequence out (with a single running sequence that makes no sense)
+  const bool try_in = swap_space && preempt_ids.empty() &&
+                      (bm_->usage() < kSwapThreshold * 0.9f || (running_.empty() && bm_->usage() <= 0.3f));
+  if (try_in) {
+    try_swap_in(now);
+  } else if (!preempt_ids.empty() || bm_->usage() > kSwapThreshold) {
     const int cached = bm_->prefix_cache_blocks();
-    if (cached > 0) bm_->evict_prefix_cache(std::max(1, cached / 10));  // 10 % under pressure (:305-338)
+    const int evicted = cached > 0 ? bm_->evict_prefix_cache(std::max(1, cached / 10)) : 0;
+    if (evicted == 0 && swap_space && !preempt_ids.empty() && running_.size() > 1) {
+      int oldest = preempt_ids[0];
+      for (int i : preempt_ids)
+        if (running_[i].id < running_[oldest].id) oldest = i;
+      try_swap_out(oldest, now);
+    }
   }
   const int decode_max = std::max(cfg_.max_num_seqs, kMinScheduledReqs);
   for (int idx = 0; idx < (int)running_.size(); idx++) {
     if ((int)decode_ids.size() >= decode_max) break;
     Sequence& seq = running_[idx];
+    if (seq.status != SeqStatus::Running) continue;  // a failed swap-in parks its (finished) sequence here until collected
     if (!bm_->can_append(seq)) continue;  // unable to acquire resources this step
     if (!bm_->may_append(seq)) continue;
     decode_ids.push_back(idx);
@@ -451,8 +525,87 @@ std::vector<Sequence> Scheduler::clear_finished() {
   return done;
 }
 
+// :904-954 — one sequence a time; its blocks go back to the free list at once, the copy runs before the next forward
+bool Scheduler::try_swap_out(int idx, double now) {
+  if (idx < 0 || idx >= (int)running_.size()) return false;
+  Sequence& seq = running_[idx];
+  if (seq.block_table.empty() || seq.status != SeqStatus::Running || !bm_->can_swap_out(seq)) return false;
+  if (!bm_->ensure_allocate(seq)) return false;  // the same number of blocks on the way back in
+  SwapOp op;
+  op.to_gpu = false;
+  op.seq_id = seq.id;
+  if (!bm_->swap_out(seq, &op.pairs)) return false;
+  swap_ops_.push_back(std::move(op));
+  Sequence s = std::move(running_[idx]);
+  running_.erase(running_.begin() + idx);
+  s.status = SeqStatus::Swapped;
+  s.swapped_ms = now;
+  bm_->deallocate(s);
+  s.block_table.clear();  // reallocated at swap-in (:944)
+  swapped_.push_back(std::move(s));
+  return true;
+}
+
+// :830-901 — at most one sequence per step, and only after the cooling period
+void Scheduler::try_swap_in(double now) {
+  for (size_t i = 0; i < swapped_.size(); i++) {
+    Sequence& c = swapped_[i];
+    if (now - c.swapped_ms < (double)cfg_.swap_cooling_ms) continue;
+    const long available = (long)bm_->num_free_blocks() * bm_->block_size();
+    if (!bm_->can_swap_in(c) || available - c.len() < cfg_.min_tokens_left_for_swap) {
+      if (!running_.empty()) continue;  // wait for the running sequences to finish
+      if (bm_->evict_prefix_cache_until_free(c.num_blocks() + 1) > 0) break;
+      // nothing running, nothing to evict and still no room: the sequence can never come back (:871-876)
+      Sequence s = std::move(swapped_[i]);
+      swapped_.erase(swapped_.begin() + i);
+      bm_->free_cpu_swap_for_seq(s.id);
+      s.status = SeqStatus::Finished;
+      s.aborted = true;
+      s.finished_ms = now;
+      last_error = "no KV cache left to swap a sequence back in";
+      running_.push_back(std::move(s));
+      break;
+    }
+    Sequence s = std::move(swapped_[i]);
+    swapped_.erase(swapped_.begin() + i);
+    s.swapped_ms = now;
+    s.block_table.clear();
+    if (!bm_->ensure_allocate(s)) {  // (the reference drops the sequence here; it goes back to the swapped list instead)
+      bm_->deallocate(s);
+      s.block_table.clear();
+      swapped_.insert(swapped_.begin() + i, std::move(s));
+      continue;
+    }
+    SwapOp op;
+    op.to_gpu = true;
+    op.seq_id = s.id;
+    if (bm_->swap_in(s, &op.pairs)) {
+      swap_ops_.push_back(std::move(op));
+      s.status = SeqStatus::Running;
+    } else {
+      bm_->deallocate(s);
+      s.status = SeqStatus::Finished;
+      s.aborted = true;
+      s.finished_ms = now;
+      last_error = "swap-in failed";
+    }
+    running_.push_back(std::move(s));
+    break;
+  }
+}
+
 bool Scheduler::abort_one(double now) {
   if (running_.empty()) {
+    if (waiting_.empty() && !swapped_.empty()) {  // a swapped-out sequence that will never fit
+      Sequence s = std::move(swapped_.back());
+      swapped_.pop_back();
+      bm_->free_cpu_swap_for_seq(s.id);
+      s.status = SeqStatus::Finished;
+      s.aborted = true;
+      s.finished_ms = now;
+      running_.push_back(std::move(s));
+      return true;
+    }
     if (waiting_.empty()) return false;
     Sequence s = std::move(waiting_.back());
     waiting_.pop_back();

@@ -8,7 +8,9 @@
 //        behaviour is observable.
 //   A1   `ignore_eos` is honoured (the reference declares it and never reads it) so that synthetic-
 //        weight benchmarks generate a fixed number of tokens.
-//   CPU swap / PD transfer / mamba / images / tool-call stop are out of scope (§8 "next").
+//   PD transfer / mamba / images / tool-call stop are out of scope (§8 "next").  CPU swap follows
+//   block_manager.rs:870-1010 and scheduler.rs:303-338,826-955; the scheduler only decides and records the block copies,
+//   the engine executes them on its stream before the step that follows (SwapOp).
 #pragma once
 #include <stdint.h>
 
@@ -20,7 +22,7 @@
 
 namespace vra {
 
-enum class SeqStatus { Waiting, Running, Finished };
+enum class SeqStatus { Waiting, Running, Finished, Swapped };
 
 // src/core/sequence.rs:140-238
 struct Sequence {
@@ -28,6 +30,7 @@ struct Sequence {
   double created_ms = 0;       // sequence.rs:163-167 — TTFT start
   double first_token_ms = 0;   // engine.rs:1004-1012 decode_start_time
   double finished_ms = 0;
+  double swapped_ms = -1;      // sequence.rs swapped_time: last swap-out / swap-in (cooling period)
   SeqStatus status = SeqStatus::Waiting;
   std::vector<uint32_t> token_ids;
   std::vector<uint32_t> output_ids;
@@ -106,7 +109,7 @@ class PrefixCache {
 // src/core/block_manager.rs (GPU blocks only)
 class BlockManager {
  public:
-  BlockManager(int num_blocks, int block_size, bool prefix_cache, float prefix_fraction);
+  BlockManager(int num_blocks, int block_size, bool prefix_cache, float prefix_fraction, int num_cpu_blocks = 0);
   int num_blocks() const { return (int)ref_.size(); }
   int num_free_blocks() const { return free_count_; }
   int block_size() const { return block_size_; }
@@ -121,6 +124,16 @@ class BlockManager {
   int prefix_cache_blocks() const { return cache_.cached_blocks(); }
   int evict_prefix_cache(int n);                // scheduler.rs evict_prefix_cache_under_pressure
   float usage() const { return 1.0f - (float)free_count_ / (float)ref_.size(); }
+  // ---- CPU swap space (block_manager.rs:870-1010).  Pairs are (source block, destination block).
+  int num_cpu_blocks() const { return num_cpu_blocks_; }
+  int num_free_cpu_blocks() const { return (int)free_cpu_.size(); }
+  bool can_swap_out(const Sequence& s) const;   // :876-893: no shared block, more free CPU blocks than the sequence has
+  bool can_swap_in(const Sequence& s) const;    // :897-906
+  bool ensure_allocate(Sequence& s);            // :255-272: block table brought up to num_blocks()
+  bool swap_out(const Sequence& s, std::vector<std::pair<int, int>>* gpu_to_cpu);  // :908-955 (caller deallocates)
+  bool swap_in(const Sequence& s, std::vector<std::pair<int, int>>* cpu_to_gpu);   // :957-995 (blocks pre-allocated)
+  void free_cpu_swap_for_seq(int64_t seq_id);   // :997-1007
+  int evict_prefix_cache_until_free(int required_free);
 
  private:
   int pop_front();
@@ -139,6 +152,16 @@ class BlockManager {
   std::vector<char> in_free_;
   int head_ = -1, tail_ = -1, free_count_ = 0;
   PrefixCache cache_;
+  int num_cpu_blocks_ = 0;
+  std::deque<int> free_cpu_;
+  std::unordered_map<int64_t, std::vector<int>> swapped_map_;
+};
+
+// one batch of whole-block copies the engine has to run (vra_swap_blocks per layer and K/V) before its next forward
+struct SwapOp {
+  bool to_gpu = false;
+  int64_t seq_id = 0;
+  std::vector<std::pair<int, int>> pairs;  // (source block, destination block)
 };
 
 struct SchedulerConfig {
@@ -148,6 +171,8 @@ struct SchedulerConfig {
   int prefill_chunk = 8192;        // scheduler.rs:203
   int max_step_tokens = 16384;     // practical cap on tokens per prefill step (activation buffers)
   int max_model_len = 0;
+  int swap_cooling_ms = 5000;       // scheduler.rs:49 SWAP_COOLING_PERIOD
+  int min_tokens_left_for_swap = 1000;  // scheduler.rs:50
 };
 
 // src/core/scheduler.rs
@@ -163,7 +188,17 @@ class Scheduler {
   std::vector<Sequence> clear_finished();                                        // :631-660
   std::vector<Sequence>& running() { return running_; }
   const std::deque<Sequence>& waiting() const { return waiting_; }
-  bool has_unfinished() const { return !running_.empty() || !waiting_.empty(); }
+  const std::vector<Sequence>& swapped() const { return swapped_; }
+  bool has_unfinished() const { return !running_.empty() || !waiting_.empty() || !swapped_.empty(); }
+  // true when the only thing left to do is to wait for a swapped-out sequence's cooling period
+  bool only_swapped_left() const { return running_.empty() && waiting_.empty() && !swapped_.empty(); }
+  std::vector<SwapOp> take_swap_ops() {  // the copies decided by the last schedule(), in order
+    std::vector<SwapOp> r;
+    r.swap(swap_ops_);
+    return r;
+  }
+  bool try_swap_out(int running_idx, double now_ms);  // :904-954
+  void try_swap_in(double now_ms);                    // :830-901
   // drops the most recently admitted running sequence when nothing can make progress (engine.rs:1103-1120)
   bool abort_one(double now_ms);
   std::string last_error;
@@ -173,6 +208,8 @@ class Scheduler {
   SchedulerConfig cfg_;
   std::deque<Sequence> waiting_;
   std::vector<Sequence> running_;
+  std::vector<Sequence> swapped_;  // the reference keeps these in `cached` with status Swapped
+  std::vector<SwapOp> swap_ops_;
   int64_t next_id_ = 1;
   bool is_last_prefill_ = false;
 };

@@ -8,7 +8,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <map>
+#include <thread>
 #include <memory>
 
 #include "../csrc/scratch.h"
@@ -103,6 +105,44 @@ class Engine {
   bool dry() const { return ec_.device < 0; }
   std::vector<int> pend_ids_;
   bool pend_prefill_ = false, pend_valid_ = false;
+  int num_cpu_blocks_ = 0;
+  std::vector<void*> h_swap_k_, h_swap_v_;
+  int64_t swap_out_blocks_ = 0, swap_in_blocks_ = 0;  // statistics (vra_engine_swap_stats)
+  // the block copies the scheduler decided, on the engine stream, before the forward that follows (cache::swap_blocks,
+  // runner.rs:1641-1645).  A host-only engine only counts them.
+  bool execute_swaps() {
+    for (auto& op : sched_->take_swap_ops()) {
+      (op.to_gpu ? swap_in_blocks_ : swap_out_blocks_) += (int64_t)op.pairs.size();
+      if (dry() || op.pairs.empty()) continue;
+      std::vector<int64_t> pairs;
+      for (auto& pr : op.pairs) pairs.push_back(pr.first), pairs.push_back(pr.second);
+      const int64_t bb = (int64_t)model_.kv_block_bytes();
+      for (int l = 0; l < mc_.num_layers; l++) {
+        if (op.to_gpu) {
+          vra_swap_blocks(h_swap_k_[l], model_.k_cache(l), pairs.data(), (int)op.pairs.size(), bb, 2, (int64_t)stream_);
+          vra_swap_blocks(h_swap_v_[l], model_.v_cache(l), pairs.data(), (int)op.pairs.size(), bb, 2, (int64_t)stream_);
+        } else {
+          vra_swap_blocks(model_.k_cache(l), h_swap_k_[l], pairs.data(), (int)op.pairs.size(), bb, 1, (int64_t)stream_);
+          vra_swap_blocks(model_.v_cache(l), h_swap_v_[l], pairs.data(), (int)op.pairs.size(), bb, 1, (int64_t)stream_);
+        }
+      }
+      const char* e = vra_last_error();
+      if (e && e[0]) return fail(std::string("swap: ") + e);
+    }
+    return true;
+  }
+  // nothing was scheduled: drop a sequence if that is the only way forward; a swapped-out sequence inside its cooling
+  // period is progress of its own (the caller's step loop polls)
+  void nothing_scheduled() {
+    collect();
+    if (!sched_->has_unfinished()) return;
+    if (sched_->only_swapped_left()) {
+      std::this_thread::sleep_for(std::chrono::milliseconds(1));
+      return;
+    }
+    sched_->abort_one(now_ms());
+    collect();
+  }
   InputMetadata pend_md_;
   bool finalize_dry() {
     if (ec_.num_gpu_blocks < 2) return fail("dry engine needs an explicit num_gpu_blocks");
@@ -118,8 +158,12 @@ class Engine {
   }
   void setup_host(int64_t nb) {
     max_blocks_per_seq_ = (max_model_len_ + ec_.block_size - 1) / ec_.block_size;
-    bm_.reset(new BlockManager((int)nb, ec_.block_size, ec_.enable_prefix_cache != 0, ec_.prefix_cache_fraction));
+    // CPU swap space (kvcache_allocator.rs:673): num_cpu_blocks = gpu blocks x cpu_mem_fold
+    num_cpu_blocks_ = ec_.cpu_mem_fold > 0.f ? (int)((double)nb * ec_.cpu_mem_fold) : 0;
+    bm_.reset(new BlockManager((int)nb, ec_.block_size, ec_.enable_prefix_cache != 0, ec_.prefix_cache_fraction, num_cpu_blocks_));
     SchedulerConfig sc;
+    if (ec_.swap_cooling_ms) sc.swap_cooling_ms = std::max(0, ec_.swap_cooling_ms);
+    if (ec_.min_tokens_left_for_swap) sc.min_tokens_left_for_swap = std::max(0, ec_.min_tokens_left_for_swap);
     sc.max_num_seqs = ec_.max_num_seqs > 0 ? ec_.max_num_seqs : 32;  // the scheduler applies its own floor of 5 (scheduler.rs:44)
     sc.max_num_batched_tokens = (int)std::min<int64_t>(nb * ec_.block_size, 1 << 30);
     sc.block_size = ec_.block_size;
@@ -178,6 +222,15 @@ class Engine {
     if (nb > (1 << 24)) nb = 1 << 24;
     if (!model_.init_kv_cache((int)nb)) return fail("kv cache: " + model_.error);
     setup_host(nb);
+    if (num_cpu_blocks_ > 0) {  // pinned host copies of whole blocks, per layer: K then V (kvcache_allocator.rs:905-930)
+      const size_t bytes = (size_t)num_cpu_blocks_ * model_.kv_block_bytes();
+      h_swap_k_.assign(mc_.num_layers, nullptr);
+      h_swap_v_.assign(mc_.num_layers, nullptr);
+      for (int l = 0; l < mc_.num_layers; l++)
+        if (hipHostMalloc(&h_swap_k_[l], bytes, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc(&h_swap_v_[l], bytes, hipHostMallocDefault) != hipSuccess)
+          return fail("pinned alloc for the CPU swap space failed");
+    }
     const size_t B = max_seqs_;
     if (hipHostMalloc((void**)&h_meta_, meta_bytes_, hipHostMallocDefault) != hipSuccess) return fail("pinned alloc failed");
     if (hipMalloc((void**)&d_meta_, meta_bytes_) != hipSuccess) return fail("meta alloc failed");
@@ -484,11 +537,9 @@ class Engine {
     pend_ids_ = sched_->schedule(&is_prefill);
     pend_prefill_ = is_prefill;
     if (is_prefill_out) *is_prefill_out = is_prefill ? 1 : 0;
+    execute_swaps();
     if (pend_ids_.empty()) {
-      if (sched_->has_unfinished()) {
-        sched_->abort_one(now_ms());
-        collect();
-      }
+      nothing_scheduled();
       return 0;
     }
     int nb = 0;
@@ -534,11 +585,9 @@ class Engine {
     bool is_prefill = false;
     std::vector<int> ids = sched_->schedule(&is_prefill);
     if (is_prefill_out) *is_prefill_out = is_prefill ? 1 : 0;
+    if (!execute_swaps()) return -1;
     if (ids.empty()) {
-      if (sched_->has_unfinished()) {
-        sched_->abort_one(now_ms());
-        collect();
-      }
+      nothing_scheduled();
       return 0;
     }
     std::vector<uint32_t> tokens;
@@ -726,6 +775,13 @@ extern "C" int32_t vra_engine_set_num_gpu_blocks(void* e, int32_t n) {
   }
   en->ec_.num_gpu_blocks = n;
   return 0;
+}
+extern "C" void vra_engine_swap_stats(const void* e, int64_t* out4) {
+  const Engine* en = static_cast<const Engine*>(e);
+  out4[0] = en->num_cpu_blocks_;
+  out4[1] = en->bm_ ? en->bm_->num_free_cpu_blocks() : 0;
+  out4[2] = en->swap_out_blocks_;
+  out4[3] = en->swap_in_blocks_;
 }
 extern "C" int32_t vra_engine_num_gpu_blocks(const void* e) { return static_cast<const Engine*>(e)->model_.num_blocks(); }
 extern "C" int64_t vra_engine_add_request(void* e, const uint32_t* h_prompt, int32_t n_prompt, int32_t max_tokens, int32_t ignore_eos,

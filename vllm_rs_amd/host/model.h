@@ -72,6 +72,10 @@ class Model {
   // kv cache
   bool init_kv_cache(int num_blocks);
   int num_blocks() const { return num_blocks_; }
+  // one block of one layer's K (or V) cache: contiguous, [Hkv, BS, D] (or [Hkv, D, BS]) elements
+  size_t kv_block_bytes() const { return (size_t)hkv_ * ec_.block_size * mc_.head_dim * (ec_.fp8_kvcache ? 1 : es_); }
+  void* k_cache(int l) const { return kc_[l]; }
+  void* v_cache(int l) const { return vc_[l]; }
   // activations are sized for max_tokens rows
   bool init_buffers(int max_tokens, int max_seqs);
   void set_comm(void* comm) { comm_ = comm; }
