@@ -138,7 +138,7 @@ def test_forward_long_prefill_wide_projections(arch, qm):
     eng.close()
 
 
-@pytest.mark.parametrize("B,wide", [(9, False), (16, False), (32, False), (6, True)])  # (32, True) passes too: 2 min of CPU oracle
+@pytest.mark.parametrize("B,wide", [(9, False), (16, False), (32, False), (6, True), (12, True), (20, True), (32, True)])
 def test_forward_decode_large_batch(B, wide):
     """decode batches of 5..32 rows: kernel C (kernel B at the small widths); `wide` = the Llama-3-8B widths, one layer"""
     cfg = small_cfg(hidden_size=4096, intermediate_size=14336, num_layers=1, num_heads=32, num_kv_heads=8, head_dim=128, vocab_size=2048,

@@ -661,6 +661,17 @@ static void launch_attn(const PagedAttnArgs& a, int D, bool kv8, dim3 grid, hipS
     vra_set_error("paged attention: head_dim %d not supported (64, 128)", D);
   }
 }
+#ifdef VRA_GEMV_TS
+static unsigned long long* g_pf_ts = nullptr;
+static unsigned long long* vra_attn_pf_ts_buf() {
+  if (!g_pf_ts) {
+    (void)hipMalloc(&g_pf_ts, 4096 * 32 * 8);
+    (void)hipMemset(g_pf_ts, 0, 4096 * 32 * 8);
+  }
+  return g_pf_ts;
+}
+extern "C" void vra_debug_attn_pf_ts(unsigned long long* host, int n) { (void)hipMemcpy(host, vra_attn_pf_ts_buf(), (size_t)n * 8, hipMemcpyDeviceToHost); }
+#endif
 // kv_dtype: the activation dtype (16-bit cache) or VRA_FP8_E4M3
 static bool kv_dtype_ok(const char* who, int dtype, int kv_dtype) {
   if (kv_dtype == dtype || kv_dtype == VRA_FP8_E4M3) return true;
@@ -756,13 +767,17 @@ extern "C" void vra_paged_attention_prefill(void* out, const void* q, const void
   a.softcap = softcap;
   a.decode = 0;
   a.nsplit = 1;
-  if (block_tables && (head_dim == 128 || head_dim == 64) && !getenv("VRA_NO_PREFILL_TILED")) {
+  if (block_tables && (head_dim == 128 || head_dim == 64) && (block_size & (block_size - 1)) == 0 && !getenv("VRA_NO_PREFILL_TILED")) {
     // the LDS-tiled prefill kernel (attn_prefill.cuh); 2 row tiles per wave once that still leaves >= 2 workgroups per CU
     PrefillAttnArgs p = {};
     p.out = out, p.q = q, p.kc = k_cache, p.vc = v_cache;
     p.block_tables = block_tables, p.context_lens = context_lens, p.cu_q = cu_seqlens_q;
     p.Hq = q_heads, p.Hkv = kv_heads, p.BS = block_size, p.max_blocks = max_blocks_per_seq;
+    p.bs_shift = __builtin_ctz((unsigned)block_size);
     p.scale = scale, p.scale_log2e = a.scale_log2e, p.softcap = softcap;
+#ifdef VRA_GEMV_TS
+    p.ts = vra_attn_pf_ts_buf();
+#endif
     const bool kv8 = kv_dtype == VRA_FP8_E4M3;
     const long wgs2 = (long)((max_seqlen_q + 127) / 128) * q_heads * batch;
     const int mt = wgs2 >= 512 ? 2 : 1;

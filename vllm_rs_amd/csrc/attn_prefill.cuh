@@ -37,8 +37,22 @@ struct PrefillAttnArgs {
   const uint32_t* context_lens;  // [B]
   const uint32_t* cu_q;          // [B+1]
   int Hq, Hkv, BS, max_blocks;
+  int bs_shift;  // log2(BS): this kernel takes power-of-two block sizes (others run paged_attn_kernel)
   float scale_log2e, softcap, scale;
+  unsigned long long* ts;  // -DVRA_GEMV_TS builds: per-wave phase cycle sums (tools/attn_prefill_ts.py)
 };
+#ifdef VRA_GEMV_TS
+#define PF_STAMP(v)                               \
+  do {                                            \
+    __builtin_amdgcn_sched_barrier(0);            \
+    v = (long long)__builtin_readcyclecounter();  \
+    __builtin_amdgcn_sched_barrier(0);            \
+  } while (0)
+#else
+#define PF_STAMP(v) \
+  do {              \
+  } while (0)
+#endif
 
 template <int D>
 __device__ __forceinline__ int pf_kswz(int key, int c) {  // K tile: chunk c of row `key` -> swizzled chunk
@@ -109,34 +123,48 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(const Prefi
   const kv_t* vcache = static_cast<const kv_t*>(a.vc);
   const uint32_t* bt = a.block_tables + (size_t)b * a.max_blocks;
   raw_t kst[KLD], vst[KLD];
-  // thread -> chunks of the tile.  K: chunk i = n*256 + tid of [64 keys][KCH chunks]; V: chunk i of [D channels][8 chunks]
-  auto issue_loads = [&](int tile) {
-    const int T0 = tile << 6;
-    // the two 32-token halves of the tile: block and offset (a half never straddles a block: BS % 32 == 0); wave-uniform.
-    // A half that starts past the context has no block: it reads block 0 (any mapped memory will do — its scores are masked
-    // and store_tile zeroes its V tokens); nothing here selects on loaded data, so the loads stay in flight over the compute
-    size_t kb[2], vb[2];
+  // block ids of a tile's two 32-token halves (a half never straddles a block: BS % 32 == 0); wave-uniform.  They are
+  // fetched ONE TILE AHEAD of the loads that need them: looked up at issue time, the dependent block-table round trip
+  // stood in front of every tile's K/V loads.  A half that starts past the context has no block: it reads block 0 (any
+  // mapped memory will do — its scores are masked and store_tile zeroes its V tokens); nothing selects on loaded data, so
+  // the loads stay in flight over the compute.
+  auto block_of = [&](int tok) -> int { return tok >> a.bs_shift; };  // BS is a power of two (launcher)
+  auto load_blocks = [&](int tile, uint32_t (&blk)[2]) {
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-      const int tok = T0 + 32 * h;
-      const uint32_t blk = tok < ctx ? bt[tok / a.BS] : 0u;
-      const int off = tok % a.BS;
-      kb[h] = (((size_t)blk * a.Hkv + hk) * a.BS + off) * D;
-      vb[h] = (((size_t)blk * a.Hkv + hk) * D) * a.BS + off;
+      const int tok = (tile << 6) + 32 * h;
+      blk[h] = tok < ctx ? bt[block_of(tok)] : 0u;
     }
+  };
+  // thread -> chunks of the tile.  K: chunk i = n*256 + tid of [64 keys][KCH chunks]; V: chunk i of [D channels][8 chunks].
+  // The 2*KLD loads of the next tile are NOT issued as one burst behind the barrier: all waves of the workgroup would
+  // queue 32 KB at the CU's texture-address unit at the same moment and sit in the issue stall (1600 of 5500 cycles per
+  // tile in the phase timers).  next_bases() computes the wave-uniform bases, the loads go out one by one between the MFMA
+  // groups of the S and P.V phases.
+  size_t kb0 = 0, kb1 = 0, vb0 = 0, vb1 = 0;  // (scalars, not arrays: an array captured by the lambdas below lands in scratch)
+  auto next_bases = [&](int tile, const uint32_t (&blk)[2]) {
+    const int T0 = tile << 6;
+    const int off0 = T0 - block_of(T0) * a.BS, off1 = T0 + 32 - block_of(T0 + 32) * a.BS;
+    kb0 = (((size_t)blk[0] * a.Hkv + hk) * a.BS + off0) * D;
+    kb1 = (((size_t)blk[1] * a.Hkv + hk) * a.BS + off1) * D;
+    vb0 = (((size_t)blk[0] * a.Hkv + hk) * D) * a.BS + off0;
+    vb1 = (((size_t)blk[1] * a.Hkv + hk) * D) * a.BS + off1;
+  };
+  auto issue_k = [&](int n) {
+    const int i = n * PF_THREADS + tid;
+    const int key = i / KCH, c = i % KCH;
+    const bool h = ((n * PF_THREADS / KCH) >> 5) != 0;  // compile-time: 256 chunks never span two halves
+    kst[n] = *reinterpret_cast<const raw_t*>(kcache + (h ? kb1 : kb0) + (size_t)(key & 31) * D + c * 8);
+  };
+  auto issue_v = [&](int n) {
+    const int i = n * PF_THREADS + tid;
+    const int ch = i >> 3, c = i & 7, h = c >> 2;
+    vst[n] = *reinterpret_cast<const raw_t*>(vcache + (h ? vb1 : vb0) + (size_t)ch * a.BS + (c & 3) * 8);
+  };
+  auto issue_loads = [&](int tile, const uint32_t (&blk)[2]) {
+    next_bases(tile, blk);
 #pragma unroll
-    for (int n = 0; n < KLD; n++) {
-      const int i = n * PF_THREADS + tid;
-      {
-        const int key = i / KCH, c = i % KCH;
-        const int h = (n * PF_THREADS / KCH) >> 5;  // compile-time: 256 chunks never span two halves
-        kst[n] = *reinterpret_cast<const raw_t*>(kcache + kb[h] + (size_t)(key & 31) * D + c * 8);
-      }
-      {
-        const int ch = i >> 3, c = i & 7, h = c >> 2;
-        vst[n] = *reinterpret_cast<const raw_t*>(vcache + (h ? vb[1] : vb[0]) + (size_t)ch * a.BS + (c & 3) * 8);
-      }
-    }
+    for (int n = 0; n < KLD; n++) issue_k(n), issue_v(n);
   };
   auto widen = [&](const raw_t& r) -> u32x4 {
     if constexpr (KV8) return vra_unpack_e4m3x8<DT>(r);
@@ -165,108 +193,180 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(const Prefi
     }
   };
 
-  issue_loads(0);
+  long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0, t7 = 0, sA = 0, sB = 0, sC = 0, sD = 0, sE = 0, sF = 0, sG = 0;
+  (void)t0, (void)t1, (void)t2, (void)t3, (void)t4, (void)t5, (void)t6, (void)t7;
+  (void)sA, (void)sB, (void)sC, (void)sD, (void)sE, (void)sF, (void)sG;
+  uint32_t blk_next[2];
+  load_blocks(0, blk_next);
+  issue_loads(0, blk_next);
+  load_blocks(1, blk_next);
   for (int tile = 0; tile < ntiles; tile++) {
     const int T0 = tile << 6;
+    PF_STAMP(t0);
     __syncthreads();  // every wave is done reading the previous tile
+    PF_STAMP(t1);
     store_tile(tile);
+    PF_STAMP(t2);
     __syncthreads();
-    if (tile + 1 < ntiles) issue_loads(tile + 1);
-    if (!wave_live || T0 > w_last_pos) continue;  // wave-uniform; the wave still takes part in loads and barriers
+    PF_STAMP(t3);
+    const bool more = tile + 1 < ntiles;  // (the last tile re-requests itself: never stored)
+    next_bases(more ? tile + 1 : tile, blk_next);
+    if (more) load_blocks(tile + 2, blk_next);  // (past the last tile: positions >= ctx, no access)
+    if (!wave_live || T0 > w_last_pos) {  // wave-uniform; the wave still takes part in loads and barriers
+#pragma unroll
+      for (int n = 0; n < KLD; n++) issue_k(n), issue_v(n);
+      continue;
+    }
+    PF_STAMP(t4);
+    sA += t1 - t0, sB += t2 - t1, sC += t3 - t2, sD += t4 - t3;
 
-    // ---- S^T for the four 16-key sub-tiles
+    // ---- S^T for the four 16-key sub-tiles.  The K fragments of sub-tile u+1 are read from LDS before the MFMAs of
+    // sub-tile u are issued (the MFMAs are volatile asm in program order: hipcc does not hoist the reads by itself, and
+    // read -> wait -> 2 MFMAs left the matrix pipe idle for the LDS latency: 1577 cycles for 32 MFMAs)
     f32x4 s[MT][4];
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
       for (int u = 0; u < 4; u++) s[mt][u] = vra_zero_acc();
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
+    auto k_frags = [&](int u, u32x4 (&kf)[DJ]) {
       const int key = 32 * (u >> 1) + (rq >> 2) * 8 + (u & 1) * 4 + (rq & 3);
 #pragma unroll
-      for (int j = 0; j < DJ; j++) {
-        const u32x4 kf = *reinterpret_cast<const u32x4*>(Ks + key * D + pf_kswz<D>(key, j * 4 + oct) * 8);
+      for (int j = 0; j < DJ; j++) kf[j] = *reinterpret_cast<const u32x4*>(Ks + key * D + pf_kswz<D>(key, j * 4 + oct) * 8);
+    };
+    {
+      u32x4 kfr[2][DJ];
+      k_frags(0, kfr[0]);
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++) DT::mfma(s[mt][u], __builtin_bit_cast(s16x8, kf), qf[mt][j]);
+      for (int u = 0; u < 4; u++) {
+        if (u + 1 < 4) k_frags(u + 1, kfr[(u + 1) & 1]);
+        if (u * KLD / 4 < KLD && (u * KLD) % 4 == 0) issue_k(u * KLD / 4);  // KLD = 4: one per sub-tile; KLD = 2: u = 0, 2
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < DJ; j++)
+#pragma unroll
+          for (int mt = 0; mt < MT; mt++) DT::mfma(s[mt][u], __builtin_bit_cast(s16x8, kfr[u & 1][j]), qf[mt][j]);
       }
     }
+    // the first V fragments are requested now: they land while the softmax runs
+    auto v_frags = [&](int t, u32x4 (&vf)[2]) {
+      const int ch = t * 16 + rq;
+#pragma unroll
+      for (int h = 0; h < 2; h++) vf[h] = *reinterpret_cast<const u32x4*>(Vs + ch * PF_KEYS + pf_vswz(ch, h * 4 + oct) * 8);
+    };
+    u32x4 vfr[3][2];
+    v_frags(0, vfr[0]);
+    v_frags(1, vfr[1]);
     VRA_MFMA_DRAIN();  // s (and the previous tile's O updates) are complete past this point
-    // ---- softmax update, row tile by row tile; scores in the log2 domain
+    PF_STAMP(t5);
+    // ---- softmax update, row tile by row tile; scores in the log2 domain.  The maximum is taken over the raw scores
+    // (scale > 0) and the scale rides in the FMA in front of the exp: exp2(s*c - m*c).
     const bool need_mask = T0 + PF_KEYS - 1 > w_first_pos || T0 + PF_KEYS > ctx;  // wave-uniform
     s16x8 pf[MT][2];
+    float x[MT][16], tmax[MT];
+    float cs = a.scale_log2e;  // x[] -> log2-domain logit: x * cs
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
-      float x[16];
-      float tmax = -INFINITY;
 #pragma unroll
       for (int u = 0; u < 4; u++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          float v = s[mt][u][r];
-          if (a.softcap > 0.f) v = a.softcap * tanhf(v * a.scale / a.softcap) * 1.44269504088896f;
-          else v *= a.scale_log2e;
-          x[u * 4 + r] = v;
-        }
-      if (need_mask) {
+        for (int r = 0; r < 4; r++) x[mt][u * 4 + r] = s[mt][u][r];
+    }
+    if (a.softcap > 0.f) {  // wave-uniform, ONE branch around all elements
+      const float inv = a.scale / a.softcap;
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) x[mt][e] = tanhf(x[mt][e] * inv);
+      cs = a.softcap * 1.44269504088896f;
+    }
+    if (need_mask) {
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++)
 #pragma unroll
         for (int u = 0; u < 4; u++)
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             const int tok = T0 + 32 * (u >> 1) + oct * 8 + (u & 1) * 4 + r;
-            if (tok > row_pos[mt] || tok >= ctx) x[u * 4 + r] = -INFINITY;
+            if (tok > row_pos[mt] || tok >= ctx) x[mt][u * 4 + r] = -INFINITY;
           }
-      }
+    }
+    // row maxima of all row tiles together: in-lane, then the two cross-lane steps as VALU lane swaps (no LDS round trip)
 #pragma unroll
-      for (int e = 0; e < 16; e++) tmax = fmaxf(tmax, x[e]);
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-      const float m_new = fmaxf(m_run[mt], tmax);
+    for (int mt = 0; mt < MT; mt++) {
+      float m = x[mt][0];
+#pragma unroll
+      for (int e = 1; e < 16; e++) m = fmaxf(m, x[mt][e]);
+      tmax[mt] = m;
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) tmax[mt] = vra_xor16_max(tmax[mt]);
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) tmax[mt] = vra_xor32_max(tmax[mt]);
+    float alpha[MT];
+    bool moved = false;
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+      const float m_new = fmaxf(m_run[mt], tmax[mt] * cs);
       const float m_safe = m_new == -INFINITY ? 0.f : m_new;
-      const float alpha = __builtin_amdgcn_exp2f(m_run[mt] - m_safe);
+      alpha[mt] = __builtin_amdgcn_exp2f(m_run[mt] - m_safe);
+      moved = moved || alpha[mt] != 1.0f;
       float psum = 0.f;
 #pragma unroll
       for (int e = 0; e < 16; e++) {
-        x[e] = __builtin_amdgcn_exp2f(x[e] - m_safe);
-        psum += x[e];
+        x[mt][e] = __builtin_amdgcn_exp2f(__builtin_fmaf(x[mt][e], cs, -m_safe));
+        psum += x[mt][e];
       }
-      l_run[mt] = l_run[mt] * alpha + psum;  // this lane's share of the row sum (its own 16 keys of every tile)
+      l_run[mt] = l_run[mt] * alpha[mt] + psum;  // this lane's share of the row sum (its own 16 keys of every tile)
       m_run[mt] = m_new;
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         u32x4 pa;
-        pa[0] = DT::pack2(x[h * 8 + 0], x[h * 8 + 1]);
-        pa[1] = DT::pack2(x[h * 8 + 2], x[h * 8 + 3]);
-        pa[2] = DT::pack2(x[h * 8 + 4], x[h * 8 + 5]);
-        pa[3] = DT::pack2(x[h * 8 + 6], x[h * 8 + 7]);
+        pa[0] = DT::pack2(x[mt][h * 8 + 0], x[mt][h * 8 + 1]);
+        pa[1] = DT::pack2(x[mt][h * 8 + 2], x[mt][h * 8 + 3]);
+        pa[2] = DT::pack2(x[mt][h * 8 + 4], x[mt][h * 8 + 5]);
+        pa[3] = DT::pack2(x[mt][h * 8 + 6], x[mt][h * 8 + 7]);
         pf[mt][h] = __builtin_bit_cast(s16x8, pa);
       }
-      // rescale O (row rq is this lane's own row): skipped when no row of the wave moved its maximum
-      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+    }
+    // rescale O (row rq is this lane's own row): skipped when no row of the wave moved its maximum
+    if (__builtin_amdgcn_ballot_w64(moved) != 0) {
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++)
 #pragma unroll
         for (int t = 0; t < DT16; t++)
 #pragma unroll
-          for (int r = 0; r < 4; r++) o[mt][t][r] *= alpha;
-      }
+          for (int r = 0; r < 4; r++) o[mt][t][r] *= alpha[mt];
     }
-    // ---- O^T += V^T.P^T
+    PF_STAMP(t6);
+    // ---- O^T += V^T.P^T, the V fragments two channel tiles ahead of their MFMAs
 #pragma unroll
     for (int t = 0; t < DT16; t++) {
-      const int ch = t * 16 + rq;
+      if (t + 2 < DT16) v_frags(t + 2, vfr[(t + 2) % 3]);
+      if ((t * KLD) % DT16 == 0) issue_v(t * KLD / DT16);  // spread over the channel tiles
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const u32x4 vf = *reinterpret_cast<const u32x4*>(Vs + ch * PF_KEYS + pf_vswz(ch, h * 4 + oct) * 8);
+      for (int h = 0; h < 2; h++)
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++) DT::mfma(o[mt][t], __builtin_bit_cast(s16x8, vf), pf[mt][h]);
-      }
+        for (int mt = 0; mt < MT; mt++) DT::mfma(o[mt][t], __builtin_bit_cast(s16x8, vfr[t % 3][h]), pf[mt][h]);
+    }
+    PF_STAMP(t7);
+    sE += t5 - t4, sF += t6 - t5, sG += t7 - t6;
+  }
+#ifdef VRA_GEMV_TS
+  if (a.ts && lane == 0) {
+    const size_t wg = (size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (wg < 4096) {
+      unsigned long long* t = a.ts + (wg * 4 + wave) * 8;
+      t[0] = (unsigned long long)sA, t[1] = (unsigned long long)sB, t[2] = (unsigned long long)sC, t[3] = (unsigned long long)sD;
+      t[4] = (unsigned long long)sE, t[5] = (unsigned long long)sF, t[6] = (unsigned long long)sG, t[7] = (unsigned long long)ntiles;
     }
   }
+#endif
   VRA_MFMA_DRAIN();  // O is read by the VALU below
   if (!wave_live) return;
 #pragma unroll
   for (int mt = 0; mt < MT; mt++) {
-    float l = l_run[mt];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    float l = vra_xor32_sum(vra_xor16_sum(l_run[mt]));
     const int qtok = w_i0 + mt * 16 + rq;
     if (qtok >= lq) continue;
     const float inv = l > 0.f ? 1.0f / l : 0.f;

@@ -50,6 +50,30 @@ static inline hipStream_t as_stream(int64_t s) { return reinterpret_cast<hipStre
     asm volatile("s_nop 7\n\ts_nop 4"); \
     __builtin_amdgcn_sched_barrier(0);  \
   } while (0)
+// xor-16 / xor-32 lane exchanges as VALU ops (gfx950 v_permlane16_swap / v_permlane32_swap) instead of __shfl_xor, which
+// lowers to ds_bpermute_b32 — an LDS round trip (~100+ cycles) per step.  permlane32_swap(a, b) exchanges a[32..63] with
+// b[0..31]; with a = b = x the two results hold x's lower half twice and x's upper half twice, so combining them lane by
+// lane is the xor-32 combination; permlane16_swap does the same with the odd and even rows of 16 lanes (xor 16).
+__device__ __forceinline__ float vra_xor32_max(float x) {
+  const unsigned u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float vra_xor16_max(float x) {
+  const unsigned u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float vra_xor32_sum(float x) {
+  const unsigned u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float vra_xor16_sum(float x) {
+  const unsigned u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 __device__ __forceinline__ f32x4 vra_zero_acc() {
   f32x4 z = {0.f, 0.f, 0.f, 0.f};
   asm volatile("" : "+v"(z));

@@ -522,7 +522,8 @@ class Engine {
       vra_argmax_f32(model_.logits(), d_tokens_, B, mc_.vocab_size, (int64_t)stream_);
     } else {
       // one fresh seed per call, as `self.rng.lock().next_u64()` (logits_processor.rs:223-226)
-      const uint64_t seed = (uint64_t)vra_hash32_host(ec_.seed ? ec_.seed : 1234, ++sample_calls_) << 32 | vra_hash32_host(ec_.seed + 1, sample_calls_);
+      ++sample_calls_;
+      const uint64_t seed = (uint64_t)vra_hash32_host(ec_.seed ? ec_.seed : 1234, sample_calls_) << 32 | vra_hash32_host(ec_.seed + 1, sample_calls_);
       vra_sample(model_.logits(), d_tokens_, B, mc_.vocab_size, c.k, c.p, c.temperature, seed, nullptr, nullptr, (int64_t)stream_);
     }
     const char* e = vra_last_error();
