@@ -382,7 +382,24 @@ def main():
                 res.append(t["first_token_ms"] - t["created_ms"])
             line["ttft_p50_ms"]["bs1_prompt32768"] = res[0]
             line["ttft_p50_ms"]["bs1_prompt32768_prefix_hit_511_blocks"] = res[1]
+            # ... then 8 prompts that share its first 16 384 tokens (256 cached blocks) and differ in their last 1024
+            import numpy as np
+            tails = make_prompts(8, 1024, V, seed=6)
+            rids = [e5.add_request(np.concatenate([p32[:16384], t]), max_tokens=2, ignore_eos=True) for t in tails]
+            while e5.has_unfinished():
+                e5.step()
+            tt = sorted(e5.times(r)["first_token_ms"] - e5.times(r)["created_ms"] for r in rids)
+            line["ttft_p50_ms"]["bs8_prompt17408_shared_16k_prefix"] = 0.5 * (tt[3] + tt[4])
             e5.close()
+            # ---------------- FP8 (E4M3) KV cache: the KV term of long-context decode at half the bytes
+            e8 = E.Engine(cfg, max_num_seqs=32, max_model_len=8192, num_gpu_blocks=a.blocks, use_graph=not a.no_graph, device=local_rank,
+                          seed=1234, fp8_kvcache=True).init_synthetic()
+            lc8 = {}
+            for bs, ctx in ((1, 8000), (32, 4096)):
+                dtl, _, _ = run_decode(e8, make_prompts(bs, ctx, V, seed=77 + ctx), 4, 16, lambda: L.vra_device_sync())
+                lc8[f"bs{bs}_ctx{ctx}"] = {"tokens_per_s": bs * 16 / dtl, "ms_per_step": dtl * 1e3 / 16, "kv_GB_per_step": bs * (ctx + 10) * 65536 / 1e9}
+            line["long_context_decode_fp8_kv"] = lc8
+            e8.close()
             # ---------------- the reference's binding path
             line["ffi_path"] = ffi_path(L, cfg)
             line["ffi_path"]["native_family_ms_per_token"] = line["roofline"]["family_ms_per_token"]
