@@ -46,7 +46,10 @@ def main():
             with open(os.path.join(P, dst), "w") as f:
                 f.write(txt)
                 if kind:
-                    f.write(notes[kind].replace("{B}", "32" if "bs32" in src else "1"))
+                    note = notes[kind].replace("{B}", "32" if "bs32" in src else "1")
+                    if "prefill" in src:  # the prefill runs profile tools/prefill_once.py (two 4096-token prompts), not bench.py
+                        note = note.replace("python bench.py --steps 32 --warmup 4 --batch 1 --no-graph --no-extras", "python tools/prefill_once.py")
+                    f.write(note)
             print("wrote", dst)
     sha = open(os.path.join(G, "prof_lib_sha16.txt")).read().strip() if os.path.exists(os.path.join(G, "prof_lib_sha16.txt")) else None
     fetch = parse_pmc(os.path.join(G, "prof_pmc_fetch_bs1.summary.txt"))
