@@ -96,12 +96,26 @@ def lib_sha16():
     return hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16]
 
 
+def src_sha16():
+    """hash of the sources the library is built from (csrc + host + the header): unlike the .so hash it survives a rebuild
+    on another checkout, and any kernel edit changes it"""
+    import glob
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "vllm_rs_amd", "csrc", "*.*")) + glob.glob(os.path.join(ROOT, "vllm_rs_amd", "host", "*.*")) +
+                    glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        if f.endswith((".hip", ".cuh", ".h", ".cpp")) or os.path.basename(f) == "Makefile":
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc FETCH_SIZE pass — ONLY if that pass was taken
-    with this very library (the .so hash is stored next to the counters): a kernel change can never leave a stale number."""
+    with a library built from these very sources (the source hash, and the .so hash of that build, are stored next to the
+    counters): a kernel change can never leave a stale number in the line."""
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
-        if pmc.get("lib_sha16") != lib_sha16():
+        if pmc.get("src_sha16") != src_sha16() and pmc.get("lib_sha16") != lib_sha16():
             return None
         return pmc["kernels"][kernel]["hbm_bytes_per_launch"]
     except Exception:
@@ -349,7 +363,7 @@ def main():
                             "traffic": pmc_traffic(dom["kernel"]) if a.batch == 1 else None,
                             "algorithmic_bytes_per_launch": dom["bytes"], "avg_launch_ms": dom["ms"],
                             "family": per, "family_GBps": tot_b / tot_ms / 1e6, "family_frac": tot_b / tot_ms / 1e6 / HBM_PEAK_GBS,
-                            "family_ms_per_token": tot_ms * cfg["num_layers"], "lib_sha16": lib_sha16()}
+                            "family_ms_per_token": tot_ms * cfg["num_layers"], "lib_sha16": lib_sha16(), "src_sha16": src_sha16()}
         # ---------------- bs=32 decode
         if a.batch != 32:
             dt32, _, _ = run_decode(eng, make_prompts(32, a.prompt_len, V, seed=43), 8, 64, lambda: L.vra_device_sync())

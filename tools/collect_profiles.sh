@@ -31,7 +31,9 @@ python -c "
 import hashlib,sys
 sys.path.insert(0,'$R')
 from vllm_rs_amd import _lib
-print(hashlib.sha256(open(_lib.LIB_PATH,'rb').read()).hexdigest()[:16])" > $OUT/prof_lib_sha16.txt
+import bench
+print(hashlib.sha256(open(_lib.LIB_PATH,'rb').read()).hexdigest()[:16])
+print(bench.src_sha16())" > $OUT/prof_lib_sha16.txt
 # drop the raw databases (tens of MB): the summaries are what is committed
 find $OUT -name "*.db" -path "*prof_*" -delete
 ls $OUT
