@@ -74,6 +74,14 @@ __device__ __forceinline__ float vra_xor16_sum(float x) {
   const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
+// s_setprio takes an immediate: a wave-uniform priority 0..3 through scalar branches (no memory operation inside, so the
+// s_waitcnt bookkeeping of the surrounding loop is unaffected)
+__device__ __forceinline__ void vra_setprio_dyn(int p) {
+  if (p == 0) __builtin_amdgcn_s_setprio(0);
+  else if (p == 1) __builtin_amdgcn_s_setprio(1);
+  else if (p == 2) __builtin_amdgcn_s_setprio(2);
+  else __builtin_amdgcn_s_setprio(3);
+}
 __device__ __forceinline__ f32x4 vra_zero_acc() {
   f32x4 z = {0.f, 0.f, 0.f, 0.f};
   asm volatile("" : "+v"(z));

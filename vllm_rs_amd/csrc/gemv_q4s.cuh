@@ -84,6 +84,9 @@ static inline size_t gemv_q4s_lds_bytes(int ns, int tpw, int max_units) {
 #define GS_MIN_WAVES_PER_SIMD 4
 #endif
 #ifndef GS_RING_PAIR
+#ifndef GS_ROTATE_PRIO
+#define GS_ROTATE_PRIO 0  // measured: levels the waves (spread 4.4 -> 3.0 us) but the launch takes the same 16.1 us — see below
+#endif
 #define GS_RING_PAIR 2  // ring depth (tile-steps of 2 KiB) of the gate/up pair stream (measured: 2 beats 1 by 2 % of the decode step)
 #endif
 template <class DT, int NS, bool AWQ>
@@ -257,6 +260,11 @@ __global__ __launch_bounds__(GS_THREADS, GS_MIN_WAVES_PER_SIMD) void gemv_q4s_ke
 #pragma unroll
   for (int b = 0; b < NS; b++) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
   int cu = 0, ct = 0;  // consume cursor
+  // The four waves of a SIMD are served oldest first: the oldest wave of every SIMD finishes its (equal) share ~4 us before
+  // the youngest (per-wave stamps, tools/gemv_s_ts.py).  Alternating priorities (GS_ROTATE_PRIO) level them, but the last
+  // wave ends at the same time: the stream phase of the gate/up launch already moves 272 KB per CU in 9.6 us = 6.3 TB/s
+  // chip-wide, i.e. it is bandwidth-bound and only the order in which the waves are served changes.
+  const int pgrp = wave >> 2;
   const int S_pad = (S + D - 1) / D * D;  // the only loop exit is the back edge (see gemv_q4.cuh)
   for (int s0 = 0; s0 < S_pad; s0 += D) {
 #pragma unroll
@@ -265,13 +273,15 @@ __global__ __launch_bounds__(GS_THREADS, GS_MIN_WAVES_PER_SIMD) void gemv_q4s_ke
         const bool valid = wave + 16 * ct < KT;
         const unsigned char* xp = xfrag + (size_t)ct * GS_TILE_LDS;
         f32x4 ag[NS];
-#pragma unroll
-        for (int b = 0; b < NS; b++) ag[b] = vra_zero_acc();
+        if (GS_ROTATE_PRIO) vra_setprio_dyn((r & 1) ? 3 - pgrp : pgrp);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           const s16x8 xf = __builtin_bit_cast(s16x8, *reinterpret_cast<const u32x4*>(xp + j * 64));
 #pragma unroll
-          for (int b = 0; b < NS; b++) DT::mfma(ag[b], xf, magic_word<DT>(wb[r][b][j]));
+          for (int b = 0; b < NS; b++) {
+            if (j == 0) DT::mfma0(ag[b], xf, magic_word<DT>(wb[r][b][j]));  // C = 0: no accumulator to clear
+            else DT::mfma(ag[b], xf, magic_word<DT>(wb[r][b][j]));
+          }
         }
         VRA_MFMA_DRAIN();
         const f32x4 sx = *reinterpret_cast<const f32x4*>(xw + (size_t)ct * GS_TILE_LDS + 1088);  // Σx of rows 0..3 over this tile
@@ -300,6 +310,9 @@ __global__ __launch_bounds__(GS_THREADS, GS_MIN_WAVES_PER_SIMD) void gemv_q4s_ke
     }
   }
   GEMV_STAMP(15);
+#ifdef VRA_GEMV_TS
+  if (a.ts && lane == 0 && blockIdx.x < 1024) a.ts[(size_t)2048 * 32 + (size_t)blockIdx.x * 16 + wave] = wall_clock64();  // every wave's loop end
+#endif
 
   // ---- tail prefetch: the first tile-steps of this (workgroup, wave) in the next launch, into this XCD's L2
   // (two 1 KiB requests per wave = the next launch's first ring fill: (stream 0, tile 0) and (stream 1, tile 0) of a pair,
@@ -316,6 +329,7 @@ __global__ __launch_bounds__(GS_THREADS, GS_MIN_WAVES_PER_SIMD) void gemv_q4s_ke
 
   // ---- all partial tiles of the workgroup meet once; units*64 threads finish the outputs
   __syncthreads();
+  GEMV_STAMP(17);
   if (e_act) {
     const float* rf = reinterpret_cast<const float*>(red);
     float v = 0.f, v2 = 0.f;
