@@ -62,6 +62,12 @@ struct GemmDArgs {
   GemvSeg xseg[2];
   const float* xsum;  // [M][K/128] row sums of x per k-tile (xsum_rows_kernel), set by the launcher
   unsigned long long* ts;  // -DVRA_GEMV_TS builds: per-workgroup phase cycle sums (tools/gemm_big_ts.py)
+  // split-K (gridDim.z slices; short prefills where the output tiles alone do not fill the chip): the exchange of kernels
+  // B/C — write-through fp32 slabs, one flag line per slice, the last slice reduces in fixed order
+  int splitk;
+  float* slabs;
+  uint32_t* counters;
+  uint32_t* err;
 };
 #ifdef VRA_GEMV_TS
 #define GD_STAMP(v)                         \
@@ -198,6 +204,9 @@ __global__ __launch_bounds__(GD_THREADS, 2) void gemm_q4_big_kernel(const GemmDA
   for (int b = 0; b < NB; b++)
 #pragma unroll
     for (int t = 0; t < MB; t++) acc[b][t][0] = acc[b][t][1] = f32x2{0.f, 0.f};
+  // this workgroup's k-tiles: all of them, or slice blockIdx.z of a.splitk
+  const int SK = a.splitk > 1 ? a.splitk : 1, zi = (int)blockIdx.z;
+  const int kt0 = (int)((long)KT * zi / SK), kt1 = (int)((long)KT * (zi + 1) / SK);
 
   u32x4 wq[NB];
   u32x2 scw[NB];
@@ -205,10 +214,10 @@ __global__ __launch_bounds__(GD_THREADS, 2) void gemm_q4_big_kernel(const GemmDA
   float sxn[MB];
   {
     u32x4 x0[XPT], x1[XPT];
-    x_load(0, x0);
-    x_load(min(1, KT - 1), x1);
-    w_load(0, wq, scw, zw);
-    sum_load(0, sxn);
+    x_load(kt0, x0);
+    x_load(min(kt0 + 1, kt1 - 1), x1);
+    w_load(kt0, wq, scw, zw);
+    sum_load(kt0, sxn);
     x_store(0, x0);
     x_store(1, x1);
   }
@@ -216,8 +225,8 @@ __global__ __launch_bounds__(GD_THREADS, 2) void gemm_q4_big_kernel(const GemmDA
 
   long long tA = 0, tB = 0, tC = 0, tD = 0, tE = 0, sB = 0, sC = 0, sD = 0, sE = 0;
   (void)tA, (void)tB, (void)tC, (void)tD, (void)tE, (void)sB, (void)sC, (void)sD, (void)sE;
-  for (int kt = 0; kt < KT; kt++) {
-    const int buf = kt % 3;
+  for (int kt = kt0; kt < kt1; kt++) {
+    const int buf = (kt - kt0) % 3;
     GD_STAMP(tA);
     // ---- the k-tile's 4 x 4 weight fragments (C + q), its scales and row sums; then the loads of the next k-tile
     s16x8 af[NB][4];
@@ -236,9 +245,9 @@ __global__ __launch_bounds__(GD_THREADS, 2) void gemm_q4_big_kernel(const GemmDA
     }
 #pragma unroll
     for (int mt = 0; mt < MB; mt++) sxc[mt] = sxn[mt];
-    const int ktn = min(kt + 1, KT - 1);  // the last iteration re-loads its own tile (never consumed)
+    const int ktn = min(kt + 1, kt1 - 1);  // the last iteration re-loads its own tile (never consumed)
     u32x4 xr[XPT];
-    x_load(min(kt + 2, KT - 1), xr);
+    x_load(min(kt + 2, kt1 - 1), xr);
     w_load(ktn, wq, scw, zw);
     sum_load(ktn, sxn);
     GD_STAMP(tB);
@@ -288,7 +297,7 @@ __global__ __launch_bounds__(GD_THREADS, 2) void gemm_q4_big_kernel(const GemmDA
       }
     }
     GD_STAMP(tC);
-    x_store((kt + 2) % 3, xr);
+    x_store((kt - kt0 + 2) % 3, xr);
     GD_STAMP(tD);
     __syncthreads();
     GD_STAMP(tE);
@@ -300,6 +309,57 @@ __global__ __launch_bounds__(GD_THREADS, 2) void gemm_q4_big_kernel(const GemmDA
     t[0] = (unsigned long long)sB, t[1] = (unsigned long long)sC, t[2] = (unsigned long long)sD, t[3] = (unsigned long long)sE;
   }
 #endif
+
+  // ---- split-K: the slices of a tile meet through memory (see gemm_skinny.cuh): write-through 16-byte stores, one flag
+  // line per slice, the last slice ("owner") polls, adds the slabs to its own partial in slice order and resets the flags
+  if (SK > 1) {
+    const int tile = (int)(blockIdx.y * gridDim.x + blockIdx.x), ntiles = (int)(gridDim.x * gridDim.y);
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a.slabs, 0, 0x7FFFFFF0, RSRC3);
+    auto slab_off = [&](int z, int b, int mt) {  // bytes: [slice][tile][n-block][m-tile][thread] x 16 B
+      return (uint32_t)((((z * ntiles + tile) * NB + b) * MB + mt) * GD_THREADS + tid) * 16u;
+    };
+    uint32_t* fl = a.counters + (size_t)tile * SK * 16;
+    if (zi != SK - 1) {
+#pragma unroll
+      for (int b = 0; b < NB; b++)
+#pragma unroll
+        for (int mt = 0; mt < MB; mt++) {
+          const u32x4 v = {__float_as_uint(acc[b][mt][0][0]), __float_as_uint(acc[b][mt][0][1]), __float_as_uint(acc[b][mt][1][0]),
+                           __float_as_uint(acc[b][mt][1][1])};
+          __builtin_amdgcn_raw_buffer_store_b128(v, srs, slab_off(zi, b, mt), 0, 16);
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // write-through stores: acknowledged by memory
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(fl + zi * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    if (tid < SK - 1) {
+      const uint64_t t0 = __builtin_readcyclecounter();
+      while (__hip_atomic_load(fl + tid * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        __builtin_amdgcn_s_sleep(1);
+        if (__builtin_readcyclecounter() - t0 > (1ull << 31)) {  // never hang the device on a lost slice
+          __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+      __hip_atomic_store(fl + tid * 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    for (int z = 0; z < SK - 1; z++) {  // one slice per round trip: NB*MB 16-byte loads in flight per lane; fixed order
+      u32x4 p[NB][MB];
+#pragma unroll
+      for (int b = 0; b < NB; b++)
+#pragma unroll
+        for (int mt = 0; mt < MB; mt++) p[b][mt] = __builtin_amdgcn_raw_buffer_load_b128(srs, slab_off(z, b, mt), 0, 16);
+#pragma unroll
+      for (int b = 0; b < NB; b++)
+#pragma unroll
+        for (int mt = 0; mt < MB; mt++) {
+          acc[b][mt][0] += f32x2{__uint_as_float(p[b][mt][0]), __uint_as_float(p[b][mt][1])};
+          acc[b][mt][1] += f32x2{__uint_as_float(p[b][mt][2]), __uint_as_float(p[b][mt][3])};
+        }
+    }
+  }
 
   // ---- epilogue: D[column (lane>>4)*4 + r][row lane&15] of tile (b, mt)
   constexpr int NBO = DUAL ? 2 : NB;  // output n-blocks of the wave

@@ -564,7 +564,7 @@ int vra_gemm_q4_big_fits(bool dual, int M, int cols, int K, int group_size, cons
   // e.g. M = 512: o 50.9 (B) / 39.8 (D, mb 2) / 58.3 (mb 4); down 143 / 117 / 180; gate/up 169 (mb 4) / 189 (mb 2).
   const int gx = dual ? (cols + 127) / 128 : (cols + 255) / 256;
   const int cus = num_cus();
-  if (mb_env && (atoi(mb_env) == 2 || atoi(mb_env) == 4)) return atoi(mb_env);
+  if (mb_env && (atoi(mb_env) == 2 || atoi(mb_env) == 4) && !getenv("VRA_GD_SPLITK")) return atoi(mb_env);
   const double kf = (double)K / 4096.0;
   auto est_d = [&](int mb) {
     const long w = (long)gx * ((M + 16 * mb - 1) / (16 * mb));
@@ -574,10 +574,34 @@ int vra_gemm_q4_big_fits(bool dual, int M, int cols, int K, int group_size, cons
   };
   const double flops = 2.0 * (double)M * (double)cols * (dual ? 2.0 : 1.0) * (double)K;
   const double est_b = 17.0 + flops / ((dual ? 650.0 : 490.0) * 1e6);
+  double best = est_b;
+  int pick = 0;
   const double d4 = est_d(4), d2 = est_d(2);
-  if (d4 <= d2 && d4 < est_b) return 4;
-  if (d2 < est_b) return 2;
-  return 0;
+  if (d2 < best) best = d2, pick = 2;
+  if (d4 <= best) best = d4, pick = 4;
+  // split-K (short prefills: the output tiles alone leave most CUs idle): S slices of >= 4 k-tiles each, one exchange
+  // (write-through slabs + flags, ~6 us + the owner's S-1 slab reads) on top of a slice's share of the k loop
+  static const char* sk_env = getenv("VRA_GD_SPLITK");  // tuning / test aid: 0 = never, N = force N slices where legal
+  const int sk_force = sk_env ? atoi(sk_env) : -1;
+  const int KT = K / 128;
+  if (vra_scratch_slabs() && vra_scratch_counters() && sk_force != 0) {
+    for (int mb = 4; mb >= 2; mb -= 2)
+      for (int S = 2; S <= 16; S *= 2) {
+        if (KT % S || KT / S < 4) continue;
+        const long tiles = (long)gx * ((M + 16 * mb - 1) / (16 * mb));
+        if (tiles * S > 2L * cus) continue;  // owners must find their slices resident: the whole grid is co-resident
+        if (sk_force > 1) {
+          if (S == sk_force) return mb | (S << 8);
+          continue;
+        }
+        const long q = (tiles * S + cus - 1) / cus;
+        const double pair = mb == 4 ? 82.0 : 46.0, lone = mb == 4 ? 47.0 : 28.0;
+        const double body = ((double)(q / 2) * pair + (double)(q % 2) * lone) * kf / S;
+        const double est = 15.0 + 3.0 + body + 6.0 + (mb == 4 ? 0.5 : 0.25) * (S - 1);
+        if (est < best) best = est, pick = mb | (S << 8);
+      }
+  }
+  return pick;
 }
 template <class DT, bool DUAL, int MB>
 static void launch_gemm_q4_big_t(const GemmDArgs& a, bool awq, dim3 grid, hipStream_t st) {
@@ -592,12 +616,14 @@ static void launch_gemm_q4_big_t(const GemmDArgs& a, bool awq, dim3 grid, hipStr
   if (awq) gemm_q4_big_kernel<DT, DUAL, true, MB><<<grid, GD_THREADS, lds, st>>>(a);
   else gemm_q4_big_kernel<DT, DUAL, false, MB><<<grid, GD_THREADS, lds, st>>>(a);
 }
-void vra_launch_gemm_q4_big(const GemmDArgs& a0, bool dual, bool awq, int mb, int dtype, int64_t stream) {
+static const size_t kXsumBytes = (size_t)16 << 20;  // the row-sum table lives in the LAST 16 MiB of the slab region
+void vra_launch_gemm_q4_big(const GemmDArgs& a0, bool dual, bool awq, int mb_sk, int dtype, int64_t stream) {
   GemmDArgs a = a0;
-  {  // row sums of x per k-tile, once per GEMM (scratch: the split-K slab region — kernel D does not slice K)
-    float* tbl = vra_scratch_slabs();
+  const int mb = mb_sk & 0xff, sk = mb_sk >> 8 > 1 ? mb_sk >> 8 : 1;  // vra_gemm_q4_big_fits: m-tiles | split-K << 8
+  {  // row sums of x per k-tile, once per GEMM (scratch: the tail of the split-K slab region)
+    float* tbl = vra_scratch_slabs() ? vra_scratch_slabs() + (vra_scratch_slab_bytes() - kXsumBytes) / 4 : nullptr;
     const int KT = a.K >> 7;
-    if (!tbl || (size_t)a.M * KT * 4 > vra_scratch_slab_bytes()) {
+    if (!tbl || (size_t)a.M * KT * 4 > kXsumBytes) {
       vra_set_error("gemm_q4_big: scratch for the row sums unavailable (%d x %d)", a.M, KT);
       return;
     }
@@ -610,7 +636,18 @@ void vra_launch_gemm_q4_big(const GemmDArgs& a0, bool dual, bool awq, int mb, in
   a.ts = vra_gemv_ts_buf();
 #endif
   const int cols = dual ? a.N : (a.nseg > 1 ? a.xseg[a.nseg - 2].blk_start * 16 + a.xseg[a.nseg - 2].n : a.N);
-  dim3 grid(dual ? (cols + 127) / 128 : (cols + 255) / 256, (a.M + 16 * GD_WM * mb - 1) / (16 * GD_WM * mb));
+  dim3 grid(dual ? (cols + 127) / 128 : (cols + 255) / 256, (a.M + 16 * GD_WM * mb - 1) / (16 * GD_WM * mb), sk);
+  a.splitk = sk;
+  if (sk > 1) {
+    a.slabs = vra_scratch_slabs();
+    a.counters = vra_scratch_counters();
+    a.err = vra_scratch_error_word();
+    const size_t need = (size_t)sk * grid.x * grid.y * GD_NB * mb * GD_THREADS * 16;
+    if (!a.slabs || !a.counters || need > vra_scratch_slab_bytes() - kXsumBytes || (size_t)grid.x * grid.y * sk * 16 > vra_scratch_counter_count()) {
+      vra_set_error("gemm_q4_big: split-K scratch unavailable");
+      return;
+    }
+  }
   hipStream_t st = as_stream(stream);
   const bool bf = dtype == VRA_BF16;
 #define VRA_GD(DU, MBV)                                                   \
