@@ -139,7 +139,7 @@ __global__ __launch_bounds__(GD_THREADS, 2) void gemm_q4_big_kernel(const GemmDA
       }
     }
   }
-  // n-block b of the wave: tensor tb(b), block nbv(b); a missing block streams block 0 with zeroed scales
+  // n-block b of the wave: tensor tb(b), block nbv(b); a missing block streams block 0 (its results are never stored)
   auto tb = [&](int b) { return DUAL ? (b >> 1) : 0; };
   auto nbv = [&](int b) { return nb0 + (DUAL ? (b & 1) : b); };
   bool ok[NB];
@@ -238,8 +238,7 @@ __global__ __launch_bounds__(GD_THREADS, 2) void gemm_q4_big_kernel(const GemmDA
       for (int j = 0; j < 4; j++) af[b][j] = magic_word<DT>(wq[b][j]);
       float s4[4], z4[4];
       unpack_scale4<DT>(scw[b], zw[b], nbc[b] * 16 + oct * 4, s4, z4);
-#pragma unroll
-      for (int r = 0; r < 4; r++) s4[r] = ok[b] ? s4[r] : 0.f;
+      // (a missing n-block streams block 0 with block 0's scales: its accumulators are never stored — no masking here)
       sc2[b][0] = f32x2{s4[0], s4[1]}, sc2[b][1] = f32x2{s4[2], s4[3]};
       nzc2[b][0] = f32x2{-z4[0], -z4[1]}, nzc2[b][1] = f32x2{-z4[2], -z4[3]};
     }
