@@ -937,8 +937,25 @@ extern "C" int32_t vra_engine_forward_raw(void* e, const uint32_t* h_ids, const 
     return -1;
   }
   if (hipMemcpyAsync(h_logits_out, en->model_.logits(), (size_t)n_seqs * en->mc_.vocab_size * 4, hipMemcpyDeviceToHost, en->stream_) != hipSuccess) return -1;
+  // the device error words (a split-K slice or a tensor-parallel peer that never arrived) ride along, as in step()
+  uint32_t* dev_err = vra_scratch_error_word();
+  uint32_t* comm_err = en->comm_ ? vra_comm_error_word(en->comm_) : nullptr;
+  if (dev_err) (void)hipMemcpyAsync(en->h_err_, dev_err, 4, hipMemcpyDeviceToHost, en->stream_);
+  if (comm_err) (void)hipMemcpyAsync(en->h_err_ + 1, comm_err, 4, hipMemcpyDeviceToHost, en->stream_);
   if (hipStreamSynchronize(en->stream_) != hipSuccess) {
     en->error = "stream error in forward_raw";
+    return -1;
+  }
+  if (comm_err && en->h_err_[1]) {
+    en->h_err_[1] = 0;
+    (void)hipMemsetAsync(comm_err, 0, 4, en->stream_);
+    en->error = "one-shot all-reduce timed out waiting for a peer (results of this forward are invalid)";
+    return -1;
+  }
+  if (dev_err && en->h_err_[0]) {
+    en->h_err_[0] = 0;
+    (void)hipMemsetAsync(dev_err, 0, 4, en->stream_);
+    en->error = "split-K exchange timed out on the device (results of this forward are invalid)";
     return -1;
   }
   return 0;
