@@ -639,7 +639,13 @@ static int decode_nsplit(int batch, int kv_heads, int max_context_len) {
   int wg = batch * kv_heads;
   int tiles = (max_context_len + 31) / 32;
   int s = 1;
-  while (wg * s < 512 && tiles / (s * 2) >= 8 && s < 64) s *= 2;
+  // a split keeps >= 8 tiles (2 per wave) — or >= 4 (one per wave) while there are fewer than 64 workgroups: at bs 1 the
+  // eight (sequence, kv head) workgroups leave the chip idle and the shorter tile chain pays for the merge launch
+  // (bs 1, ctx 130..380: 534 -> 554 tok/s), at bs 32 it does not (3.46 -> 3.54 ms per step), and past 64 workgroups the
+  // wider merge loses (bs 1, ctx 8000: 2.36 -> 2.60 ms with 32 splits instead of 16)
+  static const char* e = getenv("VRA_ATTN_SPLIT_TILES");  // tuning aid: fewest tiles a split keeps (overrides both)
+  const int forced = e && atoi(e) > 0 ? atoi(e) : 0;
+  while (wg * s < 512 && tiles / (s * 2) >= (forced ? forced : (wg * s < 64 ? 4 : 8)) && s < 64) s *= 2;
   return s;
 }
 

@@ -369,11 +369,16 @@ class Engine {
     while (b < n) b *= 2;
     return b;
   }
+  // context buckets 256, then 512 * 4^k: the split-KV decision of the decode attention is taken for the bucket, and below
+  // 256 tokens splitting (plus its merge launch) is a loss at every batch size (bs = 32 at ctx ~200: 3.61 ms per step with
+  // the 512 bucket's two splits, 3.49 ms eager with one)
   static int ctx_bucket(int c) {
+    if (c <= 256) return 256;
     int b = 512;
     while (b < c) b *= 4;
     return b;
   }
+  static int next_ctx_bucket(int cb) { return cb < 512 ? 512 : cb * 4; }
 
   // ---- GraphCapturer::capture (graph.rs:267-308, 448-560): the decode forward of `bucket` lanes with contexts up to `cb`,
   // static buffers, relaxed mode.  Returns null (error left empty) when capture is unavailable: the caller runs eagerly.
@@ -408,7 +413,7 @@ class Engine {
     for (int b = 1; b <= std::min(max_seqs_, 15); b++) bs.push_back(b);
     for (int b = 16; b <= max_seqs_; b *= 2) bs.push_back(b);
     for (int b : bs)
-      for (int cb = 512;; cb *= 4) {
+      for (int cb = 256;; cb = next_ctx_bucket(cb)) {
         if (!graph_for(b, cb) && !error.empty()) return false;
         if (cb >= max_model_len_) break;
       }
