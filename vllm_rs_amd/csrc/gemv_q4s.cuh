@@ -89,14 +89,59 @@ static inline size_t gemv_q4s_lds_bytes(int ns, int tpw, int max_units) {
 #endif
 #define GS_RING_PAIR 2  // ring depth (tile-steps of 2 KiB) of the gate/up pair stream (measured: 2 beats 1 by 2 % of the decode step)
 #endif
-template <class DT, int NS, bool AWQ>
-__global__ __launch_bounds__(GS_THREADS, GS_MIN_WAVES_PER_SIMD) void gemv_q4s_kernel(const GemvSArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// ---- grid barrier of the two-phase launch (gemv_q4s2_kernel): per-workgroup flag lines + a launch counter in device memory
+// (monotonic epochs: replayable from a hipGraph, nothing to reset).  Every workgroup of the grid must be resident — the
+// launcher keeps the grid <= the CU count and uses the two-phase form only in a single-process engine; the wait is bounded.
+struct GemvSBar {
+  uint32_t* flags;  // [grid] x 16 words (one 64-byte line each)
+  uint32_t* count;  // launches completed so far
+  uint32_t* err;    // device error word (a workgroup that never arrived)
+  int grid;
+};
+__device__ __forceinline__ void gs_bar_arrive(const GemvSBar& b, uint32_t epoch, int tid, int wg) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's write-through stores are acknowledged
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(b.flags + (size_t)wg * 16, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void gs_bar_wait(const GemvSBar& b, uint32_t epoch, int tid) {
+  if (tid < 64) {  // one wave polls all flags (a poller per wave next to a weight stream costs the stream ~9 %)
+    // each lane watches up to 8 flags and requests them TOGETHER: polled one after the other, four dependent round trips stood
+    // between the last arrival and the release (3.2 us in the timeline, against ~1 for one round trip)
+    const uint64_t t0 = wall_clock64();
+    bool done = false;
+    while (!done) {
+      uint32_t v[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int i = tid + 64 * k;
+        v[k] = i < b.grid ? __hip_atomic_load(b.flags + (size_t)i * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
+      }
+      done = true;
+#pragma unroll
+      for (int k = 0; k < 8; k++) done = done && (int32_t)(v[k] - epoch) >= 0;
+      if (!done) {
+        __builtin_amdgcn_s_sleep(1);
+        if (wall_clock64() - t0 > 50000000ull) {  // 0.5 s at 100 MHz: never hang the device
+          __hip_atomic_store(b.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// PH: 0 = a launch of its own; 1 = first phase of a two-phase launch (outputs written through: the second phase of OTHER
+// workgroups reads them in the same launch); 2 = second phase (the weight ring is requested BEFORE the grid barrier — it
+// does not depend on the first phase — and lands while the barrier completes; x is read past the L1 after it)
+template <class DT, int NS, bool AWQ, int PH>
+__device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char* smem, const GemvSBar& bar, uint32_t epoch) {
   constexpr int D = NS == 2 ? GS_RING_PAIR : GS_RING_KIB;  // ring depth in tile-steps (1 KiB per stream and step)
   // every kernel argument the way to the first load needs, requested in ONE batch of scalar loads
-  asm volatile("" ::"s"(a.x), "s"(a.x_ld), "s"(a.norm_w), "s"(a.K), "s"(a.M), "s"(a.KT), "s"(a.TPW), "s"(a.gsh), "s"(a.units_q), "s"(a.units_r),
-               "s"(a.w[0]), "s"(a.scales[0]), "s"(a.s_grp_stride), "s"(a.s_unit_stride), "s"(a.marlin), "s"(a.residual), "s"(a.res_ld),
-               "s"(a.nseg), "s"(a.seg[0].out), "s"(a.seg[0].bias), "s"(a.seg[0].out_ld), "s"(a.seg[1].unit_start), "s"(a.seg[2].unit_start));
+  if (PH != 2)
+    asm volatile("" ::"s"(a.x), "s"(a.x_ld), "s"(a.norm_w), "s"(a.K), "s"(a.M), "s"(a.KT), "s"(a.TPW), "s"(a.gsh), "s"(a.units_q), "s"(a.units_r),
+                 "s"(a.w[0]), "s"(a.scales[0]), "s"(a.s_grp_stride), "s"(a.s_unit_stride), "s"(a.marlin), "s"(a.residual), "s"(a.res_ld),
+                 "s"(a.nseg), "s"(a.seg[0].out), "s"(a.seg[0].bias), "s"(a.seg[0].out_ld), "s"(a.seg[1].unit_start), "s"(a.seg[2].unit_start));
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nn = lane & 15, oct = lane >> 4;
@@ -162,19 +207,27 @@ __global__ __launch_bounds__(GS_THREADS, GS_MIN_WAVES_PER_SIMD) void gemv_q4s_ke
   };
 
 #ifdef GS_RING_FIRST
-  // variant: the ring is filled BEFORE the x loads (x then returns behind the first weight tiles)
-#pragma unroll
-  for (int r = 0; r < D; r++) {
-    issue(iu, it, wb[r], sb[r], zb[r]);
-    advance_issue();
-  }
-  __builtin_amdgcn_sched_barrier(0);
+  constexpr bool RING_FIRST = true;  // variant: the ring is filled BEFORE the x loads (x then returns behind the first weight tiles)
+#else
+  constexpr bool RING_FIRST = PH == 2;
 #endif
+  if (RING_FIRST) {
+#pragma unroll
+    for (int r = 0; r < D; r++) {
+      issue(iu, it, wb[r], sb[r], zb[r]);
+      advance_issue();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  GEMV_STAMP(19);
+  if (PH == 2) gs_bar_wait(bar, epoch, tid);  // every workgroup's first-phase outputs are in memory past this point
+  GEMV_STAMP(20);
   // ---- prologue: this wave's x slices.  Staging lane = (row group oct, octet nn): region `oct` of a tile holds row
   // min(oct, M-1), so rows >= M alias the last row (their outputs are never stored).
   const bool norm = a.norm_w != nullptr;
   const uint16_t* xrow = static_cast<const uint16_t*>(a.x) + (size_t)min(oct, M - 1) * a.x_ld + nn * 8;
   const uint16_t* nwp = static_cast<const uint16_t*>(a.norm_w) + nn * 8;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, 0x7FFFFFF0, 0x00020000);
   u32x4 nr[GS_NORM_TPW];
   float ss = 0.f;
   for (int t0 = 0; t0 < TPW; t0 += 4) {
@@ -182,7 +235,8 @@ __global__ __launch_bounds__(GS_THREADS, GS_MIN_WAVES_PER_SIMD) void gemv_q4s_ke
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int kt = min(wave + 16 * min(t0 + i, TPW - 1), KT - 1);
-      xv[i] = *reinterpret_cast<const u32x4*>(xrow + (size_t)kt * 128);
+      if (PH == 2) xv[i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (uint32_t)(((size_t)min(oct, M - 1) * a.x_ld + nn * 8 + (size_t)kt * 128) * 2), 0, 16);  // sc1
+      else xv[i] = *reinterpret_cast<const u32x4*>(xrow + (size_t)kt * 128);
       if (norm && t0 == 0) nr[i] = *reinterpret_cast<const u32x4*>(nwp + (size_t)kt * 128);  // (norm => TPW <= 4)
     }
 #pragma unroll
@@ -208,17 +262,17 @@ __global__ __launch_bounds__(GS_THREADS, GS_MIN_WAVES_PER_SIMD) void gemv_q4s_ke
   GEMV_STAMP(16);
 
   // the ring is filled right behind the x loads (in order per wave: x first); the staging below overlaps the first HBM round trip
-#ifndef GS_RING_FIRST
+  if (!RING_FIRST) {
 #ifdef GS_XWAIT  // variant: x (L2) complete before the first HBM load is queued — measured equal to not waiting
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 #endif
 #pragma unroll
-  for (int r = 0; r < D; r++) {
-    issue(iu, it, wb[r], sb[r], zb[r]);
-    advance_issue();
+    for (int r = 0; r < D; r++) {
+      issue(iu, it, wb[r], sb[r], zb[r]);
+      advance_issue();
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
-  __builtin_amdgcn_sched_barrier(0);
-#endif
   GEMV_STAMP(1);
 
   if (norm) {
@@ -311,7 +365,7 @@ __global__ __launch_bounds__(GS_THREADS, GS_MIN_WAVES_PER_SIMD) void gemv_q4s_ke
   }
   GEMV_STAMP(15);
 #ifdef VRA_GEMV_TS
-  if (a.ts && lane == 0 && blockIdx.x < 1024) a.ts[(size_t)2048 * 32 + (size_t)blockIdx.x * 16 + wave] = wall_clock64();  // every wave's loop end
+  if (PH != 2 && a.ts && lane == 0 && blockIdx.x < 1024) a.ts[(size_t)2048 * 32 + (size_t)blockIdx.x * 16 + wave] = wall_clock64();  // every wave's loop end
 #endif
 
   // ---- tail prefetch: the first tile-steps of this (workgroup, wave) in the next launch, into this XCD's L2
@@ -350,9 +404,31 @@ __global__ __launch_bounds__(GS_THREADS, GS_MIN_WAVES_PER_SIMD) void gemv_q4s_ke
       v = sl * v2;
     }
     if (a.residual) v = rnd_dt<DT>(v) + e_res;
-    static_cast<uint16_t*>(e_out)[(size_t)e_m * e_ld + e_col] = DT::from_f32(v);
+    uint16_t* const op = static_cast<uint16_t*>(e_out) + (size_t)e_m * e_ld + e_col;
+    if (PH == 1) __hip_atomic_store(op, DT::from_f32(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through
+    else *op = DT::from_f32(v);
   }
   if (have_next) asm volatile("" ::"v"(pf0), "v"(pf1));  // keep the prefetch loads alive until they have landed
   GEMV_STAMP(14);
+}
+
+template <class DT, int NS, bool AWQ>
+__global__ __launch_bounds__(GS_THREADS, GS_MIN_WAVES_PER_SIMD) void gemv_q4s_kernel(const GemvSArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  gemv_q4s_body<DT, NS, AWQ, 0>(a, smem, GemvSBar{}, 0u);
+}
+
+// Two dependent GEMVs of the decode layer in ONE launch: o_proj (+residual) -> RMSNorm + gate/up + SiLU*mul, or
+// down (+residual) -> the next layer's RMSNorm + q/k/v.  What it removes is not the barrier (a flag barrier costs about what
+// the kernel boundary does) but the second launch's dead time in front of its first tile: its weight ring is in flight
+// across the barrier.  Same arithmetic, same per-unit summation order as two launches: bit-identical outputs.
+template <class DT, int NSA, int NSB, bool AWQ>
+__global__ __launch_bounds__(GS_THREADS, GS_MIN_WAVES_PER_SIMD) void gemv_q4s2_kernel(const GemvSArgs a, const GemvSArgs b, const GemvSBar bar) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t epoch = *bar.count + 1u;  // the same for every workgroup: the counter moves at the END of a launch
+  gemv_q4s_body<DT, NSA, AWQ, 1>(a, smem, bar, epoch);
+  gs_bar_arrive(bar, epoch, (int)threadIdx.x, (int)blockIdx.x);
+  gemv_q4s_body<DT, NSB, AWQ, 2>(b, smem, bar, epoch);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *bar.count = epoch;
 }
 
