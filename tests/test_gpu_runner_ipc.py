@@ -1,7 +1,9 @@
 """GPU test of the drop-in `runner` process: this test plays the reference's ENGINE process
 (src/core/engine.rs:187-330 spawn + Init + InitAck, :844-892 RunPrefill / RunDecode) over the reference's wire format —
 abstract-namespace Unix socket, `ready` line, JSON `Init`, bincode afterwards, 1-byte acks (vllm_rs_amd/wire.py) — against
-`python -m vllm_rs_amd.runner_ipc` loading an HF checkpoint directory from disk.  Tokens must be the oracle's greedy tokens."""
+the native `vra_runner` binary (vllm_rs_amd/host/runner_main.cpp: C++ over the C ABI, what the reference's engine would
+spawn) and against its Python twin `python -m vllm_rs_amd.runner_ipc`, both loading an HF checkpoint directory from disk
+(f16 scales in a bf16 model, as AutoGPTQ writes them).  Tokens must be the oracle's greedy tokens."""
 import json
 import os
 import socket
@@ -21,10 +23,25 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_reference_engine_protocol_drives_the_runner_process(tmp_path):
+RUNNER_BIN = os.path.join(ROOT, "vllm_rs_amd", "vra_runner")
+
+
+@pytest.mark.parametrize("which", ["native", "python"])
+def test_reference_engine_protocol_drives_the_runner_process(tmp_path, which):
     cfg = small_cfg(quant_method="gptq")
     w = om.make_random_checkpoint(cfg, 13)
-    on_disk = {k: ((a, "bf16") if a.dtype == np.uint16 else (a.view(np.int32), "i32")) for k, a in w.items()}
+    # scales travel as F16 (checkpoints store them so even for bf16 models, wna16.rs:97-109); the synthetic bf16 scales lie in
+    # f16's normal range, so the f16 copy is exact and the runner's f16 -> bf16 cast must give back the oracle's bits
+    def disk(k, a):
+        if a.dtype != np.uint16:
+            return (a.view(np.int32), "i32")
+        if k.endswith(".scales"):
+            f = (a.astype(np.uint32) << 16).view(np.float32)
+            h = f.astype(np.float16)
+            assert (h.astype(np.float32) == f).all()
+            return (h.view(np.uint16), "f16")
+        return (a, "bf16")
+    on_disk = {k: disk(k, a) for k, a in w.items()}
     write_safetensors(tmp_path / "model.safetensors", on_disk)
     hf = dict(architectures=["LlamaForCausalLM"], hidden_size=cfg["hidden_size"], intermediate_size=cfg["intermediate_size"],
               num_hidden_layers=cfg["num_layers"], num_attention_heads=cfg["num_heads"], num_key_value_heads=cfg["num_kv_heads"],
@@ -38,7 +55,14 @@ def test_reference_engine_protocol_drives_the_runner_process(tmp_path):
     srv.listen(1)
     srv.settimeout(180)
     env = dict(os.environ, PYTHONPATH=ROOT)
-    proc = subprocess.Popen([sys.executable, "-m", "vllm_rs_amd.runner_ipc", "--sock", name, "--uuid", "t"], cwd=ROOT, env=env)
+    name += "-" + which
+    srv.close()
+    srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    srv.bind("\0" + name)
+    srv.listen(1)
+    srv.settimeout(180)
+    cmd = [RUNNER_BIN] if which == "native" else [sys.executable, "-m", "vllm_rs_amd.runner_ipc"]
+    proc = subprocess.Popen(cmd + ["--sock", name, "--uuid", "t"], cwd=ROOT, env=env)
     try:
         conn, _ = srv.accept()
         conn.settimeout(180)

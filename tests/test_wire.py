@@ -158,3 +158,84 @@ def test_message_loop_over_an_abstract_unix_socket_with_the_oracle_as_model():
     assert not th.is_alive()
     conn.close()
     srv.close()
+
+
+# ------------------------------------------------------------------------------------------------ the C++ codec (vra_runner)
+import os
+import subprocess
+
+RUNNER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vllm_rs_amd", "vra_runner")
+needs_runner = pytest.mark.skipif(not os.path.exists(RUNNER), reason="vllm_rs_amd/vra_runner is not built (make -C vllm_rs_amd/csrc)")
+
+
+def _echo(payload, *mode):
+    out = subprocess.run([RUNNER, *mode], input=payload, capture_output=True, timeout=60)
+    assert out.returncode == 0, out.stderr.decode()
+    return out.stdout
+
+
+@needs_runner
+def test_cpp_codec_reproduces_the_hand_built_frames_and_every_variant():
+    """host/wire.h (the codec of the native `vra_runner` binary) decodes and re-encodes each frame to the same bytes: the
+    hand-built golden frames above, and one message of every variant the runner exchanges with all optional fields set"""
+    sp = dict(temperature=0.5, top_k=7, top_p=0.9, stop_sequences=["a", "bc"], grammar='{"x":1}', grammar_json="{}", reasoning_effort="High",
+              max_tokens=99, session_id="s", thinking=True, mcp_mode=False, frequency_penalty=0.25, presence_penalty=-0.5, ignore_eos=True)
+    seq = dict(id=3, created_time=11, token_ids=[1, 2, 3], block_table=[9, 8], num_cached_tokens=1, sampling_params=sp, status="Swapped", swapped_time=5,
+               stop_sequence="zz", pd_first_token=4, mamba_prefix_hash=77, output_ids=[3], is_tool_call_end=True, hit_stop_sequence=True, block_size=32)
+    msgs = [("InitAck", True), ("LoadingProgress", (3, 9)), ("RunPrefill", ([seq, dict(id=4, token_ids=[5], block_table=[1], sampling_params=None)], True)),
+            ("RunDecode", ([dict(id=1, last_token=5, len=70, last_block_tokens=6, block_table_last=4, block_tables=[3, 4], sampling_params=sp)], False)),
+            ("RunResponse", [1, 2, 3]), ("RunResponse", []), ("FinishDecode", 12), ("Error", "boom é"), ("Heartbeat", None), ("Shutdown", None),
+            ("KVCacheSwap", ({1: 2, 3: 4}, True)), ("KVCacheSwapResponse", False), ("ClearBlocks", [4, 5]), ("ClearBlocksResponse", True)]
+    for m in msgs:
+        b = wire.encode(m)
+        assert _echo(b, "--wire-echo") == b, m[0]
+    gold = u32(4) + u64(1) + (u64(9) + u32(123) + u64(130) + u64(2) + u32(17) + vec_u32([5, 6, 17]) + golden_sampling_params(0.7, 32, 0.95, 0.5)) + u8(0)
+    assert _echo(gold, "--wire-echo") == gold
+    # malformed input is refused, not guessed at
+    bad = subprocess.run([RUNNER, "--wire-echo"], input=wire.encode(("RunResponse", [1, 2]))[:-1], capture_output=True, timeout=60)
+    assert bad.returncode != 0 and b"truncated" in bad.stderr
+
+
+@needs_runner
+def test_cpp_init_json_maps_to_the_same_model_config():
+    """MessageType::Init as serde_json writes it -> the vra_model_config / vra_engine_config the Python runner derives"""
+    init = dict(rank=1, dev_id=0, num_shards=2, model_type="LLaMa", dtype="F16", is_gguf=False,
+                config=dict(architectures=["Qwen2ForCausalLM"], hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                            num_key_value_heads=2, vocab_size=1000, max_position_embeddings=2048, rms_norm_eps=1e-6, rope_theta=1e6,
+                            rope_scaling=dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0, original_max_position_embeddings=8192),
+                            quantization_config=dict(quant_method="AWQ", bits=4, group_size=64), tie_word_embeddings=None, head_dim=None),
+                econfig=dict(block_size=32, max_num_seqs=4, num_blocks=99, seed=7, fp8_kvcache=True, max_model_len=None),
+                nccl_id=bytes(range(128)), model_pathes=dict(config_filename="/x/config.json", filenames=["a", "b"]))
+    line = _echo(wire.encode_init_json(init), "--init-echo").decode().split()
+    kv = dict(zip(line[0::2], line[1::2]))
+    cfg = wire.model_cfg_from_init(wire.decode_init_json(wire.encode_init_json(init)))
+    assert (kv["rank"], kv["world"], kv["arch"], kv["H"], kv["I"], kv["L"], kv["Hq"], kv["Hkv"], kv["D"], kv["V"]) == ("1", "2", "1", "256", "512", "2", "4", "2", "64", "1000")
+    assert cfg["arch"] == "qwen2" and cfg["head_dim"] == 64 and cfg["quant_method"] == "awq" and cfg["group_size"] == 64 and cfg["dtype"] == 1
+    assert (kv["quant"], kv["g"], kv["dtype"], kv["bias"], kv["rope"], kv["maxpos"]) == ("2", "64", "1", "1", "2", "2048")
+    assert float(kv["theta"]) == 1e6 and abs(float(kv["eps"]) - 1e-6) < 1e-12
+    assert (kv["bs"], kv["seqs"], kv["blocks"], kv["seed"], kv["fp8"], kv["nccl"], kv["files"]) == ("32", "4", "99", "7", "1", "128", "2")
+    for broken in (b'{"Init": {"config": {}}}', b'{"RunPrefill": 1}', b'{"Init": '):
+        assert subprocess.run([RUNNER, "--init-echo"], input=broken, capture_output=True, timeout=60).returncode != 0
+
+
+@needs_runner
+def test_cpp_checkpoint_dtype_conversions_match_numpy():
+    """the safetensors loader of vra_runner converts f16 <-> bf16 <-> f32 in software (scales and biases are f16 on disk even
+    for bf16 models, wna16.rs:97-109): exhaustive over all 65536 half patterns, and round-to-nearest-even from f32"""
+    from vllm_rs_amd.checkpoint import f32_to_bf16_bits
+    allh = np.arange(65536, dtype=np.uint16)
+    wide = np.frombuffer(_echo(allh.tobytes(), "--cvt", "f16-f32"), np.float32)
+    ref = allh.view(np.float16).astype(np.float32)
+    assert (wide.view(np.uint32) == ref.view(np.uint32))[~np.isnan(ref)].all() and np.isnan(wide[np.isnan(ref)]).all()
+    widb = np.frombuffer(_echo(allh.tobytes(), "--cvt", "bf16-f32"), np.float32)
+    assert (widb.view(np.uint32) == (allh.astype(np.uint32) << 16)).all()
+    r = np.random.default_rng(0)
+    x = np.concatenate([r.standard_normal(200000).astype(np.float32) * np.float32(10.0) ** r.integers(-9, 6, 200000).astype(np.float32),
+                        ref[~np.isnan(ref)], np.array([65504.0, 65519.9, 65520.0, 1e9, -1e9, 5.96e-8, 2.98e-8, 2.9e-8, 0.0, -0.0, np.inf, -np.inf], np.float32),
+                        (ref[~np.isnan(ref)].astype(np.float64) * (1 + 2.0 ** -12)).astype(np.float32)])
+    with np.errstate(over="ignore"):
+        want16 = x.astype(np.float16).view(np.uint16)
+    got16 = np.frombuffer(_echo(x.tobytes(), "--cvt", "f32-f16"), np.uint16)
+    assert (got16 == want16).all(), np.flatnonzero(got16 != want16)[:5]
+    gotb = np.frombuffer(_echo(x.tobytes(), "--cvt", "f32-bf16"), np.uint16)
+    assert (gotb == f32_to_bf16_bits(x)).all()

@@ -309,7 +309,7 @@ def model_cfg_from_init(req):
                 head_dim=c.get("head_dim") or c["hidden_size"] // c["num_attention_heads"], vocab_size=c["vocab_size"],
                 max_position_embeddings=c["max_position_embeddings"], rms_norm_eps=c["rms_norm_eps"], rope_theta=c.get("rope_theta") or 10000.0,
                 rope_scaling=rs, attention_bias=bool(c.get("attention_bias") or c.get("qkv_bias") or (arch.startswith("Qwen2"))),
-                quant_method=qc.get("quant_method"), group_size=qc.get("group_size", 128), dtype={"BF16": 0, "F16": 1}[req.get("dtype", "BF16")],
+                quant_method=(qc.get("quant_method") or None) and str(qc.get("quant_method")).lower(), group_size=qc.get("group_size", 128), dtype={"BF16": 0, "F16": 1}[req.get("dtype", "BF16")],
                 tie_word_embeddings=bool(c.get("tie_word_embeddings")))
 
 
