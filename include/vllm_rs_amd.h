@@ -404,6 +404,10 @@ int32_t vra_engine_init_synthetic(void* eng);
 int32_t vra_engine_load_tensor(void* eng, const char* name, const void* h_data, const int64_t* shape,
                                int32_t ndim, int32_t elem_bytes);
 int32_t vra_engine_finalize_weights(void* eng); /* repack + scale layout + KV cache + graphs */
+/* ModelRunner::swap_kvcache (runner.rs:1626-1670; MessageType::KVCacheSwap): copy whole blocks between the GPU cache and the
+ * engine's pinned swap space (vra_engine_config.cpu_mem_fold > 0), all layers, K and V.  h_pairs = 2*n_pairs int64
+ * (source block, destination block): GPU -> CPU ids when swap_in == 0, CPU -> GPU ids when 1.  0 = done (synchronous). */
+int32_t vra_engine_swap_blocks(void* eng, const int64_t* h_pairs, int32_t n_pairs, int32_t swap_in);
 /* CPU swap (block_manager.rs:870-1010): out4 = {cpu blocks, free cpu blocks, blocks swapped out so far, blocks swapped in} */
 void vra_engine_swap_stats(const void* engine, int64_t* out4);
 int32_t vra_engine_num_gpu_blocks(const void* eng);

@@ -94,6 +94,24 @@ def test_reference_engine_protocol_drives_the_runner_process(tmp_path, which):
             assert all(t == wv or g < 0.04 for t, wv, g in zip(toks, want, gaps)), (toks, want, gaps)
             for s, t in zip(seqs, want):
                 s.append(t)
+        # MessageType::KVCacheSwap (runner.rs:297-312, ModelRunner::swap_kvcache): sequence b's block 7 goes out to CPU block 0
+        # and comes back into GPU block 9; decoding continues from the moved block exactly as the oracle does from the old one
+        wire.send_frame(conn, wire.encode(("KVCacheSwap", ({7: 0}, False))))
+        assert wire.decode(wire.recv_frame(conn)) == ("KVCacheSwapResponse", True)
+        wire.send_frame(conn, wire.encode(("KVCacheSwap", ({0: 9}, True))))
+        assert wire.decode(wire.recv_frame(conn)) == ("KVCacheSwapResponse", True)
+        moved = [[3, 4], [9]]
+        ds = [dict(id=i + 1, last_token=s[-1], len=len(s), last_block_tokens=len(s) - (len(t) - 1) * 64, block_table_last=t[-1], block_tables=t,
+                   sampling_params=greedy) for i, (s, t) in enumerate(zip(seqs, moved))]
+        wire.send_frame(conn, wire.encode(("RunDecode", (ds, False))))
+        _, toks = wire.decode(wire.recv_frame(conn))
+        ds_ref = [dict(d, block_table_last=t[-1], block_tables=t) for d, t in zip(ds, tables)]
+        ref = oracle.forward(*runner_ipc.step_inputs_decode(ds_ref, 64))
+        want = orc.argmax_f32(ref).tolist()
+        gaps = [np.sort(r)[-1] - np.sort(r)[-2] for r in ref]
+        assert all(t == wv or g < 0.04 for t, wv, g in zip(toks, want, gaps)), ("after the swap", toks, want, gaps)
+        wire.send_frame(conn, wire.encode(("KVCacheSwap", ({31: 99}, False))))   # CPU block 99 does not exist: refused, not executed
+        assert wire.decode(wire.recv_frame(conn)) == ("KVCacheSwapResponse", False)
         wire.send_frame(conn, wire.encode(("FinishDecode", 1)))
         wire.send_frame(conn, wire.encode(("Shutdown", None)))
         assert proc.wait(60) == 0

@@ -186,6 +186,7 @@ def load():
     _sig(lib, "vra_engine_finalize_weights", c_i32, P)
     _sig(lib, "vra_engine_num_gpu_blocks", c_i32, P)
     _sig(lib, "vra_engine_swap_stats", None, P, P)
+    _sig(lib, "vra_engine_swap_blocks", c_i32, P, P, c_i32, c_i32)
     _sig(lib, "vra_engine_plan_kv_blocks", c_i64, P)
     _sig(lib, "vra_engine_set_num_gpu_blocks", c_i32, P, c_i32)
     _sig(lib, "vra_engine_add_request", c_i64, P, P, c_i32, c_i32, c_i32, P, c_i32)

@@ -782,6 +782,41 @@ extern "C" int32_t vra_engine_set_num_gpu_blocks(void* e, int32_t n) {
   en->ec_.num_gpu_blocks = n;
   return 0;
 }
+// cache::swap_blocks as the runner executes it for the reference's engine (runner.rs:1626-1670, MessageType::KVCacheSwap):
+// whole blocks (source id, destination id) between the GPU cache and this engine's pinned swap space, every layer, K and V,
+// on the engine stream.  The block ids are the CALLER's bookkeeping (the engine process owns the block manager there).
+extern "C" int32_t vra_engine_swap_blocks(void* e, const int64_t* h_pairs, int32_t n_pairs, int32_t swap_in) {
+  auto* en = static_cast<Engine*>(e);
+  if (en->dry() || !en->sched_ || en->num_cpu_blocks_ <= 0 || en->h_swap_k_.empty()) {
+    en->error = "vra_engine_swap_blocks: no CPU swap space (vra_engine_config.cpu_mem_fold = 0, or a host-only engine)";
+    return -1;
+  }
+  const int64_t ngpu = en->model_.num_blocks(), ncpu = en->num_cpu_blocks_;
+  for (int i = 0; i < n_pairs; i++) {
+    const int64_t src = h_pairs[2 * i], dst = h_pairs[2 * i + 1];
+    if (src < 0 || dst < 0 || src >= (swap_in ? ncpu : ngpu) || dst >= (swap_in ? ngpu : ncpu)) {
+      en->error = "vra_engine_swap_blocks: block id out of range";
+      return -1;
+    }
+  }
+  const int64_t bb = (int64_t)en->model_.kv_block_bytes();
+  for (int l = 0; l < en->mc_.num_layers; l++) {
+    if (swap_in) {
+      vra_swap_blocks(en->h_swap_k_[l], en->model_.k_cache(l), h_pairs, n_pairs, bb, 2, (int64_t)en->stream_);
+      vra_swap_blocks(en->h_swap_v_[l], en->model_.v_cache(l), h_pairs, n_pairs, bb, 2, (int64_t)en->stream_);
+    } else {
+      vra_swap_blocks(en->model_.k_cache(l), en->h_swap_k_[l], h_pairs, n_pairs, bb, 1, (int64_t)en->stream_);
+      vra_swap_blocks(en->model_.v_cache(l), en->h_swap_v_[l], h_pairs, n_pairs, bb, 1, (int64_t)en->stream_);
+    }
+  }
+  (swap_in ? en->swap_in_blocks_ : en->swap_out_blocks_) += n_pairs;
+  const char* err = vra_last_error();
+  if ((err && err[0]) || hipStreamSynchronize(en->stream_) != hipSuccess) {
+    en->error = std::string("vra_engine_swap_blocks: ") + (err && err[0] ? err : "stream error");
+    return -1;
+  }
+  return 0;
+}
 extern "C" void vra_engine_swap_stats(const void* e, int64_t* out4) {
   const Engine* en = static_cast<const Engine*>(e);
   out4[0] = en->num_cpu_blocks_;

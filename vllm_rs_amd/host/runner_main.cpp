@@ -147,6 +147,7 @@ static bool init_from_json(const std::string& text, Init* out, std::string* err)
   out->seed = (uint64_t)e->i64("seed", 1234);
   ec.seed = out->seed;
   ec.fp8_kvcache = e->boolean("fp8_kvcache", false);
+  ec.cpu_mem_fold = (float)e->num("cpu_mem_fold", 0.2);  // kvcache_allocator.rs:317: unwrap_or(0.2) — the engine plans its CPU block ids with it
   if (const Json* id = req->get("nccl_id"))
     if (id->t == Json::Str) {
       if (!base64_decode(id->s, &out->nccl_id) || out->nccl_id.size() != 128) return *err = "nccl_id: expected 128 bytes", false;
@@ -549,7 +550,13 @@ int main(int argc, char** argv) {
     else if (m.name == "RunDecode") out.name = "RunResponse", out.ids = r.run_decode(m.dseqs);
     else if (m.name == "FinishDecode" || m.name == "LoadingProgress" || m.name == "Heartbeat") continue;  // bookkeeping only, no reply (runner.rs:294-315)
     else if (m.name == "ClearBlocks") out.name = "ClearBlocksResponse", out.flag = true;
-    else if (m.name == "KVCacheSwap") out.name = "KVCacheSwapResponse", out.flag = false;  // the engine-side swap space is not wired through this path
+    else if (m.name == "KVCacheSwap") {  // runner.rs:297-312 -> ModelRunner::swap_kvcache
+      std::vector<int64_t> pairs;
+      for (auto& kv : m.map) pairs.push_back((int64_t)kv.first), pairs.push_back((int64_t)kv.second);
+      out.name = "KVCacheSwapResponse";
+      out.flag = vra_engine_swap_blocks(eng, pairs.data(), (int)m.map.size(), m.flag ? 1 : 0) == 0;
+      if (!out.flag) fprintf(stderr, "vra_runner: KvCache swap failed: %s\n", vra_engine_last_error(eng));
+    }
     else out.name = "Error", out.text = "unsupported message " + m.name;
     send_msg(fd, out);
   }

@@ -71,8 +71,8 @@ class RunnerServer:
     """the message loop of runner.rs:246-430 around a forward function `forward(ids, pos, slots, bt, ctx, cu_q) -> f32 logits [B, V]`
     and a sampler `sample(logits, strategy) -> token ids`"""
 
-    def __init__(self, sock, forward, sample, block_size=64):
-        self.sock, self.forward, self.sample, self.BS = sock, forward, sample, block_size
+    def __init__(self, sock, forward, sample, block_size=64, swap=None):
+        self.sock, self.forward, self.sample, self.BS, self.swap = sock, forward, sample, block_size, swap
         self.cached_strategy = "unset"
 
     def _run(self, seqs, is_prefill):
@@ -98,8 +98,9 @@ class RunnerServer:
                 pass  # runner.rs:294-315: bookkeeping only, no reply
             elif name == "ClearBlocks":
                 wire.send_frame(self.sock, wire.encode(("ClearBlocksResponse", True)))
-            elif name == "KVCacheSwap":
-                wire.send_frame(self.sock, wire.encode(("KVCacheSwapResponse", False)))  # CPU swap space is not part of this path
+            elif name == "KVCacheSwap":  # runner.rs:297-312 -> ModelRunner::swap_kvcache
+                ok = bool(self.swap(p[0], p[1])) if self.swap else False
+                wire.send_frame(self.sock, wire.encode(("KVCacheSwapResponse", ok)))
             else:
                 wire.send_frame(self.sock, wire.encode(("Error", f"unsupported message {name}")))
 
@@ -135,7 +136,8 @@ def main():
             raise RuntimeError("vra_comm_create: " + L.vra_last_error().decode())
     kw = dict(block_size=ec.get("block_size", 64), max_num_seqs=ec.get("max_num_seqs", 32), max_model_len=ec.get("max_model_len") or 0,
               num_gpu_blocks=ec.get("num_blocks", 0), enable_prefix_cache=False, use_graph=False, tp_rank=rank, tp_world_size=world, device=dev,
-              seed=ec.get("seed") or 1234, comm=comm, fp8_kvcache=bool(ec.get("fp8_kvcache")))
+              seed=ec.get("seed") or 1234, comm=comm, fp8_kvcache=bool(ec.get("fp8_kvcache")),
+              cpu_mem_fold=ec.get("cpu_mem_fold") if ec.get("cpu_mem_fold") is not None else 0.2)  # kvcache_allocator.rs:317
     paths = req.get("model_pathes") or {}
     cfg_file = paths.get("config_filename")
     if cfg_file and os.path.exists(cfg_file):
@@ -159,7 +161,10 @@ def main():
         L.vra_free(d_l), L.vra_free(d_o)
         return out
     wire.send_frame(sock, wire.encode(("InitAck", True)))
-    RunnerServer(sock, eng.forward_raw, sample, kw["block_size"]).serve()
+    def swap(mapping, swap_in):
+        pairs = np.array([[k, v] for k, v in mapping.items()], np.int64).reshape(-1)
+        return L.vra_engine_swap_blocks(eng.h, pairs.ctypes.data_as(C.c_void_p), len(mapping), int(bool(swap_in))) == 0
+    RunnerServer(sock, eng.forward_raw, sample, kw["block_size"], swap).serve()
     eng.close()
     if comm:
         L.vra_comm_destroy(comm)
