@@ -8,9 +8,12 @@
 //   Sᵀ = K·Qᵀ   A = K rows (lane: token l&15, 8 channels)   B = Qᵀ (held in registers)
 //        -> lane (row l&15) holds 4+4 scores of tokens (l>>4)*4+r of the two 16-token halves,
 //   softmax statistics per row: in-lane + 2 xor-shuffles (16, 32),
-//   O += P·V    A = P: the lane's own 8 probabilities ARE the MFMA A fragment when the contraction
-//        index is mapped as k=(oct,e) -> token (e<4 ? oct*4+e : 16+oct*4+e-4); B = V read token-minor
-//        from the transposed V cache with two 8-byte loads.
+//   O += P·V    A = P: the lane's own 8 probabilities ARE the MFMA A fragment.  The 16 K rows of the first / second MFMA of
+//        a tile are the tokens kappa(h, i) = (i>>2)*8 + h*4 + (i&3), so the lane's 4+4 scores belong to the 8 CONSECUTIVE
+//        tokens oct*8 .. +7; B = V read token-minor from the transposed V cache with ONE load per channel tile (16 bytes
+//        from a 16-bit cache, 8 from an FP8 one).  (Round 1 used rows 0..15 / 16..31: a lane's tokens were two runs of 4 and
+//        V took two loads of half the size — the FP8 cache then read half the bytes in the same number of load instructions
+//        and was only 9 % faster than the 16-bit one at bs 32 / ctx 4096; with this map it is 26 % faster.)
 // Roofline: HBM (KV bytes) for decode; MFMA for long prefill.
 #include "common.cuh"
 #include "kvcache.cuh"
@@ -56,6 +59,10 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_kernel(const PagedAttnA
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches, no exec masking
   const int rq = lane & 15, oct = lane >> 4;
+  // token of K row rq within the first 16-key MFMA of a 32-token tile (the second: + 4): kappa(h, i) = (i>>2)*8 + h*4 + (i&3).
+  // The lane then owns the scores of the 8 CONSECUTIVE tokens oct*8 .. +7 — its P fragment's k-order — and reads V as one
+  // 16-byte (16-bit cache) or 8-byte (FP8) load per channel tile instead of two loads half that size.
+  const int krow_tok = (rq >> 2) * 8 + (rq & 3);
   const int G = a.Hq / a.Hkv;
   const int b = blockIdx.z;
 
@@ -134,13 +141,13 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_kernel(const PagedAttnA
     if (a.block_tables) {
       const uint32_t blk = a.block_tables[(size_t)b * a.max_blocks + T0 / a.BS];
       const int off = T0 % a.BS;
-      kc0 = kcache + (((size_t)blk * a.Hkv + hk) * a.BS + off + rq) * D;
-      kc1 = kc0 + 16 * D;
+      kc0 = kcache + (((size_t)blk * a.Hkv + hk) * a.BS + off + krow_tok) * D;
+      kc1 = kc0 + 4 * D;
       vbase = (((size_t)blk * a.Hkv + hk) * D) * a.BS + off;
     } else {
       // fallback: rows beyond ctx are clamped (their scores are masked below)
       const size_t kb = a.cu_k[b];
-      int t0 = min(T0 + rq, ctx - 1), t1 = min(T0 + 16 + rq, ctx - 1);
+      int t0 = min(T0 + krow_tok, ctx - 1), t1 = min(T0 + krow_tok + 4, ctx - 1);
       krow0 = static_cast<const uint16_t*>(a.kflat) + ((kb + t0) * a.Hkv + hk) * D;
       krow1 = static_cast<const uint16_t*>(a.kflat) + ((kb + t1) * a.Hkv + hk) * D;
     }
@@ -158,13 +165,11 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_kernel(const PagedAttnA
         kf1[j] = *reinterpret_cast<const u32x4*>(krow1 + j * 32 + oct * 8);
       }
     }
-    u32x2 vlo[DT16], vhi[DT16];
+    u32x4 vfr[DT16];  // 8 consecutive tokens of a channel: one load per channel tile
     if (a.block_tables) {
 #pragma unroll
       for (int t = 0; t < DT16; t++) {
-        const kv_t* vp = vcache + vbase + (size_t)(t * 16 + rq) * a.BS + oct * 4;
-        vlo[t] = kv_load4<DT, KV8>(vp);
-        vhi[t] = kv_load4<DT, KV8>(vp + 16);
+        vfr[t] = kv_load8<DT, KV8>(vcache + vbase + (size_t)(t * 16 + rq) * a.BS + oct * 8);
       }
     }
 #pragma unroll
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_kernel(const PagedAttnA
     float tmax = -INFINITY;
 #pragma unroll
     for (int e = 0; e < 8; e++) {
-      const int tok = T0 + (e < 4 ? 0 : 16) + oct * 4 + (e & 3);
+      const int tok = T0 + oct * 8 + e;
       float x = (e < 4 ? s0[e] : s1[e - 4]);
       if (a.softcap > 0.f) x = a.softcap * tanhf(x * a.scale / a.softcap) * 1.44269504088896f;
       else x *= a.scale_log2e;
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_kernel(const PagedAttnA
     if (tail) {
 #pragma unroll
       for (int e = 0; e < 8; e++) {
-        const int tok = T0 + (e < 4 ? 0 : 16) + oct * 4 + (e & 3);
+        const int tok = T0 + oct * 8 + e;
         if (tok >= ctx) vm[e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
       }
     }
@@ -224,13 +229,13 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_kernel(const PagedAttnA
     for (int t = 0; t < DT16; t++) {
       u32x4 vv;
       if (a.block_tables) {
-        vv = u32x4{vlo[t][0], vlo[t][1], vhi[t][0], vhi[t][1]};
+        vv = vfr[t];
       } else {
         const size_t kb = a.cu_k[b];
         uint16_t tmp[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) {
-          int tok = min(T0 + (e < 4 ? 0 : 16) + oct * 4 + (e & 3), ctx - 1);
+          int tok = min(T0 + oct * 8 + e, ctx - 1);
           tmp[e] = static_cast<const uint16_t*>(a.vflat)[((kb + tok) * a.Hkv + hk) * D + t * 16 + rq];
         }
         vv = u32x4{(uint32_t)tmp[0] | ((uint32_t)tmp[1] << 16), (uint32_t)tmp[2] | ((uint32_t)tmp[3] << 16),
@@ -364,6 +369,7 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rq = lane & 15, oct = lane >> 4;
+  const int krow_tok = (rq >> 2) * 8 + (rq & 3);  // see paged_attn_kernel: K row -> token map that makes a lane's 8 scores consecutive tokens
   FD_STAMP(0);
   const int G = a.Hq / a.Hkv;
   const int b = blockIdx.z, hk = blockIdx.y, split = blockIdx.x;
@@ -481,13 +487,13 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
     const uint32_t blk = blk_cur;
     const int off = a.bs_shift >= 0 ? T0 & (a.BS - 1) : T0 % a.BS;
     blk_cur = a.block_tables[tile_blk_index(min(tile + 1, ntiles - 1))];  // next tile's block id, in flight during this tile
-    const kv_t* krow0 = kcache + (((size_t)blk * a.Hkv + hk) * a.BS + off + rq) * D;
-    const kv_t* krow1 = krow0 + 16 * D;
+    const kv_t* krow0 = kcache + (((size_t)blk * a.Hkv + hk) * a.BS + off + krow_tok) * D;
+    const kv_t* krow1 = krow0 + 4 * D;
     const size_t vbase = (((size_t)blk * a.Hkv + hk) * D) * a.BS + off;
     const bool has_new = last >= T0 && last < T0 + 32;  // wave-uniform: the tile that holds the new token
     if (has_new) {  // its K row comes from LDS (the cache write of split 0 may not be visible yet)
-      if (T0 + rq == last) krow0 = knew;
-      if (T0 + 16 + rq == last) krow1 = knew;
+      if (T0 + krow_tok == last) krow0 = knew;
+      if (T0 + krow_tok + 4 == last) krow1 = knew;
     }
     u32x4 k0[DJ], k1[DJ];
 #pragma unroll
@@ -496,13 +502,9 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
       k1[j] = kv_load8<DT, KV8>(krow1 + j * 32 + oct * 8);
     }
     // V: issue the loads now (they only depend on the block table), consume after the softmax
-    u32x2 vlo[DT16], vhi[DT16];
+    u32x4 vfr[DT16];
 #pragma unroll
-    for (int t = 0; t < DT16; t++) {
-      const kv_t* vp = vcache + vbase + (size_t)(t * 16 + rq) * a.BS + oct * 4;
-      vlo[t] = kv_load4<DT, KV8>(vp);
-      vhi[t] = kv_load4<DT, KV8>(vp + 16);
-    }
+    for (int t = 0; t < DT16; t++) vfr[t] = kv_load8<DT, KV8>(vcache + vbase + (size_t)(t * 16 + rq) * a.BS + oct * 8);
     FD_STAMP(5);
     f32x4 s0 = vra_zero_acc(), s1 = vra_zero_acc();
 #pragma unroll
@@ -516,7 +518,7 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
     float tmax = -INFINITY;
 #pragma unroll
     for (int e = 0; e < 8; e++) {
-      const int tok = T0 + (e < 4 ? 0 : 16) + oct * 4 + (e & 3);
+      const int tok = T0 + oct * 8 + e;
       float x = (e < 4 ? s0[e] : s1[e - 4]) * a.scale_log2e;
       if (tok >= ctx) x = -INFINITY;
       sv[e] = x;
@@ -551,14 +553,14 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
     if (tail || has_new) {
 #pragma unroll
       for (int e = 0; e < 8; e++) {
-        const int tok = T0 + (e < 4 ? 0 : 16) + oct * 4 + (e & 3);
+        const int tok = T0 + oct * 8 + e;
         if (tok >= ctx) vm[e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
         if (tok == last) new_e = e;
       }
     }
 #pragma unroll
     for (int t = 0; t < DT16; t++) {
-      u32x4 vv = u32x4{vlo[t][0], vlo[t][1], vhi[t][0], vhi[t][1]};
+      u32x4 vv = vfr[t];
       if (has_new && new_e >= 0) {
         const uint32_t nv = vnew[t * 16 + rq];
 #pragma unroll
