@@ -51,6 +51,7 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
   const int nu = a.units_q + (wg < a.units_r ? 1 : 0);
   const int max_u = a.units_q + (a.units_r ? 1 : 0);
   const bool has_res = a.residual != nullptr;
+  GEMV_STAMP(0);
 
   // ---- LDS carve-up
   f32x4* red = reinterpret_cast<f32x4*>(smem);  // [2][wave][NS][MT][64 lanes]
@@ -75,12 +76,12 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
     ld = s2 ? a.seg[2].out_ld : (s1 ? a.seg[1].out_ld : a.seg[0].out_ld);
     col0 = (unit - (s2 ? a.seg[2].unit_start : (s1 ? a.seg[1].unit_start : a.seg[0].unit_start))) * 16;
   };
-  // (requested and written BEFORE the x fragments are loaded: their registers are gone by then — at 32 rows the fragments
-  // alone take half of the wave's 128 VGPRs; skipped entirely when the launch has neither bias nor residual)
+  // (requested BEFORE the x fragments and written to LDS behind their issue: the round trip of the residual then runs under
+  // the x loads instead of in front of them; skipped entirely when the launch has neither bias nor residual)
   const bool any_bias = a.seg[0].bias || (a.nseg > 1 && a.seg[1].bias) || (a.nseg > 2 && a.seg[2].bias);
-  if (has_res || any_bias) {
-    constexpr int EPI_IT = GW_MAX_UNITS * OPU / GW_THREADS;
-    uint16_t e_res[EPI_IT], e_b0[EPI_IT], e_b1[EPI_IT];
+  constexpr int EPI_IT = GW_MAX_UNITS * OPU / GW_THREADS;
+  uint16_t e_res[EPI_IT], e_b0[EPI_IT], e_b1[EPI_IT];
+  auto request_epilogue_operands = [&]() {
 #pragma unroll
     for (int it = 0; it < EPI_IT; it++) {
       const int idx = tid + it * GW_THREADS;
@@ -98,6 +99,8 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
         }
       }
     }
+  };
+  auto stage_epilogue_operands = [&]() {
 #pragma unroll
     for (int it = 0; it < EPI_IT; it++) {
       const int idx = tid + it * GW_THREADS;
@@ -110,31 +113,11 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
         }
       }
     }
-  }
-
-  __builtin_amdgcn_sched_barrier(0);  // (phase boundaries are scheduling barriers: hipcc otherwise interleaves the phases for
-                                      // ILP and the prologue, not the main loop, sets the register peak)
-  // ---- x fragments of this wave's two k-tiles: lane (oct, nn) holds row mt*16 + nn, columns kt*128 + j*32 + oct*8 ..
-  constexpr bool norm = NORM;
-  u32x4 xf[GW_TPW][4][MT];
-  float ss[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; mt++) ss[mt] = 0.f;
-#pragma unroll
-  for (int ti = 0; ti < GW_TPW; ti++) {
-    // (a wave without this k-tile re-reads the last one: its scale is zeroed in the main loop and its Σx² share below — a
-    // select on the loaded fragments would double their registers)
-    const int kt = min(wave + GW_WAVES * ti, KT - 1);
-#pragma unroll
-    for (int mt = 0; mt < MT; mt++) {
-      const uint16_t* xr = static_cast<const uint16_t*>(a.x) + (size_t)min(mt * 16 + nn, M - 1) * a.x_ld + kt * 128 + oct * 8;
-#pragma unroll
-      for (int j = 0; j < 4; j++) xf[ti][j][mt] = *reinterpret_cast<const u32x4*>(xr + j * 32);
-    }
-  }
+  };
 
   __builtin_amdgcn_sched_barrier(0);
-  // ---- the weight stream: step = (unit ui, tile ti); branch-free issue
+  // ---- the weight stream: step = (unit ui, tile ti); branch-free issue.  (Its first four tiles are requested BEFORE the x
+  // fragments: the HBM round trip then runs under the x loads, which keep the CU's texture path busy for ~4 µs at 32 rows.)
   u32x4 wb[D][NS];
   uint32_t sb[D][NS];
   uint32_t zb[D][AWQ ? NS : 1];
@@ -156,41 +139,78 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
   };
 #pragma unroll
   for (int ti = 0; ti < GW_TPW; ti++) issue(0, ti, wb[ti], sb[ti], zb[ti]);
-  __builtin_amdgcn_sched_barrier(0);
+  if (has_res || any_bias) request_epilogue_operands();
+  GEMV_STAMP(1);
 
-  // ---- fused RMSNorm + Σx per (tile, row)
+  __builtin_amdgcn_sched_barrier(0);  // (phase boundaries are scheduling barriers: hipcc otherwise interleaves the phases for
+                                      // ILP and the prologue, not the main loop, sets the register peak)
+  // ---- x fragments of this wave's two k-tiles: lane (oct, nn) holds row mt*16 + nn, columns kt*128 + j*32 + oct*8 ..
+  constexpr bool norm = NORM;
+  u32x4 xf[GW_TPW][4][MT];
+#pragma unroll
+  for (int ti = 0; ti < GW_TPW; ti++) {
+    // (a wave without this k-tile re-reads the last one: its scale is zeroed in the main loop and its Σx² share below — a
+    // select on the loaded fragments would double their registers)
+    const int kt = min(wave + GW_WAVES * ti, KT - 1);
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+      const uint16_t* xr = static_cast<const uint16_t*>(a.x) + (size_t)min(mt * 16 + nn, M - 1) * a.x_ld + kt * 128 + oct * 8;
+      // (odd rows fetch the two 64-byte halves of a 128-byte line in the opposite order and swap the registers afterwards:
+      // with all 16 rows of a wave-load at the SAME offset inside their lines — the row stride is a multiple of 128 bytes —
+      // the L1 served them at half rate; any row stride that is an odd multiple of 16..64 bytes measured 2.3..2.8 µs faster
+      // per launch at 32 rows, and this is that effect without touching the layout)
+#pragma unroll
+      for (int j = 0; j < 4; j++) xf[ti][j][mt] = *reinterpret_cast<const u32x4*>(xr + (j ^ (nn & 1)) * 32);
+    }
+  }
+
+  __builtin_amdgcn_sched_barrier(0);
+  GEMV_STAMP(2);
+  if (has_res || any_bias) stage_epilogue_operands();
+  if (nn & 1) {
+#pragma unroll
+    for (int ti = 0; ti < GW_TPW; ti++)
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int jp = 0; jp < 4; jp += 2)
+#pragma unroll
+          for (int c = 0; c < 4; c++) asm volatile("v_swap_b32 %0, %1" : "+v"(xf[ti][jp][mt][c]), "+v"(xf[ti][jp + 1][mt][c]));
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- fused RMSNorm.  Σx² and Σx come from the MATRIX cores: with A = B = a wave's x fragment the MFMA returns X·Xᵀ, whose
+  // diagonal is the rows' Σx² (bf16 x bf16 products are exact in f32); with B = ones it returns the rows' Σx in exactly the
+  // D layout the fix-up reads (lane (oct, ·): rows oct*4 .. +3).  The round-1 VALU form (convert + fma per element, convert +
+  // add + two ds_bpermute per tile) was ~1250 VALU instructions per wave at 32 rows — x 2 waves per SIMD x 4 cycles: the
+  // launch was VALU-bound BEFORE its first weight MFMA (tools/gemv_w_ts.py: 10 of 18.6 µs of the q/k/v launch).
   if (norm) {
+    f32x4 g2[GW_TPW][MT];
 #pragma unroll
-    for (int ti = 0; ti < GW_TPW; ti++) {
-      const float tmask = wave + GW_WAVES * ti < KT ? 1.0f : 0.0f;
+    for (int ti = 0; ti < GW_TPW; ti++)  // (a chain per tile: a tile this wave does not have is masked on the VALU side)
 #pragma unroll
-      for (int j = 0; j < 4; j++)
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++) {
-          float f[8], t8 = 0.f;
-          unpack8<DT>(xf[ti][j][mt], f);
-#pragma unroll
-          for (int e = 0; e < 8; e++) t8 += f[e] * f[e];
-          ss[mt] += t8 * tmask;
-          __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-#pragma unroll
-    for (int mt = 0; mt < MT; mt++) {  // sum over the 4 column groups (lanes nn, nn+16, nn+32, nn+48)
-      float v = ss[mt];
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      if (oct == 0) part[wave * 32 + mt * 16 + nn] = v;
-    }
-    __syncthreads();
-    // (opaque to the optimiser: without this hipcc keeps the UNPACKED f32 copies of all fragments alive from the Σx² pass to
-    // the normalisation below — 8 floats per fragment, more than the whole register file)
+      for (int mt = 0; mt < MT; mt++) g2[ti][mt] = vra_zero_acc();
 #pragma unroll
     for (int ti = 0; ti < GW_TPW; ti++)
 #pragma unroll
       for (int j = 0; j < 4; j++)
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++) asm volatile("" : "+v"(xf[ti][j][mt]));
+        for (int mt = 0; mt < MT; mt++) DT::mfma(g2[ti][mt], __builtin_bit_cast(s16x8, xf[ti][j][mt]), __builtin_bit_cast(s16x8, xf[ti][j][mt]));
+    VRA_MFMA_DRAIN();
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {  // the diagonal: lane (oct, nn) holds rows oct*4 + e of column nn -> row nn sits in lane (nn >> 2, nn), e = nn & 3
+      float v = 0.f;
+#pragma unroll
+      for (int ti = 0; ti < GW_TPW; ti++) {
+        const float tmask = wave + GW_WAVES * ti < KT ? 1.0f : 0.0f;
+        const f32x4 g = g2[ti][mt];
+        const float d01 = (nn & 1) ? g[1] : g[0], d23 = (nn & 1) ? g[3] : g[2];
+        v = fmaf((nn & 2) ? d23 : d01, tmask, v);
+      }
+      if (oct == (nn >> 2)) part[wave * 32 + mt * 16 + nn] = v;
+    }
+    GEMV_STAMP(3);
+    __syncthreads();
+    GEMV_STAMP(4);
     float rstd[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
@@ -218,19 +238,33 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
       }
     }
   }
+  GEMV_STAMP(5);
+  {  // Σx of rows (mt, oct*4 .. +3) over tile ti, over the ROUNDED values the weight MFMAs will see -> this wave's LDS table
+    const uint32_t one2 = (uint32_t)DT::from_f32(1.0f) * 0x10001u;
+    u32x4 ones = u32x4{one2, one2, one2, one2};
+    asm volatile("" : "+v"(ones));
+    f32x4 sx[GW_TPW][MT];
 #pragma unroll
-  for (int ti = 0; ti < GW_TPW; ti++)
+    for (int ti = 0; ti < GW_TPW; ti++)
 #pragma unroll
-    for (int mt = 0; mt < MT; mt++) {  // Σx of row (mt, nn) over tile ti, over the ROUNDED values the MFMA will see
-      float s = 0.f;
+      for (int mt = 0; mt < MT; mt++) sx[ti][mt] = vra_zero_acc();
 #pragma unroll
-      for (int j = 0; j < 4; j++) s += octet_sum<DT>(xf[ti][j][mt]);
-      s += __shfl_xor(s, 16, 64);
-      s += __shfl_xor(s, 32, 64);
-      if (oct == 0) xsum[ti * 32 + mt * 16 + nn] = s;
-      __builtin_amdgcn_sched_barrier(0);
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int ti = 0; ti < GW_TPW; ti++)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) DT::mfma(sx[ti][mt], __builtin_bit_cast(s16x8, xf[ti][j][mt]), __builtin_bit_cast(s16x8, ones));
+    VRA_MFMA_DRAIN();
+    if (nn == 0) {
+#pragma unroll
+      for (int ti = 0; ti < GW_TPW; ti++)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) *reinterpret_cast<f32x4*>(xsum + ti * 32 + mt * 16 + oct * 4) = sx[ti][mt];
     }
-  __syncthreads();  // epilogue operands staged (and, without a norm, the first barrier of the kernel)
+  }
+  GEMV_STAMP(6);
+  // (no workgroup barrier here: the Σx table is private to the wave — DS operations of one wave execute in order — and the
+  // staged epilogue operands are first read behind the barrier of the first unit)
 
   // ---- main loop: one unit = four tile-steps (ring slots 0..3)
   const int zsh = 4 * awq_rev(nn & 7);
@@ -269,6 +303,7 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
       }
       issue(ui + 1, ti, wb[ti], sb[ti], zb[ti]);  // the same tile of the next unit (clamped: re-reads the last unit, never consumed)
     }
+    GEMV_STAMP(8 + 3 * min(ui, 1));
     // ---- the unit's partial tiles meet in LDS (double-buffered by unit parity: one barrier per unit)
     f32x4* rbuf = red + (size_t)(ui & 1) * GW_WAVES * NS * MT * 64;
 #pragma unroll
@@ -276,6 +311,7 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
 #pragma unroll
       for (int mt = 0; mt < MT; mt++) rbuf[((wave * NS + b) * MT + mt) * 64 + lane] = acc[b][mt];
     __syncthreads();
+    GEMV_STAMP(9 + 3 * min(ui, 1));
     if (tid < OPU) {
       const int row = tid >> 4, col = tid & 15, mt = row >> 4;
       const int dl = (((row & 15) >> 2) << 4) + col, r = row & 3;  // D layout: lane = (row/4)*16 + column, register = row % 4
@@ -298,8 +334,10 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
       if (has_res) v = rnd_dt<DT>(v) + DT::to_f32(ress[ui * OPU + tid]);
       outs[ui * OPU + tid] = DT::from_f32(v);
     }
+    GEMV_STAMP(10 + 3 * min(ui, 1));
   }
   __syncthreads();
+  GEMV_STAMP(14);
   // ---- everything is stored after the stream has ended
   for (int idx = tid; idx < nu * OPU; idx += GW_THREADS) {
     const int ui = idx / OPU, rem = idx - ui * OPU, row = rem >> 4, col = rem & 15;
@@ -310,4 +348,5 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
     seg_of(u0 + ui, o_, b_, ld_, c0);
     static_cast<uint16_t*>(o_)[(size_t)row * ld_ + c0 + col] = outs[idx];
   }
+  GEMV_STAMP(15);
 }

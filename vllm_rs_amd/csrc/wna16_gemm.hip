@@ -514,7 +514,11 @@ static void launch_gemv_w_n(GemvSArgs a, hipStream_t st) {
   vra_gemv_s_plan(a.n_units, &grid, &a.units_q, &a.units_r);
   const size_t lds = gemv_q4w_lds_bytes(NS, MT, a.units_q + (a.units_r ? 1 : 0), a.residual != nullptr);
   a.dbg = 0;
+#ifdef VRA_GEMV_TS
+  a.ts = vra_gemv_ts_buf();
+#else
   a.ts = nullptr;
+#endif
   kern<<<grid, GW_THREADS, lds, st>>>(a);
 }
 template <class DT, int NS, int MT, bool AWQ>
