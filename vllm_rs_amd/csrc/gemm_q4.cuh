@@ -248,37 +248,57 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
     constexpr int PTHREADS = GC_PW * 64;
     const int per = (ROWS * OPC) / PTHREADS;            // octets per thread and chunk (4 .. 16)
     const int osh = OPC == 128 ? 7 : 6;                 // OPC is 64 or 128
-    auto stage = [&](int c, int buf) {
-      uint32_t* dst = xs + (size_t)buf * XS_U32;
-      for (int r0 = 0; r0 < per; r0 += 16) {  // the lane's whole share of the chunk in flight (per is 4, 8 or 16): staging
-                                                // throughput = bytes per L2 round trip
-        u32x4 v[16];
+    // A chunk is REQUESTED two chunks ahead of the one the compute waves are on, into one of two register sets, and written
+    // to LDS one chunk ahead: the first touch of x by an XCD is an L2 miss behind the weight streams of every workgroup —
+    // tools/gemm_c_ts.py showed 3.7 µs from request to staged against 2.7 µs of MFMA work per chunk, i.e. the compute waves
+    // waited for the producers at every chunk barrier.  All loads are unconditional (a thread with a smaller share re-reads
+    // its first octet) so that hipcc's vmcnt for the older set stays exact while the younger one is in flight.
+    constexpr int PER_MAX = ROWS * 128 / PTHREADS;      // 8 (16 rows) or 16 (32 rows)
+    // (buffer loads: ONE per-lane offset for all of a thread's loads — its octet within the row — and a wave-uniform SGPR
+    // offset per load for the row and the chunk; with flat addresses the two register sets spilled)
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, 0x7FFFFFF0, 0x00020000);
+    const uint32_t vo = (uint32_t)(pt & (OPC - 1)) * 16u;
+    const int prow = __builtin_amdgcn_readfirstlane(pt >> osh);  // a wave-load covers 64 consecutive octets of ONE row
+    const int rstep = PTHREADS >> osh;                            // rows between consecutive loads of a thread
+    auto request = [&](int c, u32x4 (&v)[PER_MAX]) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-          if (r0 + r < per) {
-            const int i = pt + (r0 + r) * PTHREADS;
-            const int row = i >> osh, o = i & (OPC - 1);
-            const int m = min(m0 + row, M - 1);           // rows >= M alias row M-1 (never stored)
-            v[r] = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.x) + (size_t)m * a.x_ld + (size_t)kt0 * 128 + (size_t)c * KC + o * 8);
-          }
-        }
+      for (int r = 0; r < PER_MAX; r++) {
+        const int m = min(m0 + prow + (r < per ? r : 0) * rstep, M - 1);  // rows >= M alias row M-1 (never stored)
+        v[r] = __builtin_amdgcn_raw_buffer_load_b128(rx, vo, (uint32_t)((m * a.x_ld + kt0 * 128 + c * KC) * 2), 0);
+      }
+    };
+    auto commit = [&](int buf, const u32x4 (&v)[PER_MAX]) {
+      // (the address walks down the rows behind an opaque copy: left to itself hipcc keeps the 16 addresses of both buffers
+      // in registers across the chunk loop and spills)
+      uint32_t off = (uint32_t)(buf * XS_U32 + prow * RS + (pt & (OPC - 1)) * 4);  // in u32
+      asm volatile("" : "+v"(off));
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-          if (r0 + r < per) {
-            const int i = pt + (r0 + r) * PTHREADS;
-            const int row = i >> osh, o = i & (OPC - 1);
-            *reinterpret_cast<u32x4*>(dst + (size_t)row * RS + o * 4) = v[r];
-          }
-        }
+      for (int r = 0; r < PER_MAX; r++) {
+        if (r < per) *reinterpret_cast<u32x4*>(xs + off) = v[r];
+        off += (uint32_t)(rstep * RS);
       }
     };
     for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
       GC_STAMP(16);
-      stage(0, 0);
+      u32x4 va[PER_MAX], vb[PER_MAX];
+      request(0, va);
+      request(min(1, NC - 1), vb);
+      commit(0, va);
       GC_STAMP(17);
-      __syncthreads();
-      for (int c = 1; c < NC; c++) {
-        stage(c, c & 1);
+      __syncthreads();  // chunk 0 is staged
+      int c = 1;
+      for (; c + 1 < NC; c += 2) {  // chunks c (held in vb) and c + 1 (va)
+        request(c + 1, va);
+        commit(1, vb);
+        GC_STAMP(17 + (c < 6 ? c : 6));
+        __syncthreads();
+        request(min(c + 2, NC - 1), vb);
+        commit(0, va);
+        GC_STAMP(17 + (c + 1 < 6 ? c + 1 : 6));
+        __syncthreads();
+      }
+      if (c < NC) {
+        commit(1, vb);
         GC_STAMP(17 + (c < 6 ? c : 6));
         __syncthreads();
       }
