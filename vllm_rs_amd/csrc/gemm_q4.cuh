@@ -69,8 +69,12 @@ template <class DT, int NBW, int MT, bool AWQ>
 __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int ROWS = 16 * MT;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // logical wave / thread ids: the FIRST four hardware waves are the producers (logical waves 8..11).  A workgroup's waves are
+  // launched in order and x is on the critical path of the start — the compute waves only have their ring to request.
+  const int lane = (int)threadIdx.x & 63;
+  const int hw_wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int wave = hw_wave < GC_PW ? hw_wave + GC_CW : hw_wave - GC_PW;
+  const int tid = wave * 64 + lane;
   const bool is_prod = wave >= GC_CW;
   const int nn = lane & 15, oct = lane >> 4;
   const int K = a.K, M = a.M, KT = K >> 7;
@@ -242,6 +246,7 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
   // with): team index of this thread, producers first
   const int ET_ALL = GC_THREADS, et_all = is_prod ? tid - GC_CW * 64 : tid + GC_PW * 64;
   const bool owner = zi == KZ - 1;
+  const bool single = n_items <= (int)gridDim.x;  // one item per workgroup: the epilogue is not overlapped with a next item
   if (is_prod) {
     // ============================== producer waves: x chunks -> LDS, then the epilogue of every item
     const int pt = tid - GC_CW * 64;                   // 0..255
@@ -339,6 +344,8 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
         __syncthreads();
         GC_STAMP(26);
         if (owner) finish_units(it, et_all, ET_ALL);
+      } else if (single) {
+        finish_units(it, et_all, ET_ALL);  // one item per workgroup: nothing for the compute waves to run ahead into — all 12 waves finish it
       } else {
         finish_units(it, pt, PTHREADS);
       }
@@ -492,6 +499,8 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
       __syncthreads();
       __syncthreads();
       if (owner) finish_units(it, et_all, ET_ALL);
+    } else if (single) {
+      finish_units(it, et_all, ET_ALL);
     }
   }
 }
