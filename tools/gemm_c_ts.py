@@ -46,3 +46,14 @@ if items and g % items == 0 and g > items:
             c = t[z * items:(z + 1) * items, st]
             if (c != 0).all(): print(f"   z={z} {nm}: p50 {np.median((c - base) / 100.0):6.2f} max {((c - base) / 100.0).max():6.2f}")
         print(f"slice z={z}: p:start p50 {np.median(s0):6.2f} max {s0.max():6.2f}   p:epilogue min {r.min():6.2f} p50 {np.median(r):6.2f} max {r.max():6.2f}" + ("   <- owner (sums the slabs)" if z == kz - 1 else ""))
+
+# per-wave phase cycle sums of the compute waves (shader clock): chunk barriers | ring wait + dequant + MFMAs | fix-up + refill
+ph = np.frombuffer(buf, dtype=np.uint64)[2048 * 32:2048 * 32 + g * 8 * 4].reshape(g, 8, 4).astype(np.float64)
+ok = (ph[:, :, 3] > 0).all(axis=1)
+print("phase sums present for", int(ok.sum()), "of", g, "workgroups")
+if ok.any():
+    ph = ph[ok]
+    steps = ph[:, :, 3]
+    print("cycles per tile-step, mean over workgroups, by compute wave (barrier | wait+dequant+mfma | fix-up+refill); steps per wave", int(steps[0, 0]))
+    for w in range(8):
+        print(f"  wave {w}: {(ph[:, w, 0] / steps[:, w]).mean():7.0f} | {(ph[:, w, 1] / steps[:, w]).mean():7.0f} | {(ph[:, w, 2] / steps[:, w]).mean():7.0f}")

@@ -55,8 +55,15 @@ struct GemmCArgs {
       a.ts[((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 32 + (i)] = wall_clock64();               \
     __builtin_amdgcn_sched_barrier(0);                                                                \
   } while (0)
+#define GC_CYC(v)                                 \
+  do {                                            \
+    __builtin_amdgcn_sched_barrier(0);            \
+    v = (long long)__builtin_readcyclecounter();  \
+    __builtin_amdgcn_sched_barrier(0);            \
+  } while (0)
 #else
 #define GC_STAMP(i) do {} while (0)
+#define GC_CYC(v) do {} while (0)
 #endif
 
 static inline size_t gemm_q4_lds_bytes(int nbw, int mt, int kc) {
@@ -368,43 +375,53 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
     const int fb = it * CGN + cg;
     const bool have = fb < a.n_blocks;
     const int fbc = have ? fb : a.n_blocks - 1;  // a wave without an n-block streams the last one with zeroed scales
-    // wave-uniform tensor pointers of this item
-    const u32x4* wp[NBW];
-    const uint16_t* sp[NBW];
-    const uint32_t* qp[NBW];
+    // wave-uniform tensor bases of this item as buffer resources: every ring load is (resource, ONE per-lane offset fixed for
+    // the item, an SGPR offset for the tile / scale group) — no per-load 64-bit VALU address arithmetic.  The loop of this
+    // kernel is VALU bound at 32 rows (110 VALU instructions per tile-step against 24 MFMAs; two compute waves per SIMD).
+    __amdgpu_buffer_rsrc_t rw[NBW], rs[NBW], rz[NBW];
     int ncols[NBW], nbv;
     if (NBW == 2) {
       nbv = fbc;
 #pragma unroll
       for (int b = 0; b < NBW; b++) {
-        wp[b] = reinterpret_cast<const u32x4*>(a.seg[b].w) + (size_t)nbv * KT * 64 + lane;
-        sp[b] = static_cast<const uint16_t*>(a.seg[b].scales);
-        qp[b] = a.seg[b].qzeros;
+        rw[b] = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.seg[b].w), 0, 0x7FFFFFF0, 0x00020000);
+        rs[b] = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.seg[b].scales), 0, 0x7FFFFFF0, 0x00020000);
+        rz[b] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(AWQ ? a.seg[b].qzeros : reinterpret_cast<const uint32_t*>(a.seg[b].scales)), 0, 0x7FFFFFF0, 0x00020000);
         ncols[b] = a.seg[b].n;
       }
     } else {
       const bool s1 = fbc >= blk1, s2 = fbc >= blk2;
-      const GemvSeg& sg = s2 ? a.seg[2] : (s1 ? a.seg[1] : a.seg[0]);
+      const void* w_ = s2 ? a.seg[2].w : (s1 ? a.seg[1].w : a.seg[0].w);
+      const void* s_ = s2 ? a.seg[2].scales : (s1 ? a.seg[1].scales : a.seg[0].scales);
+      const uint32_t* z_ = s2 ? a.seg[2].qzeros : (s1 ? a.seg[1].qzeros : a.seg[0].qzeros);
       nbv = fbc - (s2 ? blk2 : (s1 ? blk1 : 0));
-      wp[0] = reinterpret_cast<const u32x4*>(sg.w) + (size_t)nbv * KT * 64 + lane;
-      sp[0] = static_cast<const uint16_t*>(sg.scales);
-      qp[0] = sg.qzeros;
-      ncols[0] = sg.n;
+      rw[0] = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(w_), 0, 0x7FFFFFF0, 0x00020000);
+      rs[0] = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(s_), 0, 0x7FFFFFF0, 0x00020000);
+      rz[0] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(AWQ ? z_ : reinterpret_cast<const uint32_t*>(s_)), 0, 0x7FFFFFF0, 0x00020000);
+      ncols[0] = s2 ? a.seg[2].n : (s1 ? a.seg[1].n : a.seg[0].n);
     }
+    const uint32_t vo_w = (uint32_t)lane * 16u;
+    const uint32_t vo_s = (uint32_t)((nbv * 16 + nn) >> 1) * 4u;  // the 32-bit word that holds the lane's 16-bit scale
+    const uint32_t vo_z = (uint32_t)(nbv * 2 + (nn >> 3)) * 4u;
     // ring depth: only 8 streaming waves per workgroup (and one workgroup per CU when LDS is full): 8 KiB per wave in
     // flight = 64 KiB per CU (a 2-step ring measured a ~34 us latency floor: every step waited for HBM)
-    constexpr int D = (MT == 2 ? 6 : 8) / NBW;  // (MT = 2 holds twice the accumulators and x fragments: a shorter ring avoids spills)
+#ifndef GC_RING_MT2
+#define GC_RING_MT2 6
+#endif
+#ifndef GC_RING_MT2_PAIR
+#define GC_RING_MT2_PAIR 3
+#endif
+    constexpr int D = MT == 2 ? (NBW == 2 ? GC_RING_MT2_PAIR : GC_RING_MT2) : 8 / NBW;  // (MT = 2 holds twice the accumulators and x fragments: a shorter ring avoids spills)
     u32x4 wb[D][NBW];
     uint32_t sb[D][NBW], zb[D][NBW];
     auto issue = [&](int i, u32x4 (&w)[NBW], uint32_t (&sc)[NBW], uint32_t (&zp)[NBW]) {
       const int kt = kt0 + ksi + KS * min(i, T - 1);  // steps past the end re-read the last tile (never consumed)
+      const int grp = (kt * 128) >> gsh;
 #pragma unroll
       for (int b = 0; b < NBW; b++) {
-        w[b] = __builtin_nontemporal_load(wp[b] + (size_t)kt * 64);
-        const int grp = (kt * 128) >> gsh;
-        const int64_t si = (int64_t)grp * ncols[b] + nbv * 16 + nn;
-        sc[b] = reinterpret_cast<const uint32_t*>(sp[b])[si >> 1];
-        if (AWQ) zp[b] = qp[b][(size_t)grp * (ncols[b] >> 3) + nbv * 2 + (nn >> 3)];
+        w[b] = __builtin_amdgcn_raw_buffer_load_b128(rw[b], vo_w, (uint32_t)((nbv * KT + kt) * 1024), 2);  // nt
+        sc[b] = __builtin_amdgcn_raw_buffer_load_b32(rs[b], vo_s, (uint32_t)(grp * ncols[b] * 2), 0);
+        if (AWQ) zp[b] = __builtin_amdgcn_raw_buffer_load_b32(rz[b], vo_z, (uint32_t)(grp * (ncols[b] >> 3) * 4), 0);
         else zp[b] = 0;
       }
     };
@@ -420,31 +437,31 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
       for (int mt = 0; mt < MT; mt++) acc[b][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int T_pad = (T + D - 1) / D * D;
+    long long cA = 0, cB = 0, cyc[3] = {0, 0, 0};  // TS builds: cycles in chunk barriers | ring wait + dequant + MFMAs | fix-up + refill
+    (void)cA, (void)cB, (void)cyc;
     for (int i0 = 0; i0 < T_pad; i0 += D) {
 #pragma unroll
       for (int r = 0; r < D; r++) {
         const int i = i0 + r;
         if (i < T && (i & (SC - 1)) == 0) {
           GC_STAMP(2 + 2 * ((i >> sc_sh) < 5 ? (i >> sc_sh) : 5));
+          GC_CYC(cA);
           __syncthreads();  // chunk i/SC is staged (and chunk i/SC - 2's buffer is free)
+          GC_CYC(cB);
+          cyc[0] += cB - cA;
           GC_STAMP(3 + 2 * ((i >> sc_sh) < 5 ? (i >> sc_sh) : 5));
         }
         if (i < T) {
+          GC_CYC(cA);
           const int ktl = ksi + KS * i;  // tile within this workgroup's K slice
           const int c = ktl >> tpc_sh, tl = ktl & (TPC - 1);
           const uint32_t* xb = xs + (size_t)(c & 1) * XS_U32;
-          f32x4 ag[NBW][MT];
-#pragma unroll
-          for (int b = 0; b < NBW; b++)
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++) ag[b][mt] = vra_zero_acc();
+          f32x4 ag[NBW][MT];  // (every chain STARTS with the C = 0 form of the MFMA: no accumulator is zeroed on the VALU)
           // LDS reads run one k-step (j) ahead of the MFMAs that consume them.  The row sums Σx of the zero-point fix-up
           // come from one extra MFMA per (j, m-tile) against an all-ones B fragment: D[m][n] = Σ_k x[m][k] lands in
           // exactly the lanes that need it, and the producers only have to move bytes.
           u32x4 xv[2][MT];
           f32x4 sxv[MT];
-#pragma unroll
-          for (int mt = 0; mt < MT; mt++) sxv[mt] = vra_zero_acc();
 #pragma unroll
           for (int mt = 0; mt < MT; mt++) {
             const int o = tl * 16 + oct;
@@ -464,11 +481,17 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
             for (int mt = 0; mt < MT; mt++) {
               const s16x8 afrag = __builtin_bit_cast(s16x8, xv[j & 1][mt]);
 #pragma unroll
-              for (int b = 0; b < NBW; b++) DT::mfma(ag[b][mt], afrag, bfrag[b]);
-              DT::mfma(sxv[mt], afrag, ones);
+              for (int b = 0; b < NBW; b++) {
+                if (j == 0) DT::mfma0(ag[b][mt], afrag, bfrag[b]);
+                else DT::mfma(ag[b][mt], afrag, bfrag[b]);
+              }
+              if (j == 0) DT::mfma0(sxv[mt], afrag, ones);
+              else DT::mfma(sxv[mt], afrag, ones);
             }
           }
           VRA_MFMA_DRAIN();
+          GC_CYC(cB);
+          cyc[1] += cB - cA;
 #pragma unroll
           for (int b = 0; b < NBW; b++) {
             float s = DT::to_f32((uint16_t)(shalf ? sb[r][b] >> 16 : sb[r][b]));
@@ -483,8 +506,16 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
           }
         }
         issue(i + D, wb[r], sb[r], zb[r]);  // unconditional refill (clamped)
+        GC_CYC(cA);
+        cyc[2] += cA - cB;
       }
     }
+#ifdef VRA_GEMV_TS
+    if (a.ts && lane == 0) {
+      unsigned long long* o = a.ts + (size_t)2048 * 32 + (((size_t)blockIdx.z * gridDim.x + blockIdx.x) * GC_CW + wave) * 4;
+      o[0] = (unsigned long long)cyc[0], o[1] = (unsigned long long)cyc[1], o[2] = (unsigned long long)cyc[2], o[3] = (unsigned long long)T;
+    }
+#endif
     // ---- hand the partial tiles to the producer waves (they alias the x buffers: every wave must be done reading x)
     GC_STAMP(14);
     __syncthreads();
