@@ -491,10 +491,6 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
     const kv_t* krow1 = krow0 + 4 * D;
     const size_t vbase = (((size_t)blk * a.Hkv + hk) * D) * a.BS + off;
     const bool has_new = last >= T0 && last < T0 + 32;  // wave-uniform: the tile that holds the new token
-    if (has_new) {  // its K row comes from LDS (the cache write of split 0 may not be visible yet)
-      if (T0 + krow_tok == last) krow0 = knew;
-      if (T0 + krow_tok + 4 == last) krow1 = knew;
-    }
     u32x4 k0[DJ], k1[DJ];
 #pragma unroll
     for (int j = 0; j < DJ; j++) {
@@ -506,6 +502,19 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
 #pragma unroll
     for (int t = 0; t < DT16; t++) vfr[t] = kv_load8<DT, KV8>(vcache + vbase + (size_t)(t * 16 + rq) * a.BS + oct * 8);
     FD_STAMP(5);
+    // the new token's K row comes from LDS (the cache write of split 0 may not be visible yet).  Patched in AFTER the loads:
+    // selecting the row POINTER (cache or LDS) made every K load of the loop a flat_load — slower to issue than global_load
+    // and counted in both vmcnt and lgkmcnt
+    if (has_new) {
+      if (T0 + krow_tok == last) {
+#pragma unroll
+        for (int j = 0; j < DJ; j++) k0[j] = kv_load8<DT, KV8>(knew + j * 32 + oct * 8);
+      }
+      if (T0 + krow_tok + 4 == last) {
+#pragma unroll
+        for (int j = 0; j < DJ; j++) k1[j] = kv_load8<DT, KV8>(knew + j * 32 + oct * 8);
+      }
+    }
     f32x4 s0 = vra_zero_acc(), s1 = vra_zero_acc();
 #pragma unroll
     for (int j = 0; j < DJ; j++) {
