@@ -174,9 +174,11 @@ def test_gemv_w_formats_bias_residual(M, dt, awq, gs, layout):
 
 
 @pytest.mark.parametrize("M", [6, 16, 32])
-def test_gemv_w_fused_rms_norm_qkv_shape(M):
-    K, N, dt = 4096, 6144, BF16
-    r = rng(M + 55)
+@pytest.mark.parametrize("K,N,dt", [(4096, 6144, BF16), (2048, 4096, BF16), (3584, 4608, F16), (1024, 2048, F16)])
+def test_gemv_w_fused_rms_norm_qkv_shape(M, K, N, dt):
+    """K < 4096: waves without a k-tile (their share of the row's sum of squares is masked after the X·Xᵀ MFMAs); K = 3584: the
+    fourth tile exists for half of the waves only"""
+    r = rng(M + 55 + K)
     q = make_quant(r, K, N, 128, dt, False)
     x, nw = rand_dt(r, (M, K), dt, 2.0), orc.to_dt((1.0 + 0.1 * r.standard_normal(K)).astype(np.float32), dt)
     bias = rand_dt(r, (N,), dt)
