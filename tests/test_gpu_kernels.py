@@ -192,6 +192,24 @@ def test_dense_gemm(M, out_f32):
         assert_close_dt(out.numpy(np.uint16, (M, N)), ref, BF16, name="dense", abs_floor=2e-3)
 
 
+@pytest.mark.parametrize("M", [8, 9, 16, 17, 32])
+@pytest.mark.parametrize("K,N,dt,with_bias", [(4096, 4112, BF16, False), (2048, 8192, BF16, True), (3584, 4096, F16, False), (1024, 2064, F16, True)])
+def test_dense_gemm_decode_batches(M, K, N, dt, with_bias):
+    """9..32 rows, K <= 4096: kernel W's dense variant (gemv_dw.cuh) — ragged unit distribution (N/16 not a multiple of the
+    grid), waves without a k-tile (K < 4096), bias, both dtypes, f32 output == the model-dtype value widened"""
+    r = rng(M + K + N)
+    x, w = rand_dt(r, (M, K), dt), rand_dt(r, (N, K), dt, 0.05)
+    bias = rand_dt(r, (N,), dt) if with_bias else None
+    out = ops.dense_gemm(ops.dev(x), ops.dev(w), ops.dev(bias) if with_bias else None, M, K, N, dt, F32)
+    ref = orc.dense_gemm(x, w, bias, dt, F32)
+    got = out.numpy(np.float32, (M, N))
+    assert np.array_equal(orc.from_dt(orc.to_dt(got, dt), dt), got), "f32 output must be representable in the model dtype"
+    g0 = np.abs(orc.dense_gemm(x, w, None, dt, F32)) if with_bias else None  # the sum is rounded before the bias is added
+    assert_close_dt(orc.to_dt(got, dt), orc.to_dt(ref, dt), dt, name="dense decode batch", abs_floor=2e-3, mag=g0)
+    out16 = ops.dense_gemm(ops.dev(x), ops.dev(w), ops.dev(bias) if with_bias else None, M, K, N, dt, dt)
+    assert np.array_equal(out16.numpy(np.uint16, (M, N)), orc.to_dt(got, dt)), "16-bit output == the f32 output narrowed"
+
+
 # ---------------------------------------------------------------- norms / elementwise
 @pytest.mark.parametrize("dt", [BF16, F16])
 @pytest.mark.parametrize("T,H", [(1, 4096), (7, 2048), (33, 3584)])

@@ -1077,6 +1077,45 @@ extern "C" void vra_wna16_gate_up_silu(const void* in, const void* qw_gate, cons
   }
 }
 
+bool vra_gemv_dw_fits(int M, int K, int N) {
+  static const char* off = getenv("VRA_NO_GEMV_DW");
+  if (off && off[0] == '1') return false;
+  static const char* mn_env = getenv("VRA_GDW_MIN_M");  // tuning aid: fewest rows routed here
+  const int min_m = mn_env ? atoi(mn_env) : 5;  // (callers ask kernel A first: it keeps x in LDS and wins where it fits — up to 7 rows at K = 4096)
+  if (M < min_m || M > 32 || K % 128 || K > 128 * GW_WAVES * GW_TPW || N % 16) return false;
+  const int units = N / 16;
+  if (units < num_cus() / 2) return false;
+  int grid, q, r;
+  vra_gemv_s_plan(units, &grid, &q, &r);
+  const int mu = q + (r ? 1 : 0);
+  return mu <= GDW_MAX_UNITS && gemv_dw_lds_bytes(M > 16 ? 2 : 1, mu) <= (size_t)kMaxDynLds;
+}
+template <class DT, int MT, bool NORM>
+static void launch_gemv_dw_n(GemvDWArgs a, hipStream_t st) {
+  static uint64_t attr_devs = 0;
+  auto kern = gemv_dw_kernel<DT, MT, NORM>;
+  if (!dev_seen(attr_devs)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+    dev_mark(attr_devs);
+  }
+  a.KT = a.K / 128;
+  a.n_units = a.n_units > 0 ? a.n_units : 0;
+  int grid;
+  vra_gemv_s_plan(a.n_units, &grid, &a.units_q, &a.units_r);
+  const size_t lds = gemv_dw_lds_bytes(MT, a.units_q + (a.units_r ? 1 : 0));
+  kern<<<grid, GW_THREADS, lds, st>>>(a);
+}
+void vra_launch_gemv_dw(GemvDWArgs a, int dtype, int64_t stream) {
+  hipStream_t st = as_stream(stream);
+  const bool two = a.M > 16, norm = a.norm_w != nullptr;
+  if (dtype == VRA_BF16) {
+    if (two) norm ? launch_gemv_dw_n<BF16, 2, true>(a, st) : launch_gemv_dw_n<BF16, 2, false>(a, st);
+    else norm ? launch_gemv_dw_n<BF16, 1, true>(a, st) : launch_gemv_dw_n<BF16, 1, false>(a, st);
+  } else {
+    if (two) norm ? launch_gemv_dw_n<F16, 2, true>(a, st) : launch_gemv_dw_n<F16, 2, false>(a, st);
+    else norm ? launch_gemv_dw_n<F16, 1, true>(a, st) : launch_gemv_dw_n<F16, 1, false>(a, st);
+  }
+}
 extern "C" void vra_dense_gemm(const void* x, const void* w, const void* bias, void* out, int32_t m, int32_t k, int32_t n,
                                int32_t dtype, int32_t out_dtype, int64_t stream) {
   VRA_CHECK_ARG(x && w && out, "vra_dense_gemm: null pointer");
@@ -1094,6 +1133,11 @@ extern "C" void vra_dense_gemm(const void* x, const void* w, const void* bias, v
     a.group_size = -1;
     a.out_f32 = out_dtype == VRA_F32;
     vra_launch_gemv(a, false, dtype, stream);
+  } else if (vra_gemv_dw_fits(m, k, n)) {
+    GemvDWArgs a = {};
+    a.x = x, a.x_ld = k, a.w = w, a.bias = bias, a.out = out, a.out_ld = n, a.out_f32 = out_dtype == VRA_F32;
+    a.M = m, a.K = k, a.n_units = n / 16;
+    vra_launch_gemv_dw(a, dtype, stream);
   } else {
     GemmBArgs b = {};
     b.w0 = w;

@@ -803,6 +803,12 @@ bool Model::forward(const InputMetadata& md, int64_t stream) {
     a.group_size = -1;
     a.out_f32 = 1;
     vra_launch_gemv(a, false, dt_, stream);
+  } else if (vra_gemv_dw_fits(rows, H, lm_head_.N)) {  // 9..32 rows: final norm + lm_head in one launch (gemv_dw.cuh)
+    GemvDWArgs a = {};
+    a.x = xin, a.x_ld = H, a.norm_w = final_norm_, a.eps = mc_.rms_norm_eps;
+    a.w = lm_head_.w, a.out = logits_, a.out_ld = lm_head_.N, a.out_f32 = 1;
+    a.M = rows, a.K = H, a.n_units = lm_head_.N / 16;
+    vra_launch_gemv_dw(a, dt_, stream);
   } else {
     vra_rms_norm(xin, final_norm_, xn_, rows, H, mc_.rms_norm_eps, dt_, stream);
     vra_dense_gemm(xn_, lm_head_.w, nullptr, logits_, rows, H, lm_head_.N, dt_, VRA_F32, stream);
