@@ -47,17 +47,6 @@ __device__ __forceinline__ float gq_scale_f32(uint32_t raw16) { return DT::to_f3
 #define GEMV_STAMP_E(i) do {} while (0)
 #endif
 
-#ifdef VRA_GEMV_TS
-#define GEMV_STAMP_E(i)                                                                \
-  do {                                                                                 \
-    __builtin_amdgcn_sched_barrier(0);                                                 \
-    if (a.ts && lane == 0) a.ts[(size_t)blockIdx.x * 32 + (i)] = wall_clock64();        \
-    __builtin_amdgcn_sched_barrier(0);                                                 \
-  } while (0)
-#else
-#define GEMV_STAMP_E(i) do {} while (0)
-#endif
-
 // Element `nl` (0..15, per lane) of 16 consecutive 16-bit values at a WAVE-UNIFORM address, fetched with
 // scalar loads (constant address space => s_load_dwordx8, lgkmcnt): the epilogue's bias / residual reads
 // must stay out of the vector-memory queue, or their s_waitcnt vmcnt(0) would drain the weight ring.
