@@ -245,8 +245,8 @@ def cpu_baseline(cfg_int4, cfg_tiny):
     """`cpu_baseline` of the JSON line = the workload of the headline metric (Llama-3-8B int4 decode, bs 1; kind "port": the
     reference has no int4 CPU path, src/utils/gptq.rs:212-222, and cannot be built here); `cpu_baseline_config1` = BASELINE
     config 1, the shape the reference COULD run on its CPU backend (TinyLlama-1.1B bf16 greedy decode)."""
-    b = oracle_decode_tokens_per_s(cfg_int4, 2, 12, 32, "Llama-3-8B-shape GPTQ int4 g128 bs=1 decode")
-    a = oracle_decode_tokens_per_s(cfg_tiny, 4, 16, 32, "TinyLlama-1.1B-shape bf16 bs=1 decode (BASELINE config 1)")
+    b = oracle_decode_tokens_per_s(cfg_int4, 8, 16, 32, "Llama-3-8B-shape GPTQ int4 g128 bs=1 decode")   # ~10 s on the box's 128 host threads
+    a = oracle_decode_tokens_per_s(cfg_tiny, 11, 16, 32, "TinyLlama-1.1B-shape bf16 bs=1 decode (BASELINE config 1)")  # ~3 s
     return b, a
 
 
