@@ -1,4 +1,4 @@
-// gemv_dw.cuh — "kernel W, dense": 16-bit [N, K] weights (the lm_head) for decode batches of 8..32 rows and K <= 4096.
+// gemv_dw.cuh — "kernel W, dense": 16-bit [N, K] weights (the lm_head) for decode batches of 4..32 rows (engine; vra_dense_gemm: what kernel A does not take) and K <= 4096.
 //
 // Before: RMSNorm launch + kernel B (gemm_skinny.cuh), which stages x through LDS in 256-k chunks behind a workgroup barrier
 // per chunk and keeps a whole chunk of weights in registers: 222..235 µs for the Llama-3 lm_head (1.05 GB) at 8..32 rows

@@ -1081,7 +1081,7 @@ bool vra_gemv_dw_fits(int M, int K, int N) {
   static const char* off = getenv("VRA_NO_GEMV_DW");
   if (off && off[0] == '1') return false;
   static const char* mn_env = getenv("VRA_GDW_MIN_M");  // tuning aid: fewest rows routed here
-  const int min_m = mn_env ? atoi(mn_env) : 5;  // (callers ask kernel A first: it keeps x in LDS and wins where it fits — up to 7 rows at K = 4096)
+  const int min_m = mn_env ? atoi(mn_env) : 4;  // (below: kernel A, which keeps x in LDS; vra_dense_gemm asks kernel A first up to 7 rows)
   if (M < min_m || M > 32 || K % 128 || K > 128 * GW_WAVES * GW_TPW || N % 16) return false;
   const int units = N / 16;
   if (units < num_cus() / 2) return false;
