@@ -667,7 +667,6 @@ void Model::gemv_s_args(int l, int which, int M, void* out, const void* residual
       a.residual = residual, a.res_ld = L.down.N;
       break;
   }
-  if (const char* e = getenv("VRA_DBG_XLD_PAD")) a.x_ld += atoi(e);  // timing experiments only: the rows then hold garbage
 }
 static int g_gemv_s2 = -1;  // -1: take VRA_GEMV_S2 from the environment at first use
 extern "C" void vra_debug_set_gemv_s2(int on) { g_gemv_s2 = on ? 1 : 0; }
