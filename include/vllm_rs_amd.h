@@ -170,6 +170,15 @@ void vra_reshape_and_cache(const void* k, const void* v, void* k_cache, void* v_
                            const int64_t* slot_mapping, int32_t tokens, int32_t kv_heads,
                            int32_t head_dim, int32_t block_size, int32_t dtype, int32_t kv_dtype,
                            int64_t stream);
+/* vra_fused_rope (NeoX pairs over the full head, tables in `dtype`) + vra_reshape_and_cache in ONE launch, for prefill:
+ * q is rotated in place, the rotated k goes straight to its K-cache row (k itself is left as it was: prefill attention reads
+ * the cache), v to its V-cache column.  Bit-identical to the two calls it replaces (attention.rs:745-820 issues them
+ * separately). */
+void vra_rope_cache_prefill(void* q, const void* k, const void* v, void* k_cache, void* v_cache,
+                            const void* cos, const void* sin, const int64_t* positions,
+                            const int64_t* slot_mapping, int32_t tokens, int32_t q_heads, int32_t kv_heads,
+                            int32_t head_dim, int32_t block_size, int32_t dtype, int32_t kv_dtype,
+                            int64_t stream);
 /* decode half of PagedAttention::forward: one query token per sequence.
  * q/out [B,Hq,D]; block_tables [B,max_blocks] u32 (right-padded with 0, Appendix A5);
  * context_lens [B] u32 (includes the token just written). `workspace` must hold

@@ -279,6 +279,40 @@ def test_fused_rope(interleaved, table_f32, D, rot):
     assert np.array_equal(kd.numpy(np.uint16, k.shape), kr)
 
 
+@pytest.mark.parametrize("dt", [BF16, F16])
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("Hq,Hkv,D", [(32, 8, 128), (14, 2, 64)])
+def test_rope_cache_prefill_equals_the_two_launches(dt, fp8, Hq, Hkv, D):
+    """vra_rope_cache_prefill == vra_fused_rope + vra_reshape_and_cache bit for bit: rotated q, K-cache rows, V-cache columns
+    (16-bit and FP8 caches), a padded token (slot -1) writes nothing"""
+    L = ops.lib()
+    T, BS, NB = 37, 64, 8
+    r = rng(D + Hq + dt + fp8)
+    cos, sin = orc.rope_tables(D, 500000.0, 512, 2, 8.0, 1.0, 4.0, 8192)
+    cos_t, sin_t = orc.to_dt(cos, dt), orc.to_dt(sin, dt)
+    q, k, v = rand_dt(r, (T, Hq, D), dt), rand_dt(r, (T, Hkv, D), dt), rand_dt(r, (T, Hkv, D), dt)
+    pos = r.integers(0, 512, size=T).astype(np.int64)
+    slots = r.permutation(NB * BS)[:T].astype(np.int64)
+    slots[5] = -1
+    kvdt = 3 if fp8 else dt
+    nbytes = NB * Hkv * BS * D * (1 if fp8 else 2)
+    dcos, dsin, dpos, dslots = ops.dev(cos_t), ops.dev(sin_t), ops.dev(pos), ops.dev(slots)
+    # two launches
+    q1, k1, v1 = ops.dev(q), ops.dev(k), ops.dev(v)
+    kc1, vc1 = ops.DevBuf(nbytes).fill_bytes(0x11), ops.DevBuf(nbytes).fill_bytes(0x11)
+    L.vra_fused_rope(q1.ptr, k1.ptr, dcos.ptr, dsin.ptr, dpos.ptr, T, Hq, Hkv, D, D, 0, dt, dt, 0)
+    L.vra_reshape_and_cache(k1.ptr, v1.ptr, kc1.ptr, vc1.ptr, dslots.ptr, T, Hkv, D, BS, dt, kvdt, 0)
+    # one launch
+    q2, k2, v2 = ops.dev(q), ops.dev(k), ops.dev(v)
+    kc2, vc2 = ops.DevBuf(nbytes).fill_bytes(0x11), ops.DevBuf(nbytes).fill_bytes(0x11)
+    L.vra_rope_cache_prefill(q2.ptr, k2.ptr, v2.ptr, kc2.ptr, vc2.ptr, dcos.ptr, dsin.ptr, dpos.ptr, dslots.ptr, T, Hq, Hkv, D, BS, dt, kvdt, 0)
+    ops.check_error()
+    assert np.array_equal(q1.numpy(np.uint16, q.shape), q2.numpy(np.uint16, q.shape))
+    assert np.array_equal(kc1.numpy(np.uint8, (nbytes,)), kc2.numpy(np.uint8, (nbytes,)))
+    assert np.array_equal(vc1.numpy(np.uint8, (nbytes,)), vc2.numpy(np.uint8, (nbytes,)))
+    assert np.array_equal(k2.numpy(np.uint16, k.shape), k), "k itself is left un-rotated"
+
+
 # ---------------------------------------------------------------- paged KV + attention
 def _paged_setup(r, ctxs, Hkv, D, BS, dt, NB=64):
     """random K/V history scattered into a shuffled block pool through reshape_and_cache."""

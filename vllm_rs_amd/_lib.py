@@ -103,6 +103,7 @@ def load():
     _sig(lib, "vra_silu_mul", None, P, P, P, c_i64, c_i32, c_i64)
     _sig(lib, "vra_fused_rope", None, P, P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64)
     _sig(lib, "vra_reshape_and_cache", None, P, P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64)
+    _sig(lib, "vra_rope_cache_prefill", None, P, P, P, P, P, P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64)
     _sig(lib, "vra_paged_attention_decode_workspace_bytes", c_sz, c_i32, c_i32, c_i32, c_i32)
     _sig(lib, "vra_paged_attention_decode", None, P, P, P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
          c_f32, c_f32, P, c_i32, c_i32, c_i64)

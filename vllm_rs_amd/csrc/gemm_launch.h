@@ -35,3 +35,7 @@ void vra_launch_gemv_w(GemvSArgs a, int ns, int group_size, bool awq, int dtype,
 // fuses the RMSNorm.  The launcher fills KT and the unit distribution.
 bool vra_gemv_dw_fits(int M, int K, int N);
 void vra_launch_gemv_dw(GemvDWArgs a, int dtype, int64_t stream);
+// the row-sum table of kernel D (scratch; null when unavailable) and a norm launch that fills it: a GEMM launched with
+// GemmDArgs::xsum set skips its own row-sum pass
+float* vra_gemm_q4_big_xsum_table(int M, int K);
+void vra_rms_norm_xsum(const void* x, const void* weight, void* out, float* xsum, int tokens, int hidden, float eps, int dtype, int64_t stream);

@@ -6,10 +6,13 @@
 
 // ---------------------------------------------------------------- RMSNorm (+ residual add)
 // one workgroup (256 threads) per token row; row cached in registers between the two passes.
-template <class DT, bool ADD>
+// XS: also write Σ of the ROUNDED outputs per 128-column k-tile to xsum[row][H/128] — the row-sum table kernel D (gemm_q4_big.cuh)
+// needs, in exactly the order `xsum_rows_kernel` uses (octet sums, then the 16-lane DPP tree), so a GEMM fed with this table is
+// bit-identical to one that ran the separate pass; H % 128 == 0
+template <class DT, bool ADD, bool XS = false>
 __global__ __launch_bounds__(256) void rms_norm_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ res,
                                                        const uint16_t* __restrict__ w, uint16_t* __restrict__ h_out,
-                                                       uint16_t* __restrict__ out, int H, float eps) {
+                                                       uint16_t* __restrict__ out, int H, float eps, float* __restrict__ xsum = nullptr) {
   __shared__ float red[4];
   const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int octs = H >> 3;
@@ -52,7 +55,12 @@ __global__ __launch_bounds__(256) void rms_norm_kernel(const uint16_t* __restric
       unpack8<DT>(wr[o], g);
 #pragma unroll
       for (int e = 0; e < 8; e++) f[e] = f[e] * rstd * g[e];
-      reinterpret_cast<u32x4*>(out + (size_t)t * H)[o] = pack8<DT>(f);
+      const u32x4 pv = pack8<DT>(f);
+      reinterpret_cast<u32x4*>(out + (size_t)t * H)[o] = pv;
+      if (XS) {  // (octs % 16 == 0: the 16 lanes of a k-tile are all in or all out of this branch)
+        const float s16 = row16_sum(octet_sum<DT>(pv));
+        if ((o & 15) == 0) xsum[(size_t)t * (H >> 7) + (o >> 4)] = s16;
+      }
     }
   }
 }
@@ -74,6 +82,18 @@ extern "C" void vra_rms_norm(const void* x, const void* weight, void* out, int32
     rms_norm_kernel<BF16, false><<<tokens, 256, 0, as_stream(stream)>>>((const uint16_t*)x, nullptr, (const uint16_t*)weight, nullptr, (uint16_t*)out, hidden, eps);
   else
     rms_norm_kernel<F16, false><<<tokens, 256, 0, as_stream(stream)>>>((const uint16_t*)x, nullptr, (const uint16_t*)weight, nullptr, (uint16_t*)out, hidden, eps);
+}
+// internal (gemm_launch.h): RMSNorm + the row-sum table of kernel D in one launch
+void vra_rms_norm_xsum(const void* x, const void* weight, void* out, float* xsum, int tokens, int hidden, float eps, int dtype, int64_t stream) {
+  if (!norm_args_ok("vra_rms_norm_xsum", tokens, hidden, dtype) || tokens == 0) return;
+  if (hidden % 128) {
+    vra_set_error("vra_rms_norm_xsum: hidden %d is not a multiple of 128", hidden);
+    return;
+  }
+  if (dtype == VRA_BF16)
+    rms_norm_kernel<BF16, false, true><<<tokens, 256, 0, as_stream(stream)>>>((const uint16_t*)x, nullptr, (const uint16_t*)weight, nullptr, (uint16_t*)out, hidden, eps, xsum);
+  else
+    rms_norm_kernel<F16, false, true><<<tokens, 256, 0, as_stream(stream)>>>((const uint16_t*)x, nullptr, (const uint16_t*)weight, nullptr, (uint16_t*)out, hidden, eps, xsum);
 }
 extern "C" void vra_add_rms_norm(const void* x, const void* residual, const void* weight, void* h_out, void* out,
                                  int32_t tokens, int32_t hidden, float eps, int32_t dtype, int64_t stream) {
@@ -289,6 +309,96 @@ extern "C" void vra_reshape_and_cache(const void* k, const void* v, void* k_cach
     return;
   }
   reshape_and_cache_kernel<<<tokens, 256, 0, as_stream(stream)>>>((const uint16_t*)k, (const uint16_t*)v, (uint16_t*)k_cache, (uint16_t*)v_cache, slot_mapping, kv_heads, head_dim, block_size);
+}
+
+// ---------------------------------------------------------------- RoPE + KV scatter in one launch (prefill)
+// One workgroup per token: q is rotated in place, k is rotated straight into its K-cache row (the rotated k is not written back:
+// prefill attention reads K and V from the cache), v goes to its token-minor V-cache column.  NeoX pairs, full rotary width,
+// tables in the model dtype — the arithmetic of rope_kernel and the bytes of reshape_and_cache_kernel, i.e. bit-identical to the
+// two launches (tests/test_gpu_kernels.py); everything else takes the two launches.
+template <class DT, bool KV8>
+__global__ __launch_bounds__(256) void rope_cache_kernel(uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
+                                                         typename KVT<KV8>::elem* __restrict__ kc, typename KVT<KV8>::elem* __restrict__ vc,
+                                                         const uint16_t* __restrict__ cosv, const uint16_t* __restrict__ sinv,
+                                                         const int64_t* __restrict__ positions, const int64_t* __restrict__ slots, int Hq, int Hkv,
+                                                         int D, int BS) {
+  typedef typename KVT<KV8>::elem kv_t;
+  const int t = blockIdx.x, tid = threadIdx.x;
+  const int half = D >> 1, per_head = half >> 3;  // 16-byte pair groups per head
+  const int64_t pos = positions[t], slot = slots[t];
+  const int64_t blk = slot / BS;
+  const int off = (int)(slot % BS);
+  const uint16_t* cs_row = cosv + pos * half;
+  const uint16_t* sn_row = sinv + pos * half;
+  auto rotate = [&](const uint16_t* base, int c, u32x4& r1, u32x4& r2) {
+    float x1[8], x2[8], cs[8], sn[8], y1[8], y2[8];
+    unpack8<DT>(*reinterpret_cast<const u32x4*>(base + c * 8), x1);
+    unpack8<DT>(*reinterpret_cast<const u32x4*>(base + half + c * 8), x2);
+    unpack8<DT>(*reinterpret_cast<const u32x4*>(cs_row + c * 8), cs);
+    unpack8<DT>(*reinterpret_cast<const u32x4*>(sn_row + c * 8), sn);
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      y1[e] = x1[e] * cs[e] - x2[e] * sn[e];
+      y2[e] = x2[e] * cs[e] + x1[e] * sn[e];
+    }
+    r1 = pack8<DT>(y1), r2 = pack8<DT>(y2);
+  };
+  for (int w = tid; w < Hq * per_head; w += blockDim.x) {  // q: in place
+    const int h = w / per_head, c = w - h * per_head;
+    uint16_t* base = q + ((size_t)t * Hq + h) * D;
+    u32x4 r1, r2;
+    rotate(base, c, r1, r2);
+    *reinterpret_cast<u32x4*>(base + c * 8) = r1;
+    *reinterpret_cast<u32x4*>(base + half + c * 8) = r2;
+  }
+  if (slot < 0) return;  // padded lane: nothing is cached
+  for (int w = tid; w < Hkv * per_head; w += blockDim.x) {  // k: rotated into the cache row
+    const int h = w / per_head, c = w - h * per_head;
+    u32x4 r1, r2;
+    rotate(k + ((size_t)t * Hkv + h) * D, c, r1, r2);
+    kv_t* row = kc + ((blk * Hkv + h) * BS + off) * D;
+    kv_store8<DT, KV8>(row + c * 8, r1);
+    kv_store8<DT, KV8>(row + half + c * 8, r2);
+  }
+  for (int w = tid; w < Hkv * (D >> 3); w += blockDim.x) {  // v: 8 channels per thread, one element per (channel, token) slot
+    const int h = w / (D >> 3), c = w - h * (D >> 3);
+    const u32x4 vv = *reinterpret_cast<const u32x4*>(v + ((size_t)t * Hkv + h) * D + c * 8);
+    kv_t* col = vc + ((blk * Hkv + h) * D + c * 8) * BS + off;
+    if constexpr (KV8) {
+      const u32x2 q8 = vra_pack_e4m3x8<DT>(vv);
+#pragma unroll
+      for (int e = 0; e < 8; e++) col[(size_t)e * BS] = (uint8_t)(q8[e >> 2] >> (8 * (e & 3)));
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        col[(size_t)(2 * e) * BS] = (uint16_t)(vv[e] & 0xffffu);
+        col[(size_t)(2 * e + 1) * BS] = (uint16_t)(vv[e] >> 16);
+      }
+    }
+  }
+}
+extern "C" void vra_rope_cache_prefill(void* q, const void* k, const void* v, void* k_cache, void* v_cache, const void* cos, const void* sin,
+                                       const int64_t* positions, const int64_t* slot_mapping, int32_t tokens, int32_t q_heads, int32_t kv_heads,
+                                       int32_t head_dim, int32_t block_size, int32_t dtype, int32_t kv_dtype, int64_t stream) {
+  VRA_CHECK_ARG(dtype == VRA_BF16 || dtype == VRA_F16, "vra_rope_cache_prefill: dtype must be bf16/f16");
+  VRA_CHECK_ARG(kv_dtype == dtype || kv_dtype == VRA_FP8_E4M3, "vra_rope_cache_prefill: kv_dtype must be the activation dtype or VRA_FP8_E4M3");
+  VRA_CHECK_ARG(q && k && v && k_cache && v_cache && cos && sin && positions && slot_mapping, "vra_rope_cache_prefill: null pointer");
+  VRA_CHECK_ARG(head_dim % 16 == 0 && head_dim <= 256, "vra_rope_cache_prefill: head_dim must be a multiple of 16 (<= 256)");
+  if (tokens <= 0) return;
+  hipStream_t st = as_stream(stream);
+  const bool kv8 = kv_dtype == VRA_FP8_E4M3;
+#define VRA_RC(DT, K8)                                                                                                                     \
+  rope_cache_kernel<DT, K8><<<tokens, 256, 0, st>>>((uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, (typename KVT<K8>::elem*)k_cache, \
+                                                    (typename KVT<K8>::elem*)v_cache, (const uint16_t*)cos, (const uint16_t*)sin, positions,  \
+                                                    slot_mapping, q_heads, kv_heads, head_dim, block_size)
+  if (dtype == VRA_BF16) {
+    if (kv8) VRA_RC(BF16, true);
+    else VRA_RC(BF16, false);
+  } else {
+    if (kv8) VRA_RC(F16, true);
+    else VRA_RC(F16, false);
+  }
+#undef VRA_RC
 }
 
 // ---------------------------------------------------------------- causal mask

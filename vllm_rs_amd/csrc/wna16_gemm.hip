@@ -719,13 +719,18 @@ static void launch_gemm_q4_big_t(const GemmDArgs& a, bool awq, dim3 grid, hipStr
   else gemm_q4_big_kernel<DT, DUAL, false, MB><<<grid, GD_THREADS, lds, st>>>(a);
 }
 static const size_t kXsumBytes = (size_t)16 << 20;  // the row-sum table lives in the LAST 16 MiB of the slab region
+float* vra_gemm_q4_big_xsum_table(int M, int K) {
+  float* tbl = vra_scratch_slabs() ? vra_scratch_slabs() + (vra_scratch_slab_bytes() - kXsumBytes) / 4 : nullptr;
+  return tbl && (size_t)M * (K >> 7) * 4 <= kXsumBytes ? tbl : nullptr;
+}
 void vra_launch_gemm_q4_big(const GemmDArgs& a0, bool dual, bool awq, int mb_sk, int dtype, int64_t stream) {
   GemmDArgs a = a0;
   const int mb = mb_sk & 0xff, sk = mb_sk >> 8 > 1 ? mb_sk >> 8 : 1;  // vra_gemm_q4_big_fits: m-tiles | split-K << 8
-  {  // row sums of x per k-tile, once per GEMM (scratch: the tail of the split-K slab region)
-    float* tbl = vra_scratch_slabs() ? vra_scratch_slabs() + (vra_scratch_slab_bytes() - kXsumBytes) / 4 : nullptr;
+  if (!a.xsum) {  // row sums of x per k-tile, once per GEMM (scratch: the tail of the split-K slab region) — unless the caller's
+                  // norm launch already left them there (vra_gemm_q4_big_xsum_table + vra_rms_norm_xsum)
+    float* tbl = vra_gemm_q4_big_xsum_table(a.M, a.K);
     const int KT = a.K >> 7;
-    if (!tbl || (size_t)a.M * KT * 4 > kXsumBytes) {
+    if (!tbl) {
       vra_set_error("gemm_q4_big: scratch for the row sums unavailable (%d x %d)", a.M, KT);
       return;
     }

@@ -472,9 +472,31 @@ bool Model::linear_fused_norm(const QLinear* ls, int nl, void* const* outs, cons
     vra_launch_gemv(a, ls[0].quant, dt_, stream);
     return !take_err(error, "fused norm gemv");
   }
-  vra_rms_norm(x, norm_w, xn_, M, K, mc_.rms_norm_eps, dt_, stream);
   bool same = ls[0].quant && nl <= GEMV_MAX_SEG;
   for (int i = 1; i < nl; i++) same = same && ls[i].quant && ls[i].K == K && ls[i].awq == ls[0].awq;
+  // prefill: q/k/v in ONE launch of kernel D when the problem fills the chip — decided before the norm launch, which then also
+  // leaves kernel D's row-sum table (one launch less per layer)
+  GemmDArgs d = {};
+  int mb_d = 0;
+  if (same && nl <= 3 && M >= 64) {
+    d.w0 = ls[0].w, d.sc0 = ls[0].scales, d.qz0 = ls[0].qzeros, d.bias0 = ls[0].bias;
+    d.out = outs[0], d.out_ld = ls[0].N, d.N = ls[0].N;
+    d.nseg = nl;
+    int cols = ls[0].N;
+    for (int i = 1; i < nl; i++) {
+      d.xseg[i - 1] = GemvSeg{ls[i].w, ls[i].scales, ls[i].qzeros, ls[i].bias, outs[i], ls[i].N, ls[i].N, cols / 16};
+      cols += ls[i].N;
+    }
+    d.x = xn_, d.x_ld = K, d.M = M, d.K = K, d.group_size = mc_.group_size;
+    mb_d = vra_gemm_q4_big_fits(false, M, cols, K, mc_.group_size, &d);
+  }
+  float* xsum_tbl = mb_d && K % 128 == 0 ? vra_gemm_q4_big_xsum_table(M, K) : nullptr;
+  if (xsum_tbl) {
+    vra_rms_norm_xsum(x, norm_w, xn_, xsum_tbl, M, K, mc_.rms_norm_eps, dt_, stream);
+    d.xsum = xsum_tbl;
+  } else {
+    vra_rms_norm(x, norm_w, xn_, M, K, mc_.rms_norm_eps, dt_, stream);
+  }
   if (same && vra_gemm_q4_fits(1, M, K, mc_.group_size)) {  // decode batches 5..32: q/k/v in ONE launch of kernel C
     GemmCArgs c = {};
     c.nseg = nl;
@@ -492,21 +514,9 @@ bool Model::linear_fused_norm(const QLinear* ls, int nl, void* const* outs, cons
     vra_launch_gemm_q4(c, ls[0].awq, dt_, stream);
     return !take_err(error, "norm + gemm_q4");
   }
-  if (same && nl <= 3 && M > 8) {  // prefill: q/k/v in ONE launch — kernel D when the problem fills the chip, else kernel B
-    GemmDArgs d = {};
-    d.w0 = ls[0].w, d.sc0 = ls[0].scales, d.qz0 = ls[0].qzeros, d.bias0 = ls[0].bias;
-    d.out = outs[0], d.out_ld = ls[0].N, d.N = ls[0].N;
-    d.nseg = nl;
-    int cols = ls[0].N;
-    for (int i = 1; i < nl; i++) {
-      d.xseg[i - 1] = GemvSeg{ls[i].w, ls[i].scales, ls[i].qzeros, ls[i].bias, outs[i], ls[i].N, ls[i].N, cols / 16};
-      cols += ls[i].N;
-    }
-    d.x = xn_, d.x_ld = K, d.M = M, d.K = K, d.group_size = mc_.group_size;
-    if (const int mb = vra_gemm_q4_big_fits(false, M, cols, K, mc_.group_size, &d)) {
-      vra_launch_gemm_q4_big(d, false, ls[0].awq, mb, dt_, stream);
-      return !take_err(error, "norm + gemm_q4_big (segments)");
-    }
+  if (mb_d) {
+    vra_launch_gemm_q4_big(d, false, ls[0].awq, mb_d, dt_, stream);
+    return !take_err(error, "norm + gemm_q4_big (segments)");
   }
   if (same && nl <= 3 && M > 8) {  // q/k/v in ONE launch of kernel B (k and v alone are 8 workgroups wide)
     GemmBArgs b = {};
@@ -553,9 +563,22 @@ bool Model::gate_up(const LayerWeights& L, const void* x, const void* norm_w, vo
       a.is_awq = L.gate.awq ? 1 : 0;
       vra_launch_gemv(a, true, dt_, stream);
     } else {
-      vra_rms_norm(x, norm_w, xn_, M, K, mc_.rms_norm_eps, dt_, stream);
-      vra_wna16_gate_up_silu(xn_, L.gate.w, L.gate.scales, L.gate.qzeros, L.up.w, L.up.scales, L.up.qzeros, act, M, K, N,
-                             mc_.group_size, L.gate.awq ? 1 : 0, VRA_SCALES_ROWMAJOR, dt_, stream);
+      // prefill through kernel D: the norm launch also leaves the GEMM's row-sum table (one launch less per layer)
+      const int mb = M >= 64 && K % 128 == 0 ? vra_gemm_q4_big_fits(true, M, N, K, mc_.group_size, nullptr) : 0;
+      float* tbl = mb ? vra_gemm_q4_big_xsum_table(M, K) : nullptr;
+      if (tbl) {
+        vra_rms_norm_xsum(x, norm_w, xn_, tbl, M, K, mc_.rms_norm_eps, dt_, stream);
+        GemmDArgs d = {};
+        d.w0 = L.gate.w, d.w1 = L.up.w, d.sc0 = L.gate.scales, d.sc1 = L.up.scales, d.qz0 = L.gate.qzeros, d.qz1 = L.up.qzeros;
+        d.x = xn_, d.x_ld = K, d.out = act, d.out_ld = N;
+        d.M = M, d.N = N, d.K = K, d.group_size = mc_.group_size;
+        d.xsum = tbl;
+        vra_launch_gemm_q4_big(d, true, L.gate.awq && L.gate.qzeros != nullptr, mb, dt_, stream);
+      } else {
+        vra_rms_norm(x, norm_w, xn_, M, K, mc_.rms_norm_eps, dt_, stream);
+        vra_wna16_gate_up_silu(xn_, L.gate.w, L.gate.scales, L.gate.qzeros, L.up.w, L.up.scales, L.up.qzeros, act, M, K, N,
+                               mc_.group_size, L.gate.awq ? 1 : 0, VRA_SCALES_ROWMAJOR, dt_, stream);
+      }
     }
     return !take_err(error, "gate_up");
   }
@@ -746,8 +769,9 @@ bool Model::forward(const InputMetadata& md, int64_t stream) {
       if (!linear_fused_norm(qkv, 3, outs, h_, L.attn_norm, T, stream)) return false;
     }
     if (md.is_prefill) {
-      vra_fused_rope(q_, k_, cos_, sin_, md.positions, T, hq_, hkv_, D, D, 0, dt_, dt_, stream);
-      vra_reshape_and_cache(k_, v_, kc_[l], vc_[l], md.slot_mapping, T, hkv_, D, ec_.block_size, dt_, kv_dt, stream);
+      // RoPE + KV write in one launch (two in the reference: rotary_emb.rs:88-103, attention.rs:808-820)
+      vra_rope_cache_prefill(q_, k_, v_, kc_[l], vc_[l], cos_, sin_, md.positions, md.slot_mapping, T, hq_, hkv_, D, ec_.block_size, dt_,
+                             kv_dt, stream);
       vra_paged_attention_prefill(attn_, q_, nullptr, nullptr, kc_[l], vc_[l], md.block_tables, md.context_lens, md.cu_seqlens_q,
                                   nullptr, B, T, md.max_seqlen_q, hq_, hkv_, D, ec_.block_size, md.max_blocks, scale, 0.f, dt_, kv_dt, stream);
     } else {
