@@ -281,18 +281,30 @@ def test_fused_rope(interleaved, table_f32, D, rot):
 
 @pytest.mark.parametrize("dt", [BF16, F16])
 @pytest.mark.parametrize("fp8", [False, True])
-@pytest.mark.parametrize("Hq,Hkv,D", [(32, 8, 128), (14, 2, 64)])
-def test_rope_cache_prefill_equals_the_two_launches(dt, fp8, Hq, Hkv, D):
+@pytest.mark.parametrize("Hq,Hkv,D,T", [(32, 8, 128, 37), (14, 2, 64, 37), (32, 8, 128, 1100), (8, 2, 64, 1029)])
+def test_rope_cache_prefill_equals_the_two_launches(dt, fp8, Hq, Hkv, D, T):
     """vra_rope_cache_prefill == vra_fused_rope + vra_reshape_and_cache bit for bit: rotated q, K-cache rows, V-cache columns
-    (16-bit and FP8 caches), a padded token (slot -1) writes nothing"""
+    (16-bit and FP8 caches), a padded token (slot -1) writes nothing.  T >= 1024: workgroups take 8 tokens and write V with one
+    vector store per channel where the 8 slots are consecutive and aligned inside a block — runs of consecutive slots through
+    shuffled blocks, a run that starts mid-block at an odd offset, a hole, and a ragged last group"""
     L = ops.lib()
-    T, BS, NB = 37, 64, 8
-    r = rng(D + Hq + dt + fp8)
+    BS = 64
+    NB = max(8, (T + BS - 1) // BS + 3)
+    r = rng(D + Hq + dt + fp8 + T)
     cos, sin = orc.rope_tables(D, 500000.0, 512, 2, 8.0, 1.0, 4.0, 8192)
     cos_t, sin_t = orc.to_dt(cos, dt), orc.to_dt(sin, dt)
     q, k, v = rand_dt(r, (T, Hq, D), dt), rand_dt(r, (T, Hkv, D), dt), rand_dt(r, (T, Hkv, D), dt)
     pos = r.integers(0, 512, size=T).astype(np.int64)
-    slots = r.permutation(NB * BS)[:T].astype(np.int64)
+    if T < 1024:
+        slots = r.permutation(NB * BS)[:T].astype(np.int64)
+    else:  # two "sequences": one from the start of its blocks, one that continues 13 tokens into a block
+        blocks = r.permutation(NB)
+        n1 = T // 2 + 3
+        s1 = np.array([int(blocks[j // BS]) * BS + j % BS for j in range(n1)], np.int64)
+        nb1 = (n1 + BS - 1) // BS
+        s2 = np.array([int(blocks[nb1 + (13 + j) // BS]) * BS + (13 + j) % BS for j in range(T - n1)], np.int64)
+        slots = np.concatenate([s1, s2])
+        slots[100] = -1
     slots[5] = -1
     kvdt = 3 if fp8 else dt
     nbytes = NB * Hkv * BS * D * (1 if fp8 else 2)

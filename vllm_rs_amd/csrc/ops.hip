@@ -316,21 +316,23 @@ extern "C" void vra_reshape_and_cache(const void* k, const void* v, void* k_cach
 // prefill attention reads K and V from the cache), v goes to its token-minor V-cache column.  NeoX pairs, full rotary width,
 // tables in the model dtype — the arithmetic of rope_kernel and the bytes of reshape_and_cache_kernel, i.e. bit-identical to the
 // two launches (tests/test_gpu_kernels.py); everything else takes the two launches.
-template <class DT, bool KV8>
+// TG = tokens per workgroup.  8 consecutive tokens whose slots are consecutive inside one block (the normal case of a prefill:
+// positions and slots run together) write the token-minor V cache with ONE 16-byte (FP8: 8-byte) store per channel instead of
+// 8 two-byte stores 128 bytes apart — the scattered stores were 3/4 of this kernel's time at 4096 tokens.  Groups that are not
+// (chunk edges, block edges that are not multiples of 8, padded lanes) take the per-token stores.  Same bytes either way.
+template <class DT, bool KV8, int TG>
 __global__ __launch_bounds__(256) void rope_cache_kernel(uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
                                                          typename KVT<KV8>::elem* __restrict__ kc, typename KVT<KV8>::elem* __restrict__ vc,
                                                          const uint16_t* __restrict__ cosv, const uint16_t* __restrict__ sinv,
-                                                         const int64_t* __restrict__ positions, const int64_t* __restrict__ slots, int Hq, int Hkv,
-                                                         int D, int BS) {
+                                                         const int64_t* __restrict__ positions, const int64_t* __restrict__ slots, int T, int Hq,
+                                                         int Hkv, int D, int BS) {
   typedef typename KVT<KV8>::elem kv_t;
-  const int t = blockIdx.x, tid = threadIdx.x;
+  extern __shared__ __attribute__((aligned(16))) unsigned char rc_smem[];  // TG == 8: the group's V rows [8][Hkv*D] in cache format
+  const int tid = threadIdx.x;
+  const int t0 = blockIdx.x * TG, nt = min(TG, T - t0);
   const int half = D >> 1, per_head = half >> 3;  // 16-byte pair groups per head
-  const int64_t pos = positions[t], slot = slots[t];
-  const int64_t blk = slot / BS;
-  const int off = (int)(slot % BS);
-  const uint16_t* cs_row = cosv + pos * half;
-  const uint16_t* sn_row = sinv + pos * half;
-  auto rotate = [&](const uint16_t* base, int c, u32x4& r1, u32x4& r2) {
+  const int n = Hkv * D;
+  auto rotate = [&](const uint16_t* base, int c, const uint16_t* cs_row, const uint16_t* sn_row, u32x4& r1, u32x4& r2) {
     float x1[8], x2[8], cs[8], sn[8], y1[8], y2[8];
     unpack8<DT>(*reinterpret_cast<const u32x4*>(base + c * 8), x1);
     unpack8<DT>(*reinterpret_cast<const u32x4*>(base + half + c * 8), x2);
@@ -343,36 +345,80 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(uint16_t* __restrict__ 
     }
     r1 = pack8<DT>(y1), r2 = pack8<DT>(y2);
   };
-  for (int w = tid; w < Hq * per_head; w += blockDim.x) {  // q: in place
-    const int h = w / per_head, c = w - h * per_head;
-    uint16_t* base = q + ((size_t)t * Hq + h) * D;
-    u32x4 r1, r2;
-    rotate(base, c, r1, r2);
-    *reinterpret_cast<u32x4*>(base + c * 8) = r1;
-    *reinterpret_cast<u32x4*>(base + half + c * 8) = r2;
-  }
-  if (slot < 0) return;  // padded lane: nothing is cached
-  for (int w = tid; w < Hkv * per_head; w += blockDim.x) {  // k: rotated into the cache row
-    const int h = w / per_head, c = w - h * per_head;
-    u32x4 r1, r2;
-    rotate(k + ((size_t)t * Hkv + h) * D, c, r1, r2);
-    kv_t* row = kc + ((blk * Hkv + h) * BS + off) * D;
-    kv_store8<DT, KV8>(row + c * 8, r1);
-    kv_store8<DT, KV8>(row + half + c * 8, r2);
-  }
-  for (int w = tid; w < Hkv * (D >> 3); w += blockDim.x) {  // v: 8 channels per thread, one element per (channel, token) slot
-    const int h = w / (D >> 3), c = w - h * (D >> 3);
-    const u32x4 vv = *reinterpret_cast<const u32x4*>(v + ((size_t)t * Hkv + h) * D + c * 8);
-    kv_t* col = vc + ((blk * Hkv + h) * D + c * 8) * BS + off;
-    if constexpr (KV8) {
-      const u32x2 q8 = vra_pack_e4m3x8<DT>(vv);
+  // the group's slots: vector V stores need slot0 % 8 == 0 inside one block and slots slot0 .. slot0 + 7
+  bool vec = TG == 8 && nt == 8;
+  const int64_t slot0 = slots[t0];
+  if (TG == 8) {
 #pragma unroll
-      for (int e = 0; e < 8; e++) col[(size_t)e * BS] = (uint8_t)(q8[e >> 2] >> (8 * (e & 3)));
-    } else {
+    for (int i = 0; i < 8; i++) vec = vec && i < nt && slots[t0 + min(i, nt - 1)] == slot0 + i;
+    vec = vec && slot0 >= 0 && (slot0 % BS) % 8 == 0 && (slot0 % BS) + 8 <= BS;
+  }
+  for (int ti = 0; ti < nt; ti++) {
+    const int t = t0 + ti;
+    const int64_t pos = positions[t], slot = slots[t];
+    const uint16_t* cs_row = cosv + pos * half;
+    const uint16_t* sn_row = sinv + pos * half;
+    for (int w = tid; w < Hq * per_head; w += blockDim.x) {  // q: in place
+      const int h = w / per_head, c = w - h * per_head;
+      uint16_t* base = q + ((size_t)t * Hq + h) * D;
+      u32x4 r1, r2;
+      rotate(base, c, cs_row, sn_row, r1, r2);
+      *reinterpret_cast<u32x4*>(base + c * 8) = r1;
+      *reinterpret_cast<u32x4*>(base + half + c * 8) = r2;
+    }
+    if (slot < 0) continue;  // padded lane: nothing is cached
+    const int64_t blk = slot / BS;
+    const int off = (int)(slot % BS);
+    for (int w = tid; w < Hkv * per_head; w += blockDim.x) {  // k: rotated into the cache row
+      const int h = w / per_head, c = w - h * per_head;
+      u32x4 r1, r2;
+      rotate(k + ((size_t)t * Hkv + h) * D, c, cs_row, sn_row, r1, r2);
+      kv_t* row = kc + ((blk * Hkv + h) * BS + off) * D;
+      kv_store8<DT, KV8>(row + c * 8, r1);
+      kv_store8<DT, KV8>(row + half + c * 8, r2);
+    }
+    for (int w = tid; w < Hkv * (D >> 3); w += blockDim.x) {  // v: 8 channels per thread
+      const int h = w / (D >> 3), c = w - h * (D >> 3);
+      const u32x4 vv = *reinterpret_cast<const u32x4*>(v + ((size_t)t * Hkv + h) * D + c * 8);
+      if (TG == 8 && vec) {  // staged in cache format; stored token-minor below
+        kv_store8<DT, KV8>(reinterpret_cast<kv_t*>(rc_smem) + (size_t)ti * n + h * D + c * 8, vv);
+        continue;
+      }
+      kv_t* col = vc + ((blk * Hkv + h) * D + c * 8) * BS + off;
+      if constexpr (KV8) {
+        const u32x2 q8 = vra_pack_e4m3x8<DT>(vv);
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
-        col[(size_t)(2 * e) * BS] = (uint16_t)(vv[e] & 0xffffu);
-        col[(size_t)(2 * e + 1) * BS] = (uint16_t)(vv[e] >> 16);
+        for (int e = 0; e < 8; e++) col[(size_t)e * BS] = (uint8_t)(q8[e >> 2] >> (8 * (e & 3)));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          col[(size_t)(2 * e) * BS] = (uint16_t)(vv[e] & 0xffffu);
+          col[(size_t)(2 * e + 1) * BS] = (uint16_t)(vv[e] >> 16);
+        }
+      }
+    }
+  }
+  if (TG == 8 && vec) {
+    __syncthreads();
+    const int64_t blk = slot0 / BS;
+    const int off = (int)(slot0 % BS);
+    const kv_t* sv = reinterpret_cast<const kv_t*>(rc_smem);
+    for (int i = tid; i < n; i += blockDim.x) {  // channel i = (h, d): its 8 tokens are 8 consecutive cache elements
+      const int h = i / D, d = i - h * D;
+      kv_t tok[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) tok[e] = sv[(size_t)e * n + i];
+      kv_t* dst = vc + ((blk * Hkv + h) * D + d) * BS + off;
+      if constexpr (KV8) {
+        u32x2 o;
+        o[0] = (uint32_t)tok[0] | ((uint32_t)tok[1] << 8) | ((uint32_t)tok[2] << 16) | ((uint32_t)tok[3] << 24);
+        o[1] = (uint32_t)tok[4] | ((uint32_t)tok[5] << 8) | ((uint32_t)tok[6] << 16) | ((uint32_t)tok[7] << 24);
+        *reinterpret_cast<u32x2*>(dst) = o;
+      } else {
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[e] = (uint32_t)tok[2 * e] | ((uint32_t)tok[2 * e + 1] << 16);
+        *reinterpret_cast<u32x4*>(dst) = o;
       }
     }
   }
@@ -387,10 +433,22 @@ extern "C" void vra_rope_cache_prefill(void* q, const void* k, const void* v, vo
   if (tokens <= 0) return;
   hipStream_t st = as_stream(stream);
   const bool kv8 = kv_dtype == VRA_FP8_E4M3;
-#define VRA_RC(DT, K8)                                                                                                                     \
-  rope_cache_kernel<DT, K8><<<tokens, 256, 0, st>>>((uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, (typename KVT<K8>::elem*)k_cache, \
-                                                    (typename KVT<K8>::elem*)v_cache, (const uint16_t*)cos, (const uint16_t*)sin, positions,  \
-                                                    slot_mapping, q_heads, kv_heads, head_dim, block_size)
+  // groups of 8 tokens (vector V stores) when there are enough tokens to fill the chip that way and the staging fits in LDS
+  const size_t lds8 = (size_t)8 * kv_heads * head_dim * (kv8 ? 1 : 2);
+  const bool g8 = tokens >= 1024 && lds8 <= 64 * 1024 && block_size % 8 == 0;
+#define VRA_RC(DT, K8)                                                                                                                    \
+  do {                                                                                                                                    \
+    if (g8)                                                                                                                               \
+      rope_cache_kernel<DT, K8, 8><<<(tokens + 7) / 8, 256, lds8, st>>>((uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,             \
+                                                                        (typename KVT<K8>::elem*)k_cache, (typename KVT<K8>::elem*)v_cache, \
+                                                                        (const uint16_t*)cos, (const uint16_t*)sin, positions, slot_mapping, \
+                                                                        tokens, q_heads, kv_heads, head_dim, block_size);                  \
+    else                                                                                                                                  \
+      rope_cache_kernel<DT, K8, 1><<<tokens, 256, 0, st>>>((uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,                           \
+                                                           (typename KVT<K8>::elem*)k_cache, (typename KVT<K8>::elem*)v_cache,              \
+                                                           (const uint16_t*)cos, (const uint16_t*)sin, positions, slot_mapping, tokens,     \
+                                                           q_heads, kv_heads, head_dim, block_size);                                       \
+  } while (0)
   if (dtype == VRA_BF16) {
     if (kv8) VRA_RC(BF16, true);
     else VRA_RC(BF16, false);
