@@ -5,6 +5,7 @@
 #include <math.h>
 #include <string.h>
 
+#include "../csrc/decode_step.h"
 #include "../csrc/gemm_launch.h"
 #include "../csrc/scratch.h"
 #include "host_utils.h"
@@ -383,7 +384,8 @@ bool Model::init_kv_cache(int num_blocks) {
     (void)hipMemset(kc_[l], 0, per);
     (void)hipMemset(vc_[l], 0, per);
   }
-  return hipDeviceSynchronize() == hipSuccess;
+  if (hipDeviceSynchronize() != hipSuccess) return false;
+  return build_decode_step();
 }
 
 bool Model::init_buffers(int max_tokens, int max_seqs) {
@@ -400,7 +402,7 @@ bool Model::init_buffers(int max_tokens, int max_seqs) {
   }
   const size_t ws = vra_paged_attention_decode_workspace_bytes(max_seqs, hq_, mc_.head_dim, mc_.max_position_embeddings);
   if (!(attn_ws_ = dalloc(ws))) return false;
-  return true;
+  return build_decode_step();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -739,6 +741,123 @@ bool Model::gemv_s(int l, int which, int M, void* out, const void* residual, int
 }
 
 // ---------------------------------------------------------------------------------------------
+// persistent decode step (csrc/decode_step.hip)
+// ---------------------------------------------------------------------------------------------
+bool Model::build_decode_step() {
+  if (dp_layers_ || !finalized_ || !h_ || kc_.empty() || world_ > 1 || mc_.quant_method == 0) return true;  // (not an error: the step keeps its launches)
+  const LayerWeights& L0 = layers_[0];
+  if (!L0.qkv_s_um || !L0.o.s_um || !L0.gate.s_um || !L0.up.s_um || !L0.down.s_um) return true;
+  if ((L0.q.N | L0.k.N | L0.v.N | L0.o.N | L0.gate.N | L0.down.N) % 16) return true;
+  if ((L0.q.K | L0.o.K | L0.gate.K | L0.down.K) % 128) return true;
+  if (mc_.head_dim != 64 && mc_.head_dim != 128) return true;
+  if (ec_.block_size % 32 || hq_ % hkv_ || hq_ / hkv_ > 16) return true;
+  if (!vra_decode_step_init()) return true;
+  const int grid = vra_decode_step_grid();
+  if (grid < 8) return true;
+  int max_kt = 0, max_red = 0;
+  std::vector<DPLayer> tab(mc_.num_layers);
+  for (int l = 0; l < mc_.num_layers; l++) {
+    const LayerWeights& L = layers_[l];
+    DPLayer& T = tab[l];
+    memset(&T, 0, sizeof(T));
+    int rot = 0;  // the workgroups that own one unit more rotate from GEMV to GEMV, so that no CU's stream is the longest in all
+    for (int which = 0; which < 4; which++) {
+      DPGemv& g = T.g[which];
+      int K, units, ns;
+      bool norm;
+      gemv_s_shape(L, which, &K, &units, &ns, &norm);
+      const int gs = mc_.group_size > 0 && mc_.group_size < K ? mc_.group_size : K;
+      if (gs < K && (gs < 128 || (gs & (gs - 1)))) return true;
+      const int G = K / gs;
+      g.K = K, g.KT = K / 128, g.TPW = (g.KT + 15) / 16, g.G = G, g.NS = ns;
+      g.gsh = gs < K ? 31 - __builtin_clz((unsigned)gs) : 31;
+      if (norm && g.TPW > 4) return true;
+      g.n_units = units, g.units_q = units / grid, g.units_r = units % grid, g.rot = rot;
+      rot = (rot + g.units_r) % grid;
+      g.sc_bytes = units * G * 32, g.zr_bytes = units * G * 8;
+      if (g.sc_bytes < 512 || (L.q.awq && g.zr_bytes < 128)) return true;
+      g.nseg = 1;
+      switch (which) {
+        case 0:
+          g.w[0] = L.qkv_w, g.sc[0] = L.qkv_s_um, g.zr[0] = L.qkv_z_um;
+          g.x = h_, g.x_ld = mc_.hidden_size, g.norm_w = L.attn_norm;
+          g.nseg = 3;
+          g.out[0] = q_, g.out[1] = k_, g.out[2] = v_;
+          g.bias[0] = L.q.bias, g.bias[1] = L.k.bias, g.bias[2] = L.v.bias;
+          g.out_ld[0] = L.q.N, g.out_ld[1] = L.k.N, g.out_ld[2] = L.v.N;
+          g.unit_start[1] = L.q.N / 16, g.unit_start[2] = (L.q.N + L.k.N) / 16;
+          break;
+        case 1:
+          g.w[0] = L.o.w, g.sc[0] = L.o.s_um, g.zr[0] = L.o.z_um;
+          g.x = attn_, g.x_ld = L.o.K;
+          g.out[0] = h_, g.out_ld[0] = L.o.N, g.bias[0] = L.o.bias;
+          g.residual = h_, g.res_ld = L.o.N;
+          break;
+        case 2:
+          g.w[0] = L.gate.w, g.sc[0] = L.gate.s_um, g.zr[0] = L.gate.z_um;
+          g.w[1] = L.up.w, g.sc[1] = L.up.s_um, g.zr[1] = L.up.z_um;
+          g.x = h_, g.x_ld = mc_.hidden_size, g.norm_w = L.ffn_norm;
+          g.out[0] = act_, g.out_ld[0] = L.gate.N, g.bias[0] = L.gate.bias, g.bias[1] = L.up.bias;
+          break;
+        default:
+          g.w[0] = L.down.w, g.sc[0] = L.down.s_um, g.zr[0] = L.down.z_um;
+          g.x = act_, g.x_ld = L.down.K;
+          g.out[0] = h_, g.out_ld[0] = L.down.N, g.bias[0] = L.down.bias;
+          g.residual = h_, g.res_ld = L.down.N;
+          break;
+      }
+      max_kt = std::max(max_kt, g.KT);
+      max_red = std::max(max_red, (g.units_q + (g.units_r ? 1 : 0)) * ns);
+    }
+    T.kc = kc_[l], T.vc = vc_[l];
+  }
+  bool any = false;
+  for (int M = 1; M <= DP_MAX_ROWS; M++) {
+    DPPlan p;
+    if (!vra_decode_step_plan(M, max_kt, max_red, hq_ / hkv_, mc_.head_dim, &p)) continue;
+    if (M * hkv_ > grid) continue;
+    dp_plan_[M][0] = p.nslot, dp_plan_[M][1] = p.ring_off, dp_plan_[M][2] = p.x_off, dp_plan_[M][3] = p.red_off, dp_plan_[M][4] = p.xt,
+    dp_plan_[M][5] = p.lds_bytes;
+    any = true;
+  }
+  if (!any) return true;
+  if (!(dp_layers_ = dalloc(tab.size() * sizeof(DPLayer)))) return false;
+  if (hipMemcpy(dp_layers_, tab.data(), tab.size() * sizeof(DPLayer), hipMemcpyHostToDevice) != hipSuccess) {
+    error = "decode step table upload failed";
+    return false;
+  }
+  // one (sequence, kv head) per workgroup and 4 waves over its 32-token tiles: past this context the split-KV launches win
+  const char* e = getenv("VRA_DP_MAX_CTX");
+  dp_max_ctx_ = e && atoi(e) > 0 ? atoi(e) : 1024;
+  return true;
+}
+bool Model::decode_step_ok(int M, int max_context_len) const {
+  return dp_layers_ && vra_decode_step_enabled() && M >= 1 && M <= DP_MAX_ROWS && dp_plan_[M][0] > 0 && max_context_len <= dp_max_ctx_;
+}
+bool Model::launch_decode_phases(const InputMetadata& md, int ph0, int ph1, int64_t stream) {
+  const int M = md.n_tokens;
+  if (md.is_prefill || !decode_step_ok(M, md.max_context_len) || md.n_seqs != M) {
+    error = "decode step: not applicable to this batch";
+    return false;
+  }
+  DPStepArgs a = {};
+  a.layers = static_cast<const DPLayer*>(dp_layers_);
+  a.n_layers = mc_.num_layers;
+  a.M = M;
+  a.ph0 = ph0, a.ph1 = ph1;
+  a.eps = mc_.rms_norm_eps;
+  a.q = q_, a.k = k_, a.v = v_, a.attn = attn_;
+  a.cosv = cos_, a.sinv = sin_;
+  a.positions = md.positions, a.slots = md.slot_mapping, a.block_tables = md.block_tables, a.context_lens = md.context_lens;
+  a.Hq = hq_, a.Hkv = hkv_, a.BS = ec_.block_size, a.max_blocks = md.max_blocks;
+  a.bs_shift = (ec_.block_size & (ec_.block_size - 1)) == 0 ? 31 - __builtin_clz((unsigned)ec_.block_size) : -1;
+  a.scale_log2e = (1.0f / sqrtf((float)mc_.head_dim)) * 1.44269504088896f;
+  a.nslot = dp_plan_[M][0], a.ring_off = dp_plan_[M][1], a.x_off = dp_plan_[M][2], a.red_off = dp_plan_[M][3], a.xt = dp_plan_[M][4];
+  vra_launch_decode_step(a, dt_, layers_[0].q.awq, ec_.fp8_kvcache != 0, mc_.head_dim, stream);
+  return !take_err(error, "decode step");
+}
+
+// ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
 bool Model::forward(const InputMetadata& md, int64_t stream) {
@@ -757,7 +876,10 @@ bool Model::forward(const InputMetadata& md, int64_t stream) {
   // embed_forward (llama.rs:260-267)
   vra_embedding(md.input_ids, embed_, h_, T, H, mc_.vocab_size, dt_, stream);
   bool qkv_done = false, mlp_in_done = false;
-  for (int l = 0; l < mc_.num_layers; l++) {
+  // decode of 1..2 sequences at short contexts: all layers in ONE persistent launch (csrc/decode_step.hip)
+  const bool one_launch = !md.is_prefill && B == T && decode_step_ok(T, md.max_context_len);
+  if (one_launch && !launch_decode_phases(md, 0, mc_.num_layers * DP_PHASES_PER_LAYER, stream)) return false;
+  for (int l = one_launch ? mc_.num_layers : 0; l < mc_.num_layers; l++) {
     const LayerWeights& L = layers_[l];
     // ---- attention block (llama.rs:115-126): norm -> q,k,v -> rope -> cache + attention -> o_proj (+ residual)
     const QLinear qkv[3] = {L.q, L.k, L.v};

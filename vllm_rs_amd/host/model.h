@@ -14,6 +14,7 @@
 #include "../../include/vllm_rs_amd.h"
 
 struct GemvSArgs;  // csrc/gemv_q4s.cuh
+struct DPStepArgs;  // csrc/decode_step.h
 
 namespace vra {
 
@@ -90,6 +91,12 @@ class Model {
   int local_heads() const { return hq_; }
   int local_kv_heads() const { return hkv_; }
   size_t weight_bytes() const { return weight_bytes_; }
+  // the persistent decode step (csrc/decode_step.hip): every layer of a decode step for 1..2 sequences in ONE launch.
+  // decode_step_ok: the model / batch / context fit it.  launch_decode_phases runs phases [ph0, ph1) of the step
+  // (5 per layer: q/k/v, attention, o_proj, gate/up, down) on the static activation buffers — the whole step, or a
+  // slice for the per-phase parity tests.
+  bool decode_step_ok(int M, int max_context_len) const;
+  bool launch_decode_phases(const InputMetadata& md, int ph0, int ph1, int64_t stream);
   // microbenchmark hooks (bench.py roofline leg): launch one decode-shaped GEMM of layer `layer`
   // which: 0 qkv(fused norm) 1 o_proj 2 gate_up 3 down 4 lm_head ; M rows
   bool launch_gemm(int which, int layer, int M, int64_t stream);
@@ -102,6 +109,7 @@ class Model {
   bool linear_fused_norm(const QLinear* ls, int nl, void* const* outs, const void* x, const void* norm_w, int M, int64_t stream);
   bool gate_up(const LayerWeights& L, const void* x, const void* norm_w, void* act, int M, int64_t stream);
   bool build_decode_streams();
+  bool build_decode_step();  // descriptor table of the persistent decode step (needs weights, buffers and the KV cache)
   // kernel E launch of one decode GEMV of layer `l` (which: 0 norm+q/k/v, 1 o_proj, 2 norm+gate/up+SiLU*mul, 3 down);
   // false = shape not covered (the caller takes the general path).  `out`/`residual` as for linear().
   bool gemv_s(int l, int which, int M, void* out, const void* residual, int64_t stream);
@@ -136,6 +144,10 @@ class Model {
   void *h_ = nullptr, *xn_ = nullptr, *q_ = nullptr, *k_ = nullptr, *v_ = nullptr, *attn_ = nullptr, *act_ = nullptr,
        *tmp_ = nullptr, *gate_ = nullptr, *up_ = nullptr, *last_ = nullptr, *attn_ws_ = nullptr;
   float* logits_ = nullptr;
+  // persistent decode step
+  void* dp_layers_ = nullptr;     // device: DPLayer[num_layers]
+  int dp_plan_[3][6] = {};        // per row count M = 1..2: nslot, ring_off, x_off, red_off, xt, lds_bytes (nslot 0: not usable)
+  int dp_max_ctx_ = 0;            // longest context the single-workgroup attention phase takes
 };
 
 }  // namespace vra
