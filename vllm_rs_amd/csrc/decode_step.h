@@ -10,7 +10,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
-#define DP_NC 4                       // consumer waves (one per SIMD; the loader shares one)
+#define DP_NC 8                       // consumer waves (two per SIMD: a lone wave cannot issue fast enough to keep up with HBM)
 #define DP_WAVES (DP_NC + 1)          // + the loader (wave 0)
 #define DP_THREADS (DP_WAVES * 64)
 #define DP_SLOT_W 16384               // 16 tiles of 1 KiB: k-tiles 16*ti .. 16*ti+15 of one unit (one contiguous run)
@@ -73,7 +73,9 @@ struct DPStepArgs {
   uint32_t* counters;        // 8 shards x 16 words (one line each)
   uint32_t* count;           // phases completed by earlier launches
   uint32_t* err;             // device error word (a wait timed out)
-  unsigned long long* ts;    // VRA_GEMV_TS builds: [grid][phases][8] stamps
+  unsigned long long* ts;    // VRA_GEMV_TS builds: [grid][phases][8] stamps, then [grid][64 slots][4] of phase ts_phase
+  int ts_phase;
+  int dbg;                   // timing experiments (VRA_DP_DBG; results are garbage): 1 = the loader never waits for a free slot, 2 = consumers never wait for a landed one
 };
 
 struct DPPlan {
@@ -83,7 +85,7 @@ bool vra_decode_step_init();  // per device, outside graph capture
 // LDS plan for a model: max_kt = largest K/128 of a GEMV, max_red = largest (units per workgroup x NS) of a GEMV,
 // group = q heads per kv head, D = head size; false = does not fit (the caller keeps the launch-per-op path)
 bool vra_decode_step_plan(int M, int max_kt, int max_red, int group, int D, DPPlan* plan);
-bool vra_decode_step_enabled();  // VRA_NO_DECODE_STEP=1 / vra_debug_set_decode_step(0) keep the launch-per-op decode
+bool vra_decode_step_enabled();  // off unless VRA_DECODE_STEP=1 / vra_debug_set_decode_step(1)
 int vra_decode_step_grid();   // workgroups of a launch (= CUs)
 void vra_decode_step_sync_ptrs(uint32_t** counters, uint32_t** count, uint32_t** err);
 uint32_t* vra_decode_step_error_word();  // device word (null before init): non-zero = a wait of some launch timed out
