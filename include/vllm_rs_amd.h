@@ -413,6 +413,13 @@ int32_t vra_engine_init_synthetic(void* eng);
 int32_t vra_engine_load_tensor(void* eng, const char* name, const void* h_data, const int64_t* shape,
                                int32_t ndim, int32_t elem_bytes);
 int32_t vra_engine_finalize_weights(void* eng); /* repack + scale layout + KV cache + graphs */
+/* The reference's runner sizes its KV cache only AFTER the engine process has answered the first InitAck with
+ * MessageType::UsableMemoryLeft(EngineConfig) (src/core/runner.rs:443-455, src/core/engine.rs:355-378): weights first
+ * (vra_engine_finalize_model: repack + decode layouts, nothing else is allocated), then the negotiated configuration
+ * (vra_engine_update_config: num_gpu_blocks, max_num_seqs, max_model_len, cpu_mem_fold, kv_fraction — allowed
+ * until buffers exist), then vra_engine_finalize_weights for activations, KV cache and graphs. */
+int32_t vra_engine_finalize_model(void* eng);
+int32_t vra_engine_update_config(void* eng, const vra_engine_config* cfg);
 /* ModelRunner::swap_kvcache (runner.rs:1626-1670; MessageType::KVCacheSwap): copy whole blocks between the GPU cache and the
  * engine's pinned swap space (vra_engine_config.cpu_mem_fold > 0), all layers, K and V.  h_pairs = 2*n_pairs int64
  * (source block, destination block): GPU -> CPU ids when swap_in == 0, CPU -> GPU ids when 1.  0 = done (synchronous). */

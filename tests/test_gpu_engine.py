@@ -389,3 +389,36 @@ def test_no_device_side_timeouts():
     """runs last in this file: no split-K exchange of the engine's GEMMs timed out"""
     from vllm_rs_amd import ops
     assert ops.lib().vra_take_device_error() == 0
+
+
+def test_forward_raw_rejects_metadata_that_would_index_outside_the_cache():
+    """forward_raw is driven by a peer (the runner process): ids, slots, block ids, contexts and cu_seqlens are
+    range-checked on the host; nothing out of range reaches a kernel"""
+    cfg = small_cfg()
+    eng, _ = build(cfg, seed=1)  # 64 blocks of 64 tokens, vocab 512
+    good = dict(ids=np.array([5], np.uint32), pos=np.array([3], np.int64), slots=np.array([3], np.int64), bt=np.array([[0]], np.uint32),
+                ctx=np.array([4], np.uint32))
+    eng.forward_raw(np.arange(1, 5, dtype=np.uint32), np.arange(4, dtype=np.int64), np.arange(4, dtype=np.int64), good["bt"], good["ctx"],
+                    np.array([0, 4], np.uint32))
+    bad_cases = {
+        "token id": dict(ids=np.array([512], np.uint32)),
+        "slot past the cache": dict(slots=np.array([64 * 64], np.int64)),
+        "negative slot": dict(slots=np.array([-7], np.int64)),
+        "block id": dict(bt=np.array([[64]], np.uint32)),
+        "context beyond the table": dict(ctx=np.array([65], np.uint32)),
+        "position": dict(pos=np.array([1 << 40], np.int64)),
+    }
+    for what, over in bad_cases.items():
+        a = dict(good, **over)
+        with pytest.raises(RuntimeError):
+            eng.forward_raw(a["ids"], a["pos"], a["slots"], a["bt"], a["ctx"], None)
+    # prefill: a fully cached sequence (no query tokens) and a cu_seqlens that does not cover the tokens
+    with pytest.raises(RuntimeError):
+        eng.forward_raw(np.arange(1, 5, dtype=np.uint32), np.arange(4, dtype=np.int64), np.arange(4, dtype=np.int64), np.array([[0], [1]], np.uint32),
+                        np.array([4, 4], np.uint32), np.array([0, 4, 4], np.uint32))
+    with pytest.raises(RuntimeError):
+        eng.forward_raw(np.arange(1, 5, dtype=np.uint32), np.arange(4, dtype=np.int64), np.arange(4, dtype=np.int64), good["bt"], good["ctx"],
+                        np.array([0, 3], np.uint32))
+    # the engine still works afterwards
+    eng.forward_raw(good["ids"], good["pos"], good["slots"], good["bt"], good["ctx"], None)
+    eng.close()

@@ -1,5 +1,6 @@
-"""GPU test of the drop-in `runner` process: this test plays the reference's ENGINE process
-(src/core/engine.rs:187-330 spawn + Init + InitAck, :844-892 RunPrefill / RunDecode) over the reference's wire format —
+"""GPU test of the drop-in `runner` process: this test plays the reference's ENGINE process in the reference's
+ORDER (src/core/engine.rs:300-378: accept, `ready`, Init as JSON -> InitAck, KV plan, UsableMemoryLeft(EngineConfig) as JSON ->
+InitAck; src/utils/heartbeat.rs: the command channel; :844-892 RunPrefill / RunDecode) over the reference's wire format —
 abstract-namespace Unix socket, `ready` line, JSON `Init`, bincode afterwards, 1-byte acks (vllm_rs_amd/wire.py) — against
 the native `vra_runner` binary (vllm_rs_amd/host/runner_main.cpp: C++ over the C ABI, what the reference's engine would
 spawn) and against its Python twin `python -m vllm_rs_amd.runner_ipc`, both loading an HF checkpoint directory from disk
@@ -62,16 +63,47 @@ def test_reference_engine_protocol_drives_the_runner_process(tmp_path, which):
     srv.listen(1)
     srv.settimeout(180)
     cmd = [RUNNER_BIN] if which == "native" else [sys.executable, "-m", "vllm_rs_amd.runner_ipc"]
-    proc = subprocess.Popen(cmd + ["--sock", name, "--uuid", "t"], cwd=ROOT, env=env)
+    uuid = f"t{os.getpid()}{which}"
+    # the engine's heartbeat command channel (heartbeat.rs:8-78, command.rs:91-172): "command_{uuid}@vllm-rs-runner-heartbeat.sock"
+    hb_srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    hb_srv.bind("\0command_" + uuid + "@vllm-rs-runner-heartbeat.sock")
+    hb_srv.listen(1)
+    hb_srv.settimeout(30)
+    proc = subprocess.Popen(cmd + ["--sock", name, "--uuid", uuid], cwd=ROOT, env=env)
+    hb = None
     try:
         conn, _ = srv.accept()
         conn.settimeout(180)
         assert wire._recv_exact(conn, 6) == b"ready\n"
+        if which == "native":  # the C++ runner runs the reference's heartbeat worker; the Python twin (test scaffolding) does not
+            hb, _ = hb_srv.accept()
+            hb.settimeout(30)
+            assert wire._recv_exact(hb, 6) == b"ready\n"
+            heartbeat = bytes([4, 0, 0, 0, 14, 0, 0, 0])  # golden frame: length 4 | bincode variant 14 = MessageType::Heartbeat
+            assert wire.encode(("Heartbeat", None)) == heartbeat[4:]
+            hb.sendall(heartbeat)
+            assert wire._recv_exact(hb, 1) == b"\x01"
+        # Init: num_blocks is the reference's placeholder (config.rs:458) — the cache must NOT be sized from it
         init = dict(rank=0, dev_id=0, num_shards=1, model_type="LLaMa", dtype="BF16", is_gguf=False, is_rope_i=False,
-                    config=dict(hf, num_hidden_layers=cfg["num_layers"]), econfig=dict(block_size=64, max_num_seqs=8, num_blocks=32, max_model_len=512, seed=5),
+                    config=dict(hf, num_hidden_layers=cfg["num_layers"]), econfig=dict(block_size=64, max_num_seqs=8, num_blocks=128, max_model_len=512, seed=5),
                     model_pathes=dict(config_filename=str(tmp_path / "config.json"), filenames=[str(tmp_path / "model.safetensors")]))
         wire.send_frame(conn, wire.encode_init_json(init))
-        assert wire.decode(wire.recv_frame(conn)) == ("InitAck", True)
+        # InitAck #1 (model loaded), hand-assembled: u32 length 5 | variant 1 | bool true; the ack byte goes back by hand
+        assert wire._recv_exact(conn, 9) == bytes([5, 0, 0, 0, 1, 0, 0, 0, 1])
+        conn.sendall(b"\x01")
+        # the engine's KV plan: MessageType::UsableMemoryLeft(EngineConfig) as JSON, fields as serde writes them (config.rs:285-328)
+        ecfg = dict(model_id=None, weight_path=str(tmp_path), weight_file=None, enforce_parser=None, hf_token=None, hf_token_path=None, num_blocks=32,
+                    kv_fraction=0.5, mamba_fraction=None, cpu_mem_fold=0.5, kvcache_memory_bytes=32 * 2 * 2 * 64 * 64 * 2 * 2, mamba_memory_bytes=0,
+                    mamba_slot_bytes=0, mamba_cache_capacity=None, block_size=64, max_num_seqs=8, max_num_batched_tokens=2048, config_model_len=512,
+                    max_model_len=512, max_tokens=None, isq=None, num_shards=1, device_ids=[0], generation_cfg=None, seed=5, prefix_cache=False,
+                    prefix_cache_max_tokens=None, fp8_kvcache=False, server_mode=False, pd_config=None, mcp_command=None, mcp_config=None, mcp_args=None,
+                    tool_prompt_template=None, pd_server_prefix_cache_ratio=None, pd_client_prefix_cache_ratio=None, yarn_scaling_factor=None,
+                    disable_reasoning=False)
+        frame = wire.encode_usable_memory_left_json(ecfg)
+        assert frame.startswith(b'{"UsableMemoryLeft": {"model_id": null')
+        wire.send_frame(conn, frame)
+        assert wire._recv_exact(conn, 9) == bytes([5, 0, 0, 0, 1, 0, 0, 0, 1])  # InitAck #2: cache sized, (graphs captured)
+        conn.sendall(b"\x01")
         oracle = om.OracleModel(cfg, w, num_blocks=32)
         greedy = dict(temperature=0.0)
         a = dict(id=1, token_ids=list(range(5, 75)), block_table=[3, 4], num_cached_tokens=0, sampling_params=greedy, status="Running")
@@ -112,6 +144,20 @@ def test_reference_engine_protocol_drives_the_runner_process(tmp_path, which):
         assert all(t == wv or g < 0.04 for t, wv, g in zip(toks, want, gaps)), ("after the swap", toks, want, gaps)
         wire.send_frame(conn, wire.encode(("KVCacheSwap", ({31: 99}, False))))   # CPU block 99 does not exist: refused, not executed
         assert wire.decode(wire.recv_frame(conn)) == ("KVCacheSwapResponse", False)
+        # the cache has the NEGOTIATED 32 blocks (cpu_mem_fold 0.5 -> 16 CPU blocks), not Init's placeholder 128: a block id past it
+        # never reaches the device — the step is answered with an empty RunResponse, as a failed step in the reference
+        bad = [dict(ds[0], block_table_last=40, block_tables=[40])]
+        wire.send_frame(conn, wire.encode(("RunDecode", (bad, False))))
+        assert wire.decode(wire.recv_frame(conn)) == ("RunResponse", [])
+        wire.send_frame(conn, wire.encode(("KVCacheSwap", ({5: 15}, False))))   # CPU block 15 exists (32 x 0.5 = 16), 16 does not
+        assert wire.decode(wire.recv_frame(conn)) == ("KVCacheSwapResponse", True)
+        wire.send_frame(conn, wire.encode(("KVCacheSwap", ({5: 16}, False))))
+        assert wire.decode(wire.recv_frame(conn)) == ("KVCacheSwapResponse", False)
+        # a message this path does not serve is logged and NOT answered (runner.rs:246-430): the stream stays in step
+        import struct
+        wire.send_frame(conn, struct.pack("<IQ", wire.VIDX["CheckPrefillStatus"], 3))
+        wire.send_frame(conn, wire.encode(("ClearBlocks", [1, 2])))
+        assert wire.decode(wire.recv_frame(conn)) == ("ClearBlocksResponse", True)
         wire.send_frame(conn, wire.encode(("FinishDecode", 1)))
         wire.send_frame(conn, wire.encode(("Shutdown", None)))
         assert proc.wait(60) == 0
@@ -119,3 +165,6 @@ def test_reference_engine_protocol_drives_the_runner_process(tmp_path, which):
         if proc.poll() is None:
             proc.kill()
         srv.close()
+        hb_srv.close()
+        if hb:
+            hb.close()

@@ -69,6 +69,7 @@ struct DPStepArgs {
   int nslot;                 // ring slots
   int ring_off, x_off, red_off;
   int xt;                    // bytes of the x region per k-tile: M rows x 272 + 16 (sums)
+  int zero_off;              // an all-zero k-tile (x rows and sums): what a played wave without a k-tile multiplies, as in kernel E
   // grid synchronisation (device memory, zeroed once; monotonic: replayable from a hipGraph)
   uint32_t* counters;        // 8 shards x 16 words (one line each)
   uint32_t* count;           // phases completed by earlier launches
@@ -79,7 +80,7 @@ struct DPStepArgs {
 };
 
 struct DPPlan {
-  int nslot, ring_off, x_off, red_off, xt, lds_bytes;
+  int nslot, ring_off, x_off, red_off, xt, lds_bytes, zero_off;
 };
 bool vra_decode_step_init();  // per device, outside graph capture
 // LDS plan for a model: max_kt = largest K/128 of a GEMV, max_red = largest (units per workgroup x NS) of a GEMV,

@@ -503,7 +503,9 @@ __device__ __forceinline__ void dp_gemv(const DPStepArgs& a, DPGemvC& g, unsigne
         }
         const int kt = c + DP_NC * i + 16 * ti;
         valid[i] = kt < KT;
-        const unsigned char* xt = xreg + (size_t)min(kt, KT - 1) * XT;
+        // a played wave without this k-tile multiplies the all-zero tile (its own tiles are the only ones it may read without a
+        // barrier: another consumer's slices may not be staged yet)
+        const unsigned char* xt = valid[i] ? xreg + (size_t)kt * XT : smem + a.zero_off;
         const unsigned char* xp = xt + arow * 272 + oct * 16;
 #pragma unroll
         for (int j = 0; j < 4; j++) xf[j][i] = *reinterpret_cast<const u32x4*>(xp + j * 64);
@@ -891,6 +893,7 @@ __global__ __launch_bounds__(DP_THREADS) void decode_step_kernel(const DPStepArg
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   uint32_t* ctl = reinterpret_cast<uint32_t*>(smem);
   if (tid < DP_CTL_BYTES / 4) ctl[tid] = 0u;
+  for (int i = tid; i < (a.xt + 3) / 4; i += DP_THREADS) reinterpret_cast<uint32_t*>(smem + a.zero_off)[i] = 0u;
   const uint32_t base = *a.count;  // phases completed by earlier launches (written at the END of a launch)
   __syncthreads();
   if (wave == 0) {
@@ -966,6 +969,9 @@ bool vra_decode_step_plan(int M, int max_kt, int max_red, int group, int D, DPPl
   const size_t attn_bytes = (size_t)4 * group * (D + 4) * 4 + (size_t)4 * group * 8 + 512;
   if (attn_bytes > xbytes) xbytes = attn_bytes;
   xbytes = (xbytes + 15) & ~(size_t)15;
+  const size_t zero_off = DP_CTL_BYTES;  // (filled in below: behind the ring, at the end of the x region)
+  (void)zero_off;
+  xbytes += (size_t)((xt + 15) & ~15);  // the all-zero k-tile
   const size_t red_bytes = (size_t)max_red * 16 * M * 16 * 4;
   const size_t fixed = DP_CTL_BYTES + xbytes + red_bytes;
   if (fixed + 3 * (size_t)DP_SLOT_BYTES > (size_t)kDpMaxLds) return false;
@@ -977,6 +983,7 @@ bool vra_decode_step_plan(int M, int max_kt, int max_red, int group, int D, DPPl
   plan->ring_off = DP_CTL_BYTES;
   plan->x_off = DP_CTL_BYTES + nslot * DP_SLOT_BYTES;
   plan->red_off = plan->x_off + (int)xbytes;
+  plan->zero_off = plan->red_off - ((xt + 15) & ~15);
   plan->xt = xt;
   plan->lds_bytes = plan->red_off + (int)red_bytes;
   return true;

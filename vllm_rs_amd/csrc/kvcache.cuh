@@ -18,9 +18,11 @@ struct KVT<true> {
   typedef uint8_t elem;
 };
 
+// saturating at +-448; a NaN stays a NaN (E4M3 has a NaN encoding: a cache that turned NaN keys into -448 would hide an
+// upstream numerical failure that the 16-bit cache shows)
+__device__ __forceinline__ float vra_e4m3_clamp(float x) { return x != x ? x : fminf(fmaxf(x, -448.f), 448.f); }
 __device__ __forceinline__ uint32_t vra_f32x4_to_e4m3(float a, float b, float c, float d) {
-  a = fminf(fmaxf(a, -448.f), 448.f), b = fminf(fmaxf(b, -448.f), 448.f);
-  c = fminf(fmaxf(c, -448.f), 448.f), d = fminf(fmaxf(d, -448.f), 448.f);
+  a = vra_e4m3_clamp(a), b = vra_e4m3_clamp(b), c = vra_e4m3_clamp(c), d = vra_e4m3_clamp(d);
   int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
   r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
   return (uint32_t)r;

@@ -114,8 +114,21 @@ class Engine:
         self._check(self.L.vra_engine_finalize_weights(self.h), "finalize")
         return self
 
+    def finalize_model(self):
+        """weights only (repack + decode layouts): the KV cache is sized later, from the engine process's plan"""
+        self._check(self.L.vra_engine_finalize_model(self.h), "finalize_model")
+        return self
+
+    def update_config(self, num_gpu_blocks=0, max_num_seqs=0, max_model_len=0, cpu_mem_fold=0.0, kv_fraction=0.0):
+        """the negotiated EngineConfig of MessageType::UsableMemoryLeft, before `finalize` allocates anything"""
+        ec = self.ec
+        ec.num_gpu_blocks, ec.max_num_seqs, ec.max_model_len = int(num_gpu_blocks), int(max_num_seqs), int(max_model_len)
+        ec.cpu_mem_fold, ec.kv_fraction = float(cpu_mem_fold), float(kv_fraction)
+        self._check(self.L.vra_engine_update_config(self.h, C.byref(ec)), "update_config")
+        return self
+
     @classmethod
-    def from_pretrained(cls, model_dir, dtype=None, **kw):
+    def from_pretrained(cls, model_dir, dtype=None, finalize=True, **kw):
         """HF checkpoint directory (config.json + *.safetensors, GPTQ / AWQ int4 or dense) -> engine
         (`EngineBuilder::build` + `WNA16::new`, src/api.rs:25-114, wna16.rs:56-152)."""
         from . import checkpoint
@@ -125,7 +138,8 @@ class Engine:
             shape = (C.c_int64 * a.ndim)(*a.shape)
             eng._check(eng.L.vra_engine_load_tensor(eng.h, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim, a.itemsize),
                        f"load_tensor({name})")
-        eng._check(eng.L.vra_engine_finalize_weights(eng.h), "finalize")
+        if finalize:
+            eng._check(eng.L.vra_engine_finalize_weights(eng.h), "finalize")
         return eng
 
     @property

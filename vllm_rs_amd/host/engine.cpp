@@ -552,7 +552,7 @@ class Engine {
     pend_ids_ = sched_->schedule(&is_prefill);
     pend_prefill_ = is_prefill;
     if (is_prefill_out) *is_prefill_out = is_prefill ? 1 : 0;
-    execute_swaps();
+    if (!execute_swaps()) return -1;
     if (pend_ids_.empty()) {
       nothing_scheduled();
       return 0;
@@ -769,6 +769,28 @@ extern "C" int32_t vra_engine_finalize_weights(void* e) {
   }
   return en->finalize() ? 0 : -1;
 }
+extern "C" int32_t vra_engine_finalize_model(void* e) {
+  auto* en = static_cast<Engine*>(e);
+  if (en->dry()) return 0;
+  if (!en->model_.finalize_weights()) {
+    en->error = en->model_.error;
+    return -1;
+  }
+  return 0;
+}
+extern "C" int32_t vra_engine_update_config(void* e, const vra_engine_config* cfg) {
+  auto* en = static_cast<Engine*>(e);
+  if (!cfg || en->prepared_ || en->sched_) {
+    en->error = "vra_engine_update_config: only before the engine has allocated its buffers (before finalize / plan_kv_blocks)";
+    return -1;
+  }
+  en->ec_.num_gpu_blocks = cfg->num_gpu_blocks;
+  if (cfg->max_num_seqs > 0) en->ec_.max_num_seqs = cfg->max_num_seqs;
+  if (cfg->max_model_len > 0) en->ec_.max_model_len = cfg->max_model_len;
+  en->ec_.cpu_mem_fold = cfg->cpu_mem_fold;
+  if (cfg->kv_fraction > 0.f) en->ec_.kv_fraction = cfg->kv_fraction;
+  return 0;
+}
 // KVCacheAllocator plan of THIS rank before the cache is allocated (weights repacked, activation buffers reserved):
 // the block count `finalize` would choose from free memory x kv_fraction.  Tensor-parallel launchers call it on every
 // rank, take the minimum and hand it to vra_engine_set_num_gpu_blocks, so that all schedulers see the same cache.
@@ -957,6 +979,39 @@ extern "C" int32_t vra_engine_forward_raw(void* e, const uint32_t* h_ids, const 
   if (!is_prefill && n_tokens != n_seqs) {
     en->error = "forward_raw: a decode step carries one token per sequence";
     return -1;
+  }
+  // The metadata comes from a peer (the runner process hands over what the engine process sent): nothing reaches the device
+  // that could index outside the cache, the block tables, the embedding or the logits rows.
+  if (n_tokens <= 0 || n_seqs <= 0 || max_blocks <= 0 || !h_ids || !h_positions || !h_slot_mapping || !h_block_tables || !h_context_lens ||
+      !h_logits_out || (is_prefill && !h_cu_seqlens_q)) {
+    en->error = "forward_raw: empty batch or null argument";
+    return -1;
+  }
+  {
+    const int64_t n_slots = (int64_t)en->model_.num_blocks() * en->ec_.block_size;
+    const int64_t max_ctx = (int64_t)max_blocks * en->ec_.block_size;
+    for (int t = 0; t < n_tokens; t++) {
+      if (h_ids[t] >= (uint32_t)en->mc_.vocab_size) return en->error = "forward_raw: token id " + std::to_string(h_ids[t]) + " outside the vocabulary", -1;
+      if (h_slot_mapping[t] >= n_slots) return en->error = "forward_raw: slot " + std::to_string(h_slot_mapping[t]) + " outside the KV cache", -1;
+      if (is_prefill ? h_slot_mapping[t] < 0 : h_slot_mapping[t] < -1)  // (-1: a padded decode lane writes nothing)
+        return en->error = "forward_raw: negative slot", -1;
+      if (h_positions[t] < 0 || h_positions[t] >= en->mc_.max_position_embeddings)
+        return en->error = "forward_raw: position " + std::to_string(h_positions[t]) + " outside the rotary table", -1;
+    }
+    for (int b = 0; b < n_seqs; b++) {
+      if ((int64_t)h_context_lens[b] > max_ctx) return en->error = "forward_raw: context length beyond the block table", -1;
+      const int used = (int)(((int64_t)h_context_lens[b] + en->ec_.block_size - 1) / en->ec_.block_size);
+      for (int k = 0; k < used; k++)
+        if (h_block_tables[(size_t)b * max_blocks + k] >= (uint32_t)en->model_.num_blocks())
+          return en->error = "forward_raw: block id " + std::to_string(h_block_tables[(size_t)b * max_blocks + k]) + " outside the KV cache", -1;
+    }
+    if (is_prefill) {
+      if (h_cu_seqlens_q[0] != 0 || h_cu_seqlens_q[n_seqs] != (uint32_t)n_tokens) return en->error = "forward_raw: cu_seqlens_q does not cover the tokens", -1;
+      for (int b = 0; b < n_seqs; b++) {
+        if (h_cu_seqlens_q[b + 1] <= h_cu_seqlens_q[b]) return en->error = "forward_raw: a sequence without tokens in a prefill step", -1;
+        if (h_cu_seqlens_q[b + 1] - h_cu_seqlens_q[b] > h_context_lens[b]) return en->error = "forward_raw: more query tokens than context", -1;
+      }
+    }
   }
   memcpy(en->h_meta_ + (is_prefill ? en->off_ids_ : en->off_dids_), h_ids, (size_t)n_tokens * 4);
   memcpy(en->h_meta_ + (is_prefill ? en->off_pos_ : en->off_dpos_), h_positions, (size_t)n_tokens * 8);

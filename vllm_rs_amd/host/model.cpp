@@ -817,7 +817,7 @@ bool Model::build_decode_step() {
     if (!vra_decode_step_plan(M, max_kt, max_red, hq_ / hkv_, mc_.head_dim, &p)) continue;
     if (M * hkv_ > grid) continue;
     dp_plan_[M][0] = p.nslot, dp_plan_[M][1] = p.ring_off, dp_plan_[M][2] = p.x_off, dp_plan_[M][3] = p.red_off, dp_plan_[M][4] = p.xt,
-    dp_plan_[M][5] = p.lds_bytes;
+    dp_plan_[M][5] = p.lds_bytes, dp_plan_[M][6] = p.zero_off;
     any = true;
   }
   if (!any) return true;
@@ -853,6 +853,7 @@ bool Model::launch_decode_phases(const InputMetadata& md, int ph0, int ph1, int6
   a.bs_shift = (ec_.block_size & (ec_.block_size - 1)) == 0 ? 31 - __builtin_clz((unsigned)ec_.block_size) : -1;
   a.scale_log2e = (1.0f / sqrtf((float)mc_.head_dim)) * 1.44269504088896f;
   a.nslot = dp_plan_[M][0], a.ring_off = dp_plan_[M][1], a.x_off = dp_plan_[M][2], a.red_off = dp_plan_[M][3], a.xt = dp_plan_[M][4];
+  a.zero_off = dp_plan_[M][6];
   vra_launch_decode_step(a, dt_, layers_[0].q.awq, ec_.fp8_kvcache != 0, mc_.head_dim, stream);
   return !take_err(error, "decode step");
 }

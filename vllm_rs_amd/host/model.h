@@ -146,7 +146,7 @@ class Model {
   float* logits_ = nullptr;
   // persistent decode step
   void* dp_layers_ = nullptr;     // device: DPLayer[num_layers]
-  int dp_plan_[3][6] = {};        // per row count M = 1..2: nslot, ring_off, x_off, red_off, xt, lds_bytes (nslot 0: not usable)
+  int dp_plan_[3][7] = {};        // per row count M = 1..2: nslot, ring_off, x_off, red_off, xt, lds_bytes, zero_off (nslot 0: not usable)
   int dp_max_ctx_ = 0;            // longest context the single-workgroup attention phase takes
 };
 

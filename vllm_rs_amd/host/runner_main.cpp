@@ -5,8 +5,10 @@
 // is what an unmodified vllm.rs engine spawns per GPU (src/core/engine.rs:187-330): it connects to the engine's
 // GenericNamespaced local socket (a Linux abstract-namespace Unix socket, "\0<name>"), writes "ready\n", takes `Init` as
 // JSON (model config, rank, device, NCCL id, checkpoint paths), loads its shard of the checkpoint (safetensors, by HF tensor
-// name: the library slices for tensor parallelism and repacks int4 itself), answers `InitAck`, then serves `RunPrefill` /
-// `RunDecode` (bincode) with `RunResponse` token ids until `Shutdown`.  As in the reference the ENGINE owns scheduler and
+// name: the library slices for tensor parallelism and repacks int4 itself), answers `InitAck`, takes the engine's
+// `UsableMemoryLeft(EngineConfig)` (JSON: the negotiated KV plan), sizes its cache from it, answers `InitAck` again, then
+// serves `RunPrefill` / `RunDecode` (bincode) with `RunResponse` token ids until `Shutdown`; a heartbeat thread answers the
+// engine's command channel (src/utils/heartbeat.rs).  As in the reference the ENGINE owns scheduler and
 // block manager; the runner builds the step's InputMetadata from the sequences it is handed (ModelRunner::prepare_prefill /
 // prepare_decode, src/core/runner.rs:978-1388) and runs forward + sampling (runner.rs:1390-1570).
 // The Python twin (vllm_rs_amd/runner_ipc.py) exists for the tests' engine side; wire.h / wire.py share known-answer bytes.
@@ -16,6 +18,8 @@
 #include <errno.h>
 #include <fcntl.h>
 #include <math.h>
+#include <pthread.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <sys/mman.h>
@@ -58,9 +62,11 @@ static bool read_all(int fd, void* p, size_t n) {
   }
   return true;
 }
+static const uint32_t kMaxFrame = 1u << 30;  // a frame is a step's sequences (a 1M-token batch is ~4 MB): a larger length prefix is a corrupt stream
 static std::vector<uint8_t> recv_frame(int fd) {  // receive_local: length, payload, then acknowledge with 0x01
   uint32_t n = 0;
   if (!read_all(fd, &n, 4)) die("peer closed the stream");
+  if (n > kMaxFrame) die("frame length " + std::to_string(n) + " exceeds the limit: corrupt stream");
   std::vector<uint8_t> b(n);
   if (n && !read_all(fd, b.data(), n)) die("peer closed the stream inside a frame");
   const uint8_t ack = 1;
@@ -91,6 +97,17 @@ struct Init {
   std::vector<std::string> files;
   uint64_t seed = 1234;
 };
+// EngineConfig (config.rs:285-328) as it travels in Init.econfig and again, after the engine's allocation plan, in
+// MessageType::UsableMemoryLeft: the fields this path uses
+static void econfig_from_json(const Json& e, vra_engine_config* ecp) {
+  vra_engine_config& ec = *ecp;
+  ec.block_size = (int)e.i64("block_size", 64), ec.max_num_seqs = (int)e.i64("max_num_seqs", 32);
+  ec.max_model_len = (int)e.i64("max_model_len", 0), ec.num_gpu_blocks = (int)e.i64("num_blocks", 0);
+  ec.kv_fraction = 0.f, ec.prefill_chunk = 8192, ec.enable_prefix_cache = 0, ec.prefix_cache_fraction = 0.65f, ec.use_graph = 0;
+  ec.seed = (uint64_t)e.i64("seed", 1234);
+  ec.fp8_kvcache = e.boolean("fp8_kvcache", false);
+  ec.cpu_mem_fold = (float)e.num("cpu_mem_fold", 0.2);  // kvcache_allocator.rs:317: unwrap_or(0.2) — the engine plans its CPU block ids with it
+}
 static bool init_from_json(const std::string& text, Init* out, std::string* err) {
   Json root;
   if (!parse_json(text, &root, err)) return false;
@@ -140,14 +157,9 @@ static bool init_from_json(const std::string& text, Init* out, std::string* err)
   const Json* e = req->get("econfig");
   static const Json none;
   if (!e || e->t != Json::Obj) e = &none;
-  ec.block_size = (int)e->i64("block_size", 64), ec.max_num_seqs = (int)e->i64("max_num_seqs", 32);
-  ec.max_model_len = (int)e->i64("max_model_len", 0), ec.num_gpu_blocks = (int)e->i64("num_blocks", 0);
-  ec.kv_fraction = 0.f, ec.prefill_chunk = 8192, ec.enable_prefix_cache = 0, ec.prefix_cache_fraction = 0.65f, ec.use_graph = 0;
+  econfig_from_json(*e, &ec);
   ec.tp_rank = out->rank, ec.tp_world_size = out->world, ec.device = out->dev;
-  out->seed = (uint64_t)e->i64("seed", 1234);
-  ec.seed = out->seed;
-  ec.fp8_kvcache = e->boolean("fp8_kvcache", false);
-  ec.cpu_mem_fold = (float)e->num("cpu_mem_fold", 0.2);  // kvcache_allocator.rs:317: unwrap_or(0.2) — the engine plans its CPU block ids with it
+  out->seed = ec.seed;
   if (const Json* id = req->get("nccl_id"))
     if (id->t == Json::Str) {
       if (!base64_decode(id->s, &out->nccl_id) || out->nccl_id.size() != 128) return *err = "nccl_id: expected 128 bytes", false;
@@ -359,7 +371,10 @@ struct Runner {
       for (int64_t p = cached; p < cached + n; p++) {
         ids.push_back(s.token_ids[(size_t)p]);
         pos.push_back(p);
-        if ((size_t)(p / block_size) >= s.block_table.size()) die("RunPrefill: block table shorter than the chunk");
+        if ((size_t)(p / block_size) >= s.block_table.size()) {
+          fprintf(stderr, "vra_runner: RunPrefill: block table shorter than the chunk\n");
+          return {};
+        }
         slots.push_back((int64_t)s.block_table[(size_t)(p / block_size)] * block_size + p % block_size);
       }
       cu.push_back((uint32_t)ids.size());
@@ -368,8 +383,10 @@ struct Runner {
     }
     logits.resize((size_t)B * vocab);
     if (vra_engine_forward_raw(eng, ids.data(), pos.data(), slots.data(), (int)ids.size(), 1, bt.data(), (int)mb, ctx.data(), cu.data(), B,
-                               logits.data()) != 0)
-      die(std::string("forward (prefill): ") + vra_engine_last_error(eng));
+                               logits.data()) != 0) {
+      fprintf(stderr, "vra_runner: forward (prefill) failed: %s\n", vra_engine_last_error(eng));
+      return {};  // RunResponse([]): runner.rs:246-292
+    }
     cached = strategy_of(seqs[0].sampling_params), have_strategy = true;
     return sample(B, cached);
   }
@@ -390,13 +407,59 @@ struct Runner {
       ctx.push_back((uint32_t)s.len);
     }
     logits.resize((size_t)B * vocab);
-    if (vra_engine_forward_raw(eng, ids.data(), pos.data(), slots.data(), B, 0, bt.data(), (int)mb, ctx.data(), nullptr, B, logits.data()) != 0)
-      die(std::string("forward (decode): ") + vra_engine_last_error(eng));
+    if (vra_engine_forward_raw(eng, ids.data(), pos.data(), slots.data(), B, 0, bt.data(), (int)mb, ctx.data(), nullptr, B, logits.data()) != 0) {
+      // a runner error is answered with an empty RunResponse, as the reference does (runner.rs:246-292): the engine fails the
+      // step, the other ranks and later steps live on
+      fprintf(stderr, "vra_runner: forward (decode) failed: %s\n", vra_engine_last_error(eng));
+      return {};
+    }
     Strategy st = cached;
     if (!have_strategy) st.greedy = false, st.k = 32, st.p = 0.95f, st.t = 0.7f;
     return sample(B, st);
   }
 };
+
+// ---------------------------------------------------------------- heartbeat (src/utils/heartbeat.rs:8-78, src/utils/command.rs:91-172)
+// The daemon side: connect to the engine's command channel "command_{uuid}@vllm-rs-runner-heartbeat.sock" (retry once a second,
+// up to 120 times), announce `ready`, then acknowledge one bincode frame (MessageType::Heartbeat) per second; when the engine
+// goes away (EOF / broken pipe) the runner exits, as the reference's does.
+static void* heartbeat_main(void* arg) {
+  const std::string name = "command_" + *static_cast<std::string*>(arg) + "@vllm-rs-runner-heartbeat.sock";
+  delete static_cast<std::string*>(arg);
+  int fd = -1;
+  for (int attempt = 0; attempt < 120 && fd < 0; attempt++) {
+    fd = socket(AF_UNIX, SOCK_STREAM, 0);
+    if (fd < 0) return nullptr;
+    sockaddr_un addr{};
+    addr.sun_family = AF_UNIX;
+    if (name.size() + 1 > sizeof(addr.sun_path)) return nullptr;
+    memcpy(addr.sun_path + 1, name.data(), name.size());
+    if (connect(fd, (sockaddr*)&addr, (socklen_t)(offsetof(sockaddr_un, sun_path) + 1 + name.size())) != 0) {
+      close(fd);
+      fd = -1;
+      sleep(1);
+    }
+  }
+  if (fd < 0) {
+    fprintf(stderr, "vra_runner: no heartbeat channel %s (continuing without)\n", name.c_str());
+    return nullptr;
+  }
+  if (write(fd, "ready\n", 6) != 6) return nullptr;
+  for (;;) {
+    uint32_t n = 0;
+    if (!read_all(fd, &n, 4)) break;
+    std::vector<uint8_t> b(n > kMaxFrame ? 0 : n);
+    if (n > kMaxFrame || (n && !read_all(fd, b.data(), n))) break;
+    const uint8_t ack = 1;
+    if (write(fd, &ack, 1) != 1) break;
+  }
+  fprintf(stderr, "vra_runner: parent process disconnected, exiting\n");
+  _exit(0);
+}
+static void start_heartbeat(const std::string& uuid) {
+  pthread_t th;
+  if (pthread_create(&th, nullptr, heartbeat_main, new std::string(uuid)) == 0) pthread_detach(th);
+}
 
 static std::string read_stdin() {
   std::string s;
@@ -476,6 +539,7 @@ int main(int argc, char** argv) {
   }
   if (fd < 0) die("cannot connect to the engine's socket " + sock_name);
   write_all(fd, "ready\n", 6);
+  if (!uuid.empty()) start_heartbeat(uuid);  // heartbeat_worker(None, true, ..) (runner.rs:71)
 
   // ---- Init (JSON) -> engine
   const std::vector<uint8_t> first = recv_frame(fd);
@@ -521,10 +585,37 @@ int main(int argc, char** argv) {
   }
   if (have_ckpt) {
     for (auto& f : files) load_safetensors(eng, f, in.mc);
-    if (vra_engine_finalize_weights(eng) != 0) die(std::string("finalize: ") + vra_engine_last_error(eng));
+    if (vra_engine_finalize_model(eng) != 0) die(std::string("finalize (weights): ") + vra_engine_last_error(eng));
   } else if (vra_engine_init_synthetic(eng) != 0) {  // no checkpoint on this box: synthetic weights of the configured shape (bench mode)
     die(std::string("init_synthetic: ") + vra_engine_last_error(eng));
   }
+  // ---- the reference's handshake (src/core/engine.rs:340-378 on the engine side, src/core/runner.rs:443-455 and
+  // src/runner/runner.rs:214-236 on this side): the model is loaded -> InitAck #1 -> the engine plans the KV cache from the
+  // memory that is left and answers with MessageType::UsableMemoryLeft(EngineConfig) as JSON -> the cache is sized from THAT
+  // configuration (Init.econfig.num_blocks is only the placeholder 128, config.rs:458) -> InitAck #2 -> bincode loop.
+  {
+    Message ack;
+    ack.name = "InitAck", ack.flag = true;
+    send_msg(fd, ack);
+  }
+  {
+    const std::vector<uint8_t> second = recv_frame(fd);
+    Json j;
+    std::string jerr;
+    const Json* uml = nullptr;
+    if (parse_json(std::string((const char*)second.data(), second.size()), &j, &jerr)) uml = j.get("UsableMemoryLeft");
+    if (uml && uml->t == Json::Obj) {
+      vra_engine_config neg = in.ec;
+      econfig_from_json(*uml, &neg);
+      if (neg.block_size != in.ec.block_size) die("UsableMemoryLeft: block_size differs from Init.econfig");
+      if (vra_engine_update_config(eng, &neg) != 0) die(std::string("update_config: ") + vra_engine_last_error(eng));
+      in.ec.num_gpu_blocks = neg.num_gpu_blocks, in.ec.max_num_seqs = neg.max_num_seqs, in.ec.max_model_len = neg.max_model_len;
+    } else {
+      fprintf(stderr, "vra_runner: expected UsableMemoryLeft after the first InitAck (%s); keeping Init.econfig\n", jerr.c_str());
+    }
+  }
+  if (in.ec.block_size <= 0) die("econfig.block_size must be positive");
+  if (vra_engine_finalize_weights(eng) != 0) die(std::string("finalize: ") + vra_engine_last_error(eng));
   Runner r;
   r.eng = eng, r.vocab = in.mc.vocab_size, r.block_size = in.ec.block_size, r.seed = in.seed;
   {
@@ -538,9 +629,9 @@ int main(int argc, char** argv) {
     const std::vector<uint8_t> b = recv_frame(fd);
     Message m;
     if (!decode(b.data(), b.size(), &m, &err)) {
-      Message e;
-      e.name = "Error", e.text = err;
-      send_msg(fd, e);
+      // the reference only logs what it cannot decode or does not serve; a reply here would be read by the engine as the
+      // 1-byte acknowledgment of its NEXT frame
+      fprintf(stderr, "vra_runner: undecodable frame (%s): ignored\n", err.c_str());
       err.clear();
       continue;
     }
@@ -556,8 +647,10 @@ int main(int argc, char** argv) {
       out.name = "KVCacheSwapResponse";
       out.flag = vra_engine_swap_blocks(eng, pairs.data(), (int)m.map.size(), m.flag ? 1 : 0) == 0;
       if (!out.flag) fprintf(stderr, "vra_runner: KvCache swap failed: %s\n", vra_engine_last_error(eng));
+    } else {
+      fprintf(stderr, "vra_runner: message %s is not served on this path: ignored\n", m.name.c_str());
+      continue;
     }
-    else out.name = "Error", out.text = "unsupported message " + m.name;
     send_msg(fd, out);
   }
   if (r.d_logits) vra_free(r.d_logits), vra_free(r.d_tokens);

@@ -287,7 +287,7 @@ struct Rd {
   }
   std::string str() {
     const uint64_t k = u64();
-    if (!ok() || i + k > n) {
+    if (!ok() || k > n - i) {  // (i <= n always; `i + k > n` wraps for a length near 2^64)
       if (ok()) err = "truncated string";
       return std::string();
     }

@@ -1,6 +1,8 @@
 """A `runner` process that speaks the reference's engine <-> runner protocol (vllm_rs_amd/wire.py; src/runner/runner.rs
 main loop, src/runner/mod.rs): connect to the engine's local socket, announce `ready`, take `Init` (JSON), load the model shard,
-answer `InitAck`, then serve `RunPrefill` / `RunDecode` with `RunResponse` token ids until `Shutdown`.
+answer `InitAck`, take `UsableMemoryLeft(EngineConfig)` (JSON: the engine's KV plan, src/core/engine.rs:355-378), size the cache
+from it, answer `InitAck` again (src/core/runner.rs:443-455, src/runner/runner.rs:214-236), then serve `RunPrefill` / `RunDecode`
+with `RunResponse` token ids until `Shutdown`.
 
     python -m vllm_rs_amd.runner_ipc --sock <name> [--uuid <id>]
 
@@ -76,6 +78,13 @@ class RunnerServer:
         self.cached_strategy = "unset"
 
     def _run(self, seqs, is_prefill):
+        try:
+            return self._run_checked(seqs, is_prefill)
+        except Exception as e:  # a runner error is answered with an empty RunResponse (runner.rs:246-292)
+            print(f"runner_ipc: step failed: {e}", flush=True)
+            return []
+
+    def _run_checked(self, seqs, is_prefill):
         if is_prefill:
             inp = step_inputs_prefill(seqs, self.BS)
             self.cached_strategy = strategy_of(seqs[0]["sampling_params"])  # cached for the decode steps (A3)
@@ -87,7 +96,11 @@ class RunnerServer:
 
     def serve(self):
         while True:
-            name, p = wire.decode(wire.recv_frame(self.sock))
+            try:
+                name, p = wire.decode(wire.recv_frame(self.sock))
+            except wire.WireError as e:  # logged, not answered (runner.rs:246-430)
+                print(f"runner_ipc: undecodable or unserved frame ({e}): ignored", flush=True)
+                continue
             if name == "Shutdown":
                 return
             if name == "RunPrefill":
@@ -101,8 +114,8 @@ class RunnerServer:
             elif name == "KVCacheSwap":  # runner.rs:297-312 -> ModelRunner::swap_kvcache
                 ok = bool(self.swap(p[0], p[1])) if self.swap else False
                 wire.send_frame(self.sock, wire.encode(("KVCacheSwapResponse", ok)))
-            else:
-                wire.send_frame(self.sock, wire.encode(("Error", f"unsupported message {name}")))
+            else:  # the reference only logs what it does not serve (a reply would be read as the ack of the engine's next frame)
+                print(f"runner_ipc: message {name} is not served on this path: ignored", flush=True)
 
 
 def connect(sock_name):
@@ -141,9 +154,17 @@ def main():
     paths = req.get("model_pathes") or {}
     cfg_file = paths.get("config_filename")
     if cfg_file and os.path.exists(cfg_file):
-        eng = Engine.from_pretrained(os.path.dirname(cfg_file), **kw)
+        eng = Engine.from_pretrained(os.path.dirname(cfg_file), finalize=False, **kw)
     else:  # no checkpoint on this box: synthetic weights of the configured shape (bench mode)
-        eng = Engine(cfg, **kw).init_synthetic()
+        eng = Engine(cfg, **kw).init_synthetic(finalize=False)
+    eng.finalize_model()
+    # the model is loaded: InitAck #1, then the engine's KV plan (JSON), then the cache, then InitAck #2
+    wire.send_frame(sock, wire.encode(("InitAck", True)))
+    neg = wire.decode_usable_memory_left_json(wire.recv_frame(sock))
+    if neg is not None:
+        eng.update_config(num_gpu_blocks=neg.get("num_blocks", 0), max_num_seqs=neg.get("max_num_seqs", 0), max_model_len=neg.get("max_model_len") or 0,
+                          cpu_mem_fold=neg.get("cpu_mem_fold") if neg.get("cpu_mem_fold") is not None else 0.2)
+    eng.finalize()
     calls = [0]
 
     def sample(logits, strat):
@@ -160,7 +181,8 @@ def main():
         L.vra_device_sync()
         L.vra_free(d_l), L.vra_free(d_o)
         return out
-    wire.send_frame(sock, wire.encode(("InitAck", True)))
+    wire.send_frame(sock, wire.encode(("InitAck", True)))  # InitAck #2: the cache exists
+
     def swap(mapping, swap_in):
         pairs = np.array([[k, v] for k, v in mapping.items()], np.int64).reshape(-1)
         return L.vra_engine_swap_blocks(eng.h, pairs.ctypes.data_as(C.c_void_p), len(mapping), int(bool(swap_in))) == 0

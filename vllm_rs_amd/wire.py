@@ -282,6 +282,23 @@ def encode_init_json(req):
     return json.dumps({"Init": body}).encode()
 
 
+def encode_usable_memory_left_json(econfig):
+    """MessageType::UsableMemoryLeft(EngineConfig) as the engine sends it after the first InitAck (send_and_expect_ack -> JSON,
+    src/runner/mod.rs:300-312, src/core/engine.rs:372-377)"""
+    return json.dumps({"UsableMemoryLeft": econfig}).encode()
+
+
+def decode_usable_memory_left_json(b):
+    """-> the EngineConfig dict, or None when the frame is something else (the reference then keeps Init.econfig)"""
+    try:
+        d = json.loads(bytes(b).decode())
+    except (UnicodeDecodeError, json.JSONDecodeError):
+        return None
+    if isinstance(d, dict) and isinstance(d.get("UsableMemoryLeft"), dict):
+        return d["UsableMemoryLeft"]
+    return None
+
+
 def decode_init_json(b):
     """-> dict(rank, dev_id, num_shards, model_type, config (HF-style keys as the reference's Config serialises them), econfig,
     model_pathes, is_gguf, dtype, is_rope_i, nccl_id bytes or None)"""
