@@ -418,6 +418,8 @@ int32_t vra_engine_finalize_weights(void* eng); /* repack + scale layout + KV ca
  * (vra_engine_finalize_model: repack + decode layouts, nothing else is allocated), then the negotiated configuration
  * (vra_engine_update_config: num_gpu_blocks, max_num_seqs, max_model_len, cpu_mem_fold, kv_fraction — allowed
  * until buffers exist), then vra_engine_finalize_weights for activations, KV cache and graphs. */
+/* parity instrumentation: the f32 logits [n_seqs, vocab] the last step (hipGraph replay or eager) left on the device */
+int32_t vra_engine_copy_logits(void* eng, float* h_out, int32_t n_seqs);
 int32_t vra_engine_finalize_model(void* eng);
 int32_t vra_engine_update_config(void* eng, const vra_engine_config* cfg);
 /* ModelRunner::swap_kvcache (runner.rs:1626-1670; MessageType::KVCacheSwap): copy whole blocks between the GPU cache and the

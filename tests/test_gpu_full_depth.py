@@ -1,0 +1,107 @@
+"""Full-depth parity of the headline configs against the oracle (tests/full_depth.py): Llama-3-8B GPTQ (32 layers, vocabulary
+128 256) and Qwen2-7B AWQ (28 layers, vocabulary 152 064), synthetic weights, prompt 32 + 16 greedy steps on the engine's
+hipGraph path — the configuration bench.py times — plus one tensor-parallel run (TP = 2 at the Llama-3-8B widths).
+
+What was measured when this file was written (MI355X, round 3):
+  * Llama-3-8B: all 17 steps token-for-token; max |dlogit| 0.0312 = ONE bf16 ulp at the row's logit scale (5.9) at every step,
+    mean 0.0009, 93 % of the logits within 1e-3 of the logit scale, 66 % within 1e-3 absolute.
+  * Qwen2-7B AWQ: max 15 ulp, mean |d| 0.06 — and that is the noise floor of this SYNTHETIC network, not of the engine: with
+    uniformly random AWQ zero points the dequantised weights carry a large common-mode term per group and the bf16 roundings of
+    the reference op sequence are amplified ~10x compared with the symmetric GPTQ recipe.  The oracle itself sits 0.052 rms from
+    a float64 evaluation of the same 4-layer network, the engine 0.052, and they are 0.019 apart (Llama widths: 0.0047 / 0.0047
+    / 0.0025): the engine is as close to the unrounded truth as the oracle is, which is what the third test asserts."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import model as om
+from oracle import oracle as orc
+from tests import full_depth, truth64
+from tests.test_gpu_engine import BF16, check_logits
+from vllm_rs_amd import engine as E
+from vllm_rs_amd.engine import Engine
+
+pytestmark = pytest.mark.gpu
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+
+
+def _save(name, rep):
+    if os.path.isdir(OUT):
+        json.dump(rep, open(os.path.join(OUT, f"full_depth_{name}.json"), "w"))
+
+
+def _near_tie_or_equal(rep):
+    if rep["tokens_equal"]:
+        return True
+    fd = rep["first_divergence"]  # greedy tokens may differ only where the oracle's own top-2 gap is within the deviation measured there
+    return fd["oracle_top2_gap"] <= 2.0 * rep["per_step_max_abs"][fd["step"]]
+
+
+def test_llama3_8b_full_depth_token_for_token():
+    rep = full_depth.run(dict(E.LLAMA3_8B))
+    _save("llama3-8b-gptq", rep)
+    assert rep["n_steps"] >= 16
+    assert rep["max_ulp_of_row_scale"] <= 2.0, rep  # measured 1.00 at every step
+    assert rep["min_frac_within_1e3_of_scale"] >= 0.85, rep  # measured 0.926
+    assert _near_tie_or_equal(rep), rep
+
+
+def test_qwen2_7b_awq_full_depth():
+    rep = full_depth.run(dict(E.QWEN2_7B))
+    _save("qwen2-7b-awq", rep)
+    assert rep["n_steps"] >= 16
+    assert rep["max_ulp_of_row_scale"] <= 24.0, rep  # measured 15.1: the synthetic AWQ network's own rounding noise (module docstring)
+    assert _near_tie_or_equal(rep), rep
+
+
+@pytest.mark.parametrize("name", ["qwen2-7b-awq", "llama3-8b-gptq"])
+def test_engine_is_as_close_to_float64_truth_as_the_oracle_at_the_real_widths(name):
+    """4 layers at the real widths (a float64 copy of all 28 / 32 would need ~50 GB): distance of engine and oracle to the
+    unrounded float64 forward (tests/truth64.py) over a 32-token prefill and one decode step"""
+    cfg = dict({"llama3-8b-gptq": E.LLAMA3_8B, "qwen2-7b-awq": E.QWEN2_7B}[name], num_layers=4, vocab_size=32000, max_position_embeddings=2048)
+    eng = Engine(cfg, max_num_seqs=8, max_model_len=2048, num_gpu_blocks=16, use_graph=False, seed=1234).init_synthetic()
+    w = full_depth.synthetic_checkpoint(cfg, 1234)
+    oracle, truth = om.OracleModel(cfg, w, num_blocks=16), truth64.TruthModel(cfg, w)
+    n = 32
+    prompt = np.random.default_rng(42).integers(1000, cfg["vocab_size"] - 1000, size=n).astype(np.uint32)
+    pos, bt = np.arange(n, dtype=np.int64), np.arange(16, dtype=np.uint32)[None]
+    rms = lambda a: float(np.sqrt((a * a).mean()))
+    steps = [(prompt, pos, np.array([n], np.uint32), np.array([0, n], np.uint32))]
+    rep = {}
+    for i in range(2):
+        ids, p, ctx, cu = steps[-1]
+        g = eng.forward_raw(ids, p, p.copy(), bt, ctx, cu)[0].astype(np.float64)
+        o = oracle.forward(ids, p, p.copy(), bt, ctx, cu)[0].astype(np.float64)
+        t = truth.forward(ids, p)[0]
+        rep[("prefill", "decode")[i]] = dict(engine_truth=rms(g - t), oracle_truth=rms(o - t), engine_oracle=rms(g - o), scale=float(np.abs(t).max()))
+        assert rms(g - t) <= 1.15 * rms(o - t) + 1e-4, rep  # not (materially) further from the truth than the oracle
+        assert rms(g - o) <= rms(o - t), rep                  # and closer to the oracle than the oracle is to the truth
+        steps.append((np.array([int(np.argmax(o))], np.uint32), np.array([n + i], np.int64), np.array([n + i + 1], np.uint32), None))
+    print(f"[truth] {name} 4 layers: {rep}")
+    _save(f"truth_{name}", rep)
+    eng.close()
+
+
+def test_tp2_at_the_llama3_8b_widths_against_the_tp_oracle():
+    """north_star's TP arithmetic at real widths: 4 layers of Llama-3-8B over two ranks (one-shot all-reduce on one GPU), prompt 32
+    + 8 greedy steps against oracle/model.py's tensor-parallel restatement (per-rank partial sums rounded, summed in rank order)"""
+    from vllm_rs_amd.runner import TPEngine
+    cfg = dict(E.LLAMA3_8B, num_layers=4, vocab_size=32000, max_position_embeddings=2048)
+    w = full_depth.synthetic_checkpoint(cfg, 77)
+    oracle = om.OracleModel(cfg, w, num_blocks=16, tp_world=2)
+    n = 32
+    prompt = np.random.default_rng(5).integers(1000, cfg["vocab_size"] - 1000, size=n).astype(np.uint32)
+    bt = np.arange(16, dtype=np.uint32)[None]
+    worst = 0.0
+    with TPEngine(cfg, 2, devices=[0, 0], transport="ipc", tensors=w, num_gpu_blocks=16, max_num_seqs=4, max_model_len=2048, use_graph=False) as tp:
+        ids, pos, ctx, cu = prompt, np.arange(n, dtype=np.int64), np.array([n], np.uint32), np.array([0, n], np.uint32)
+        for step in range(9):
+            got = tp.forward_raw(ids, pos, pos.copy(), bt, ctx, cu)
+            ref = oracle.forward(ids, pos, pos.copy(), bt, ctx, cu)
+            assert (got[0] == got[1]).all(), f"step {step}: the two ranks disagree (A21)"
+            worst = max(worst, check_logits(got[0], ref, f"tp2 llama3-8b widths step {step}", BF16, max_ulps=4.0))
+            t = int(orc.argmax_f32(ref)[0])
+            ids, pos, ctx, cu = np.array([t], np.uint32), np.array([n + step], np.int64), np.array([n + step + 1], np.uint32), None
+    _save("tp2_llama3-8b-widths_4layers", dict(max_ulp_of_row_scale=worst, steps=9))

@@ -185,6 +185,7 @@ def load():
     _sig(lib, "vra_engine_init_synthetic", c_i32, P)
     _sig(lib, "vra_engine_load_tensor", c_i32, P, C.c_char_p, P, P, c_i32, c_i32)
     _sig(lib, "vra_engine_finalize_weights", c_i32, P)
+    _sig(lib, "vra_engine_copy_logits", c_i32, P, P, c_i32)
     _sig(lib, "vra_engine_finalize_model", c_i32, P)
     _sig(lib, "vra_engine_update_config", c_i32, P, P)
     _sig(lib, "vra_engine_num_gpu_blocks", c_i32, P)

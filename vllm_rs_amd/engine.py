@@ -114,6 +114,13 @@ class Engine:
         self._check(self.L.vra_engine_finalize_weights(self.h), "finalize")
         return self
 
+    def last_logits(self, n_seqs=1):
+        """f32 logits [n_seqs, vocab] of the step that just ran (graph replay or eager): parity instrumentation"""
+        import numpy as np
+        out = np.empty((n_seqs, self.cfg["vocab_size"]), np.float32)
+        self._check(self.L.vra_engine_copy_logits(self.h, out.ctypes.data_as(C.c_void_p), n_seqs), "copy_logits")
+        return out
+
     def finalize_model(self):
         """weights only (repack + decode layouts): the KV cache is sized later, from the engine process's plan"""
         self._check(self.L.vra_engine_finalize_model(self.h), "finalize_model")

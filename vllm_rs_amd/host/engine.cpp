@@ -769,6 +769,19 @@ extern "C" int32_t vra_engine_finalize_weights(void* e) {
   }
   return en->finalize() ? 0 : -1;
 }
+extern "C" int32_t vra_engine_copy_logits(void* e, float* h_out, int32_t n_seqs) {
+  auto* en = static_cast<Engine*>(e);
+  if (en->dry() || !en->sched_ || !h_out || n_seqs < 1 || n_seqs > en->max_seqs_) {
+    en->error = "vra_engine_copy_logits: finalised GPU engine and 1..max_num_seqs rows";
+    return -1;
+  }
+  if (hipMemcpyAsync(h_out, en->model_.logits(), (size_t)n_seqs * en->mc_.vocab_size * 4, hipMemcpyDeviceToHost, en->stream_) != hipSuccess ||
+      hipStreamSynchronize(en->stream_) != hipSuccess) {
+    en->error = "vra_engine_copy_logits: copy failed";
+    return -1;
+  }
+  return 0;
+}
 extern "C" int32_t vra_engine_finalize_model(void* e) {
   auto* en = static_cast<Engine*>(e);
   if (en->dry()) return 0;
