@@ -5,7 +5,10 @@ node, synthetic weights/prompts of that shape (SURVEY.md §8d recipe).
 A "step" = one decode step of the running batch through the whole engine (scheduler, metadata upload, hipGraph replay of
 the forward, argmax, token download).  Weights and KV cache are resident in HBM when the timed region starts.  At N > 1
 every rank is an independent replica (the 8B model fits one GPU: north_star asks for TP only "where the model is too
-large") — no data-path collective, scaling "weak".  `--tp N` instead runs ONE tensor-parallel engine over N ranks
+large") — no data-path collective, scaling "weak".  `--gpus N` run directly spawns its own N ranks (one process per
+GPU); under `python -m torch.distributed.run` the launcher's RANK / LOCAL_RANK / WORLD_SIZE are used.  The barrier and the
+max-over-ranks of the contract run over a Unix socket between the ranks of the node (NodeRendezvous): no PyTorch in the
+harness of a no-PyTorch product.  `--tp N` instead runs ONE tensor-parallel engine over N ranks
 (BASELINE config 4's mechanics: RCCL + one-shot all-reduce, vllm_rs_amd/runner.py) and reports its tokens/s.
 
 Prints ONE JSON line on rank 0.  Extra legs (not in the timed region): the roofline of the dequant-GEMM family (HIP-event
@@ -40,6 +43,7 @@ def parse():
     ap.add_argument("--model", default="llama3-8b-gptq")
     ap.add_argument("--no-extras", action="store_true", help="skip the roofline / bs=32 / TTFT / ffi / qwen / cpu legs")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the full-depth parity leg (the oracle over all layers, ~20 s)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches (rocprofv3 kernel tracing crashes on hipGraph replay)")
     ap.add_argument("--blocks", type=int, default=8192, help="KV blocks (64 tokens each); 0 = kv_fraction of free HBM")
     ap.add_argument("--tp", type=int, default=0, help="run ONE tensor-parallel engine over this many ranks (spawns its own runner processes)")
@@ -114,9 +118,11 @@ def pmc_traffic(kernel):
     with a library built from these very sources (the source hash, and the .so hash of that build, are stored next to the
     counters): a kernel change can never leave a stale number in the line."""
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc.json")))
         if pmc.get("src_sha16") != src_sha16() and pmc.get("lib_sha16") != lib_sha16():
             return None
+        if kernel == "family":  # the four launches of a layer: norm+qkv, o_proj, down (<..,1,..>) and the gate/up pair (<..,2,..>)
+            return 3 * pmc["kernels"]["gemv_q4s_kernel<BF16,1,false>"]["hbm_bytes_per_launch"] + pmc["kernels"]["gemv_q4s_kernel<BF16,2,false>"]["hbm_bytes_per_launch"]
         return pmc["kernels"][kernel]["hbm_bytes_per_launch"]
     except Exception:
         return None
@@ -250,29 +256,96 @@ def cpu_baseline(cfg_int4, cfg_tiny):
     return b, a
 
 
-def dist_init(world, local_rank, backend="nccl"):
-    """one process per GPU (torchrun env); backend "nccl" is RCCL on ROCm, "gloo" is used by the CPU tests."""
-    if world <= 1:
-        return None
-    import torch
-    import torch.distributed as dist_mod
-    if backend == "nccl":
-        torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        dist_mod.init_process_group(backend)
-    return dist_mod
+class NodeRendezvous:
+    """barrier + max-over-ranks for the ranks of ONE node over an abstract-namespace Unix socket: rank 0 listens on
+    "\\0vra-bench-<key>", the others connect (retrying until it is there).  key = VRA_BENCH_RDZV (self-spawned ranks) or
+    MASTER_PORT (torch.distributed.run).  world 1: no socket at all."""
+
+    def __init__(self, rank, world, key=None, timeout=600.0):
+        import socket
+        import struct
+        self.rank, self.world, self._struct = rank, world, struct
+        self.peers, self.sock = [], None
+        if world <= 1:
+            return
+        key = key or os.environ.get("VRA_BENCH_RDZV") or os.environ.get("MASTER_PORT") or "default"
+        addr = "\0vra-bench-" + str(key)
+        if rank == 0:
+            srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+            srv.bind(addr)
+            srv.listen(world)
+            srv.settimeout(timeout)
+            got = {}
+            while len(got) < world - 1:
+                c, _ = srv.accept()
+                c.settimeout(timeout)
+                r = struct.unpack("<i", self._recv(c, 4))[0]
+                got[r] = c
+            self.peers = [got[r] for r in sorted(got)]
+            srv.close()
+        else:
+            t0 = time.time()
+            while True:
+                try:
+                    self.sock = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+                    self.sock.connect(addr)
+                    break
+                except (FileNotFoundError, ConnectionRefusedError):
+                    self.sock.close()
+                    if time.time() - t0 > timeout:
+                        raise TimeoutError("rank 0 of the bench never opened the rendezvous socket")
+                    time.sleep(0.05)
+            self.sock.settimeout(timeout)
+            self.sock.sendall(struct.pack("<i", rank))
+
+    @staticmethod
+    def _recv(c, n):
+        b = b""
+        while len(b) < n:
+            k = c.recv(n - len(b))
+            if not k:
+                raise ConnectionError("a rank of the bench went away")
+            b += k
+        return b
+
+    def max(self, x):
+        """the maximum of x over all ranks, on every rank (doubles as the barrier)"""
+        if self.world <= 1:
+            return float(x)
+        st = self._struct
+        if self.rank == 0:
+            m = max([float(x)] + [st.unpack("<d", self._recv(c, 8))[0] for c in self.peers])
+            for c in self.peers:
+                c.sendall(st.pack("<d", m))
+            return m
+        self.sock.sendall(st.pack("<d", float(x)))
+        return st.unpack("<d", self._recv(self.sock, 8))[0]
+
+    def barrier(self):
+        self.max(0.0)
+
+    def close(self):
+        for c in self.peers + ([self.sock] if self.sock else []):
+            c.close()
+        self.peers, self.sock = [], None
 
 
-def max_over_ranks(dist, seconds):
+def max_over_ranks(rdzv, seconds):
     """the job's time is the slowest rank's time."""
-    if dist is None:
-        return seconds
-    import torch
-    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-    t = torch.tensor([seconds], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item())
+    return float(seconds) if rdzv is None else rdzv.max(seconds)
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: one process per GPU, this script again with the launcher's environment
+    variables; rank 0 prints the JSON line.  Returns the worst exit code."""
+    import subprocess
+    import uuid
+    key = uuid.uuid4().hex[:12]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), VRA_BENCH_RDZV=key, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    return max(abs(p.wait()) for p in procs)
 
 
 def tp_main(a):
@@ -301,9 +374,13 @@ def main():
     a = parse()
     if a.tp > 1:
         return tp_main(a)
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        raise SystemExit(spawn_ranks(a.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s): the line would not be the one asked for")
     ncpu = os.cpu_count() or 1
     os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(ncpu // max(world, 1), 128))))
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")
@@ -311,17 +388,16 @@ def main():
     from vllm_rs_amd import _lib
     from vllm_rs_amd import engine as E
     L = _lib.load()
-    dist = dist_init(world, local_rank)
     if L.vra_device_count() <= local_rank:
-        raise SystemExit("bench.py needs a GPU: no HIP device for this rank (the product has no CPU fallback)")
+        raise SystemExit(f"bench.py needs {world} GPU(s): no HIP device for rank {local_rank} (the product has no CPU fallback)")
     L.vra_set_device(local_rank)
+    dist = NodeRendezvous(rank, world) if world > 1 else None
 
-    def sync():
+    def sync():  # barrier + device synchronisation on both sides of the timed region
         L.vra_device_sync()
         if dist is not None:
-            import torch
             dist.barrier()
-            torch.cuda.synchronize()
+            L.vra_device_sync()
 
     models = {"llama3-8b-gptq": E.LLAMA3_8B, "qwen2-7b-awq": E.QWEN2_7B, "llama3-70b-tp8-rank": E.LLAMA3_70B_TP8_RANK}
     cfg = dict(models[a.model])
@@ -361,10 +437,17 @@ def main():
             tot_ms += ms
         dom_name = max(per, key=lambda k: per[k]["ms"])
         dom = per[dom_name]
-        line["roofline"] = {"bound": "hbm", "kernel": f"{dom['kernel']} ({dom_name}: the launch with the largest share of the family's time)",
-                            "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS,
-                            "traffic": pmc_traffic(dom["kernel"]) if a.batch == 1 else None,
-                            "algorithmic_bytes_per_launch": dom["bytes"], "avg_launch_ms": dom["ms"],
+        # `achieved` / `frac` are the FAMILY's (the four dequant-GEMV launches of a layer = what north_star grades): algorithmic
+        # bytes of the four launches / the sum of their average durations.  The time-dominant single launch is listed beside it.
+        line["roofline"] = {"bound": "hbm", "kernel": "dequant-GEMV family: gemv_q4s_kernel<BF16,1,false> x3 (norm+qkv, o_proj, down) + "
+                                                       "gemv_q4s_kernel<BF16,2,false> (norm+gate/up+SiLU*mul) per layer",
+                            "achieved": tot_b / tot_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": tot_b / tot_ms / 1e6 / HBM_PEAK_GBS,
+                            "traffic": pmc_traffic("family") if a.batch == 1 else None,
+                            "algorithmic_bytes_per_launch": tot_b, "avg_launch_ms": tot_ms,
+                            "note": "per 'launch' = the four launches of one layer (113 475 584 B); traffic = their FETCH_SIZE x 2 from the committed counter pass",
+                            "time_dominant_launch": {"name": dom_name, "kernel": dom["kernel"], "GBps": dom["GBps"], "frac": dom["GBps"] / HBM_PEAK_GBS,
+                                                     "avg_launch_ms": dom["ms"], "algorithmic_bytes_per_launch": dom["bytes"],
+                                                     "traffic": pmc_traffic(dom["kernel"]) if a.batch == 1 else None},
                             "family": per, "family_GBps": tot_b / tot_ms / 1e6, "family_frac": tot_b / tot_ms / 1e6 / HBM_PEAK_GBS,
                             "family_ms_per_token": tot_ms * cfg["num_layers"], "lib_sha16": lib_sha16(), "src_sha16": src_sha16()}
         # ---------------- bs=32 decode
@@ -372,6 +455,16 @@ def main():
             dt32, _, _ = run_decode(eng, make_prompts(32, a.prompt_len, V, seed=43), 8, 64, lambda: L.vra_device_sync())
             line["bs32_tokens_per_s_per_gpu"] = 32 * 64 / dt32
             line["bs32_ms_per_step"] = dt32 * 1e3 / 64
+            per32, b32, ms32 = {}, 0.0, 0.0
+            for w, name in FAMILY.items():
+                ms = eng.bench_gemm(w, 32, 160)
+                b = eng.gemm_bytes(w, 32)
+                per32[name] = {"ms": ms, "bytes": b, "GBps": b / ms / 1e6}
+                b32 += b
+                ms32 += ms
+            line["roofline_bs32"] = {"bound": "hbm", "kernel": "dequant-GEMM family at 32 rows (gemv_q4w_kernel qkv / o_proj, gemm_q4_kernel gate/up / down)",
+                                     "achieved": b32 / ms32 / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b32 / ms32 / 1e6 / HBM_PEAK_GBS,
+                                     "family": per32, "family_ms_per_step": ms32 * cfg["num_layers"], "step_ms": dt32 * 1e3 / 64}
         # ---------------- the KV term ("also ctx in {1k, 8k}"): decode at long contexts
         lc = {}
         for bs, ctx in ((1, 1024), (1, 8000), (32, 1024), (32, 4096)):
@@ -432,12 +525,21 @@ def main():
             eq.close()
         if world == 1 and not a.no_cpu:
             line["cpu_baseline"], line["cpu_baseline_config1"] = cpu_baseline(E.LLAMA3_8B, E.TINYLLAMA)
+            if a.model == "llama3-8b-gptq" and not a.no_parity:
+                # ---------------- full-depth parity of the configuration that was just timed (graph path, L = 32, V = 128256): the
+                # oracle as the checker (tests/full_depth.py), ~20 s of host time
+                from tests import full_depth
+                rep = full_depth.run(dict(cfg), log=lambda *_: None)
+                line["parity_full_depth"] = {k: rep[k] for k in ("workload", "tokens_equal", "first_divergence", "n_steps", "max_abs", "mean_abs",
+                                                                   "min_frac_within_1e3_abs", "min_frac_within_1e3_of_scale", "max_ulp_of_row_scale",
+                                                                   "logit_scale", "per_step_max_abs", "seconds")}
     if eng is not None:
         eng.close()
     if dist is not None:
         dist.barrier()
-        dist.destroy_process_group()
+        dist.close()
     if rank == 0:
+        assert line["n_gpus"] == a.gpus
         print(json.dumps(line))
 
 

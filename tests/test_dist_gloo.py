@@ -30,7 +30,7 @@ def _init(rank, world, port):
 def _bench_worker(rank, world, port, q):
     _init(rank, world, port)
     import bench
-    d = bench.dist_init(world, rank, backend="gloo")
+    d = bench.NodeRendezvous(rank, world)   # key = MASTER_PORT, as under torch.distributed.run
     d.barrier()
     local_s = 0.5 + 0.25 * rank            # rank 1 is the slow one
     t = bench.max_over_ranks(d, local_s)
@@ -39,7 +39,7 @@ def _bench_worker(rank, world, port, q):
     d.barrier()
     if rank == 0:
         q.put((t, value))
-    d.destroy_process_group()
+    d.close()
 
 
 def test_bench_aggregation_two_ranks():
@@ -55,7 +55,24 @@ def test_bench_aggregation_two_ranks():
 
 def test_single_rank_needs_no_process_group():
     import bench
-    assert bench.dist_init(1, 0) is None and bench.max_over_ranks(None, 1.25) == 1.25
+    assert bench.max_over_ranks(None, 1.25) == 1.25 and bench.NodeRendezvous(0, 1).max(2.5) == 2.5
+
+
+def test_bench_gpus_n_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` without a launcher starts two ranks of itself (RANK / LOCAL_RANK / WORLD_SIZE + a private
+    rendezvous key); here, without GPUs, each rank stops at the device check — after the spawn, with its rank in the message"""
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "VRA_BENCH_RDZV"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extras"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode != 0
+    assert "no HIP device for rank 0" in p.stderr and "no HIP device for rank 1" in p.stderr, p.stderr[-2000:]
+    # a launcher that started another number of ranks than --gpus asks for is an error, not a silently different line
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--no-extras"], capture_output=True, text=True,
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), timeout=120)
+    assert p.returncode != 0 and "--gpus 4 but the launcher started 2" in p.stderr
 
 
 def _shard_cols(q, rank, world):

@@ -147,6 +147,25 @@ def test_all_reduce_against_numpy(transport, world):
             assert all((g == want2).all() for g in got), (rows, cols, dt, "fused epilogue")
 
 
+@pytest.mark.skipif(_ndev() < 2, reason="needs two GPUs: the one-shot exchange between DIFFERENT devices (a single-GPU box runs the ranks on one)")
+def test_oneshot_exchange_between_two_devices_many_launches_and_graph_replays():
+    """what a single-GPU box cannot execute: peers on OTHER devices polling each other's fine-grained exchange region
+    mid-kernel over xGMI — hipIpcOpenMemHandle across devices, 10 000 one-shot all-reduces, then a TP = 2 engine whose decode
+    steps replay the all-reduce from hipGraphs; sums bit-identical on both ranks throughout"""
+    cfg = small_cfg(quant_method="gptq")
+    w = om.make_random_checkpoint(cfg, 2)
+    r = np.random.default_rng(11)
+    with TPEngine(cfg, 2, devices=[0, 1], transport="ipc", tensors=w, num_gpu_blocks=32, max_num_seqs=4, max_model_len=512, use_graph=True) as tp:
+        data = [orc.to_dt(r.standard_normal((1, 8192)).astype(np.float32), BF16) for _ in range(2)]
+        want = orc.to_dt(orc.from_dt(data[0], BF16) + orc.from_dt(data[1], BF16), BF16)
+        got = tp.all_reduce(data, BF16, reps=10000)
+        assert all((g == want).all() for g in got)
+        outs = tp.generate([list(range(5, 60))], max_tokens=200, ignore_eos=True)
+        assert [list(o[0]) for o in outs][0] == [list(o[0]) for o in outs][1]
+    oracle = om.OracleModel(cfg, w, num_blocks=32, tp_world=2)
+    del oracle
+
+
 def test_tp_preconditions_fail_loudly():
     """kv_head_shard bails (distributed.rs:513-536), uneven shards, a missing communicator and an unset block count"""
     from vllm_rs_amd.engine import Engine

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""gpurun_out/prof_* (tools/collect_profiles.sh) -> profiles/r02_*.txt and profiles/r02_pmc.json.
+"""gpurun_out/prof_* (tools/collect_profiles.sh) -> profiles/r03_*.txt and profiles/r03_pmc.json.
 
-r02_pmc.json carries the .so hash the counters were taken with: bench.py reports `roofline.traffic` only when the library it
+r03_pmc.json carries the .so hash the counters were taken with: bench.py reports `roofline.traffic` only when the library it
 runs is that very library (a kernel change can never leave a stale number in the driver's line).
 HBM bytes per launch = FETCH_SIZE [KiB] * 1024 * 2 — the gfx950 correction of MI355X_MICROARCH.md (HBM section): FETCH_SIZE reports
 half of the bytes of a wide coalesced read.  WRITE_SIZE is reported as measured (uncalibrated on this part)."""
@@ -29,11 +29,11 @@ def parse_pmc(path):
 
 def main():
     os.makedirs(P, exist_ok=True)
-    copies = {"prof_trace_bs1.summary.txt": "r02_decode_bs1_kernel_trace.txt", "prof_trace_bs32.summary.txt": "r02_decode_bs32_kernel_trace.txt",
-              "prof_trace_prefill.summary.txt": "r02_prefill_4096_kernel_trace.txt", "prof_pmc_fetch_bs1.summary.txt": "r02_pmc_fetch_size_decode_bs1.txt",
-              "prof_pmc_write_bs1.summary.txt": "r02_pmc_write_size_decode_bs1.txt", "prof_pmc_mfma_bs1.summary.txt": "r02_pmc_mfma_decode_bs1.txt",
-              "prof_pmc_mfma_bs32.summary.txt": "r02_pmc_mfma_decode_bs32.txt", "prof_pmc_fetch_bs32.summary.txt": "r02_pmc_fetch_size_decode_bs32.txt",
-              "prof_pmc_mfma_prefill.summary.txt": "r02_pmc_mfma_prefill_4096.txt", "prof_counters_available.txt": "r02_counters_available.txt"}
+    copies = {"prof_trace_bs1.summary.txt": "r03_decode_bs1_kernel_trace.txt", "prof_trace_bs32.summary.txt": "r03_decode_bs32_kernel_trace.txt",
+              "prof_trace_prefill.summary.txt": "r03_prefill_4096_kernel_trace.txt", "prof_pmc_fetch_bs1.summary.txt": "r03_pmc_fetch_size_decode_bs1.txt",
+              "prof_pmc_write_bs1.summary.txt": "r03_pmc_write_size_decode_bs1.txt", "prof_pmc_mfma_bs1.summary.txt": "r03_pmc_mfma_decode_bs1.txt",
+              "prof_pmc_mfma_bs32.summary.txt": "r03_pmc_mfma_decode_bs32.txt", "prof_pmc_fetch_bs32.summary.txt": "r03_pmc_fetch_size_decode_bs32.txt",
+              "prof_pmc_mfma_prefill.summary.txt": "r03_pmc_mfma_prefill_4096.txt", "prof_counters_available.txt": "r03_counters_available.txt"}
     notes = {"trace": "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 32 --warmup 4 --batch {B} --no-graph --no-extras (eager launches; includes the "
                       "one-time weight-fill and prefill kernels), summarised by tools/rocpd_stats.py\n",
              "pmc": "# rocprofv3 --pmc <counters> -- python bench.py --steps 32 --warmup 4 --batch {B} --no-graph --no-extras (counter pass on its own: no trace "
@@ -68,10 +68,10 @@ def main():
         kernels.setdefault(k, {})[c + "_avg"] = val
     # kernel names as bench.py spells them (no spaces inside the template list)
     kernels = {re.sub(r",\s+", ",", k): v for k, v in kernels.items()}
-    json.dump({"source": "profiles/r02_pmc_*_decode_bs1.txt (rocprofv3 --pmc, one counter set per pass)", "lib_sha16": sha, "src_sha16": src_sha,
+    json.dump({"source": "profiles/r03_pmc_*_decode_bs1.txt (rocprofv3 --pmc, one counter set per pass)", "lib_sha16": sha, "src_sha16": src_sha,
                "correction": "hbm_bytes_per_launch = FETCH_SIZE[KiB] * 1024 * 2 (gfx950 reports half of a wide coalesced read: MI355X_MICROARCH.md HBM section)",
-               "kernels": kernels}, open(os.path.join(P, "r02_pmc.json"), "w"), indent=1)
-    print("wrote r02_pmc.json with", len(kernels), "kernels; lib", sha)
+               "kernels": kernels}, open(os.path.join(P, "r03_pmc.json"), "w"), indent=1)
+    print("wrote r03_pmc.json with", len(kernels), "kernels; lib", sha)
 
 
 if __name__ == "__main__":

@@ -252,7 +252,21 @@ extern "C" void* vra_comm_ipc_begin(void* comm, int32_t rank, int32_t world_size
     if (own) delete c;
     return nullptr;
   };
-  hipError_t e = hipMalloc((void**)&c->local, OS_REGION_BYTES);
+  // The region is polled by kernels on OTHER devices while this device's kernels write it: fine-grained (uncached) device
+  // memory, so that a peer's loads over xGMI never see a line parked in this device's L2 and stores become visible without a
+  // kernel boundary.  (Plain hipMalloc memory is coarse-grained: coherent at kernel boundaries only — it worked for ranks that
+  // share ONE device, which is all a single-GPU test box can run.)  Falls back to hipMalloc where the runtime refuses the flag.
+  hipError_t e = hipExtMallocWithFlags((void**)&c->local, OS_REGION_BYTES, hipDeviceMallocUncached);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    c->local = nullptr;
+    e = hipExtMallocWithFlags((void**)&c->local, OS_REGION_BYTES, hipDeviceMallocFinegrained);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    c->local = nullptr;
+    e = hipMalloc((void**)&c->local, OS_REGION_BYTES);
+  }
   if (e != hipSuccess) return fail("hipMalloc(exchange region)", e);
   if ((e = hipMemset(c->local, 0, OS_REGION_BYTES)) != hipSuccess) return fail("hipMemset", e);
   if ((e = hipMalloc((void**)&c->epochs, (OS_MAX_WG + 16) * 4)) != hipSuccess) return fail("hipMalloc(epochs)", e);
