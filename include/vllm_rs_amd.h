@@ -332,7 +332,7 @@ typedef struct vra_model_config {
   int32_t max_position_embeddings;
   float rms_norm_eps;
   double rope_theta;
-  int32_t rope_scaling_type; /* 0 none/default, 1 linear, 2 llama3 */
+  int32_t rope_scaling_type; /* 0 none/default, 1 linear, 2 llama3, 3 dynamic (NTK), 4 yarn  (rotary_emb.rs:143-415) */
   double rope_factor, rope_low_freq_factor, rope_high_freq_factor;
   int32_t rope_original_max_position;
   int32_t attention_bias;    /* qkv bias (qwen2 default true, attention.rs:411-415) */
@@ -340,6 +340,12 @@ typedef struct vra_model_config {
   int32_t bits, group_size;
   int32_t dtype;             /* VRA_BF16 / VRA_F16 */
   int32_t tie_word_embeddings;
+  /* rope_scaling of the dynamic / yarn types (appended: older callers that zero-initialise the struct keep their meaning).
+   * dynamic: rope_dynamic_alpha != 0 => `alpha` form (theta' = (theta*alpha)^(d/(d-2)), alpha in rope_factor), else the `factor`
+   * form (rotary_emb.rs:281-333).  yarn (rotary_emb.rs:335-415,435-541): 0 in a field = the reference's default
+   * (beta_fast 32, beta_slow 1, attn_factor 1, extrapolation_factor 1). */
+  int32_t rope_dynamic_alpha;
+  double rope_yarn_beta_fast, rope_yarn_beta_slow, rope_yarn_attn_factor, rope_yarn_extrapolation_factor;
 } vra_model_config;
 
 typedef struct vra_engine_config {

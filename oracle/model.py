@@ -75,10 +75,16 @@ class OracleModel:
         self.kc = [np.zeros((num_blocks, Hkv, block_size, D), cdt) for _ in range(L)]
         self.vc = [np.zeros((num_blocks, Hkv, D, block_size), cdt) for _ in range(L)]
         rs = cfg.get("rope_scaling") or {}
-        st = {"": 0, "default": 0, "linear": 1, "llama3": 2}[rs.get("rope_type", "")]
-        cos, sin = orc.rope_tables(D, cfg["rope_theta"], cfg["max_position_embeddings"], st, rs.get("factor", 1.0),
-                                   rs.get("low_freq_factor", 1.0), rs.get("high_freq_factor", 4.0),
-                                   rs.get("original_max_position_embeddings", cfg["max_position_embeddings"]))
+        st = {"": 0, "default": 0, "linear": 1, "llama3": 2, "dynamic": 3, "yarn": 4}[rs.get("rope_type", rs.get("type", ""))]
+        # rotary_emb.rs:150-164: the key, else max_position_embeddings / factor, else max_position_embeddings
+        omax = rs.get("original_max_position_embeddings") or (cfg["max_position_embeddings"] / rs["factor"] if rs.get("factor") else cfg["max_position_embeddings"])
+        if st >= 3:
+            cos, sin = orc.rope_tables_ext(D, cfg["rope_theta"], cfg["max_position_embeddings"], st, rs.get("alpha", rs.get("factor", 1.0)), int(omax),
+                                           "alpha" in rs, rs.get("beta_fast", 32.0), rs.get("beta_slow", 1.0), rs.get("attn_factor", 1.0),
+                                           rs.get("extrapolation_factor", 1.0))
+        else:
+            cos, sin = orc.rope_tables(D, cfg["rope_theta"], cfg["max_position_embeddings"], st, rs.get("factor", 1.0),
+                                       rs.get("low_freq_factor", 1.0), rs.get("high_freq_factor", 4.0), int(omax))
         self.cos, self.sin = orc.to_dt(cos, dt), orc.to_dt(sin, dt)  # tables cast to the model dtype (llama.rs:179-189)
         self.layers = []
         for i in range(L):

@@ -273,6 +273,17 @@ def rope_tables(rot_dim, theta, n_pos, scaling_type=0, factor=1.0, low=1.0, high
     return cos, sin
 
 
+def rope_tables_ext(rot_dim, theta, n_pos, scaling_type, factor, orig_max, dynamic_alpha=False, beta_fast=32.0, beta_slow=1.0, attn_factor=1.0,
+                    extrapolation_factor=1.0):
+    """scaling_type 3 = dynamic (NTK; `alpha` form when dynamic_alpha), 4 = yarn (rotary_emb.rs:281-415,435-541)"""
+    cos = np.empty((n_pos, rot_dim // 2), np.float32)
+    sin = np.empty((n_pos, rot_dim // 2), np.float32)
+    lib().orc_rope_tables_ext(rot_dim, C.c_double(theta), scaling_type, C.c_double(factor), int(bool(dynamic_alpha)), C.c_double(orig_max),
+                              C.c_double(beta_fast), C.c_double(beta_slow), C.c_double(attn_factor), C.c_double(extrapolation_factor), n_pos,
+                              _p(cos), _p(sin))
+    return cos, sin
+
+
 def rope(x, cos, sin, positions, is_interleaved, dt, table_dt, rot_dim=None):
     """x [T,heads,D] (copied), returns rotated copy."""
     x = np.array(x, copy=True)

@@ -464,7 +464,7 @@ void orc_embedding(const uint32_t* ids, const void* table, int T, int H, int dt,
  * 143-278): inv_freq = 1f32 / (theta^(i/d) computed in f64, cast to f32); llama3 smoothing in
  * f32; freqs = pos(f32) * inv_freq (f32); tables are cos/sin of that, returned in f32 (the caller
  * rounds to the model dtype as the reference does, llama.rs:179-189).
- * scaling_type: 0 default, 1 linear (inv_freq / factor), 2 llama3. */
+ * scaling_type: 0 default, 1 linear (inv_freq / factor), 2 llama3; 3 dynamic and 4 yarn through orc_rope_tables_ext. */
 void orc_rope_tables(int rot_dim, double theta, int scaling_type, double factor, double low_freq_factor,
                      double high_freq_factor, double original_max_pos, int n_pos, float* cosv,
                      float* sinv) {
@@ -493,6 +493,56 @@ void orc_rope_tables(int rot_dim, double theta, int scaling_type, double factor,
       float ang = (float)p * inv[i];
       cosv[(int64_t)p * half + i] = cosf(ang);
       sinv[(int64_t)p * half + i] = sinf(ang);
+    }
+  free(inv);
+}
+/* "dynamic" (rotary_emb.rs:281-333) and "yarn" (rotary_emb.rs:335-415 + YarnRotaryEmbedding, :435-541).
+ * dynamic: the DEFAULT table of a rescaled base, base' = (base * s)^(d/(d-2)) with s = alpha, or for the `factor` form
+ *   s = factor * max_len / orig - (factor - 1), max_len = (u32)(orig * factor); all in f64, then the f32 inverse frequencies.
+ * yarn: f32 throughout.  freq_extra_i = 1/base^(2i/d), freq_inter_i = 1/(factor * base^(2i/d));
+ *   low = max(floor(cd(beta_fast)), 0), high = min(ceil(cd(beta_slow)), d-1), cd(r) = d*ln(orig/(2*pi*r)) / (2*ln(base));
+ *   ramp_i = clamp((i - low) * (f32)(1/(high-low)), 0, 1) over i < d/2 (high += 0.001 when equal);
+ *   mask = (1 - ramp) * extrapolation_factor;  inv_freq = inter*(1-mask) + extra*mask;
+ *   cos/sin of pos*inv_freq times mscale = (factor <= 1 ? 1 : 0.1*ln(factor)+1) * attn_factor. */
+void orc_rope_tables_ext(int rot_dim, double theta, int scaling_type, double factor, int dynamic_alpha, double original_max_pos,
+                         double beta_fast, double beta_slow, double attn_factor, double extrapolation_factor, int n_pos, float* cosv,
+                         float* sinv) {
+  int half = rot_dim / 2;
+  float* inv = (float*)malloc(sizeof(float) * half);
+  float mscale = 1.0f;
+  if (scaling_type == 3) {
+    double s = factor;
+    if (!dynamic_alpha) {
+      uint32_t max_len = (uint32_t)(original_max_pos * factor);
+      s = (factor * (double)max_len / original_max_pos) - (factor - 1.0);
+    }
+    double base = pow(theta * s, (double)rot_dim / (double)(rot_dim - 2));
+    for (int i = 0; i < half; i++) inv[i] = 1.0f / (float)pow(base, (double)(2 * i) / (double)rot_dim);
+  } else {
+    float base = (float)theta, fac = (float)factor;
+    float two_pi = 2.0f * 3.14159265358979323846f;
+    float cd_fast = ((float)rot_dim * logf((float)(size_t)original_max_pos / ((float)beta_fast * two_pi))) / (2.0f * logf(base));
+    float cd_slow = ((float)rot_dim * logf((float)(size_t)original_max_pos / ((float)beta_slow * two_pi))) / (2.0f * logf(base));
+    float low = floorf(cd_fast), high = ceilf(cd_slow);
+    if (low < 0.0f) low = 0.0f;
+    if (high > (float)rot_dim - 1.0f) high = (float)rot_dim - 1.0f;
+    if (low == high) high += 0.001f;
+    float rmul = (float)(1.0 / ((double)high - (double)low));
+    for (int i = 0; i < half; i++) {
+      float pw = powf(base, (float)(2 * i) / (float)rot_dim);
+      float extra = 1.0f / pw, inter = 1.0f / (fac * pw);
+      float ramp = ((float)i - low) * rmul;
+      ramp = ramp < 0.0f ? 0.0f : (ramp > 1.0f ? 1.0f : ramp);
+      float mask = (1.0f - ramp) * (float)extrapolation_factor;
+      inv[i] = inter * (1.0f - mask) + extra * mask;
+    }
+    mscale = (fac <= 1.0f ? 1.0f : 0.1f * logf(fac) + 1.0f) * (float)attn_factor;
+  }
+  for (int p = 0; p < n_pos; p++)
+    for (int i = 0; i < half; i++) {
+      float ang = (float)p * inv[i];
+      cosv[(int64_t)p * half + i] = scaling_type == 4 ? cosf(ang) * mscale : cosf(ang);
+      sinv[(int64_t)p * half + i] = scaling_type == 4 ? sinf(ang) * mscale : sinf(ang);
     }
   free(inv);
 }

@@ -78,7 +78,8 @@ def check_logits(got, ref, name, dt=BF16, max_ulps=None):
     return worst
 
 
-@pytest.mark.parametrize("variant", ["llama_gptq", "qwen2_awq", "dense_bf16", "gptq_f16", "llama3_rope", "tinyllama_shape", "qwen2_7b_shape", "llama3_8b_shape"])
+@pytest.mark.parametrize("variant", ["llama_gptq", "qwen2_awq", "dense_bf16", "gptq_f16", "llama3_rope", "yarn_rope", "dynamic_rope", "tinyllama_shape", "qwen2_7b_shape",
+                                     "llama3_8b_shape"])
 def test_forward_prefill_then_decode(variant):
     cfg = {
         # BASELINE.json configs 1 and 3 at their real widths (fewer layers, smaller vocabulary for the AWQ one): TinyLlama-1.1B
@@ -93,6 +94,8 @@ def test_forward_prefill_then_decode(variant):
         "qwen2_awq": small_cfg(arch="qwen2", quant_method="awq", attention_bias=True, num_heads=8, num_kv_heads=2, head_dim=32 * 2, hidden_size=512),
         "dense_bf16": small_cfg(quant_method=None, tie_word_embeddings=True),
         "gptq_f16": small_cfg(dtype=F16),
+        "yarn_rope": small_cfg(rope_scaling=dict(rope_type="yarn", factor=4.0, original_max_position_embeddings=128, beta_fast=32.0, beta_slow=1.0)),
+        "dynamic_rope": small_cfg(rope_scaling=dict(rope_type="dynamic", factor=4.0, original_max_position_embeddings=128)),
         "llama3_rope": small_cfg(rope_theta=500000.0, rope_scaling=dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0, original_max_position_embeddings=128)),
     }[variant]
     eng, oracle = build(cfg, seed=3)

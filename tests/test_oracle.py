@@ -315,3 +315,47 @@ def test_oracle_quantized_model_consistent_with_its_dequantized_twin():
         a = OracleModel(cfg, w, 4, 8).forward(*args)
         b = OracleModel(dict(cfg, quant_method=None), dense, 4, 8).forward(*args)
         assert np.abs(a - b).max() / np.abs(b).max() < 5e-3, qm
+
+
+def test_rope_tables_dynamic_and_yarn_bit_exact_host_vs_oracle_and_numpy_kat():
+    """rotary_emb.rs:281-415,435-541: the product's table builder (vra_rope_tables_f32, host code: no GPU) against the oracle's
+    restatement, bit for bit, and both against a third evaluation in numpy float32 of the published formulas"""
+    import ctypes as C
+
+    from vllm_rs_amd import _lib
+    from vllm_rs_amd.engine import model_config
+    L = _lib.load()
+    base = dict(hidden_size=256, intermediate_size=512, num_layers=1, num_heads=4, num_kv_heads=2, head_dim=64, vocab_size=512,
+                max_position_embeddings=4096, rms_norm_eps=1e-5, rope_theta=10000.0)
+    f32 = np.float32
+    for rs in (dict(rope_type="dynamic", factor=4.0, original_max_position_embeddings=1024), dict(rope_type="dynamic", alpha=2.5),
+               dict(rope_type="dynamic", factor=2.0),  # no original_max_position_embeddings: max_position_embeddings / factor (rotary_emb.rs:150-164)
+               dict(rope_type="yarn", factor=4.0, original_max_position_embeddings=1024),
+               dict(rope_type="yarn", factor=8.0, original_max_position_embeddings=512, beta_fast=16.0, beta_slow=2.0, attn_factor=0.9)):
+        mc = model_config(dict(base, rope_scaling=rs))
+        n, d = 4096, 64
+        c, s_ = np.empty((n, d // 2), f32), np.empty((n, d // 2), f32)
+        L.vra_rope_tables_f32(C.byref(mc), n, c.ctypes.data_as(C.c_void_p), s_.ctypes.data_as(C.c_void_p))
+        st = {"dynamic": 3, "yarn": 4}[rs["rope_type"]]
+        omax = mc.rope_original_max_position
+        oc, os_ = orc.rope_tables_ext(d, 10000.0, n, st, rs.get("alpha", rs.get("factor", 1.0)), omax, "alpha" in rs, rs.get("beta_fast", 32.0),
+                                      rs.get("beta_slow", 1.0), rs.get("attn_factor", 1.0), rs.get("extrapolation_factor", 1.0))
+        assert np.array_equal(c.view(np.uint32), oc.view(np.uint32)) and np.array_equal(s_.view(np.uint32), os_.view(np.uint32)), rs
+        # ---- numpy restatement (same formulas, numpy's float32 elementary functions): agreement to a few float32 ulps of the angle
+        i = np.arange(0, d, 2)
+        if st == 3:
+            fct = rs.get("alpha", rs.get("factor"))
+            sc = fct if "alpha" in rs else fct * int(omax * fct) / omax - (fct - 1.0)
+            inv = (f32(1.0) / (np.float64(10000.0 * sc) ** (d / (d - 2))) ** (i / d)).astype(f32) if False else (1.0 / ((10000.0 * sc) ** (d / (d - 2))) ** (i / d)).astype(f32)
+            ms = f32(1.0)
+        else:
+            fac, bf, bs = f32(rs["factor"]), f32(rs.get("beta_fast", 32.0)), f32(rs.get("beta_slow", 1.0))
+            pw = np.power(f32(10000.0), (i / d).astype(f32)).astype(f32)
+            cd = lambda r: f32(d) * np.log(f32(omax) / (r * f32(2.0 * np.pi)), dtype=f32) / (f32(2.0) * np.log(f32(10000.0), dtype=f32))
+            low, high = max(np.floor(cd(bf)), f32(0.0)), min(np.ceil(cd(bs)), f32(d - 1))
+            ramp = np.clip((np.arange(d // 2, dtype=f32) - low) * f32(1.0 / (float(high) - float(low))), 0, 1).astype(f32)
+            mask = ((f32(1.0) - ramp) * f32(rs.get("extrapolation_factor", 1.0))).astype(f32)
+            inv = ((f32(1.0) / (fac * pw)) * (f32(1.0) - mask) + (f32(1.0) / pw) * mask).astype(f32)
+            ms = f32((0.1 * np.log(fac, dtype=f32) + 1.0 if fac > 1 else 1.0)) * f32(rs.get("attn_factor", 1.0))
+        ang = (np.arange(n, dtype=f32)[:, None] * inv[None, :]).astype(f32)
+        assert np.abs(np.cos(ang) * ms - c).max() < 2e-3 and np.abs(np.sin(ang) * ms - s_).max() < 2e-3, rs  # |d angle| ~ 4096 * 1e-7 rad

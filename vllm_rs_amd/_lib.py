@@ -25,6 +25,8 @@ class ModelConfig(C.Structure):
         ("rope_high_freq_factor", C.c_double), ("rope_original_max_position", c_i32),
         ("attention_bias", c_i32), ("quant_method", c_i32), ("bits", c_i32), ("group_size", c_i32),
         ("dtype", c_i32), ("tie_word_embeddings", c_i32),
+        ("rope_dynamic_alpha", c_i32), ("rope_yarn_beta_fast", C.c_double), ("rope_yarn_beta_slow", C.c_double),
+        ("rope_yarn_attn_factor", C.c_double), ("rope_yarn_extrapolation_factor", C.c_double),
     ]
 
 

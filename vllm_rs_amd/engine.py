@@ -10,7 +10,7 @@ from ._lib import EngineConfig, ModelConfig
 
 BF16, F16, F32 = 0, 1, 2
 QUANT = {None: 0, "": 0, "none": 0, "gptq": 1, "awq": 2}
-ROPE = {None: 0, "": 0, "default": 0, "linear": 1, "llama3": 2}
+ROPE = {None: 0, "": 0, "default": 0, "linear": 1, "llama3": 2, "dynamic": 3, "yarn": 4}
 
 
 def model_config(cfg):
@@ -23,9 +23,13 @@ def model_config(cfg):
         num_heads=cfg["num_heads"], num_kv_heads=cfg["num_kv_heads"], head_dim=head_dim, vocab_size=cfg["vocab_size"],
         max_position_embeddings=cfg["max_position_embeddings"], rms_norm_eps=cfg["rms_norm_eps"],
         rope_theta=cfg["rope_theta"], rope_scaling_type=ROPE[rs.get("rope_type", rs.get("type", ""))],
-        rope_factor=rs.get("factor", 1.0), rope_low_freq_factor=rs.get("low_freq_factor", 1.0),
+        rope_factor=rs.get("alpha", rs.get("factor", 1.0)), rope_low_freq_factor=rs.get("low_freq_factor", 1.0),
         rope_high_freq_factor=rs.get("high_freq_factor", 4.0),
-        rope_original_max_position=rs.get("original_max_position_embeddings", cfg["max_position_embeddings"]),
+        # rotary_emb.rs:150-164: the key, else max_position_embeddings / factor, else max_position_embeddings
+        rope_original_max_position=int(rs.get("original_max_position_embeddings") or
+                                       (cfg["max_position_embeddings"] / rs["factor"] if rs.get("factor") else cfg["max_position_embeddings"])),
+        rope_dynamic_alpha=int("alpha" in rs), rope_yarn_beta_fast=rs.get("beta_fast", 32.0), rope_yarn_beta_slow=rs.get("beta_slow", 1.0),
+        rope_yarn_attn_factor=rs.get("attn_factor", 1.0), rope_yarn_extrapolation_factor=rs.get("extrapolation_factor", 1.0),
         attention_bias=int(bool(cfg.get("attention_bias"))), quant_method=QUANT[cfg.get("quant_method")],
         bits=4, group_size=cfg.get("group_size", 128), dtype=cfg.get("dtype", BF16),
         tie_word_embeddings=int(bool(cfg.get("tie_word_embeddings"))))
@@ -58,7 +62,7 @@ TINYLLAMA = dict(arch="llama", hidden_size=2048, intermediate_size=5632, num_lay
 class Engine:
     def __init__(self, cfg, *, block_size=64, max_num_seqs=32, max_model_len=0, num_gpu_blocks=0, kv_fraction=0.0,
                  prefill_chunk=8192, enable_prefix_cache=False, use_graph=True, tp_rank=0, tp_world_size=1, device=0,
-                 seed=1234, comm=None, fp8_kvcache=False, cpu_mem_fold=0.0, swap_cooling_ms=0, min_tokens_left_for_swap=0):
+                 seed=1234, comm=None, fp8_kvcache=False, cpu_mem_fold=0.2, swap_cooling_ms=0, min_tokens_left_for_swap=0):
         self.L = _lib.load()
         if self.L.vra_device_count() <= 0:
             raise RuntimeError("vllm_rs_amd.Engine needs a GPU: no HIP device visible (there is no CPU fallback)")
@@ -245,7 +249,7 @@ class HostEngine:
     Needs no GPU; used by the CPU parity tests of scheduler.rs / block_manager.rs / runner.rs behaviour."""
 
     def __init__(self, cfg, *, num_gpu_blocks, block_size=64, max_num_seqs=32, max_model_len=0, prefill_chunk=8192,
-                 enable_prefix_cache=False, cpu_mem_fold=0.0, swap_cooling_ms=0, min_tokens_left_for_swap=0):
+                 enable_prefix_cache=False, cpu_mem_fold=0.2, swap_cooling_ms=0, min_tokens_left_for_swap=0):
         self.L = _lib.load()
         self.mc = model_config(cfg)
         self.ec = EngineConfig(block_size=block_size, max_num_seqs=max_num_seqs, max_model_len=max_model_len,

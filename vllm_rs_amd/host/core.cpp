@@ -268,7 +268,12 @@ bool BlockManager::can_append(const Sequence& s) const {
   return free_count_ >= need;
 }
 bool BlockManager::may_append(Sequence& s) {
-  if (s.len() % block_size_ == 1) {  // approaching next block (:245-253)
+  // approaching next block (:245-253).  Deliberate fix of a reference defect: the reference pushes a block
+  // whenever len % BS == 1 — also for a sequence that was swapped out at such a length before it was scheduled: swap-out and
+  // swap-in both run ensure_allocate (scheduler.rs:886,917-921), so its table already HAS the block, the second one makes
+  // `block_table.last()` (the decode slot, runner.rs:1259-1262) point at a block the attention never reads.  A block is
+  // allocated only while the table is shorter than the sequence needs — identical in every other situation.
+  if (s.len() % block_size_ == 1 && (int)s.block_table.size() < s.num_blocks()) {
     const int id = pop_front();
     if (id < 0) return false;
     ref_[id] = 1;

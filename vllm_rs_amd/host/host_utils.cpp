@@ -27,17 +27,29 @@ extern "C" int64_t vra_kv_plan_num_blocks(const vra_model_config* mc, const vra_
   return (int64_t)((double)free_bytes * frac) / per;
 }
 
-// RotaryEmbedding::new / ScalingRotaryEmbedding::new (src/models/layers/rotary_emb.rs:32-73,143-278):
-// inv_freq = 1f32 / (theta^(i/d) in f64 → f32); linear: * (f32)(1/factor); llama3: wavelength
-// smoothing in f32; freqs = pos(f32) * inv_freq; cos/sin in f32.
+// RotaryEmbedding::new / ScalingRotaryEmbedding::new (src/models/layers/rotary_emb.rs:32-73,143-415,435-541):
+// inv_freq = 1f32 / (theta^(i/d) in f64 -> f32); linear: * (f32)(1/factor); llama3: wavelength smoothing in f32; dynamic
+// (NTK): the default table of a rescaled theta (f64); yarn: interpolation / extrapolation blend of two f32 frequency sets
+// behind a linear ramp, cos / sin scaled by mscale; freqs = pos(f32) * inv_freq; cos/sin in f32.
 extern "C" void vra_rope_tables_f32(const vra_model_config* mc, int32_t n_pos, float* h_cos, float* h_sin) {
   const int rot = mc->head_dim, half = rot / 2;
   std::vector<float> inv(half);
-  for (int i = 0; i < half; i++) inv[i] = 1.0f / (float)pow(mc->rope_theta, (double)(2 * i) / (double)rot);
+  const double omax = mc->rope_original_max_position > 0 ? mc->rope_original_max_position : mc->max_position_embeddings;
+  double theta = mc->rope_theta;
+  float mscale = 1.0f;
+  if (mc->rope_scaling_type == 3) {  // "dynamic" (rotary_emb.rs:281-333)
+    const double f = mc->rope_factor;
+    if (mc->rope_dynamic_alpha) {
+      theta = pow(theta * f, (double)rot / (double)(rot - 2));
+    } else {
+      const uint32_t max_len = (uint32_t)(omax * f);
+      theta = pow(theta * ((f * (double)max_len / omax) - (f - 1.0)), (double)rot / (double)(rot - 2));
+    }
+  }
+  for (int i = 0; i < half; i++) inv[i] = 1.0f / (float)pow(theta, (double)(2 * i) / (double)rot);
   if (mc->rope_scaling_type == 1) {
     for (int i = 0; i < half; i++) inv[i] = inv[i] * (float)(1.0 / mc->rope_factor);
   } else if (mc->rope_scaling_type == 2) {
-    const double omax = mc->rope_original_max_position > 0 ? mc->rope_original_max_position : mc->max_position_embeddings;
     const float low_wl = (float)(omax / mc->rope_low_freq_factor), high_wl = (float)(omax / mc->rope_high_freq_factor);
     for (int i = 0; i < half; i++) {
       const float freq = inv[i];
@@ -51,12 +63,34 @@ extern "C" void vra_rope_tables_f32(const vra_model_config* mc, int32_t n_pos, f
         inv[i] = (1.0f - smooth) * freq / (float)mc->rope_factor + smooth * freq;
       }
     }
+  } else if (mc->rope_scaling_type == 4) {  // "yarn" (YarnRotaryEmbedding::new_yarn, rotary_emb.rs:482-540): everything in f32
+    const float base = (float)mc->rope_theta, factor = (float)mc->rope_factor;
+    const float beta_fast = mc->rope_yarn_beta_fast != 0.0 ? (float)mc->rope_yarn_beta_fast : 32.0f;
+    const float beta_slow = mc->rope_yarn_beta_slow != 0.0 ? (float)mc->rope_yarn_beta_slow : 1.0f;
+    const float attn_factor = mc->rope_yarn_attn_factor != 0.0 ? (float)mc->rope_yarn_attn_factor : 1.0f;
+    const float extrapolation = mc->rope_yarn_extrapolation_factor != 0.0 ? (float)mc->rope_yarn_extrapolation_factor : 1.0f;
+    auto corr_dim = [&](float num_rot) {  // yarn_find_correction_dim
+      return ((float)rot * logf((float)(size_t)omax / (num_rot * 2.0f * 3.14159265358979323846f))) / (2.0f * logf(base));
+    };
+    float low = floorf(corr_dim(beta_fast)), high = ceilf(corr_dim(beta_slow));
+    low = fmaxf(low, 0.0f), high = fminf(high, (float)rot - 1.0f);
+    if (low == high) high += 0.001f;
+    const float ramp_mul = (float)(1.0 / ((double)high - (double)low));  // Tensor / f64 = affine(1/rhs): the reciprocal in f64, applied in f32
+    for (int i = 0; i < half; i++) {
+      const float p = powf(base, (float)(2 * i) / (float)rot);
+      const float extra = 1.0f / p, inter = 1.0f / (factor * p);
+      float ramp = ((float)i + (float)(-(double)low)) * ramp_mul;   // (arange - min) then / (max - min)
+      ramp = fminf(fmaxf(ramp, 0.0f), 1.0f);
+      const float mask = ((ramp * -1.0f) + 1.0f) * extrapolation;   // (1 - ramp) * extrapolation_factor
+      inv[i] = inter * ((mask * -1.0f) + 1.0f) + extra * mask;
+    }
+    mscale = (factor <= 1.0f ? 1.0f : 0.1f * 1.0f * logf(factor) + 1.0f) * attn_factor;  // yarn_get_mscale(factor, 1.0) * attn_factor
   }
   for (int p = 0; p < n_pos; p++)
     for (int i = 0; i < half; i++) {
       const float ang = (float)p * inv[i];
-      h_cos[(size_t)p * half + i] = cosf(ang);
-      h_sin[(size_t)p * half + i] = sinf(ang);
+      h_cos[(size_t)p * half + i] = mc->rope_scaling_type == 4 ? cosf(ang) * mscale : cosf(ang);
+      h_sin[(size_t)p * half + i] = mc->rope_scaling_type == 4 ? sinf(ang) * mscale : sinf(ang);
     }
 }
 

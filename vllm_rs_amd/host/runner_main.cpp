@@ -133,10 +133,16 @@ static bool init_from_json(const std::string& text, Init* out, std::string* err)
   if (const Json* rs = c->get("rope_scaling"))
     if (rs->t == Json::Obj) {
       const std::string ty = rs->has("rope_type") ? rs->str("rope_type", "") : rs->str("type", "");
-      mc.rope_scaling_type = ty == "linear" ? 1 : (ty == "llama3" ? 2 : 0);
-      mc.rope_factor = rs->num("factor", 1.0), mc.rope_low_freq_factor = rs->num("low_freq_factor", 1.0);
+      mc.rope_scaling_type = ty == "linear" ? 1 : (ty == "llama3" ? 2 : (ty == "dynamic" ? 3 : (ty == "yarn" ? 4 : 0)));
+      if (!ty.empty() && ty != "default" && !mc.rope_scaling_type) return *err = "Unknown rope_type: " + ty, false;  // rotary_emb.rs:417-419
+      mc.rope_dynamic_alpha = rs->has("alpha") ? 1 : 0;
+      mc.rope_factor = rs->has("alpha") ? rs->num("alpha", 1.0) : rs->num("factor", 1.0), mc.rope_low_freq_factor = rs->num("low_freq_factor", 1.0);
       mc.rope_high_freq_factor = rs->num("high_freq_factor", 4.0);
-      mc.rope_original_max_position = (int)rs->i64("original_max_position_embeddings", mc.max_position_embeddings);
+      // rotary_emb.rs:150-164: the key, else max_position_embeddings / factor, else max_position_embeddings
+      mc.rope_original_max_position = rs->has("original_max_position_embeddings") ? (int)rs->i64("original_max_position_embeddings", 0)
+                                      : (rs->has("factor") ? (int)((double)mc.max_position_embeddings / rs->num("factor", 1.0)) : mc.max_position_embeddings);
+      mc.rope_yarn_beta_fast = rs->num("beta_fast", 32.0), mc.rope_yarn_beta_slow = rs->num("beta_slow", 1.0);
+      mc.rope_yarn_attn_factor = rs->num("attn_factor", 1.0), mc.rope_yarn_extrapolation_factor = rs->num("extrapolation_factor", 1.0);
     }
   mc.attention_bias = c->boolean("attention_bias", false) || c->boolean("qkv_bias", false) || qwen;
   mc.quant_method = 0, mc.bits = 4, mc.group_size = 128;
