@@ -205,45 +205,3 @@ def test_gemv_w_gate_up_pair(M, awq):
     # gate and up each carry a possible 1-ulp flip (f32 vs f64 accumulation, one flipped normalised activation): their product moves
     # by up to the sum of both relative errors, silu's slope adds a little: 4 ulps over 230k outputs
     assert_close_dt(out.numpy(np.uint16, (M, N)), orc.silu_mul(g, u, BF16), BF16, max_ulp=4.0, max_mismatch_frac=0.05, name="gemv_w gate/up", abs_floor=8e-3)
-
-
-# ------------------------------------------------------------------------------------------------ the two-phase launch (opt-in)
-@pytest.mark.parametrize("quant,B", [("gptq", 1), ("gptq", 3), ("awq", 2)])
-def test_two_phase_decode_launches_are_bit_identical_to_single_launches(quant, B):
-    """gemv_q4s2_kernel (o_proj -> norm + gate/up, down -> the next layer's norm + q/k/v in ONE launch each, joined by a
-    flag barrier; off by default: measured at break-even) computes every output with the same per-unit summation order as
-    the single launches — the logits of a decode step must be bit-identical with it on and off, at the Llama-3-8B widths."""
-    from oracle import model as om
-    from tests.test_gpu_engine import build, prefill_inputs, simple_tables, small_cfg
-    from vllm_rs_amd import _lib
-    cfg = small_cfg(hidden_size=4096, intermediate_size=14336, num_layers=3, num_heads=32, num_kv_heads=8, head_dim=128, vocab_size=1024,
-                    rope_theta=500000.0, quant_method=quant)
-    L = _lib.load()
-    w = om.make_random_checkpoint(cfg, 17)
-    from vllm_rs_amd.engine import Engine
-    r = np.random.default_rng(B)
-    prompts = [r.integers(0, cfg["vocab_size"], size=int(n)).tolist() for n in r.integers(3, 40, size=B)]
-    bt = simple_tables([len(p) + 4 for p in prompts])
-    outs = []
-    for on in (0, 1):
-        L.vra_debug_set_gemv_s2(on)
-        try:
-            eng = Engine(cfg, num_gpu_blocks=32, max_num_seqs=8, max_model_len=512, use_graph=False).load_weights(w)
-            ids, pos, slots, ctx, cu = prefill_inputs(prompts, bt)
-            eng.forward_raw(ids, pos, slots, bt, ctx, cu)
-            seqs = [list(p) for p in prompts]
-            step_logits = []
-            for step in range(3):
-                for s_ in seqs:
-                    s_.append(7 + step)
-                ids = np.array([s_[-1] for s_ in seqs], np.uint32)
-                pos = np.array([len(s_) - 1 for s_ in seqs], np.int64)
-                slots = np.array([int(bt[b, (len(s_) - 1) // 64]) * 64 + (len(s_) - 1) % 64 for b, s_ in enumerate(seqs)], np.int64)
-                ctx = np.array([len(s_) for s_ in seqs], np.uint32)
-                step_logits.append(eng.forward_raw(ids, pos, slots, bt, ctx))
-            eng.close()
-            outs.append(step_logits)
-        finally:
-            L.vra_debug_set_gemv_s2(0)
-    for a, b in zip(*outs):
-        assert np.isfinite(a).all() and (a.view(np.uint32) == b.view(np.uint32)).all()

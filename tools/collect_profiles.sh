@@ -2,7 +2,7 @@
 # Collects the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
 #   kernel traces of the decode bench at bs 1 and bs 32 (eager launches: kernel tracing and hipGraph replay do not mix on
 #   ROCm 7.2), and SEPARATE counter passes (never combined with a trace domain): FETCH_SIZE, WRITE_SIZE, MFMA / busy cycles.
-# Outputs land in gpurun_out/prof_*/ ; tools/summarise_profiles.py turns them into profiles/r02_*.txt + r02_pmc.json.
+# Outputs land in gpurun_out/prof_*/ ; tools/summarise_profiles.py turns them into profiles/r03_*.txt + r03_pmc.json.
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out
 mkdir -p $OUT

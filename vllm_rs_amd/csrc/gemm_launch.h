@@ -22,10 +22,6 @@ void vra_launch_gemm_q4_big(const GemmDArgs& a, bool dual, bool awq, int mb, int
 bool vra_gemv_s_fits(int ns, int M, int K, int group_size, int n_units, bool norm);
 void vra_gemv_s_plan(int n_units, int* grid, int* q, int* r);
 void vra_launch_gemv_s(GemvSArgs a, int ns, int group_size, bool awq, int dtype, int64_t stream);
-// two dependent kernel-E GEMVs in one launch (gemv_q4s2_kernel): phase A one stream (residual allowed), phase B nsb streams
-bool vra_gemv_s2_init();  // per device, outside graph capture
-bool vra_gemv_s2_fits(int nsA, int KA, int nuA, bool normA, int nsB, int KB, int nuB, bool normB, int M, int group_size);
-void vra_launch_gemv_s2(GemvSArgs a, GemvSArgs b, int nsb, int group_size, bool awq, int dtype, int64_t stream);
 void vra_scales_to_unit_major(const void* scales, void* out, int G, int N, int unit0, int64_t stream);
 void vra_zeros_to_unit_major(const uint32_t* zeros, uint32_t* out, int G, int N, int unit0, int64_t stream);
 // kernel W (gemv_q4w.cuh): int4, 5..32 rows, K <= 4096, same argument block and unit distribution as kernel E

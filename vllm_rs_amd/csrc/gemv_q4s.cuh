@@ -20,10 +20,6 @@
 //   * partial tiles of all units meet in LDS ONCE, behind the single barrier at the end of the stream; the first
 //     units*64 threads then add the 16 wave partials in fixed order and run the fused epilogue (bias, SiLU·mul, residual);
 //     bias / residual were requested before the weight stream started.
-//   * tail prefetch: after its last tile-step a wave requests the first tile-steps its twin (same workgroup id => same XCD,
-//     same wave) will need in the NEXT launch of the decode chain.  They land in that XCD's L2 while this launch drains,
-//     the launch boundary passes and the next prologue runs: the next launch's first ring fill is an L2 hit instead of
-//     the HBM round trip that otherwise sits between its prologue and its first MFMA.
 //   * scales / AWQ zeros are addressed as  grp*grp_stride + unit*unit_stride + column: row-major checkpoint tensors
 //     ([K/g, N]: strides N, 16), the unit-major copies the native runtime makes at load ([N/16][K/g][16]: strides 16,
 //     16*K/g — the scales of a workgroup's stream are then one contiguous run, like its weights) and the Marlin-permuted
@@ -67,10 +63,7 @@ struct GemvSArgs {
   int nseg;
   int M, K, KT, TPW, gsh;  // KT = K/128, TPW = ceil(KT/16), k >> gsh = scale group
   int n_units, units_q, units_r;  // workgroup b owns units_q (+1 if b < units_r) units starting at b*units_q + min(b, units_r)
-  // tail prefetch: the next launch's streams, its tiles per unit and its unit distribution (next_grid = 0: none)
-  const void* next_w[2];
-  int next_kt, next_units_q, next_units_r, next_grid;
-  int dbg;
+  int dbg;  // VRA_EXP=1: prologue only (timeline tool)
   unsigned long long* ts;
 };
 
@@ -78,68 +71,19 @@ static inline size_t gemv_q4s_lds_bytes(int ns, int tpw, int max_units) {
   return (size_t)GS_WAVES * tpw * GS_TILE_LDS + 256 + (size_t)max_units * ns * GS_WAVES * 256;
 }
 
-#ifdef GS_OCC2
-#define GS_MIN_WAVES_PER_SIMD 8  // two 16-wave workgroups per CU: at most 64 VGPRs
-#else
 #define GS_MIN_WAVES_PER_SIMD 4
-#endif
-#ifndef GS_RING_PAIR
-#ifndef GS_ROTATE_PRIO
-#define GS_ROTATE_PRIO 0  // measured: levels the waves (spread 4.4 -> 3.0 us) but the launch takes the same 16.1 us — see below
-#endif
 #define GS_RING_PAIR 2  // ring depth (tile-steps of 2 KiB) of the gate/up pair stream (measured: 2 beats 1 by 2 % of the decode step)
-#endif
-// ---- grid barrier of the two-phase launch (gemv_q4s2_kernel): per-workgroup flag lines + a launch counter in device memory
-// (monotonic epochs: replayable from a hipGraph, nothing to reset).  Every workgroup of the grid must be resident — the
-// launcher keeps the grid <= the CU count and uses the two-phase form only in a single-process engine; the wait is bounded.
-struct GemvSBar {
-  uint32_t* flags;  // [grid] x 16 words (one 64-byte line each)
-  uint32_t* count;  // launches completed so far
-  uint32_t* err;    // device error word (a workgroup that never arrived)
-  int grid;
-};
-__device__ __forceinline__ void gs_bar_arrive(const GemvSBar& b, uint32_t epoch, int tid, int wg) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's write-through stores are acknowledged
-  __syncthreads();
-  if (tid == 0) __hip_atomic_store(b.flags + (size_t)wg * 16, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void gs_bar_wait(const GemvSBar& b, uint32_t epoch, int tid) {
-  if (tid < 64) {  // one wave polls all flags (a poller per wave next to a weight stream costs the stream ~9 %)
-    // each lane watches up to 8 flags and requests them TOGETHER: polled one after the other, four dependent round trips stood
-    // between the last arrival and the release (3.2 us in the timeline, against ~1 for one round trip)
-    const uint64_t t0 = wall_clock64();
-    bool done = false;
-    while (!done) {
-      uint32_t v[8];
-#pragma unroll
-      for (int k = 0; k < 8; k++) {
-        const int i = tid + 64 * k;
-        v[k] = i < b.grid ? __hip_atomic_load(b.flags + (size_t)i * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
-      }
-      done = true;
-#pragma unroll
-      for (int k = 0; k < 8; k++) done = done && (int32_t)(v[k] - epoch) >= 0;
-      if (!done) {
-        __builtin_amdgcn_s_sleep(1);
-        if (wall_clock64() - t0 > 50000000ull) {  // 0.5 s at 100 MHz: never hang the device
-          __hip_atomic_store(b.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-      }
-    }
-  }
-  __syncthreads();
-}
+// Variants that were built, parity-green, measured and REMOVED in round 3 (their numbers: DESIGN.md §3.1): two 16-wave
+// workgroups per CU (GS_OCC2), rotating wave priorities, the ring issued before the x loads, waiting for x before the first
+// HBM load, a tail prefetch of the next launch's first tiles, and the two-phase launches joined by a grid barrier
+// (gemv_q4s2_kernel: o_proj -> gate/up and down -> next q/k/v in one launch each — break-even).  What the whole-layer form of
+// that idea became is csrc/decode_step.hip.
 
-// PH: 0 = a launch of its own; 1 = first phase of a two-phase launch (outputs written through: the second phase of OTHER
-// workgroups reads them in the same launch); 2 = second phase (the weight ring is requested BEFORE the grid barrier — it
-// does not depend on the first phase — and lands while the barrier completes; x is read past the L1 after it)
-template <class DT, int NS, bool AWQ, int PH>
-__device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char* smem, const GemvSBar& bar, uint32_t epoch) {
+template <class DT, int NS, bool AWQ>
+__device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char* smem) {
   constexpr int D = NS == 2 ? GS_RING_PAIR : GS_RING_KIB;  // ring depth in tile-steps (1 KiB per stream and step)
   // every kernel argument the way to the first load needs, requested in ONE batch of scalar loads
-  if (PH != 2)
-    asm volatile("" ::"s"(a.x), "s"(a.x_ld), "s"(a.norm_w), "s"(a.K), "s"(a.M), "s"(a.KT), "s"(a.TPW), "s"(a.gsh), "s"(a.units_q), "s"(a.units_r),
+  asm volatile("" ::"s"(a.x), "s"(a.x_ld), "s"(a.norm_w), "s"(a.K), "s"(a.M), "s"(a.KT), "s"(a.TPW), "s"(a.gsh), "s"(a.units_q), "s"(a.units_r),
                  "s"(a.w[0]), "s"(a.scales[0]), "s"(a.s_grp_stride), "s"(a.s_unit_stride), "s"(a.marlin), "s"(a.residual), "s"(a.res_ld),
                  "s"(a.nseg), "s"(a.seg[0].out), "s"(a.seg[0].bias), "s"(a.seg[0].out_ld), "s"(a.seg[1].unit_start), "s"(a.seg[2].unit_start));
   const int tid = threadIdx.x, lane = tid & 63;
@@ -206,28 +150,11 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
     iu = last ? iu : (wrap ? iu + 1 : iu);
   };
 
-#ifdef GS_RING_FIRST
-  constexpr bool RING_FIRST = true;  // variant: the ring is filled BEFORE the x loads (x then returns behind the first weight tiles)
-#else
-  constexpr bool RING_FIRST = PH == 2;
-#endif
-  if (RING_FIRST) {
-#pragma unroll
-    for (int r = 0; r < D; r++) {
-      issue(iu, it, wb[r], sb[r], zb[r]);
-      advance_issue();
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  GEMV_STAMP(19);
-  if (PH == 2) gs_bar_wait(bar, epoch, tid);  // every workgroup's first-phase outputs are in memory past this point
-  GEMV_STAMP(20);
   // ---- prologue: this wave's x slices.  Staging lane = (row group oct, octet nn): region `oct` of a tile holds row
   // min(oct, M-1), so rows >= M alias the last row (their outputs are never stored).
   const bool norm = a.norm_w != nullptr;
   const uint16_t* xrow = static_cast<const uint16_t*>(a.x) + (size_t)min(oct, M - 1) * a.x_ld + nn * 8;
   const uint16_t* nwp = static_cast<const uint16_t*>(a.norm_w) + nn * 8;
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, 0x7FFFFFF0, 0x00020000);
   u32x4 nr[GS_NORM_TPW];
   float ss = 0.f;
   for (int t0 = 0; t0 < TPW; t0 += 4) {
@@ -235,8 +162,7 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int kt = min(wave + 16 * min(t0 + i, TPW - 1), KT - 1);
-      if (PH == 2) xv[i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (uint32_t)(((size_t)min(oct, M - 1) * a.x_ld + nn * 8 + (size_t)kt * 128) * 2), 0, 16);  // sc1
-      else xv[i] = *reinterpret_cast<const u32x4*>(xrow + (size_t)kt * 128);
+      xv[i] = *reinterpret_cast<const u32x4*>(xrow + (size_t)kt * 128);
       if (norm && t0 == 0) nr[i] = *reinterpret_cast<const u32x4*>(nwp + (size_t)kt * 128);  // (norm => TPW <= 4)
     }
 #pragma unroll
@@ -262,17 +188,12 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
   GEMV_STAMP(16);
 
   // the ring is filled right behind the x loads (in order per wave: x first); the staging below overlaps the first HBM round trip
-  if (!RING_FIRST) {
-#ifdef GS_XWAIT  // variant: x (L2) complete before the first HBM load is queued — measured equal to not waiting
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-#endif
 #pragma unroll
-    for (int r = 0; r < D; r++) {
-      issue(iu, it, wb[r], sb[r], zb[r]);
-      advance_issue();
-    }
-    __builtin_amdgcn_sched_barrier(0);
+  for (int r = 0; r < D; r++) {
+    issue(iu, it, wb[r], sb[r], zb[r]);
+    advance_issue();
   }
+  __builtin_amdgcn_sched_barrier(0);
   GEMV_STAMP(1);
 
   if (norm) {
@@ -314,11 +235,9 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
 #pragma unroll
   for (int b = 0; b < NS; b++) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
   int cu = 0, ct = 0;  // consume cursor
-  // The four waves of a SIMD are served oldest first: the oldest wave of every SIMD finishes its (equal) share ~4 us before
-  // the youngest (per-wave stamps, tools/gemv_s_ts.py).  Alternating priorities (GS_ROTATE_PRIO) level them, but the last
-  // wave ends at the same time: the stream phase of the gate/up launch already moves 272 KB per CU in 9.6 us = 6.3 TB/s
-  // chip-wide, i.e. it is bandwidth-bound and only the order in which the waves are served changes.
-  const int pgrp = wave >> 2;
+  // (The four waves of a SIMD are served oldest first: the oldest wave of every SIMD finishes its (equal) share ~4 us before
+  // the youngest — tools/gemv_s_ts.py.  The stream phase of the gate/up launch already moves 272 KB per CU in 9.6 us = 6.3 TB/s
+  // chip-wide: it is bandwidth-bound, and levelling the waves with priorities did not move the launch time.)
   const int S_pad = (S + D - 1) / D * D;  // the only loop exit is the back edge (see gemv_q4.cuh)
   for (int s0 = 0; s0 < S_pad; s0 += D) {
 #pragma unroll
@@ -327,7 +246,6 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
         const bool valid = wave + 16 * ct < KT;
         const unsigned char* xp = xfrag + (size_t)ct * GS_TILE_LDS;
         f32x4 ag[NS];
-        if (GS_ROTATE_PRIO) vra_setprio_dyn((r & 1) ? 3 - pgrp : pgrp);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           const s16x8 xf = __builtin_bit_cast(s16x8, *reinterpret_cast<const u32x4*>(xp + j * 64));
@@ -365,21 +283,8 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
   }
   GEMV_STAMP(15);
 #ifdef VRA_GEMV_TS
-  if (PH != 2 && a.ts && lane == 0 && blockIdx.x < 1024) a.ts[(size_t)2048 * 32 + (size_t)blockIdx.x * 16 + wave] = wall_clock64();  // every wave's loop end
+  if (a.ts && lane == 0 && blockIdx.x < 1024) a.ts[(size_t)2048 * 32 + (size_t)blockIdx.x * 16 + wave] = wall_clock64();  // every wave's loop end
 #endif
-
-  // ---- tail prefetch: the first tile-steps of this (workgroup, wave) in the next launch, into this XCD's L2
-  // (two 1 KiB requests per wave = the next launch's first ring fill: (stream 0, tile 0) and (stream 1, tile 0) of a pair,
-  // or tiles 0 and 1 of a single stream)
-  u32x4 pf0 = u32x4{0u, 0u, 0u, 0u}, pf1 = pf0;
-  const bool have_next = a.next_grid > 0 && wg < a.next_grid && (a.dbg & 2);  // measured: a net loss as built (VRA_EXP=2 turns it on)
-  if (have_next) {
-    const int nu0 = wg * a.next_units_q + min(wg, a.next_units_r);
-    const int k0 = min(wave, a.next_kt - 1), k1 = a.next_w[1] ? k0 : min(wave + 16, a.next_kt - 1);
-    const void* w1 = a.next_w[1] ? a.next_w[1] : a.next_w[0];
-    pf0 = *(reinterpret_cast<const u32x4*>(a.next_w[0]) + ((size_t)nu0 * a.next_kt + k0) * 64 + lane);
-    pf1 = *(reinterpret_cast<const u32x4*>(w1) + ((size_t)nu0 * a.next_kt + k1) * 64 + lane);
-  }
 
   // ---- all partial tiles of the workgroup meet once; units*64 threads finish the outputs
   __syncthreads();
@@ -405,30 +310,13 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
     }
     if (a.residual) v = rnd_dt<DT>(v) + e_res;
     uint16_t* const op = static_cast<uint16_t*>(e_out) + (size_t)e_m * e_ld + e_col;
-    if (PH == 1) __hip_atomic_store(op, DT::from_f32(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through
-    else *op = DT::from_f32(v);
+    *op = DT::from_f32(v);
   }
-  if (have_next) asm volatile("" ::"v"(pf0), "v"(pf1));  // keep the prefetch loads alive until they have landed
   GEMV_STAMP(14);
 }
 
 template <class DT, int NS, bool AWQ>
 __global__ __launch_bounds__(GS_THREADS, GS_MIN_WAVES_PER_SIMD) void gemv_q4s_kernel(const GemvSArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  gemv_q4s_body<DT, NS, AWQ, 0>(a, smem, GemvSBar{}, 0u);
+  gemv_q4s_body<DT, NS, AWQ>(a, smem);
 }
-
-// Two dependent GEMVs of the decode layer in ONE launch: o_proj (+residual) -> RMSNorm + gate/up + SiLU*mul, or
-// down (+residual) -> the next layer's RMSNorm + q/k/v.  What it removes is not the barrier (a flag barrier costs about what
-// the kernel boundary does) but the second launch's dead time in front of its first tile: its weight ring is in flight
-// across the barrier.  Same arithmetic, same per-unit summation order as two launches: bit-identical outputs.
-template <class DT, int NSA, int NSB, bool AWQ>
-__global__ __launch_bounds__(GS_THREADS, GS_MIN_WAVES_PER_SIMD) void gemv_q4s2_kernel(const GemvSArgs a, const GemvSArgs b, const GemvSBar bar) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const uint32_t epoch = *bar.count + 1u;  // the same for every workgroup: the counter moves at the END of a launch
-  gemv_q4s_body<DT, NSA, AWQ, 1>(a, smem, bar, epoch);
-  gs_bar_arrive(bar, epoch, (int)threadIdx.x, (int)blockIdx.x);
-  gemv_q4s_body<DT, NSB, AWQ, 2>(b, smem, bar, epoch);
-  if (blockIdx.x == 0 && threadIdx.x == 0) *bar.count = epoch;
-}
-

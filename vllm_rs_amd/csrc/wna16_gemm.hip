@@ -315,11 +315,7 @@ void vra_launch_gemv(const GemvArgs& a, bool int4, int dtype, int64_t stream) {
 // A grid that divides the units evenly is preferred when it keeps at least 3/4 of the CUs busy (Llama-3-8B: 384 q/k/v
 // units -> 192 x 2, 896 gate/up pairs -> 224 x 4): equal streams end together, which a ragged last unit does not.
 void vra_gemv_s_plan(int n_units, int* grid, int* q, int* r) {
-#ifdef GS_OCC2
-  const int cus = 2 * num_cus();  // two resident workgroups per CU
-#else
   const int cus = num_cus();
-#endif
   int g = n_units < cus ? n_units : cus;
   static const char* mode = getenv("VRA_GS_GRID");  // tuning aid: "all" = always every CU, ragged
   if (!(mode && mode[0] == 'a')) {
@@ -386,104 +382,6 @@ void vra_launch_gemv_s(GemvSArgs a, int ns, int group_size, bool awq, int dtype,
   } else {
     if (awq) bf ? launch_gemv_s_v<BF16, 1, true>(a, st) : launch_gemv_s_v<F16, 1, true>(a, st);
     else bf ? launch_gemv_s_v<BF16, 1, false>(a, st) : launch_gemv_s_v<F16, 1, false>(a, st);
-  }
-}
-// ---- two-phase launch of kernel E (gemv_q4s2_kernel): phase A = a GEMV that writes the residual stream, phase B = the GEMV
-// that reads it.  One grid for both phases, <= the CU count (every workgroup must be resident for the grid barrier); the
-// barrier's flags and launch counter live in per-device memory allocated here on first use (outside graph capture:
-// vra_gemv_s2_init is called from vra_scratch_init's callers before any capture).
-struct GemvS2State {
-  uint32_t* flags = nullptr;  // [512][16]
-  uint32_t* count = nullptr;
-};
-static GemvS2State g_s2[64];
-bool vra_gemv_s2_init() {
-  GemvS2State& st = g_s2[cur_dev()];
-  if (st.flags) return true;
-  void* p = nullptr;
-  if (hipMalloc(&p, (512 * 16 + 16) * sizeof(uint32_t)) != hipSuccess) return false;
-  if (hipMemset(p, 0, (512 * 16 + 16) * sizeof(uint32_t)) != hipSuccess) return false;
-  st.flags = static_cast<uint32_t*>(p);
-  st.count = st.flags + 512 * 16;
-  return hipDeviceSynchronize() == hipSuccess;
-}
-// common grid: the candidate (each phase's own plan, or every CU) whose slowest workgroup streams the fewest tiles
-static int gemv_s2_grid(int nuA, int ktA, int nsA, int nuB, int ktB, int nsB) {
-  const int cus = num_cus();
-  int ga, gb, q, r;
-  vra_gemv_s_plan(nuA, &ga, &q, &r);
-  vra_gemv_s_plan(nuB, &gb, &q, &r);
-  const int cand[3] = {ga, gb, std::min(cus, std::max(nuA, nuB))};
-  int best = cand[0];
-  long best_cost = -1;
-  for (int g : cand) {
-    if (g < 1 || g > cus) continue;
-    const long cost = (long)((nuA + g - 1) / g) * ktA * nsA + (long)((nuB + g - 1) / g) * ktB * nsB;
-    if (best_cost < 0 || cost < best_cost) best_cost = cost, best = g;
-  }
-  return best;
-}
-bool vra_gemv_s2_fits(int nsA, int KA, int nuA, bool normA, int nsB, int KB, int nuB, bool normB, int M, int group_size) {
-  if (!vra_gemv_s_fits(nsA, M, KA, group_size, nuA, normA) || !vra_gemv_s_fits(nsB, M, KB, group_size, nuB, normB)) return false;
-  if (nsA != 1) return false;  // instantiated pairs: (1 -> 2) o_proj -> gate/up, (1 -> 1) down -> q/k/v
-  if (!g_s2[cur_dev()].flags) return false;
-  const int g = gemv_s2_grid(nuA, KA / 128, nsA, nuB, KB / 128, nsB);
-  const int muA = (nuA + g - 1) / g, muB = (nuB + g - 1) / g;
-  if (muA > GS_MAX_UNITS || muB > GS_MAX_UNITS) return false;
-  const size_t lds = std::max(gemv_q4s_lds_bytes(nsA, (KA / 128 + 15) / 16, muA), gemv_q4s_lds_bytes(nsB, (KB / 128 + 15) / 16, muB));
-  return lds <= (size_t)kMaxDynLds;
-}
-template <class DT, int NSB, bool AWQ>
-static void launch_gemv_s2_v(GemvSArgs a, GemvSArgs b, hipStream_t st) {
-  static uint64_t attr_devs = 0;
-  auto kern = gemv_q4s2_kernel<DT, 1, NSB, AWQ>;
-  if (!dev_seen(attr_devs)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
-    dev_mark(attr_devs);
-  }
-  a.KT = a.K / 128, a.TPW = (a.KT + 15) / 16;
-  b.KT = b.K / 128, b.TPW = (b.KT + 15) / 16;
-  const int grid = gemv_s2_grid(a.n_units, a.KT, 1, b.n_units, b.KT, NSB);
-  a.units_q = a.n_units / grid, a.units_r = a.n_units % grid;
-  b.units_q = b.n_units / grid, b.units_r = b.n_units % grid;
-  const size_t lds = std::max(gemv_q4s_lds_bytes(1, a.TPW, a.units_q + (a.units_r ? 1 : 0)), gemv_q4s_lds_bytes(NSB, b.TPW, b.units_q + (b.units_r ? 1 : 0)));
-  a.dbg = b.dbg = 0;
-  a.next_grid = b.next_grid = 0;
-#ifdef VRA_GEMV_TS
-  a.ts = vra_gemv_ts_buf();          // phase A stamps in rows 0.., phase B in rows 1024..
-  b.ts = vra_gemv_ts_buf() + (size_t)1024 * 32;
-#else
-  a.ts = b.ts = nullptr;
-#endif
-  GemvSBar bar;
-  bar.flags = g_s2[cur_dev()].flags;
-  bar.count = g_s2[cur_dev()].count;
-  bar.err = vra_scratch_error_word();
-  bar.grid = grid;
-  kern<<<grid, GS_THREADS, lds, st>>>(a, b, bar);
-}
-// phase A: one stream (o_proj / down, residual allowed); phase B: nsb streams, no residual (it would have to be read after the barrier)
-void vra_launch_gemv_s2(GemvSArgs a, GemvSArgs b, int nsb, int group_size, bool awq, int dtype, int64_t stream) {
-  hipStream_t st = as_stream(stream);
-  for (GemvSArgs* x : {&a, &b}) {
-    const bool grouped = group_size > 0 && group_size < x->K;
-    x->gsh = grouped ? 31 - __builtin_clz((unsigned)group_size) : 31;
-    if ((x->s_grp_stride | x->s_unit_stride) & 1) {
-      vra_set_error("gemv_s2: scale strides must be even");
-      return;
-    }
-  }
-  if (b.residual || !g_s2[cur_dev()].flags || !vra_scratch_error_word()) {
-    vra_set_error("gemv_s2: phase B takes no residual; vra_gemv_s2_init() and vra_scratch_init() first");
-    return;
-  }
-  const bool bf = dtype == VRA_BF16;
-  if (nsb == 2) {
-    if (awq) bf ? launch_gemv_s2_v<BF16, 2, true>(a, b, st) : launch_gemv_s2_v<F16, 2, true>(a, b, st);
-    else bf ? launch_gemv_s2_v<BF16, 2, false>(a, b, st) : launch_gemv_s2_v<F16, 2, false>(a, b, st);
-  } else {
-    if (awq) bf ? launch_gemv_s2_v<BF16, 1, true>(a, b, st) : launch_gemv_s2_v<F16, 1, true>(a, b, st);
-    else bf ? launch_gemv_s2_v<BF16, 1, false>(a, b, st) : launch_gemv_s2_v<F16, 1, false>(a, b, st);
   }
 }
 // ---- kernel W (gemv_q4w.cuh): 5..32 rows, K <= 4096

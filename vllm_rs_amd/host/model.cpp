@@ -364,7 +364,7 @@ bool Model::finalize_weights() {
   cos_ = upload(this, allocs_, cb.data(), cb.size() * 2, error);
   sin_ = upload(this, allocs_, sb.data(), sb.size() * 2, error);
   if (!cos_ || !sin_) return false;
-  if (!vra_scratch_init() || !vra_gemv_s2_init()) {
+  if (!vra_scratch_init()) {
     error = "scratch allocation failed";
     return false;
   }
@@ -693,48 +693,12 @@ void Model::gemv_s_args(int l, int which, int M, void* out, const void* residual
       break;
   }
 }
-static int g_gemv_s2 = -1;  // -1: take VRA_GEMV_S2 from the environment at first use
-extern "C" void vra_debug_set_gemv_s2(int on) { g_gemv_s2 = on ? 1 : 0; }
-// two dependent decode GEMVs in ONE launch (gemv_q4s2_kernel): (layer la, which wa) writes the residual stream h_, (lb, wb) reads it
-bool Model::gemv_s2(int la, int wa, int lb, int wb, int M, int64_t stream) {
-  // OFF by default: measured at break-even (o_proj -> gate/up 22.6 us fused against 22.0 us as two launches, down -> q/k/v 20.0
-  // against 20.4; bs 1 decode 545.8 against 546.1 tok/s) — DESIGN.md 3.1.  VRA_GEMV_S2=1 or vra_debug_set_gemv_s2(1) turns it on.
-  if (g_gemv_s2 < 0) {
-    const char* e = getenv("VRA_GEMV_S2");
-    g_gemv_s2 = e && e[0] == '1' ? 1 : 0;
-  }
-  if (!g_gemv_s2 || world_ > 1 || M > 4 || !gemv_s_ok(wa, M) || !gemv_s_ok(wb, M)) return false;
-  int KA, uA, nsA, KB, uB, nsB;
-  bool nA, nB;
-  gemv_s_shape(layers_[la], wa, &KA, &uA, &nsA, &nA);
-  gemv_s_shape(layers_[lb], wb, &KB, &uB, &nsB, &nB);
-  if (!vra_gemv_s2_fits(nsA, KA, uA, nA, nsB, KB, uB, nB, M, mc_.group_size)) return false;
-  GemvSArgs a, b;
-  gemv_s_args(la, wa, M, h_, h_, &a, &nsA);
-  gemv_s_args(lb, wb, M, nullptr, nullptr, &b, &nsB);
-  vra_launch_gemv_s2(a, b, nsB, mc_.group_size, layers_[la].q.awq, dt_, stream);
-  return !take_err(error, "gemv_s2");
-}
 bool Model::gemv_s(int l, int which, int M, void* out, const void* residual, int64_t stream) {
   if (!gemv_s_ok(which, M)) return false;
   const LayerWeights& L = layers_[l];
   GemvSArgs a;
   int ns;
   gemv_s_args(l, which, M, out, residual, &a, &ns);
-  // tail prefetch: the next decode GEMV in program order (the attention launch between q/k/v and o_proj streams little)
-  {
-    const int nw = which == 3 ? 0 : which + 1, nl = which == 3 ? l + 1 : l;
-    if (nl < mc_.num_layers && gemv_s_ok(nw, M)) {
-      const LayerWeights& N2 = layers_[nl];
-      int nK, nunits, nns;
-      bool nnorm;
-      gemv_s_shape(N2, nw, &nK, &nunits, &nns, &nnorm);
-      a.next_w[0] = nw == 0 ? N2.qkv_w : (nw == 1 ? N2.o.w : (nw == 2 ? N2.gate.w : N2.down.w));
-      a.next_w[1] = nw == 2 ? N2.up.w : nullptr;
-      a.next_kt = nK / 128;
-      vra_gemv_s_plan(nunits, &a.next_grid, &a.next_units_q, &a.next_units_r);
-    }
-  }
   if (M > 4) vra_launch_gemv_w(a, ns, mc_.group_size, L.q.awq, dt_, stream);  // kernel W: 5..32 rows, K <= 4096
   else vra_launch_gemv_s(a, ns, mc_.group_size, L.q.awq, dt_, stream);
   return !take_err(error, "gemv_s");
@@ -876,7 +840,6 @@ bool Model::forward(const InputMetadata& md, int64_t stream) {
   error.clear();
   // embed_forward (llama.rs:260-267)
   vra_embedding(md.input_ids, embed_, h_, T, H, mc_.vocab_size, dt_, stream);
-  bool qkv_done = false, mlp_in_done = false;
   // decode of 1..2 sequences at short contexts: all layers in ONE persistent launch (csrc/decode_step.hip)
   const bool one_launch = !md.is_prefill && B == T && decode_step_ok(T, md.max_context_len);
   if (one_launch && !launch_decode_phases(md, 0, mc_.num_layers * DP_PHASES_PER_LAYER, stream)) return false;
@@ -885,9 +848,7 @@ bool Model::forward(const InputMetadata& md, int64_t stream) {
     // ---- attention block (llama.rs:115-126): norm -> q,k,v -> rope -> cache + attention -> o_proj (+ residual)
     const QLinear qkv[3] = {L.q, L.k, L.v};
     void* outs[3] = {q_, k_, v_};
-    if (qkv_done) {
-      qkv_done = false;  // q/k/v of this layer came out of the previous layer's two-phase launch (down -> norm + q/k/v)
-    } else if (!gemv_s(l, 0, T, nullptr, nullptr, stream)) {
+    if (!gemv_s(l, 0, T, nullptr, nullptr, stream)) {
       if (!error.empty()) return false;
       if (!linear_fused_norm(qkv, 3, outs, h_, L.attn_norm, T, stream)) return false;
     }
@@ -910,20 +871,15 @@ bool Model::forward(const InputMetadata& md, int64_t stream) {
       if (!gemv_s(l, 1, T, tmp_, nullptr, stream) && (!error.empty() || !linear(L.o, attn_, tmp_, T, nullptr, stream, false))) return false;
       vra_all_reduce_fused(comm_, tmp_, h_, L.o.bias, h_, T, H, dt_, stream);
       if (take_err(error, "all_reduce(o_proj)")) return false;
-    } else if (!md.is_prefill && gemv_s2(l, 1, l, 2, T, stream)) {
-      mlp_in_done = true;  // o_proj (+ residual) and norm + gate/up + SiLU*mul left in one launch
     } else if (!error.empty() || (!gemv_s(l, 1, T, h_, h_, stream) && (!error.empty() || !linear(L.o, attn_, h_, T, h_, stream)))) {
       return false;
     }
     // ---- MLP block (llama.rs:127-130)
-    if (mlp_in_done) mlp_in_done = false;
-    else if (!gemv_s(l, 2, T, nullptr, nullptr, stream) && (!error.empty() || !gate_up(L, h_, L.ffn_norm, act_, T, stream))) return false;
+    if (!gemv_s(l, 2, T, nullptr, nullptr, stream) && (!error.empty() || !gate_up(L, h_, L.ffn_norm, act_, T, stream))) return false;
     if (world_ > 1) {
       if (!gemv_s(l, 3, T, tmp_, nullptr, stream) && (!error.empty() || !linear(L.down, act_, tmp_, T, nullptr, stream, false))) return false;
       vra_all_reduce_fused(comm_, tmp_, h_, L.down.bias, h_, T, H, dt_, stream);
       if (take_err(error, "all_reduce(down_proj)")) return false;
-    } else if (!md.is_prefill && l + 1 < mc_.num_layers && gemv_s2(l, 3, l + 1, 0, T, stream)) {
-      qkv_done = true;  // down (+ residual) and the NEXT layer's norm + q/k/v left in one launch
     } else if (!error.empty() || (!gemv_s(l, 3, T, h_, h_, stream) && (!error.empty() || !linear(L.down, act_, h_, T, h_, stream)))) {
       return false;
     }
@@ -970,9 +926,6 @@ bool Model::forward(const InputMetadata& md, int64_t stream) {
 bool Model::launch_gemm(int which, int layer, int M, int64_t stream) {
   if (layer < 0 || layer >= mc_.num_layers || M < 1 || M > max_tokens_) return false;
   const LayerWeights& L = layers_[layer];
-  // 4 / 5: the two-phase launches (o_proj -> gate/up; down -> the next layer's q/k/v) — in place on h_, timing only
-  if (which == 4) return gemv_s2(layer, 1, layer, 2, M, stream);
-  if (which == 5) return gemv_s2(layer, 3, (layer + 1) % mc_.num_layers, 0, M, stream);
   if (gemv_s(layer, which, M, which == 1 || which == 3 ? tmp_ : nullptr, which == 1 || which == 3 ? h_ : nullptr, stream)) return true;
   if (!error.empty()) return false;
   switch (which) {

@@ -115,8 +115,6 @@ class Model {
   bool gemv_s(int l, int which, int M, void* out, const void* residual, int64_t stream);
   bool gemv_s_ok(int which, int M) const;
   void gemv_s_args(int l, int which, int M, void* out, const void* residual, ::GemvSArgs* a, int* ns);
-  // two dependent decode GEMVs in one launch; false = not applicable (the caller launches them one by one)
-  bool gemv_s2(int la, int wa, int lb, int wb, int M, int64_t stream);
   vra_model_config mc_;
   vra_engine_config ec_;
   bool finalized_ = false;
