@@ -233,6 +233,13 @@ void vra_dense_gemm(const void* x, const void* w, const void* bias, void* out, i
                     int32_t n, int32_t dtype, int32_t out_dtype, int64_t stream);
 /* logits.argmax(-1) (logits_processor.rs:67-70): first maximal index per row. */
 void vra_argmax_f32(const float* logits, uint32_t* out, int32_t rows, int32_t cols, int64_t stream);
+/* lm_head + greedy sampling as one launch (llama.rs:311-320 followed by logits_processor.rs:67-70): f32 logits as
+ * vra_dense_gemm(..., VRA_F32) AND tokens[m] = first maximal index of row m.  Up to 8 rows the tokens come out of the GEMV
+ * itself (per-workgroup candidates, the last workgroup to arrive reduces them); beyond that it is the two launches.
+ * `workspace`: vra_dense_gemm_argmax_workspace_bytes() bytes, zeroed ONCE by the caller, one per concurrent stream. */
+int64_t vra_dense_gemm_argmax_workspace_bytes(void);
+void vra_dense_gemm_argmax(const void* x, const void* w, const void* bias, float* logits, uint32_t* tokens, void* workspace,
+                           int32_t m, int32_t k, int32_t n, int32_t dtype, int64_t stream);
 /* Stochastic sampling on the device — LogitsProcessor::sample_with_strategy for Sampling::{All, TopK, TopP,
  * TopKThenTopP} (logits_processor.rs:199-271; the reference's own device path is `sampler.sample_cuda(logits,
  * k, p, t, seed)` with k <= 256, and k = 256 standing in for "top-p only"): probabilities = softmax(logits /

@@ -210,6 +210,30 @@ def test_dense_gemm_decode_batches(M, K, N, dt, with_bias):
     assert np.array_equal(out16.numpy(np.uint16, (M, N)), orc.to_dt(got, dt)), "16-bit output == the f32 output narrowed"
 
 
+@pytest.mark.parametrize("dt", [BF16, F16])
+@pytest.mark.parametrize("M,K,N", [(1, 4096, 128256), (2, 2048, 32000), (3, 512, 2048), (8, 1024, 4112), (12, 1024, 4096)])
+def test_dense_gemm_argmax(M, K, N, dt):
+    """the greedy token out of the lm_head launch (kernel A's last-arriver reduction, <= 8 rows; two launches beyond) ==
+    vra_argmax_f32 of the logits the same launch wrote == the oracle's first maximal index; exact ties (duplicated weight
+    rows, the maximum planted at chosen columns) resolve to the smaller index; the workspace re-arms itself between launches"""
+    r = rng(M * 7 + K + N)
+    x, w = rand_dt(r, (M, K), dt), rand_dt(r, (N, K), dt, 0.05)
+    f = ops.DenseGemmArgmax()
+    dx = ops.dev(x)
+    for trial in range(3):
+        if trial:  # plant the row-0 winner's weight row at a few other columns: exact ties on both sides of it
+            ref = orc.dense_gemm(x, w, None, dt, F32)
+            win = int(np.argmax(ref[0]))
+            for c in r.integers(0, N, size=3):
+                w[int(c)] = w[win]
+        logits, toks = f(dx, ops.dev(w), None, M, K, N, dt)
+        got = logits.numpy(np.float32, (M, N))
+        assert np.array_equal(got, ops.dense_gemm(dx, ops.dev(w), None, M, K, N, dt, F32).numpy(np.float32, (M, N)))
+        assert np.array_equal(toks, ops.argmax(logits, M, N)), (trial, toks)
+        assert np.array_equal(toks, orc.argmax_f32(got)), (trial, toks)
+        assert np.array_equal(toks, np.argmax(got, axis=-1))
+
+
 # ---------------------------------------------------------------- norms / elementwise
 @pytest.mark.parametrize("dt", [BF16, F16])
 @pytest.mark.parametrize("T,H", [(1, 4096), (7, 2048), (33, 3584)])

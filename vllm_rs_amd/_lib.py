@@ -117,6 +117,8 @@ def load():
     _sig(lib, "vra_swap_blocks", None, P, P, P, c_i32, c_i64, c_i32, c_i64)
     _sig(lib, "vra_dense_gemm", None, P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64)
     _sig(lib, "vra_argmax_f32", None, P, P, c_i32, c_i32, c_i64)
+    _sig(lib, "vra_dense_gemm_argmax_workspace_bytes", c_i64)
+    _sig(lib, "vra_dense_gemm_argmax", None, P, P, P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i64)
     _sig(lib, "vra_cast", None, P, P, c_i64, c_i32, c_i32, c_i64)
     _sig(lib, "vra_sample", None, P, P, c_i32, c_i32, c_i32, c_f32, c_f32, c_u64, P, P, c_i64)
     _sig(lib, "vra_apply_penalties", None, P, P, P, c_i32, c_i32, c_i32, P, P, c_i64)

@@ -23,6 +23,20 @@
 #define GEMV_THREADS 512
 #define GEMV_WAVES 8
 #define GEMV_MAX_SEG 3
+#define GEMV_AM_MAX_GRID 2048
+#define GEMV_AM_COUNTER (8 * GEMV_AM_MAX_GRID)
+// (value, index) -> one u64 whose unsigned order is "larger value first, then smaller index"; NaN orders below everything
+__device__ __forceinline__ unsigned long long gemv_am_key(float v, uint32_t idx) {
+  v += 0.0f;  // -0 -> +0: equal values must produce equal keys
+  const uint32_t b = __float_as_uint(v);
+  const uint32_t o = (v != v) ? 0u : ((b & 0x80000000u) ? ~b : (b | 0x80000000u));
+  return ((unsigned long long)o << 32) | (unsigned long long)(0xffffffffu - idx);
+}
+__device__ __forceinline__ unsigned long long gemv_am_max(unsigned long long x, unsigned long long y) { return x > y ? x : y; }
+__device__ __forceinline__ unsigned long long gemv_am_shfl_xor(unsigned long long x, int d) {
+  const uint32_t lo = __shfl_xor((uint32_t)x, d, 64), hi = __shfl_xor((uint32_t)(x >> 32), d, 64);
+  return ((unsigned long long)hi << 32) | lo;
+}
 
 struct GemvSeg {
   const void* w;           // int4: tiled words; dense: row-major [n, K] 16-bit
@@ -57,6 +71,11 @@ struct GemvArgs {
   // (m_groups == 1), log2 of the octets per row (or -1)
   int steps_per_item, items_q, items_r, x_chunks, octs_shift;
   int dbg;        // experiment switches (VRA_EXP): 1 = prologue only, 2 = skip the x staging
+  // dense single-tensor launches with f32 output (the lm_head of 1..8-row steps): the greedy token of every row comes out of
+  // the same launch.  am_ws = [M][grid] candidate keys + the arrival counter at am_ws[GEMV_AM_COUNTER]; the last workgroup to
+  // arrive reduces the candidates and writes am_out[m] (first maximal index, as vra_argmax_f32) and re-arms the counter.
+  uint32_t* am_out;
+  unsigned long long* am_ws;
   unsigned long long* ts;  // VRA_GEMV_TS builds: [grid][32] wall-clock stamps of wave 0
 };
 #ifdef VRA_GEMV_TS
@@ -254,6 +273,7 @@ __global__ __launch_bounds__(GEMV_THREADS, 4) void gemv_kernel(const GemvArgs a)
   f32x4 acc[NBW];
 #pragma unroll
   for (int b = 0; b < NBW; b++) acc[b] = vra_zero_acc();
+  unsigned long long am_best = 0ull;  // this thread's (row, column-in-block) over its work items, ascending columns
   int item = 0, sub = 0, parity = 0;
   for (int s0 = 0; s0 < total_sub; s0 += NBUF) {
 #pragma unroll
@@ -345,6 +365,7 @@ __global__ __launch_bounds__(GEMV_THREADS, 4) void gemv_kernel(const GemvArgs a)
           v = sl * v2;
         }
         if (a.residual) v = rnd_dt<DT>(v) + DT::to_f32(static_cast<const uint16_t*>(a.residual)[(size_t)m * a.res_ld + n]);
+        if (!INT4 && NBW == 1 && a.am_out) am_best = gemv_am_max(am_best, gemv_am_key(rnd_dt<DT>(v), (uint32_t)n));
         if (a.out_f32) static_cast<float*>(sg.out)[(size_t)m * sg.out_ld + n] = rnd_dt<DT>(v);
         else static_cast<uint16_t*>(sg.out)[(size_t)m * sg.out_ld + n] = DT::from_f32(v);
       }
@@ -359,6 +380,35 @@ __global__ __launch_bounds__(GEMV_THREADS, 4) void gemv_kernel(const GemvArgs a)
       ++issued;
     }
    }
+  }
+  if (!INT4 && NBW == 1) {
+    if (a.am_out) {  // uniform.  nout = 16 * M <= 128 here (launcher), so thread t always held row t >> 4, column t & 15
+      uint32_t* flag = reinterpret_cast<uint32_t*>(red8);
+#pragma unroll
+      for (int d = 8; d > 0; d >>= 1) am_best = gemv_am_max(am_best, gemv_am_shfl_xor(am_best, d));
+      if (tid < 16 * M && (tid & 15) == 0)
+        __hip_atomic_store(a.am_ws + (size_t)(tid >> 4) * gridDim.x + blockIdx.x, am_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // no fences (an agent-scope release walks the whole L2 once per workgroup: measured +150 us per launch): the candidate is a
+      // write-through store, complete at vmcnt(0); the counter and the candidate loads below are device-scope accesses too
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        const uint32_t old = __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(a.am_ws + GEMV_AM_COUNTER), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = old == gridDim.x - 1 ? 1u : 0u;
+      }
+      __syncthreads();
+      if (*flag) {  // the last workgroup to arrive: wave w reduces row w
+        if (wave < M) {
+          unsigned long long b = 0ull;
+          for (int c = lane; c < (int)gridDim.x; c += 64)
+            b = gemv_am_max(b, __hip_atomic_load(a.am_ws + (size_t)wave * gridDim.x + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+          for (int d = 32; d > 0; d >>= 1) b = gemv_am_max(b, gemv_am_shfl_xor(b, d));
+          if (lane == 0) a.am_out[wave] = 0xffffffffu - (uint32_t)b;
+        }
+        if (tid == 0) __hip_atomic_store(reinterpret_cast<uint32_t*>(a.am_ws + GEMV_AM_COUNTER), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
   GEMV_STAMP(15);
 }

@@ -176,6 +176,10 @@ static void launch_gemv_v(GemvArgs a, int nblocks, size_t lds, hipStream_t st) {
   const int cap = num_cus() * occ_val;
   const int per = (nblocks + cap - 1) / cap;
   const int grid = (nblocks + per - 1) / per;
+  if (a.am_out && (INT4 || NBW != 1 || a.M > 8 || grid > GEMV_AM_MAX_GRID)) {
+    vra_set_error("gemv: the fused argmax serves dense single-tensor launches of <= 8 rows (grid %d)", grid);
+    return;
+  }
   kern<<<grid, GEMV_THREADS, lds, st>>>(a);
 }
 static void gemv_debug_args(GemvArgs& a) {
@@ -1056,6 +1060,31 @@ extern "C" void vra_dense_gemm(const void* x, const void* w, const void* bias, v
     b.out_f32 = out_dtype == VRA_F32;
     vra_launch_skinny(b, false, false, dtype, stream);
   }
+}
+
+extern "C" int64_t vra_dense_gemm_argmax_workspace_bytes(void) { return ((int64_t)GEMV_AM_COUNTER + 8) * 8; }
+extern "C" void vra_dense_gemm_argmax(const void* x, const void* w, const void* bias, float* logits, uint32_t* tokens, void* workspace,
+                                      int32_t m, int32_t k, int32_t n, int32_t dtype, int64_t stream) {
+  VRA_CHECK_ARG(x && w && logits && tokens && workspace, "vra_dense_gemm_argmax: null pointer");
+  VRA_CHECK_ARG(dtype == VRA_BF16 || dtype == VRA_F16, "vra_dense_gemm_argmax: dtype must be bf16/f16");
+  VRA_CHECK_ARG(m >= 1 && k % 128 == 0 && n % 16 == 0, "vra_dense_gemm_argmax: need k %% 128 == 0, n %% 16 == 0 (m=%d k=%d n=%d)", m, k, n);
+  if (m <= 8 && vra_gemv_fits(false, 1, m, k, -1)) {
+    GemvArgs a = {};
+    a.nseg = 1;
+    a.seg[0] = GemvSeg{w, nullptr, nullptr, bias, logits, n, n, 0};
+    a.x = x;
+    a.x_ld = k;
+    a.M = m;
+    a.K = k;
+    a.group_size = -1;
+    a.out_f32 = 1;
+    a.am_out = tokens;
+    a.am_ws = static_cast<unsigned long long*>(workspace);
+    vra_launch_gemv(a, false, dtype, stream);
+    return;
+  }
+  vra_dense_gemm(x, w, bias, logits, m, k, n, dtype, VRA_F32, stream);
+  vra_argmax_f32(logits, tokens, m, n, stream);
 }
 
 // ---- Section A: the seven symbols of src/utils/gptq.rs:3-6 ------------------------------------

@@ -397,8 +397,7 @@ class Engine {
     hipGraph_t g = nullptr;
     hipGraphExec_t ge = nullptr;
     if (hipStreamBeginCapture(stream_, hipStreamCaptureModeRelaxed) != hipSuccess) return nullptr;
-    const bool ok = model_.forward(cmd, (int64_t)stream_);
-    if (ok) vra_argmax_f32(model_.logits(), d_tokens_, bucket, mc_.vocab_size, (int64_t)stream_);
+    const bool ok = model_.forward(cmd, (int64_t)stream_, d_tokens_);
     const hipError_t e = hipStreamEndCapture(stream_, &g);
     if (ok && e == hipSuccess && g && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess) graphs_[key] = ge;
     else ge = nullptr;
@@ -429,8 +428,7 @@ class Engine {
       InputMetadata md = prepare_prefill(ids, &nb);
       if (md.n_tokens < 0) return fail("prefill step exceeds max_step_tokens / max_num_seqs");
       if (!upload_meta(md)) return fail("metadata upload failed");
-      if (!model_.forward(md, (int64_t)stream_)) return fail(model_.error);
-      vra_argmax_f32(model_.logits(), d_tokens_, B, mc_.vocab_size, (int64_t)stream_);
+      if (!model_.forward(md, (int64_t)stream_, d_tokens_)) return fail(model_.error);
     } else {
       const int bucket = std::min(batch_bucket(B), max_seqs_);
       InputMetadata md = prepare_decode(ids, std::max(bucket, B));
@@ -446,8 +444,7 @@ class Engine {
         }
       }
       if (!launched) {
-        if (!model_.forward(md, (int64_t)stream_)) return fail(model_.error);
-        vra_argmax_f32(model_.logits(), d_tokens_, md.n_tokens, mc_.vocab_size, (int64_t)stream_);
+        if (!model_.forward(md, (int64_t)stream_, d_tokens_)) return fail(model_.error);
       }
     }
     if (!sample_stochastic(ids, is_prefill)) return false;

@@ -397,6 +397,8 @@ bool Model::init_buffers(int max_tokens, int max_seqs) {
       !(act_ = dalloc(T * inter_ * es_)) || !(tmp_ = dalloc(T * H * es_)) || !(last_ = dalloc((size_t)max_seqs * H * es_)) ||
       !(logits_ = (float*)dalloc((size_t)max_seqs * mc_.vocab_size * 4)))
     return false;
+  const size_t am_bytes = ((size_t)GEMV_AM_COUNTER + 8) * 8;
+  if (!(argmax_ws_ = (unsigned long long*)dalloc(am_bytes)) || hipMemset(argmax_ws_, 0, am_bytes) != hipSuccess) return false;
   if (mc_.quant_method == 0) {
     if (!(gate_ = dalloc(T * inter_ * es_)) || !(up_ = dalloc(T * inter_ * es_))) return false;
   }
@@ -825,7 +827,7 @@ bool Model::launch_decode_phases(const InputMetadata& md, int ph0, int ph1, int6
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
-bool Model::forward(const InputMetadata& md, int64_t stream) {
+bool Model::forward(const InputMetadata& md, int64_t stream, uint32_t* tokens) {
   const int T = md.n_tokens, B = md.n_seqs, H = mc_.hidden_size, D = mc_.head_dim;
   if (world_ > 1 && !comm_) {
     error = "forward: tensor parallel world_size " + std::to_string(world_) + " without a communicator (vra_engine_set_comm)";
@@ -906,6 +908,10 @@ bool Model::forward(const InputMetadata& md, int64_t stream) {
     a.K = H;
     a.group_size = -1;
     a.out_f32 = 1;
+    if (tokens && rows <= 8) {  // the greedy tokens out of the same launch (the last workgroup to arrive reduces the candidates)
+      a.am_out = tokens, a.am_ws = argmax_ws_;
+      tokens = nullptr;
+    }
     vra_launch_gemv(a, false, dt_, stream);
   } else if (vra_gemv_dw_fits(rows, H, lm_head_.N)) {  // 9..32 rows: final norm + lm_head in one launch (gemv_dw.cuh)
     GemvDWArgs a = {};
@@ -917,6 +923,7 @@ bool Model::forward(const InputMetadata& md, int64_t stream) {
     vra_rms_norm(xin, final_norm_, xn_, rows, H, mc_.rms_norm_eps, dt_, stream);
     vra_dense_gemm(xn_, lm_head_.w, nullptr, logits_, rows, H, lm_head_.N, dt_, VRA_F32, stream);
   }
+  if (tokens) vra_argmax_f32(logits_, tokens, rows, lm_head_.N, stream);
   return !take_err(error, "lm_head");
 }
 

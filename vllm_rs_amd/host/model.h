@@ -85,7 +85,9 @@ class Model {
   bool has_comm() const { return comm_ != nullptr; }
   int world() const { return world_; }
   // forward → logits (device, f32 [n_seqs, vocab]) ; returns false on argument error
-  bool forward(const InputMetadata& md, int64_t stream);
+  // tokens != null: the greedy token of every logits row is written there as well (out of the lm_head launch itself where the
+  // kernel offers it, else by an argmax launch)
+  bool forward(const InputMetadata& md, int64_t stream, uint32_t* tokens = nullptr);
   float* logits() const { return logits_; }
   const vra_model_config& config() const { return mc_; }
   int local_heads() const { return hq_; }
@@ -142,6 +144,7 @@ class Model {
   void *h_ = nullptr, *xn_ = nullptr, *q_ = nullptr, *k_ = nullptr, *v_ = nullptr, *attn_ = nullptr, *act_ = nullptr,
        *tmp_ = nullptr, *gate_ = nullptr, *up_ = nullptr, *last_ = nullptr, *attn_ws_ = nullptr;
   float* logits_ = nullptr;
+  unsigned long long* argmax_ws_ = nullptr;  // kernel A's candidate keys + arrival counter (gemv.cuh)
   // persistent decode step
   void* dp_layers_ = nullptr;     // device: DPLayer[num_layers]
   int dp_plan_[3][7] = {};        // per row count M = 1..2: nslot, ring_off, x_off, red_off, xt, lds_bytes, zero_off (nslot 0: not usable)

@@ -203,6 +203,19 @@ def embedding(ids, table, tokens, hidden, vocab, dtype=BF16):
     return out
 
 
+class DenseGemmArgmax:
+    """lm_head + greedy token in one launch (vra_dense_gemm_argmax); owns the zeroed workspace the launches share"""
+
+    def __init__(self):
+        self.ws = DevBuf(lib().vra_dense_gemm_argmax_workspace_bytes()).zero()
+
+    def __call__(self, x, w, bias, m, k, n, dtype=BF16):
+        logits, toks = DevBuf(m * n * 4), DevBuf(m * 4)
+        lib().vra_dense_gemm_argmax(_ptr(x), _ptr(w), _ptr(bias), logits.ptr, toks.ptr, self.ws.ptr, m, k, n, dtype, 0)
+        check_error()
+        return logits, toks.numpy(np.uint32, (m,))
+
+
 def argmax(logits, rows, cols):
     out = DevBuf(rows * 4)
     lib().vra_argmax_f32(_ptr(logits), out.ptr, rows, cols, 0)
