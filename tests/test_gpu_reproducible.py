@@ -1,0 +1,50 @@
+"""Bit-reproducibility of batched decode steps (9..32 rows: kernels W and C).
+
+Round 3 found a race in kernel C's multi-item mode (more work items than CUs — TinyLlama widths, Qwen2-7B gate/up — csrc/gemm_q4.cuh):
+the partial tiles of an item alias x buffer 0, and a producer wave without epilogue work (KS = 8 leaves 64 units for 256
+producer threads) staged the next item's first x chunk over tiles another producer wave was still summing.  At the TinyLlama
+widths and 17..32 rows the same step differed from run to run by up to 6.8 in a logit; the parity tests (one run against the
+oracle, a tolerance) had not seen it.  Chunk c now lives in buffer (c + 1) & 1.  It was found while testing an RMSNorm run at
+the end of the o_proj launch (bit-identical to the norm launch once the race was gone, but 1.3 % slower at 32 rows: not kept,
+DESIGN.md 3.1b)."""
+import numpy as np
+import pytest
+
+from tests.test_gpu_engine import prefill_inputs, simple_tables, small_cfg
+from vllm_rs_amd.engine import Engine
+
+pytestmark = pytest.mark.gpu
+
+CFGS = {
+    "llama3_8b_widths": small_cfg(hidden_size=4096, intermediate_size=14336, num_layers=2, num_heads=32, num_kv_heads=8, head_dim=128,
+                                  vocab_size=2048, rope_theta=500000.0, max_position_embeddings=2048),
+    "tinyllama_widths_q": small_cfg(hidden_size=2048, intermediate_size=5632, num_layers=2, num_heads=32, num_kv_heads=4, head_dim=64, vocab_size=2048),
+    "qwen2_7b_widths": small_cfg(arch="qwen2", attention_bias=True, hidden_size=3584, intermediate_size=18944, num_layers=1, num_heads=28,
+                                 num_kv_heads=4, head_dim=128, vocab_size=2048, quant_method="awq", rope_theta=1e6, rms_norm_eps=1e-6),
+}
+
+
+@pytest.mark.parametrize("name", list(CFGS))
+def test_batched_decode_steps_are_bit_reproducible(name):
+    """the same 17..32-row step six times: bit-identical logits.  (Round 3 found kernel C's multi-item mode — more work items
+    than CUs: TinyLlama widths, Qwen2-7B gate/up — staging the next item's x over partial tiles that were still being summed;
+    the TinyLlama widths at 17..32 rows showed it as run-to-run differences of up to 6.8 in a logit.)"""
+    cfg = CFGS[name]
+    eng = Engine(cfg, max_num_seqs=32, max_model_len=2048, num_gpu_blocks=64, use_graph=False, seed=11).init_synthetic()
+    try:
+        for B in (9, 17, 24, 32):
+            r = np.random.default_rng(B)
+            prompts = [r.integers(0, cfg["vocab_size"], size=int(n)).tolist() for n in r.integers(3, 40, size=B)]
+            bt = simple_tables([len(p) + 8 for p in prompts])
+            ids, pos, slots, ctx, cu = prefill_inputs(prompts, bt)
+            tok = np.argmax(eng.forward_raw(ids, pos, slots, bt, ctx, cu), axis=-1)
+            seqs = [list(p) + [int(t)] for p, t in zip(prompts, tok)]
+            ids = np.array([s[-1] for s in seqs], np.uint32)
+            pos = np.array([len(s) - 1 for s in seqs], np.int64)
+            slots = np.array([int(bt[b, (len(s) - 1) // 64]) * 64 + (len(s) - 1) % 64 for b, s in enumerate(seqs)], np.int64)
+            ctx = np.array([len(s) for s in seqs], np.uint32)
+            outs = [eng.forward_raw(ids, pos, slots, bt, ctx, None) for _ in range(6)]
+            for i, o in enumerate(outs[1:]):
+                assert np.array_equal(outs[0].view(np.uint32), o.view(np.uint32)), f"{name} B={B}: run {i + 1} differs by up to {np.abs(outs[0] - o).max()}"
+    finally:
+        eng.close()

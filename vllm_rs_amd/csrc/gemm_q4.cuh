@@ -104,8 +104,12 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
   const int XS_U32 = ROWS * RS;       // one x buffer in u32
   uint32_t* xs = reinterpret_cast<uint32_t*>(smem);
   float* xsum = reinterpret_cast<float*>(smem + (size_t)2 * XS_U32 * 4);  // [2][TPC][ROWS]
-  // the partial tiles of an item ALIAS the x buffers: they are written after the item's last chunk has been consumed
-  // and read by the producers before they stage the next item's first chunk
+  // the partial tiles of an item ALIAS x buffer 0: they are written after the item's last chunk has been consumed and read by
+  // the producers while the next item's FIRST chunk is being staged — which is why chunk c lives in buffer (c + 1) & 1: chunk 0
+  // goes to buffer 1, and buffer 0 is first written (chunk 1) behind the chunk-0 barrier, which every producer wave only reaches
+  // after its share of the epilogue.  (Round 3: with chunk 0 in buffer 0 a producer wave WITHOUT epilogue work — KS = 8 leaves
+  // 64 units for 256 producer threads — staged the next item's x over partial tiles another producer wave was still summing:
+  // non-reproducible logits at the TinyLlama widths, 17..32 rows, the only test shape with more items than CUs and KS = 8.)
   f32x4* red = reinterpret_cast<f32x4*>(smem);  // [GC_CW][NBW][MT][64] (<= 32 KiB <= one x buffer)
   int* flag = reinterpret_cast<int*>(smem + (size_t)2 * XS_U32 * 4 + (size_t)2 * TPC * ROWS * 4);
 
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
     auto commit = [&](int buf, const u32x4 (&v)[PER_MAX]) {
       // (the address walks down the rows behind an opaque copy: left to itself hipcc keeps the 16 addresses of both buffers
       // in registers across the chunk loop and spills)
-      uint32_t off = (uint32_t)(buf * XS_U32 + prow * RS + (pt & (OPC - 1)) * 4);  // in u32
+      uint32_t off = (uint32_t)((buf ^ 1) * XS_U32 + prow * RS + (pt & (OPC - 1)) * 4);  // in u32; chunk parity `buf` -> buffer buf ^ 1 (see `red`)
       asm volatile("" : "+v"(off));
 #pragma unroll
       for (int r = 0; r < PER_MAX; r++) {
@@ -455,7 +459,7 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
           GC_CYC(cA);
           const int ktl = ksi + KS * i;  // tile within this workgroup's K slice
           const int c = ktl >> tpc_sh, tl = ktl & (TPC - 1);
-          const uint32_t* xb = xs + (size_t)(c & 1) * XS_U32;
+          const uint32_t* xb = xs + (size_t)((c & 1) ^ 1) * XS_U32;
           f32x4 ag[NBW][MT];  // (every chain STARTS with the C = 0 form of the MFMA: no accumulator is zeroed on the VALU)
           // LDS reads run one k-step (j) ahead of the MFMAs that consume them.  The row sums Σx of the zero-point fix-up
           // come from one extra MFMA per (j, m-tile) against an all-ones B fragment: D[m][n] = Σ_k x[m][k] lands in
