@@ -48,3 +48,15 @@ def test_batched_decode_steps_are_bit_reproducible(name):
                 assert np.array_equal(outs[0].view(np.uint32), o.view(np.uint32)), f"{name} B={B}: run {i + 1} differs by up to {np.abs(outs[0] - o).max()}"
     finally:
         eng.close()
+
+
+def test_reproducibility_sweep_over_shapes_and_step_sizes():
+    """tools/repro_sweep.py: 12 shapes (the BASELINE widths incl. Llama-3-70B and its TP=8 rank, AWQ / f16 / fine groups /
+    channel-wise / dense) x 15 prefill step shapes x 12 decode batch sizes at short and long (split-KV) contexts x 16-bit and
+    FP8 KV cache, every forward six times: all bit-identical"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("repro_sweep", os.path.join(os.path.dirname(__file__), "..", "tools", "repro_sweep.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main(list(mod.CFGS)) == 0
