@@ -60,3 +60,15 @@ def test_reproducibility_sweep_over_shapes_and_step_sizes():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.main(list(mod.CFGS)) == 0
+
+
+def test_invariance_sweep_batch_composition_and_step_shape():
+    """tools/invariance_sweep.py: a sequence's logits do not depend (beyond 6 storage ulps; measured worst 3.75) on what else is in
+    the decode step (B = 2..32 against one at a time) nor on how its prompt was cut into steps (one prefill step, prefill + a
+    decode step, two chunks over the cached prefix), over the same 12 shapes, 16-bit and FP8 KV"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("invariance_sweep", os.path.join(os.path.dirname(__file__), "..", "tools", "invariance_sweep.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main(list(mod.CFGS)) == 0
