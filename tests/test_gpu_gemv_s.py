@@ -31,6 +31,21 @@ def test_gemv_s_gptq_real_widths(M, K, N):
     assert_close_dt(out.numpy(np.uint16, (M, N)), ref, BF16, name=f"gemv_s M={M} K={K} N={N}", abs_floor=2e-3)
 
 
+@pytest.mark.parametrize("M", [1, 2, 3, 4])
+@pytest.mark.parametrize("dt", [BF16, F16])
+def test_gemv_s_qwen2_down_projection_ten_tiles_per_wave(M, dt):
+    """K = 18944 (Qwen2-7B down: 148 k-tiles, 10 per wave): four row regions per tile no longer fit the LDS, kernel E keeps M of
+    them (1..3 rows; 4 rows go to kernel A as before) — AWQ zero points, residual"""
+    K, N = 18944, 3584
+    r = rng(M + K)
+    q = make_quant(r, K, N, 128, dt, True)
+    x, res = rand_dt(r, (M, K), dt), rand_dt(r, (M, N), dt)
+    out = ops.wna16_gemm(ops.dev(x), _tiled(q, True), ops.dev(q["scales"]), ops.dev(q["qzeros"]), M, K, N, 128, True, 0, None, ops.dev(res), dtype=dt)
+    ref = orc.wna16_gemm(x, q["idx"], q["zeros"], q["scales"], 128, dt, None, res)
+    g0 = np.abs(orc.from_dt(orc.wna16_gemm(x, q["idx"], q["zeros"], q["scales"], 128, dt), dt))
+    assert_close_dt(out.numpy(np.uint16, (M, N)), ref, dt, max_ulp=2.0, name=f"gemv_s K=18944 M={M}", mag=g0)
+
+
 @pytest.mark.parametrize("M", [1, 4])
 @pytest.mark.parametrize("dt,awq,gs,layout", [(BF16, True, 128, 0), (F16, True, 128, 0), (F16, False, 128, 0), (BF16, False, 128, 1), (F16, True, 128, 1),
                                               (BF16, False, 256, 0), (BF16, True, 512, 1), (BF16, False, -1, 0), (F16, True, -1, 0)])

@@ -32,13 +32,14 @@
 #define GS_WAVES 16
 #define GS_THREADS (GS_WAVES * 64)
 #define GS_MAX_UNITS 8   // units (pairs) per workgroup at most
-#define GS_MAX_TPW 8     // k-tiles per wave and unit at most (K <= 16384)
+#define GS_MAX_TPW 10    // k-tiles per wave and unit at most (K <= 20480: Qwen2-7B's down projection, K = 18944, is 148 tiles)
 #define GS_NORM_TPW 4    // ... with a fused RMSNorm (the norm weights of a wave's tiles stay in registers)
 #define GS_MAX_SEG 3
 #ifndef GS_RING_KIB
 #define GS_RING_KIB 2
 #endif
-#define GS_TILE_LDS 1104  // bytes of a wave's LDS per k-tile: 4 rows x (256 + 16) + 16 (Σx of the 4 rows)
+#define GS_TILE_LDS 1104  // bytes of a wave's LDS per k-tile: 4 row regions x (256 + 16) + 16 (Σx of the 4 rows).  When that does not
+                          // fit (K > 16384) the launcher keeps only M row regions: xrows * 272 + 16 (GemvSArgs::xrows)
 
 struct GemvSSeg {  // output segment (q / k / v of one launch): epilogue only
   void* out;
@@ -67,8 +68,8 @@ struct GemvSArgs {
   unsigned long long* ts;
 };
 
-static inline size_t gemv_q4s_lds_bytes(int ns, int tpw, int max_units) {
-  return (size_t)GS_WAVES * tpw * GS_TILE_LDS + 256 + (size_t)max_units * ns * GS_WAVES * 256;
+static inline size_t gemv_q4s_lds_bytes(int ns, int tpw, int max_units, int xrows = 4) {
+  return (size_t)GS_WAVES * tpw * (xrows * 272 + 16) + 256 + (size_t)max_units * ns * GS_WAVES * 256;
 }
 
 #define GS_MIN_WAVES_PER_SIMD 4
@@ -79,7 +80,9 @@ static inline size_t gemv_q4s_lds_bytes(int ns, int tpw, int max_units) {
 // (gemv_q4s2_kernel: o_proj -> gate/up and down -> next q/k/v in one launch each — break-even).  What the whole-layer form of
 // that idea became is csrc/decode_step.hip.
 
-template <class DT, int NS, bool AWQ>
+// XR = row regions per tile in LDS (compile time: the addressing of the hot loop stays constant-folded): 4, or M = 1..3 for
+// K > 16384 where four do not fit
+template <class DT, int NS, bool AWQ, int XR = 4>
 __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char* smem) {
   constexpr int D = NS == 2 ? GS_RING_PAIR : GS_RING_KIB;  // ring depth in tile-steps (1 KiB per stream and step)
   // every kernel argument the way to the first load needs, requested in ONE batch of scalar loads
@@ -97,9 +100,10 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
   GEMV_STAMP(0);
 
   // ---- LDS carve-up
-  unsigned char* xw = smem + (size_t)wave * TPW * GS_TILE_LDS;  // this wave's x slices
-  float* part = reinterpret_cast<float*>(smem + (size_t)GS_WAVES * TPW * GS_TILE_LDS);  // [16 waves][4 rows] Σx²
-  f32x4* red = reinterpret_cast<f32x4*>(smem + (size_t)GS_WAVES * TPW * GS_TILE_LDS + 256);  // [unit][NS][wave][16 lanes]
+  constexpr int TLS = XR * 272 + 16;  // bytes per tile
+  unsigned char* xw = smem + (size_t)wave * TPW * TLS;  // this wave's x slices
+  float* part = reinterpret_cast<float*>(smem + (size_t)GS_WAVES * TPW * TLS);  // [16 waves][4 rows] Σx²
+  f32x4* red = reinterpret_cast<f32x4*>(smem + (size_t)GS_WAVES * TPW * TLS + 256);  // [unit][NS][wave][16 lanes]
 
   // ---- epilogue operands of the threads that will finish the outputs (requested before the weight stream starts):
   // thread -> (unit ui, row m, column nl) for tid < nu*64
@@ -150,8 +154,10 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
     iu = last ? iu : (wrap ? iu + 1 : iu);
   };
 
-  // ---- prologue: this wave's x slices.  Staging lane = (row group oct, octet nn): region `oct` of a tile holds row
-  // min(oct, M-1), so rows >= M alias the last row (their outputs are never stored).
+  // ---- prologue: this wave's x slices.  Staging lane = (row group oct, octet nn): region min(oct, XR-1) of a tile holds row
+  // min(oct, M-1), so rows >= M alias the last row (their outputs are never stored; with XR = M regions the lanes of the
+  // missing regions rewrite the last one with the same bytes).
+  const int srg = (XR == 4 ? oct : min(oct, XR - 1)) * 272;
   const bool norm = a.norm_w != nullptr;
   const uint16_t* xrow = static_cast<const uint16_t*>(a.x) + (size_t)min(oct, M - 1) * a.x_ld + nn * 8;
   const uint16_t* nwp = static_cast<const uint16_t*>(a.norm_w) + nn * 8;
@@ -171,8 +177,8 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
       if (ti < TPW) {
         const bool valid = wave + 16 * ti < KT;
         if (!valid) xv[i] = u32x4{0u, 0u, 0u, 0u};  // a wave without this k-tile: zero slice (and zeroed scales below)
-        unsigned char* tp = xw + (size_t)ti * GS_TILE_LDS;
-        *reinterpret_cast<u32x4*>(tp + oct * 272 + nn * 16) = xv[i];
+        unsigned char* tp = xw + (size_t)ti * TLS;
+        *reinterpret_cast<u32x4*>(tp + srg + nn * 16) = xv[i];
         if (norm) {
           float f[8];
           unpack8<DT>(xv[i], f);
@@ -180,7 +186,7 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
           for (int e = 0; e < 8; e++) ss += f[e] * f[e];
         } else {
           const float s8 = row16_sum(octet_sum<DT>(xv[i]));
-          if (nn == 0) reinterpret_cast<float*>(tp + 1088)[oct] = s8;
+          if (nn == 0) reinterpret_cast<float*>(tp + XR * 272)[oct] = s8;
         }
       }
     }
@@ -209,17 +215,17 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
 #pragma unroll
     for (int ti = 0; ti < GS_NORM_TPW; ti++) {
       if (ti < TPW) {
-        unsigned char* tp = xw + (size_t)ti * GS_TILE_LDS;
-        const u32x4 raw = *reinterpret_cast<const u32x4*>(tp + oct * 272 + nn * 16);
+        unsigned char* tp = xw + (size_t)ti * TLS;
+        const u32x4 raw = *reinterpret_cast<const u32x4*>(tp + srg + nn * 16);
         float f[8], g[8];
         unpack8<DT>(raw, f);
         unpack8<DT>(nr[ti], g);
 #pragma unroll
         for (int e = 0; e < 8; e++) f[e] = f[e] * rstd * g[e];
         const u32x4 v = pack8<DT>(f);
-        *reinterpret_cast<u32x4*>(tp + oct * 272 + nn * 16) = v;
+        *reinterpret_cast<u32x4*>(tp + srg + nn * 16) = v;
         const float s8 = row16_sum(octet_sum<DT>(v));  // over the ROUNDED values the MFMA will see
-        if (nn == 0) reinterpret_cast<float*>(tp + 1088)[oct] = s8;
+        if (nn == 0) reinterpret_cast<float*>(tp + XR * 272)[oct] = s8;
       }
     }
   }
@@ -227,7 +233,7 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
 
   // ---- main loop
   // A fragment: lane (oct, nn) reads row min(nn, 3) (region r holds row min(r, M-1)), columns j*32 + oct*8 ..
-  const unsigned char* xfrag = xw + min(nn, 3) * 272 + oct * 16;
+  const unsigned char* xfrag = xw + min(nn, XR - 1) * 272 + oct * 16;
   const int zsh = 4 * awq_rev(nn & 7);
   const bool shalf = a.marlin ? (nn >> 3) & 1 : nn & 1;  // which half of the loaded word is this lane's scale
   constexpr float CB = Magic<DT>::bias;
@@ -244,7 +250,7 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
     for (int r = 0; r < D; r++) {
       if (s0 + r < S) {
         const bool valid = wave + 16 * ct < KT;
-        const unsigned char* xp = xfrag + (size_t)ct * GS_TILE_LDS;
+        const unsigned char* xp = xfrag + (size_t)ct * TLS;
         f32x4 ag[NS];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -256,7 +262,7 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
           }
         }
         VRA_MFMA_DRAIN();
-        const f32x4 sx = *reinterpret_cast<const f32x4*>(xw + (size_t)ct * GS_TILE_LDS + 1088);  // Σx of rows 0..3 over this tile
+        const f32x4 sx = *reinterpret_cast<const f32x4*>(xw + (size_t)ct * TLS + XR * 272);  // Σx of rows 0..3 over this tile
 #pragma unroll
         for (int b = 0; b < NS; b++) {
           float s = DT::to_f32((uint16_t)(shalf ? sb[r][b] >> 16 : sb[r][b]));
@@ -318,5 +324,11 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
 template <class DT, int NS, bool AWQ>
 __global__ __launch_bounds__(GS_THREADS, GS_MIN_WAVES_PER_SIMD) void gemv_q4s_kernel(const GemvSArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  gemv_q4s_body<DT, NS, AWQ>(a, smem);
+  gemv_q4s_body<DT, NS, AWQ, 4>(a, smem);
+}
+// K > 16384 (Qwen2-7B down): XR = M row regions per tile
+template <class DT, bool AWQ, int XR>
+__global__ __launch_bounds__(GS_THREADS, GS_MIN_WAVES_PER_SIMD) void gemv_q4s_rows_kernel(const GemvSArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  gemv_q4s_body<DT, 1, AWQ, XR>(a, smem);
 }

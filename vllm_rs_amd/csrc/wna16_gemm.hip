@@ -345,22 +345,31 @@ bool vra_gemv_s_fits(int ns, int M, int K, int group_size, int n_units, bool nor
   int grid, q, r;
   vra_gemv_s_plan(n_units, &grid, &q, &r);
   const int mu = q + (r ? 1 : 0);
-  return mu <= GS_MAX_UNITS && gemv_q4s_lds_bytes(ns, tpw, mu) <= (size_t)kMaxDynLds;
+  // four row regions per tile in LDS, or only M of them when four do not fit (K > 16384 at 1..3 rows; single stream only)
+  return mu <= GS_MAX_UNITS && (gemv_q4s_lds_bytes(ns, tpw, mu, 4) <= (size_t)kMaxDynLds || (ns == 1 && gemv_q4s_lds_bytes(ns, tpw, mu, M) <= (size_t)kMaxDynLds));
 }
-template <class DT, int NS, bool AWQ>
-static void launch_gemv_s_v(GemvSArgs a, hipStream_t st) {
+template <class DT, int NS, bool AWQ, int XR>
+static void launch_gemv_s_x(const GemvSArgs& a, int grid, size_t lds, hipStream_t st) {
   static uint64_t attr_devs = 0;
-  auto kern = gemv_q4s_kernel<DT, NS, AWQ>;
+  void (*kern)(const GemvSArgs);
+  if constexpr (XR == 4) kern = gemv_q4s_kernel<DT, NS, AWQ>;
+  else kern = gemv_q4s_rows_kernel<DT, AWQ, XR>;
   if (!dev_seen(attr_devs)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
     dev_mark(attr_devs);
   }
+  kern<<<grid, GS_THREADS, lds, st>>>(a);
+}
+template <class DT, int NS, bool AWQ>
+static void launch_gemv_s_v(GemvSArgs a, hipStream_t st) {
   const int g = a.K / 128;
   a.KT = g;
   a.TPW = (a.KT + 15) / 16;
   int grid;
   vra_gemv_s_plan(a.n_units, &grid, &a.units_q, &a.units_r);
-  const size_t lds = gemv_q4s_lds_bytes(NS, a.TPW, a.units_q + (a.units_r ? 1 : 0));
+  const int mu = a.units_q + (a.units_r ? 1 : 0);
+  const int xrows = gemv_q4s_lds_bytes(NS, a.TPW, mu, 4) <= (size_t)kMaxDynLds ? 4 : a.M;  // (vra_gemv_s_fits: one of the two fits)
+  const size_t lds = gemv_q4s_lds_bytes(NS, a.TPW, mu, xrows);
   static const char* exp_env = getenv("VRA_EXP");
   a.dbg = exp_env ? atoi(exp_env) : 0;
 #ifdef VRA_GEMV_TS
@@ -368,9 +377,14 @@ static void launch_gemv_s_v(GemvSArgs a, hipStream_t st) {
 #else
   a.ts = nullptr;
 #endif
-  kern<<<grid, GS_THREADS, lds, st>>>(a);
+  if (xrows == 4) return launch_gemv_s_x<DT, NS, AWQ, 4>(a, grid, lds, st);
+  if constexpr (NS == 1) {  // K > 16384 (no fused norm, no pair there): only M row regions per tile
+    if (xrows == 1) return launch_gemv_s_x<DT, NS, AWQ, 1>(a, grid, lds, st);
+    if (xrows == 2) return launch_gemv_s_x<DT, NS, AWQ, 2>(a, grid, lds, st);
+    if (xrows == 3) return launch_gemv_s_x<DT, NS, AWQ, 3>(a, grid, lds, st);
+  }
+  vra_set_error("gemv_s: no LDS layout for M=%d K=%d ns=%d", a.M, a.K, NS);
 }
-// a.{KT, TPW, units_q, units_r} are filled here; a.gsh from group_size
 void vra_launch_gemv_s(GemvSArgs a, int ns, int group_size, bool awq, int dtype, int64_t stream) {
   hipStream_t st = as_stream(stream);
   const bool grouped = group_size > 0 && group_size < a.K;
