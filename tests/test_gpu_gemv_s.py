@@ -3,7 +3,7 @@ bs = 1 headline and the one `roofline` is quoted on — through the C ABI, again
 rounding: <= 1 storage ulp) at the REAL widths of the BASELINE configs:
   Llama-3-8B   o_proj 4096x4096, q/k/v 4096x6144, gate/up 4096x14336 (pair), down 14336x4096 (7 k-tiles per wave)
   Qwen2-7B     K = 3584 (28 k-tiles: waves 12..15 have one tile fewer), AWQ zero points
-  Llama-3-70B  TP=8 rank: K = 1024 (8 k-tiles: half of the waves idle) x 8192, K = 8192 (4 tiles per wave)
+  Llama-3-70B  TP=8 rank: K = 1024 (8 k-tiles: half of the waves idle) x 8192, K = 8192 (4 tiles per wave), q/k/v 8192 x 1280 (80 units)
 and across scale layouts (row-major checkpoint tensors, the Marlin-permuted scales of the reference's FFI), group sizes
 (128, 256, channel-wise), dtypes, fused bias / residual / RMSNorm / SiLU*mul."""
 import numpy as np
@@ -21,7 +21,7 @@ def _tiled(q, awq=False):
 
 
 @pytest.mark.parametrize("M", [1, 2, 3, 4])
-@pytest.mark.parametrize("K,N", [(4096, 4096), (4096, 6144), (14336, 4096), (3584, 4608), (1024, 8192), (8192, 2304), (4096, 2064)])
+@pytest.mark.parametrize("K,N", [(4096, 4096), (4096, 6144), (14336, 4096), (3584, 4608), (1024, 8192), (8192, 2304), (4096, 2064), (8192, 1280)])
 def test_gemv_s_gptq_real_widths(M, K, N):
     r = rng(M * 7 + K + N)
     q = make_quant(r, K, N, 128, BF16, False)
@@ -107,11 +107,12 @@ def test_gemv_s_gate_up_pair(M, K, N, awq):
 
 @pytest.mark.parametrize("M", [1, 2, 4])
 @pytest.mark.parametrize("dt", [BF16, F16])
-def test_gemv_s_fused_rms_norm(M, dt):
+@pytest.mark.parametrize("K,N", [(4096, 6144), (8192, 1280)])
+def test_gemv_s_fused_rms_norm(M, dt, K, N):
     """RMSNorm fused into the prologue (every wave normalises its own x slices; the only cross-wave step is the 16 x 4 table
-    of partial sums of squares) against the oracle's norm -> GEMM, and against the two separate device calls"""
-    K, N = 4096, 6144
-    r = rng(M + dt)
+    of partial sums of squares) against the oracle's norm -> GEMM, and against the two separate device calls.  8192 x 1280: the
+    q/k/v launch of a Llama-3-70B TP=8 rank — 80 units, fewer than half the CUs (kernel E since round 3)"""
+    r = rng(M + dt + N)
     q = make_quant(r, K, N, 128, dt, False)
     x, nw = rand_dt(r, (M, K), dt, 2.0), orc.to_dt((1.0 + 0.1 * r.standard_normal(K)).astype(np.float32), dt)
     bias = rand_dt(r, (N,), dt)

@@ -341,7 +341,10 @@ bool vra_gemv_s_fits(int ns, int M, int K, int group_size, int n_units, bool nor
   if (g < K && (g < 128 || (g & (g - 1)))) return false;  // power-of-two groups of >= one k-tile, or channel-wise
   const int KT = K / 128, tpw = (KT + 15) / 16;
   if (norm && tpw > GS_NORM_TPW) return false;
-  if (n_units < num_cus() / 2) return false;  // too few n-blocks to spread over the chip without slicing K: kernel A / B
+  static const char* mu_env = getenv("VRA_GS_MIN_UNITS");  // tuning aid
+  // too few n-blocks to spread over the chip without slicing K: kernel A / B.  (A quarter of the CUs, not half, since round 3:
+  // the q/k/v launch of a Llama-3-70B TP=8 rank — K = 8192, 80 units — takes 8.7 us here against 12.3 in kernel A.)
+  if (n_units < (mu_env ? atoi(mu_env) : num_cus() / 4)) return false;
   int grid, q, r;
   vra_gemv_s_plan(n_units, &grid, &q, &r);
   const int mu = q + (r ? 1 : 0);
