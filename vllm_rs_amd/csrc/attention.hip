@@ -445,7 +445,31 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
   const bool row_valid = rq < G;
   const int qhead = hk * G + rq;
   s16x8 qf[DJ];
-  {
+  // Channel map of the QK^T contraction (k-step j, lane octet oct, element e): the 16-bit cache uses j*32 + oct*8 + e (a K row is
+  // DJ 16-byte loads per lane either way); the FP8 cache uses oct*(D/4) + j*8 + e — lane-contiguous, so that a lane's share of a
+  // K row (D/4 bytes) is D/64 16-byte loads instead of DJ 8-byte ones (the FP8 cache read half the bytes in the same number
+  // of load instructions).  q is laid out to match; the contraction order inside an MFMA changes, nothing else.
+  if constexpr (KV8) {
+    const uint16_t* qp = static_cast<const uint16_t*>(a.q) + ((size_t)b * a.Hq + qhead) * D;
+    const bool first = oct < 2;  // channels oct*(D/4) .. : the first half of the head for oct 0, 1
+#pragma unroll
+    for (int j = 0; j < DJ; j++) {
+      const int c = oct * (D / 4) + j * 8, cl = c & (HALF - 1);
+      u32x4 va = {0u, 0u, 0u, 0u}, vb = {0u, 0u, 0u, 0u};
+      if (row_valid) {
+        va = *reinterpret_cast<const u32x4*>(qp + c);
+        vb = *reinterpret_cast<const u32x4*>(qp + (first ? c + HALF : c - HALF));
+      }
+      float x1[8], x2[8], cs[8], sn[8], y[8];
+      unpack8<DT>(va, x1);
+      unpack8<DT>(vb, x2);
+      unpack8<DT>(*reinterpret_cast<const u32x4*>(cosp + cl), cs);
+      unpack8<DT>(*reinterpret_cast<const u32x4*>(sinp + cl), sn);
+#pragma unroll
+      for (int e = 0; e < 8; e++) y[e] = first ? x1[e] * cs[e] - x2[e] * sn[e] : x1[e] * cs[e] + x2[e] * sn[e];
+      qf[j] = __builtin_bit_cast(s16x8, pack8<DT>(y));
+    }
+  } else {
     const uint16_t* qp = static_cast<const uint16_t*>(a.q) + ((size_t)b * a.Hq + qhead) * D;
 #pragma unroll
     for (int j = 0; j < DJ / 2; j++) {
@@ -492,10 +516,24 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
     const size_t vbase = (((size_t)blk * a.Hkv + hk) * D) * a.BS + off;
     const bool has_new = last >= T0 && last < T0 + 32;  // wave-uniform: the tile that holds the new token
     u32x4 k0[DJ], k1[DJ];
+    if constexpr (KV8) {
+      u32x4 r0[D / 64], r1[D / 64];  // a lane's D/4 bytes of each row
 #pragma unroll
-    for (int j = 0; j < DJ; j++) {
-      k0[j] = kv_load8<DT, KV8>(krow0 + j * 32 + oct * 8);
-      k1[j] = kv_load8<DT, KV8>(krow1 + j * 32 + oct * 8);
+      for (int i = 0; i < D / 64; i++) {
+        r0[i] = *reinterpret_cast<const u32x4*>(krow0 + oct * (D / 4) + i * 16);
+        r1[i] = *reinterpret_cast<const u32x4*>(krow1 + oct * (D / 4) + i * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < DJ; j++) {
+        k0[j] = vra_unpack_e4m3x8<DT>(u32x2{r0[j >> 1][(j & 1) * 2], r0[j >> 1][(j & 1) * 2 + 1]});
+        k1[j] = vra_unpack_e4m3x8<DT>(u32x2{r1[j >> 1][(j & 1) * 2], r1[j >> 1][(j & 1) * 2 + 1]});
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < DJ; j++) {
+        k0[j] = kv_load8<DT, KV8>(krow0 + j * 32 + oct * 8);
+        k1[j] = kv_load8<DT, KV8>(krow1 + j * 32 + oct * 8);
+      }
     }
     // V: issue the loads now (they only depend on the block table), consume after the softmax
     u32x4 vfr[DT16];
@@ -508,11 +546,11 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
     if (has_new) {
       if (T0 + krow_tok == last) {
 #pragma unroll
-        for (int j = 0; j < DJ; j++) k0[j] = kv_load8<DT, KV8>(knew + j * 32 + oct * 8);
+        for (int j = 0; j < DJ; j++) k0[j] = kv_load8<DT, KV8>(knew + (KV8 ? oct * (D / 4) + j * 8 : j * 32 + oct * 8));
       }
       if (T0 + krow_tok + 4 == last) {
 #pragma unroll
-        for (int j = 0; j < DJ; j++) k1[j] = kv_load8<DT, KV8>(knew + j * 32 + oct * 8);
+        for (int j = 0; j < DJ; j++) k1[j] = kv_load8<DT, KV8>(knew + (KV8 ? oct * (D / 4) + j * 8 : j * 32 + oct * 8));
       }
     }
     f32x4 s0 = vra_zero_acc(), s1 = vra_zero_acc();
