@@ -181,7 +181,7 @@ __global__ __launch_bounds__(GEMV_THREADS, 4) void gemv_kernel(const GemvArgs a)
 
   // register ring of NBUF sub-steps: a buffer is refilled (for the sub-step NBUF ahead) right after it
   // has been consumed, so NBUF*UK*NBW KiB per wave are in flight all the time and nothing is copied
-  constexpr int NBUF = 3;
+  constexpr int NBUF = (!INT4 && NBW == 2) ? 2 : 3;  // (the dense gate/up pair holds 8 x 16 B per lane and sub-step: two sub-steps fit the 128 VGPRs)
   u32x4 wbuf[NBUF][UK][NBW][LPT];
   u32x2 sbuf[NBUF][UK][NBW][NSC];
   uint32_t zbuf[NBUF][UK][NBW][NZP];

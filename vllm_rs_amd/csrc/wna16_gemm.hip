@@ -301,7 +301,11 @@ void vra_launch_gemv(const GemvArgs& a, bool int4, int dtype, int64_t stream) {
   else
     for (int s = 0; s < a.nseg; s++) nblocks += (a.seg[s].n + 15) / 16;
   const bool bf = dtype == VRA_BF16;
-  if (a.silu_dual) {
+  if (a.silu_dual && !int4) {  // dense gate/up pair + SiLU*mul (unquantised models: mlp.rs:451-469 in one launch)
+    const size_t lds = gemv_lds_bytes(false, 2, a.M, a.K, a.group_size);
+    if (bf) launch_gemv_v<BF16, false, 2, 1, false>(a, nblocks, lds, st);
+    else launch_gemv_v<F16, false, 2, 1, false>(a, nblocks, lds, st);
+  } else if (a.silu_dual) {
     if (bf) launch_gemv_q4_t<BF16, 2>(a, nblocks, st);
     else launch_gemv_q4_t<F16, 2>(a, nblocks, st);
   } else if (int4) {

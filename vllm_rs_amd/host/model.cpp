@@ -586,6 +586,18 @@ bool Model::gate_up(const LayerWeights& L, const void* x, const void* norm_w, vo
     }
     return !take_err(error, "gate_up");
   }
+  if (!L.up.quant && L.gate.K == L.up.K && L.gate.N == L.up.N && vra_gemv_fits(false, 2, M, K, -1)) {
+    // unquantised decode: norm + gate + up + SiLU*mul in ONE launch (kernel A, dense pair), as the int4 path does
+    GemvArgs a = {};
+    a.nseg = 2;
+    a.seg[0] = GemvSeg{L.gate.w, nullptr, nullptr, L.gate.bias, act, N, N, 0};
+    a.seg[1] = GemvSeg{L.up.w, nullptr, nullptr, L.up.bias, act, N, N, 0};
+    a.silu_dual = 1;
+    a.x = x, a.x_ld = K, a.norm_w = norm_w, a.eps = mc_.rms_norm_eps;
+    a.M = M, a.K = K, a.group_size = -1;
+    vra_launch_gemv(a, false, dt_, stream);
+    return !take_err(error, "gate_up dense pair");
+  }
   const QLinear ls[2] = {L.gate, L.up};
   void* outs[2] = {gate_, up_};
   if (!linear_fused_norm(ls, 2, outs, x, norm_w, M, stream)) return false;
