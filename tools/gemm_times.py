@@ -12,7 +12,7 @@ if len(sys.argv) > 2:
 eng = E.Engine(cfg, max_num_seqs=32, max_model_len=4096, num_gpu_blocks=512, use_graph=True, seed=1, cpu_mem_fold=0.0).init_synthetic()
 L = cfg["num_layers"]
 if cfg.get("quant_method"):
-    for M in (1, 32, 128, 2048):
+    for M in (1, 16, 32, 128, 2048):
         tot = 0.0
         for w, nm in ((0, "norm+qkv"), (1, "o_proj"), (2, "norm+gate_up"), (3, "down")):
             ms = eng.bench_gemm(w, M, 160 if M <= 32 else 12)
