@@ -532,9 +532,13 @@ def main():
                 # oracle as the checker (tests/full_depth.py), ~20 s of host time
                 from tests import full_depth
                 rep = full_depth.run(dict(cfg), log=lambda *_: None)
-                line["parity_full_depth"] = {k: rep[k] for k in ("workload", "tokens_equal", "first_divergence", "n_steps", "max_abs", "mean_abs",
-                                                                   "min_frac_within_1e3_abs", "min_frac_within_1e3_of_scale", "max_ulp_of_row_scale",
-                                                                   "logit_scale", "per_step_max_abs", "seconds")}
+                keys = ("workload", "tokens_equal", "first_divergence", "n_steps", "max_abs", "mean_abs", "min_frac_within_1e3_abs",
+                        "min_frac_within_1e3_of_scale", "max_ulp_of_row_scale", "logit_scale", "per_step_max_abs", "seconds")
+                line["parity_full_depth"] = {k: rep[k] for k in keys}
+                if not a.no_extras:
+                    # config 3 (Qwen2-7B AWQ, L = 28, V = 152064) the same way; zero points drawn as in real AWQ checkpoints
+                    rep = full_depth.run(dict(E.QWEN2_7B), log=lambda *_: None)
+                    line["parity_full_depth_qwen2"] = {k: rep[k] for k in keys}
     if eng is not None:
         eng.close()
     if dist is not None:

@@ -267,6 +267,9 @@ void vra_fill_uniform(void* out, int64_t numel, uint64_t seed, float lo, float h
 void vra_fill_normal(void* out, int64_t numel, uint64_t seed, float mean, float std, int32_t dtype,
                      int64_t stream);
 void vra_fill_const_u32(uint32_t* out, int64_t numel, uint32_t value, int64_t stream);
+/* packed AWQ zero points of the synthetic checkpoints: nibbles drawn from {6:1, 7:3, 8:8, 9:3, 10:1}/16 (concentrated on 8,
+ * as in real AWQ checkpoints), from the same counter hash as vra_fill_hash_u32 */
+void vra_fill_awq_zeros(uint32_t* out, int64_t numel, uint64_t seed, int64_t stream);
 
 /* AllReduce CustomOp1 (src/models/layers/distributed.rs:325-396): sum over TP ranks, bf16/f16.
  * The communicator is created from the 128-byte unique id the engine ships in MessageType::Init
@@ -382,6 +385,10 @@ int64_t vra_kv_plan_num_blocks(const vra_model_config* mc, const vra_engine_conf
                                int64_t free_bytes);
 /* rotary tables (rotary_emb.rs:32-73,126-278): f32 cos/sin [n_pos, rot_dim/2] */
 void vra_rope_tables_f32(const vra_model_config* mc, int32_t n_pos, float* h_cos, float* h_sin);
+/* rows of the table the reference builds for this config (rotary_emb.rs:44-46,296-312,519-526): max_position_embeddings, or
+ * for yarn (u32)(max_position_embeddings * factor), for dynamic-by-factor (u32)(original_max * factor) — the engine sizes its
+ * tables, max_model_len clamp and position checks with it */
+int32_t vra_rope_table_rows(const vra_model_config* mc);
 /* marlin_permute_scales (wna16.rs:180-218) on a host array of 16-bit elements [k/g, n] */
 void vra_marlin_permute_scales_u16(const uint16_t* h_in, uint16_t* h_out, int32_t rows, int32_t n,
                                    int32_t grouped);

@@ -95,6 +95,12 @@ def fill_hash_u32(n, seed):
     return out
 
 
+def fill_awq_zeros(n, seed):
+    out = np.empty(n, np.uint32)
+    lib().orc_fill_awq_zeros(_p(out), C.c_int64(out.size), C.c_uint64(seed))
+    return out
+
+
 def fill_uniform(shape, seed, lo, hi, dt):
     out = np.empty(shape, np_dt(dt))
     lib().orc_fill_uniform(_p(out), C.c_int64(out.size), C.c_uint64(seed), C.c_float(lo), C.c_float(hi), dt)

@@ -171,6 +171,18 @@ void orc_fill_hash_u32(uint32_t* out, int64_t n, uint64_t seed) {
 #pragma omp parallel for
   for (int64_t i = 0; i < n; i++) out[i] = hash32(seed, (uint64_t)i);
 }
+/* AWQ zero points of the synthetic checkpoints (BASELINE.md recipe, revised in round 4): every nibble of a hash word goes
+ * through a table concentrated on 8 (6:1 7:3 8:8 9:3 10:1 of 16), like the zero points of real AWQ checkpoints. */
+void orc_fill_awq_zeros(uint32_t* out, int64_t n, uint64_t seed) {
+  const uint64_t lut = 0xA999888888887776ull;
+#pragma omp parallel for
+  for (int64_t i = 0; i < n; i++) {
+    const uint32_t h = hash32(seed, (uint64_t)i);
+    uint32_t w = 0;
+    for (int p = 0; p < 8; p++) w |= (uint32_t)((lut >> (4 * ((h >> (4 * p)) & 0xFu))) & 0xFull) << (4 * p);
+    out[i] = w;
+  }
+}
 void orc_fill_uniform(void* out, int64_t n, uint64_t seed, float lo, float hi, int dt) {
 #pragma omp parallel for
   for (int64_t i = 0; i < n; i++) st(out, i, lo + (hi - lo) * hash_unit(seed, (uint64_t)i), dt);

@@ -33,7 +33,7 @@ def synthetic_checkpoint(cfg, seed=1234):
         w[prefix + ".qweight"] = orc.awq_pack(idx) if awq else orc.gptq_pack(idx)
         w[prefix + ".scales"] = orc.fill_uniform((K // g, N), s + 1, 0.002, 0.02, dt)
         if awq:
-            w[prefix + ".qzeros"] = orc.fill_hash_u32((K // g) * (N // 8), s + 2).reshape(K // g, N // 8)
+            w[prefix + ".qzeros"] = orc.fill_awq_zeros((K // g) * (N // 8), s + 2).reshape(K // g, N // 8)
         if with_bias:
             w[prefix + ".bias"] = orc.fill_normal((N,), s + 3, 0.0, 0.02, dt)
 

@@ -123,6 +123,7 @@ def load():
     _sig(lib, "vra_sample", None, P, P, c_i32, c_i32, c_i32, c_f32, c_f32, c_u64, P, P, c_i64)
     _sig(lib, "vra_apply_penalties", None, P, P, P, c_i32, c_i32, c_i32, P, P, c_i64)
     _sig(lib, "vra_fill_hash_u32", None, P, c_i64, c_u64, c_i64)
+    _sig(lib, "vra_fill_awq_zeros", None, P, c_i64, c_u64, c_i64)
     _sig(lib, "vra_fill_uniform", None, P, c_i64, c_u64, c_f32, c_f32, c_i32, c_i64)
     _sig(lib, "vra_fill_normal", None, P, c_i64, c_u64, c_f32, c_f32, c_i32, c_i64)
     _sig(lib, "vra_fill_const_u32", None, P, c_i64, C.c_uint32, c_i64)
@@ -161,6 +162,7 @@ def load():
     _sig(lib, "vra_kv_per_block_bytes", c_i64, MC, EC)
     _sig(lib, "vra_kv_plan_num_blocks", c_i64, MC, EC, c_i64)
     _sig(lib, "vra_rope_tables_f32", None, MC, c_i32, P, P)
+    _sig(lib, "vra_rope_table_rows", c_i32, MC)
     _sig(lib, "vra_marlin_permute_scales_u16", None, P, P, c_i32, c_i32, c_i32)
     _sig(lib, "vra_bm_create", P, c_i32, c_i32, c_i32, c_f32)
     _sig(lib, "vra_bm_destroy", None, P)

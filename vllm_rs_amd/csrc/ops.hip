@@ -146,8 +146,9 @@ extern "C" void vra_silu_mul(const void* gate, const void* up, void* out, int64_
 // ---------------------------------------------------------------- row gathers
 __global__ __launch_bounds__(256) void gather_rows_kernel(const uint32_t* __restrict__ idx, const unsigned char* __restrict__ table,
                                                           unsigned char* __restrict__ out, int rows, size_t row_bytes,
-                                                          uint32_t n_table_rows) {
+                                                          uint32_t n_table_rows, uint32_t* __restrict__ bump = nullptr) {
   const int r = blockIdx.x;
+  if (bump && r == 0 && threadIdx.x == 0) *bump += 1u;  // the forward's epoch word (qkv_attn.h): one writer, read by LATER launches
   uint32_t src = idx[r];
   if (src >= n_table_rows) src = n_table_rows - 1;  // clamp (the reference would fault)
   const u32x4* s = reinterpret_cast<const u32x4*>(table + (size_t)src * row_bytes);
@@ -160,6 +161,13 @@ extern "C" void vra_embedding(const uint32_t* ids, const void* table, void* out,
   VRA_CHECK_ARG((hidden * es) % 16 == 0, "vra_embedding: row bytes must be a multiple of 16");
   if (tokens <= 0) return;
   gather_rows_kernel<<<tokens, 256, 0, as_stream(stream)>>>(ids, (const unsigned char*)table, (unsigned char*)out, tokens, hidden * es, (uint32_t)vocab);
+}
+void vra_embedding_bump(const uint32_t* ids, const void* table, void* out, int32_t tokens, int32_t hidden, int32_t vocab, int32_t dtype,
+                        uint32_t* bump, int64_t stream) {
+  size_t es = dtype == VRA_F32 ? 4 : 2;
+  VRA_CHECK_ARG((hidden * es) % 16 == 0, "vra_embedding: row bytes must be a multiple of 16");
+  if (tokens <= 0) return;
+  gather_rows_kernel<<<tokens, 256, 0, as_stream(stream)>>>(ids, (const unsigned char*)table, (unsigned char*)out, tokens, hidden * es, (uint32_t)vocab, bump);
 }
 extern "C" void vra_index_select_rows(const void* x, const uint32_t* idx, void* out, int32_t n_idx, int32_t hidden,
                                       int32_t dtype, int64_t stream) {
@@ -607,6 +615,20 @@ extern "C" void vra_swap_blocks(const void* src, void* dst, const int64_t* h_pai
 __global__ void fill_hash_kernel(uint32_t* out, int64_t n, uint64_t seed) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = vra_hash32(seed, (uint64_t)i);
 }
+// AWQ zero points of the synthetic checkpoints: every nibble of a hash word is mapped through a 16-entry table that is
+// concentrated on 8 (6:1 7:3 8:8 9:3 10:1 of 16) — what real AWQ checkpoints look like (asymmetric min/max quantisation of
+// near-symmetric weight groups).  Uniform zero points (the recipe of rounds 1-3) put a common-mode term of up to 7.5 scales
+// on every group, which made the full-depth synthetic network a noise amplifier.  == oracle orc_fill_awq_zeros
+#define VRA_AWQ_ZERO_LUT 0xA999888888887776ull
+__global__ void fill_awq_zeros_kernel(uint32_t* out, int64_t n, uint64_t seed) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t h = vra_hash32(seed, (uint64_t)i);
+    uint32_t w = 0;
+#pragma unroll
+    for (int p = 0; p < 8; p++) w |= (uint32_t)((VRA_AWQ_ZERO_LUT >> (4 * ((h >> (4 * p)) & 0xFu))) & 0xFull) << (4 * p);
+    out[i] = w;
+  }
+}
 __global__ void fill_const_kernel(uint32_t* out, int64_t n, uint32_t v) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = v;
 }
@@ -629,6 +651,9 @@ static inline int fill_grid(int64_t n) {
 }
 extern "C" void vra_fill_hash_u32(uint32_t* out, int64_t numel, uint64_t seed, int64_t stream) {
   if (numel > 0) fill_hash_kernel<<<fill_grid(numel), 256, 0, as_stream(stream)>>>(out, numel, seed);
+}
+extern "C" void vra_fill_awq_zeros(uint32_t* out, int64_t numel, uint64_t seed, int64_t stream) {
+  if (numel > 0) fill_awq_zeros_kernel<<<fill_grid(numel), 256, 0, as_stream(stream)>>>(out, numel, seed);
 }
 extern "C" void vra_fill_const_u32(uint32_t* out, int64_t numel, uint32_t value, int64_t stream) {
   if (numel > 0) fill_const_kernel<<<fill_grid(numel), 256, 0, as_stream(stream)>>>(out, numel, value);

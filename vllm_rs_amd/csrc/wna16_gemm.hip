@@ -148,6 +148,7 @@ static unsigned long long* vra_gemv_ts_buf() {
   }
   return g_ts;
 }
+unsigned long long* vra_gemv_ts_buf_shared() { return vra_gemv_ts_buf(); }
 extern "C" void vra_debug_ts(unsigned long long* host, int n) { (void)hipMemcpy(host, vra_gemv_ts_buf(), (size_t)n * 8, hipMemcpyDeviceToHost); }
 #endif
 struct GemvArgs;

@@ -148,7 +148,7 @@ class Engine {
   bool finalize_dry() {
     if (ec_.num_gpu_blocks < 2) return fail("dry engine needs an explicit num_gpu_blocks");
     max_model_len_ = ec_.max_model_len > 0 ? ec_.max_model_len : mc_.max_position_embeddings;
-    if (max_model_len_ > mc_.max_position_embeddings) max_model_len_ = mc_.max_position_embeddings;
+    if (max_model_len_ > vra_rope_table_rows(&mc_)) max_model_len_ = vra_rope_table_rows(&mc_);  // the rotary table's rows (yarn / dynamic: > max_position_embeddings)
     max_seqs_ = std::max(ec_.max_num_seqs > 0 ? ec_.max_num_seqs : 32, kMinScheduledReqs);
     max_step_tokens_ = kMaxStepTokens;
     const int64_t nb = ec_.num_gpu_blocks;
@@ -199,7 +199,7 @@ class Engine {
     if (hipSetDevice(ec_.device) != hipSuccess) return fail("hipSetDevice failed");
     if (!stream_ && hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) != hipSuccess) return fail("stream create failed");
     max_model_len_ = ec_.max_model_len > 0 ? ec_.max_model_len : mc_.max_position_embeddings;
-    if (max_model_len_ > mc_.max_position_embeddings) max_model_len_ = mc_.max_position_embeddings;
+    if (max_model_len_ > vra_rope_table_rows(&mc_)) max_model_len_ = vra_rope_table_rows(&mc_);  // the rotary table's rows (yarn / dynamic: > max_position_embeddings)
     // every per-sequence buffer is sized for what the scheduler may batch: max(max_num_seqs, 5)
     max_seqs_ = std::max(ec_.max_num_seqs > 0 ? ec_.max_num_seqs : 32, kMinScheduledReqs);
     max_step_tokens_ = kMaxStepTokens;  // a prefill step batches prompts up to this many tokens (1.2 GB of activations for Llama-3-8B)
@@ -1005,7 +1005,7 @@ extern "C" int32_t vra_engine_forward_raw(void* e, const uint32_t* h_ids, const 
       if (h_slot_mapping[t] >= n_slots) return en->error = "forward_raw: slot " + std::to_string(h_slot_mapping[t]) + " outside the KV cache", -1;
       if (is_prefill ? h_slot_mapping[t] < 0 : h_slot_mapping[t] < -1)  // (-1: a padded decode lane writes nothing)
         return en->error = "forward_raw: negative slot", -1;
-      if (h_positions[t] < 0 || h_positions[t] >= en->mc_.max_position_embeddings)
+      if (h_positions[t] < 0 || h_positions[t] >= vra_rope_table_rows(&en->mc_))
         return en->error = "forward_raw: position " + std::to_string(h_positions[t]) + " outside the rotary table", -1;
     }
     for (int b = 0; b < n_seqs; b++) {

@@ -27,6 +27,18 @@ extern "C" int64_t vra_kv_plan_num_blocks(const vra_model_config* mc, const vra_
   return (int64_t)((double)free_bytes * frac) / per;
 }
 
+// Rows of the cos / sin tables the reference builds (rotary_emb.rs:44-46 default / linear / llama3: max_position_embeddings;
+// :296-312 dynamic: max_position_embeddings with `alpha`, else (u32)(original_max * factor); :519-526 yarn:
+// (u32)(max_position_embeddings as f32 * factor)) — the longest position a sequence may reach.
+extern "C" int32_t vra_rope_table_rows(const vra_model_config* mc) {
+  if (mc->rope_scaling_type == 4) return (int32_t)(uint32_t)((float)mc->max_position_embeddings * (float)mc->rope_factor);
+  if (mc->rope_scaling_type == 3 && !mc->rope_dynamic_alpha) {
+    const double omax = mc->rope_original_max_position > 0 ? mc->rope_original_max_position : mc->max_position_embeddings;
+    return (int32_t)(uint32_t)(omax * mc->rope_factor);
+  }
+  return mc->max_position_embeddings;
+}
+
 // RotaryEmbedding::new / ScalingRotaryEmbedding::new (src/models/layers/rotary_emb.rs:32-73,143-415,435-541):
 // inv_freq = 1f32 / (theta^(i/d) in f64 -> f32); linear: * (f32)(1/factor); llama3: wavelength smoothing in f32; dynamic
 // (NTK): the default table of a rescaled theta (f64); yarn: interpolation / extrapolation blend of two f32 frequency sets

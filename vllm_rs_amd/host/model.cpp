@@ -3,12 +3,24 @@
 
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../csrc/decode_step.h"
 #include "../csrc/gemm_launch.h"
+#include "../csrc/qkv_attn.h"
 #include "../csrc/scratch.h"
 #include "host_utils.h"
+
+// The fused decode launch of csrc/qkv_attn.hip (norm + q/k/v + RoPE + KV write + attention) is OPT-IN: measured at parity with the
+// two launches (kernel E, then decode_attn_fused_kernel [+ merge]) — bs 1 1.737 / 1.743 against 1.743 / 1.743 ms per step on
+// one box — and a spin wait inside a kernel is not taken for nothing.  VRA_FUSED_QKV_ATTN=1 or
+// vra_debug_set_fused_qkv_attn(1) turn it on (the parity tests do).
+static int g_fused_qkv_attn = [] {
+  const char* e = getenv("VRA_FUSED_QKV_ATTN");
+  return e ? atoi(e) : 0;
+}();
+extern "C" void vra_debug_set_fused_qkv_attn(int on) { g_fused_qkv_attn = on; }
 
 namespace vra {
 
@@ -52,7 +64,7 @@ void* Model::dalloc(size_t bytes) {
 // ---------------------------------------------------------------------------------------------
 bool Model::qlinear_synth(QLinear& l, int K, int N, bool bias, uint64_t seed) {
   // BASELINE.md / SURVEY §8d synthetic recipe: qweight uniform u32, GPTQ zeros 8 (stored 0x77777777),
-  // AWQ zeros uniform nibbles, scales ~ U(0.002, 0.02), dense weights ~ N(0, 0.02).
+  // AWQ zeros concentrated on 8 (vra_fill_awq_zeros; uniform nibbles until round 3), scales ~ U(0.002, 0.02), dense weights ~ N(0, 0.02).
   l.K = K;
   l.N = N;
   l.quant = mc_.quant_method != 0;
@@ -68,7 +80,7 @@ bool Model::qlinear_synth(QLinear& l, int K, int N, bool bias, uint64_t seed) {
     weight_bytes_ += words * 4 + ns * es_;
     if (l.awq) {
       if (!(l.qzeros = (uint32_t*)dalloc(ns / 8 * 4))) return false;
-      vra_fill_hash_u32(l.qzeros, (int64_t)(ns / 8), seed + 2, 0);
+      vra_fill_awq_zeros(l.qzeros, (int64_t)(ns / 8), seed + 2, 0);
       weight_bytes_ += ns / 8 * 4;
     }
   } else {
@@ -353,7 +365,7 @@ bool Model::finalize_weights() {
   }
   // rotary tables in the model dtype (llama.rs:179-189; rotary_emb.rs:32-73,208-278)
   const int half = mc_.head_dim / 2;
-  rope_rows_ = mc_.max_position_embeddings;
+  rope_rows_ = vra_rope_table_rows(&mc_);  // yarn / dynamic: longer than max_position_embeddings
   std::vector<float> c((size_t)rope_rows_ * half), s((size_t)rope_rows_ * half);
   vra_rope_tables_f32(&mc_, rope_rows_, c.data(), s.data());
   std::vector<uint16_t> cb(c.size()), sb(s.size());
@@ -402,8 +414,11 @@ bool Model::init_buffers(int max_tokens, int max_seqs) {
   if (mc_.quant_method == 0) {
     if (!(gate_ = dalloc(T * inter_ * es_)) || !(up_ = dalloc(T * inter_ * es_))) return false;
   }
-  const size_t ws = vra_paged_attention_decode_workspace_bytes(max_seqs, hq_, mc_.head_dim, mc_.max_position_embeddings);
+  const size_t ws = vra_paged_attention_decode_workspace_bytes(max_seqs, hq_, mc_.head_dim, vra_rope_table_rows(&mc_));
   if (!(attn_ws_ = dalloc(ws))) return false;
+  const size_t gb = vra_qkv_attn_granule_bytes(4, hq_, hkv_, mc_.head_dim);
+  if (!(qkv_gran_ = dalloc(gb)) || hipMemset(qkv_gran_, 0, gb) != hipSuccess) return false;
+  if (!(epoch_ = (uint32_t*)dalloc(64)) || hipMemset(epoch_, 0, 64) != hipSuccess) return false;
   return build_decode_step();
 }
 
@@ -707,6 +722,26 @@ void Model::gemv_s_args(int l, int which, int M, void* out, const void* residual
       break;
   }
 }
+// decode steps of 1..4 sequences: norm + q/k/v + RoPE + KV write + attention in ONE launch (csrc/qkv_attn.hip)
+bool Model::qkv_attn(int l, const InputMetadata& md, int64_t stream) {
+  const int M = md.n_tokens;
+  if (md.is_prefill || md.n_seqs != M || M > 4 || !gemv_s_ok(0, M) || l >= 255 || !qkv_gran_) return false;
+  const LayerWeights& L = layers_[l];
+  const int kv_dt = ec_.fp8_kvcache ? VRA_FP8_E4M3 : dt_;
+  if (!vra_qkv_attn_fits(M, L.q.K, mc_.group_size, (L.q.N + L.k.N + L.v.N) / 16, hq_, hkv_, mc_.head_dim, ec_.block_size, kv_dt, dt_, md.max_context_len))
+    return false;
+  GemvSArgs a;
+  int ns;
+  gemv_s_args(l, 0, M, nullptr, nullptr, &a, &ns);
+  QkvAttnTail t = {};
+  t.epoch = epoch_, t.layer_tag = l + 1;
+  t.out = attn_, t.kc = kc_[l], t.vc = vc_[l], t.cosv = cos_, t.sinv = sin_;
+  t.positions = md.positions, t.slots = md.slot_mapping, t.block_tables = md.block_tables, t.context_lens = md.context_lens;
+  t.B = M, t.Hq = hq_, t.Hkv = hkv_, t.BS = ec_.block_size, t.max_blocks = md.max_blocks;
+  t.scale_log2e = (1.0f / sqrtf((float)mc_.head_dim)) * 1.44269504088896f;
+  vra_launch_qkv_attn(a, t, qkv_gran_, mc_.group_size, L.q.awq, dt_, mc_.head_dim, stream);
+  return !take_err(error, "qkv_attn");
+}
 bool Model::gemv_s(int l, int which, int M, void* out, const void* residual, int64_t stream) {
   if (!gemv_s_ok(which, M)) return false;
   const LayerWeights& L = layers_[l];
@@ -853,7 +888,7 @@ bool Model::forward(const InputMetadata& md, int64_t stream, uint32_t* tokens) {
   const int kv_dt = ec_.fp8_kvcache ? VRA_FP8_E4M3 : dt_;
   error.clear();
   // embed_forward (llama.rs:260-267)
-  vra_embedding(md.input_ids, embed_, h_, T, H, mc_.vocab_size, dt_, stream);
+  vra_embedding_bump(md.input_ids, embed_, h_, T, H, mc_.vocab_size, dt_, epoch_, stream);  // (+ the forward's epoch word: qkv_attn.h)
   // decode of 1..2 sequences at short contexts: all layers in ONE persistent launch (csrc/decode_step.hip)
   const bool one_launch = !md.is_prefill && B == T && decode_step_ok(T, md.max_context_len);
   if (one_launch && !launch_decode_phases(md, 0, mc_.num_layers * DP_PHASES_PER_LAYER, stream)) return false;
@@ -862,11 +897,14 @@ bool Model::forward(const InputMetadata& md, int64_t stream, uint32_t* tokens) {
     // ---- attention block (llama.rs:115-126): norm -> q,k,v -> rope -> cache + attention -> o_proj (+ residual)
     const QLinear qkv[3] = {L.q, L.k, L.v};
     void* outs[3] = {q_, k_, v_};
-    if (!gemv_s(l, 0, T, nullptr, nullptr, stream)) {
+    const bool fused_attn = g_fused_qkv_attn && qkv_attn(l, md, stream);
+    if (!fused_attn && !error.empty()) return false;
+    if (!fused_attn && !gemv_s(l, 0, T, nullptr, nullptr, stream)) {
       if (!error.empty()) return false;
       if (!linear_fused_norm(qkv, 3, outs, h_, L.attn_norm, T, stream)) return false;
     }
-    if (md.is_prefill) {
+    if (fused_attn) {
+    } else if (md.is_prefill) {
       // RoPE + KV write in one launch (two in the reference: rotary_emb.rs:88-103, attention.rs:808-820)
       vra_rope_cache_prefill(q_, k_, v_, kc_[l], vc_[l], cos_, sin_, md.positions, md.slot_mapping, T, hq_, hkv_, D, ec_.block_size, dt_,
                              kv_dt, stream);

@@ -145,6 +145,10 @@ class Model {
        *tmp_ = nullptr, *gate_ = nullptr, *up_ = nullptr, *last_ = nullptr, *attn_ws_ = nullptr;
   float* logits_ = nullptr;
   unsigned long long* argmax_ws_ = nullptr;  // kernel A's candidate keys + arrival counter (gemv.cuh)
+  // fused q/k/v + attention decode launch (csrc/qkv_attn.hip): the q|k|v granules of a step and the forward's epoch word
+  void* qkv_gran_ = nullptr;
+  uint32_t* epoch_ = nullptr;
+  bool qkv_attn(int l, const InputMetadata& md, int64_t stream);  // false = not covered (error empty) or failed (error set)
   // persistent decode step
   void* dp_layers_ = nullptr;     // device: DPLayer[num_layers]
   int dp_plan_[3][7] = {};        // per row count M = 1..2: nslot, ring_off, x_off, red_off, xt, lds_bytes, zero_off (nslot 0: not usable)
