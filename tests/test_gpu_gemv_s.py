@@ -221,3 +221,63 @@ def test_gemv_w_gate_up_pair(M, awq):
     # gate and up each carry a possible 1-ulp flip (f32 vs f64 accumulation, one flipped normalised activation): their product moves
     # by up to the sum of both relative errors, silu's slope adds a little: 4 ulps over 230k outputs
     assert_close_dt(out.numpy(np.uint16, (M, N)), orc.silu_mul(g, u, BF16), BF16, max_ulp=4.0, max_mismatch_frac=0.05, name="gemv_w gate/up", abs_floor=8e-3)
+
+
+# ---------------------------------------------------------------------------------------------
+# kernel W in row blocks (round 4): short prefills of 33..256 rows, K <= 4096 — blockIdx.y = block of 32 rows, every workgroup an
+# independent 32-row launch of the decode kernel over a contiguous run of units (parity cases at M in {64, 128, 200, 256})
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M", [33, 64, 128, 200, 256])
+@pytest.mark.parametrize("K,N", [(4096, 4096), (4096, 6144), (3584, 4608)])
+def test_gemv_w_row_blocks_gptq_real_widths(M, K, N):
+    r = rng(M * 13 + K + N)
+    q = make_quant(r, K, N, 128, BF16, False)
+    x = rand_dt(r, (M, K), BF16)
+    out = ops.wna16_gemm(ops.dev(x), _tiled(q), ops.dev(q["scales"]), None, M, K, N, 128)
+    ref = orc.wna16_gemm(x, q["idx"], None, q["scales"], 128, BF16)
+    assert_close_dt(out.numpy(np.uint16, (M, N)), ref, BF16, name=f"gemv_w row blocks M={M} K={K} N={N}", abs_floor=2e-3)
+
+
+@pytest.mark.parametrize("M", [64, 200])
+@pytest.mark.parametrize("dt,awq,gs,layout", [(BF16, True, 128, 0), (F16, False, 128, 1), (BF16, False, 256, 0)])
+def test_gemv_w_row_blocks_formats_bias_residual_in_place(M, dt, awq, gs, layout):
+    """o_proj as the engine calls it: the residual is the output buffer (h += o_proj(attn)), every workgroup reads its own rows x
+    columns of it before the stream and writes them behind it"""
+    K, N = 4096, 4096
+    r = rng(M + gs + layout * 3 + awq + 200)
+    q = make_quant(r, K, N, gs, dt, awq)
+    x, bias, res = rand_dt(r, (M, K), dt), rand_dt(r, (N,), dt), rand_dt(r, (M, N), dt)
+    sc = orc.marlin_permute_scales(q["scales"], grouped=True) if layout == 1 else q["scales"]
+    out = ops.wna16_gemm(ops.dev(x), _tiled(q, awq), ops.dev(sc), ops.dev(q["qzeros"]) if awq else None, M, K, N, gs, awq, layout, ops.dev(bias), ops.dev(res),
+                         dtype=dt)
+    ref = orc.wna16_gemm(x, q["idx"], q["zeros"], q["scales"], gs, dt, bias, res)
+    g0 = orc.from_dt(orc.wna16_gemm(x, q["idx"], q["zeros"], q["scales"], gs, dt), dt)
+    mag = np.maximum(np.abs(g0), np.abs(g0 + orc.from_dt(bias, dt)[None, :]))
+    assert_close_dt(out.numpy(np.uint16, (M, N)), ref, dt, max_ulp=2.0, name=f"gemv_w row blocks formats dt={dt} awq={awq} gs={gs} layout={layout}", mag=mag)
+
+
+@pytest.mark.parametrize("M", [64, 128, 200, 256])
+@pytest.mark.parametrize("K,N,dt", [(4096, 6144, BF16), (3584, 4608, F16)])
+def test_gemv_w_row_blocks_fused_rms_norm_qkv_shape(M, K, N, dt):
+    r = rng(M + 77 + K)
+    q = make_quant(r, K, N, 128, dt, False)
+    x, nw = rand_dt(r, (M, K), dt, 2.0), orc.to_dt((1.0 + 0.1 * r.standard_normal(K)).astype(np.float32), dt)
+    bias = rand_dt(r, (N,), dt)
+    out = ops.rms_norm_wna16_gemm(ops.dev(x), ops.dev(nw), 1e-5, _tiled(q), ops.dev(q["scales"]), None, M, K, N, 128, bias=ops.dev(bias), dtype=dt)
+    xn = orc.rms_norm(x, nw, 1e-5, dt)
+    ref = orc.wna16_gemm(xn, q["idx"], None, q["scales"], 128, dt, bias)
+    g0 = np.abs(orc.from_dt(orc.wna16_gemm(xn, q["idx"], None, q["scales"], 128, dt), dt))
+    assert_close_dt(out.numpy(np.uint16, (M, N)), ref, dt, max_ulp=2.0, max_mismatch_frac=0.03, name="gemv_w row blocks fused norm", mag=g0, abs_floor=2e-3)
+
+
+def test_gemv_w_row_blocks_rows_are_independent_of_the_batch_they_ride_in():
+    """row m of a 200-row launch == row m of a 32-row launch of the same rows (same kernel, same summation order): bitwise"""
+    K, N = 4096, 4096
+    r = rng(4242)
+    q = make_quant(r, K, N, 128, BF16, False)
+    x = rand_dt(r, (200, K), BF16)
+    big = ops.wna16_gemm(ops.dev(x), _tiled(q), ops.dev(q["scales"]), None, 200, K, N, 128).numpy(np.uint16, (200, N))
+    for lo in (0, 96, 192):
+        hi = min(lo + 32, 200)
+        small = ops.wna16_gemm(ops.dev(x[lo:hi]), _tiled(q), ops.dev(q["scales"]), None, hi - lo, K, N, 128).numpy(np.uint16, (hi - lo, N))
+        assert np.array_equal(big[lo:hi], small), f"rows {lo}..{hi}"

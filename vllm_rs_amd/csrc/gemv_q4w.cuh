@@ -1,4 +1,4 @@
-// gemv_q4w.cuh — "kernel W": int4 GEMM for decode batches of 5..32 rows and K <= 4096 (q/k/v, o_proj, gate/up of the 7-8B
+// gemv_q4w.cuh — "kernel W": int4 GEMM for decode batches of 5..32 rows (and, in row blocks of 32, short prefills of 33..256 rows) and K <= 4096 (q/k/v, o_proj, gate/up of the 7-8B
 // shapes), on the unit distribution of kernel E (gemv_q4s.cuh): one workgroup per CU, a contiguous run of units (16-column
 // n-blocks, or gate/up pairs) per workgroup.  EIGHT waves here (two per SIMD: 256 VGPRs each), every wave streaming the
 // k-tiles w, w+8, w+16, w+24 of each unit through a 4-deep register ring (4 KiB per wave, 32 KiB per CU in flight as in E).
@@ -45,7 +45,11 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nn = lane & 15, oct = lane >> 4;
-  const int M = a.M, KT = a.KT;
+  // rows: up to 32 per launch as a decode GEMM; 33..256 rows (short prefills, round 4) as blockIdx.y ROW BLOCKS of 16*MT rows, every
+  // block an independent workgroup over its own rows and a contiguous run of units — the weights of a unit are then read once
+  // per row block (L2 / MALL hits), the x of a workgroup stays at 16*MT rows, and nothing meets across workgroups
+  const int row0 = (int)blockIdx.y * (MT * 16);
+  const int M = min(a.M - row0, MT * 16), KT = a.KT;
   const int wg = (int)blockIdx.x;
   const int u0 = wg * a.units_q + min(wg, a.units_r);
   const int nu = a.units_q + (wg < a.units_r ? 1 : 0);
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
         const void* b_;
         int ld_, c0;
         seg_of(u0 + ui, o_, b_, ld_, c0);
-        if (has_res && row < M) e_res[it] = static_cast<const uint16_t*>(a.residual)[(size_t)row * a.res_ld + c0 + col];
+        if (has_res && row < M) e_res[it] = static_cast<const uint16_t*>(a.residual)[(size_t)(row0 + row) * a.res_ld + c0 + col];
         if (row == 0) {
           if (b_) e_b0[it] = static_cast<const uint16_t*>(b_)[c0 + col];
           if (NS == 2 && a.seg[1].bias) e_b1[it] = static_cast<const uint16_t*>(a.seg[1].bias)[c0 + col];
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
     const int kt = min(wave + GW_WAVES * ti, KT - 1);
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
-      const uint16_t* xr = static_cast<const uint16_t*>(a.x) + (size_t)min(mt * 16 + nn, M - 1) * a.x_ld + kt * 128 + oct * 8;
+      const uint16_t* xr = static_cast<const uint16_t*>(a.x) + (size_t)(row0 + min(mt * 16 + nn, M - 1)) * a.x_ld + kt * 128 + oct * 8;
       // (odd rows fetch the two 64-byte halves of a 128-byte line in the opposite order and swap the registers afterwards:
       // with all 16 rows of a wave-load at the SAME offset inside their lines — the row stride is a multiple of 128 bytes —
       // the L1 served them at half rate; any row stride that is an odd multiple of 16..64 bytes measured 2.3..2.8 µs faster
@@ -346,7 +350,7 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
     const void* b_;
     int ld_, c0;
     seg_of(u0 + ui, o_, b_, ld_, c0);
-    static_cast<uint16_t*>(o_)[(size_t)row * ld_ + c0 + col] = outs[idx];
+    static_cast<uint16_t*>(o_)[(size_t)(row0 + row) * ld_ + c0 + col] = outs[idx];
   }
   GEMV_STAMP(15);
 }

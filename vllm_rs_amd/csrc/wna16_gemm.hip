@@ -410,18 +410,46 @@ void vra_launch_gemv_s(GemvSArgs a, int ns, int group_size, bool awq, int dtype,
     else bf ? launch_gemv_s_v<BF16, 1, false>(a, st) : launch_gemv_s_v<F16, 1, false>(a, st);
   }
 }
-// ---- kernel W (gemv_q4w.cuh): 5..32 rows, K <= 4096
+// ---- kernel W (gemv_q4w.cuh): 5..32 rows, K <= 4096; 33..256 rows (short prefills) as row blocks of 32
+static int gemv_w_max_rows() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("VRA_GEMV_W_MAX_ROWS");  // tuning aid: 32 puts the short prefills back on kernels B / D
+    v = e ? atoi(e) : 256;
+  }
+  return v;
+}
+// unit distribution of a launch: up to 32 rows = kernel E's (one workgroup per CU); above, `rb` row blocks of 32 rows x `grid`
+// column groups, about one workgroup per CU in total, at most GW_MAX_UNITS units per workgroup
+static void gemv_w_plan(int M, int n_units, int* grid, int* rb, int* q, int* r) {
+  if (M <= 32) {
+    *rb = 1;
+    vra_gemv_s_plan(n_units, grid, q, r);
+    return;
+  }
+  *rb = (M + 31) / 32;
+  int cg = num_cus() / *rb;
+  if (cg < 1) cg = 1;
+  const int need = (n_units + GW_MAX_UNITS - 1) / GW_MAX_UNITS;
+  if (cg < need) cg = need;
+  if (cg > n_units) cg = n_units;
+  *grid = cg, *q = n_units / cg, *r = n_units % cg;
+}
 bool vra_gemv_w_fits(int ns, int M, int K, int group_size, int n_units, bool has_res) {
   static const char* off = getenv("VRA_NO_GEMV_W");
   if (off && off[0] == '1') return false;
-  if (M < 5 || M > 32 || K % 128 || K > 4096) return false;
+  if (M < 5 || M > (ns == 1 ? gemv_w_max_rows() : 32) || K % 128 || K > 4096) return false;
   if (ns == 2 && M > 16) return false;  // pair x two m-tiles: 8 accumulator tiles + a 4-slot pair ring beside 128 fragment registers spill inside the loop: kernel C
   const int g = group_size > 0 && group_size < K ? group_size : K;
   if (g < K && (g < 128 || (g & (g - 1)))) return false;
   if (n_units < num_cus() / 2) return false;
-  int grid, q, r;
-  vra_gemv_s_plan(n_units, &grid, &q, &r);
+  int grid, rb, q, r;
+  gemv_w_plan(M, n_units, &grid, &rb, &q, &r);
   const int mu = q + (r ? 1 : 0);
+  // row blocks only while all of them run at once: with a second round of workgroups (q/k/v at 200+ rows: 336..384 workgroups)
+  // the launch measured no faster than kernels B / D (tools/short_prefill_gemm_times.py: 48.9 against 51.3 us at 200 rows, 49.8
+  // against 41.2 at 256)
+  if (rb > 1 && grid * rb > num_cus()) return false;
   return mu <= GW_MAX_UNITS && gemv_q4w_lds_bytes(ns, M > 16 ? 2 : 1, mu, has_res) <= (size_t)kMaxDynLds;
 }
 template <class DT, int NS, int MT, bool AWQ, bool NORM>
@@ -434,8 +462,8 @@ static void launch_gemv_w_n(GemvSArgs a, hipStream_t st) {
   }
   a.KT = a.K / 128;
   a.TPW = GW_TPW;
-  int grid;
-  vra_gemv_s_plan(a.n_units, &grid, &a.units_q, &a.units_r);
+  int grid, rb;
+  gemv_w_plan(a.M, a.n_units, &grid, &rb, &a.units_q, &a.units_r);
   const size_t lds = gemv_q4w_lds_bytes(NS, MT, a.units_q + (a.units_r ? 1 : 0), a.residual != nullptr);
   a.dbg = 0;
 #ifdef VRA_GEMV_TS
@@ -443,7 +471,7 @@ static void launch_gemv_w_n(GemvSArgs a, hipStream_t st) {
 #else
   a.ts = nullptr;
 #endif
-  kern<<<grid, GW_THREADS, lds, st>>>(a);
+  kern<<<dim3(grid, rb), GW_THREADS, lds, st>>>(a);
 }
 template <class DT, int NS, int MT, bool AWQ>
 static void launch_gemv_w_v(const GemvSArgs& a, hipStream_t st) {
