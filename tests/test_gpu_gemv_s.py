@@ -281,3 +281,25 @@ def test_gemv_w_row_blocks_rows_are_independent_of_the_batch_they_ride_in():
         hi = min(lo + 32, 200)
         small = ops.wna16_gemm(ops.dev(x[lo:hi]), _tiled(q), ops.dev(q["scales"]), None, hi - lo, K, N, 128).numpy(np.uint16, (hi - lo, N))
         assert np.array_equal(big[lo:hi], small), f"rows {lo}..{hi}"
+
+
+@pytest.mark.parametrize("M", [17, 32, 33, 64, 100, 128, 200, 256])
+@pytest.mark.parametrize("awq", [False, True])
+def test_gemv_w_row_blocks_gate_up_pair(M, awq):
+    """norm + gate + up + SiLU*mul of 17..256 rows in the SEQUENTIAL pair form of kernel W (PSEQ, gemv_q4w.cuh): the units of a
+    workgroup alternate gate / up blocks of the single-stream two-m-tile kernel, the up unit's epilogue applies SiLU(gate) * up.
+    Decode batches of 17..32 rows: one launch instead of a norm launch + kernel C; a 128-token prefill: 4 row blocks x 64 column
+    groups of 14 pairs instead of norm + kernel D."""
+    K, N = 4096, 14336
+    r = rng(M * 3 + K + awq)
+    qg, qu = make_quant(r, K, N, 128, BF16, awq), make_quant(r, K, N, 128, BF16, awq)
+    x, nw = rand_dt(r, (M, K), BF16, 2.0), orc.to_dt((1.0 + 0.1 * r.standard_normal(K)).astype(np.float32), BF16)
+    z = (lambda q: ops.dev(q["qzeros"])) if awq else (lambda q: None)
+    out = ops.rms_norm_wna16_gate_up_silu(ops.dev(x), ops.dev(nw), 1e-5, _tiled(qg, awq), ops.dev(qg["scales"]), z(qg), _tiled(qu, awq), ops.dev(qu["scales"]), z(qu),
+                                          M, K, N, 128, awq)
+    xn = orc.rms_norm(x, nw, 1e-5, BF16)
+    g = orc.wna16_gemm(xn, qg["idx"], qg["zeros"], qg["scales"], 128, BF16)
+    u = orc.wna16_gemm(xn, qu["idx"], qu["zeros"], qu["scales"], 128, BF16)
+    # (as test_gemv_w_gate_up_pair, over up to 3.7 M outputs instead of 230 k: gate and up each carry a possible 1-ulp flip and SiLU's
+    # slope stretches the gate's — one output in 1.4 M reached 4.x ulp at 100 rows: 6)
+    assert_close_dt(out.numpy(np.uint16, (M, N)), orc.silu_mul(g, u, BF16), BF16, max_ulp=6.0, max_mismatch_frac=0.05, name="gemv_w row blocks gate/up", abs_floor=8e-3)

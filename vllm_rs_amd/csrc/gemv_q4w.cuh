@@ -18,7 +18,8 @@
 #pragma once
 #include "gemv_q4s.cuh"
 
-#define GW_MAX_UNITS 8
+#define GW_MAX_UNITS 8         // units per workgroup of a launch with a bias or a residual (their values ride in registers: EPI_IT)
+#define GW_MAX_UNITS_PLAIN 32  // ... of a launch without either (gate/up pairs in 16-row blocks: 28 per workgroup at 128 rows)
 #define GW_WAVES 8
 #define GW_THREADS (GW_WAVES * 64)
 #define GW_TPW 4  // k-tiles per wave and unit: w + 8*ti (K <= 4096)
@@ -35,8 +36,15 @@ static inline size_t gemv_q4w_lds_bytes(int ns, int mt, int max_units, bool has_
 
 // NS = streams (2: gate/up pair with SiLU*mul), MT = 16-row m-tiles (1: up to 16 rows, 2: up to 32), NORM = fused RMSNorm
 // (compile time: a run-time branch around code that rewrites 128 fragment registers ends in spills at its merge point)
-template <class DT, int NS, int MT, bool AWQ, bool NORM>
+// PSEQ ("pair, sequential", NS = 1, MT = 2, launches without bias / residual): a gate/up pair of 17+ rows.  The pair kernel proper
+// (NS = 2) keeps one m-tile — with two it spills — and is bound by instruction issue (~2.1 us per pair and workgroup: every
+// dequantised fragment feeds ONE MFMA).  Here the units of a workgroup alternate gate block nb, up block nb, gate nb+1, ...: each
+// is an ordinary single-stream unit over two m-tiles (every fragment feeds two MFMAs), the gate result waits in the LDS output
+// tile of its unit and the up unit's epilogue applies SiLU(gate) * up — the arithmetic of the pair kernel, rounding for rounding.
+// units_q / units_r count PAIRS.
+template <class DT, int NS, int MT, bool AWQ, bool NORM, bool PSEQ = false>
 __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a) {
+  static_assert(!PSEQ || (NS == 1 && MT == 2), "PSEQ is the single-stream two-m-tile kernel over alternating gate / up units");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int D = GW_TPW;  // ring slot = the wave's tile index within a unit (w + 8*ti)
   asm volatile("" ::"s"(a.x), "s"(a.x_ld), "s"(a.norm_w), "s"(a.K), "s"(a.M), "s"(a.KT), "s"(a.gsh), "s"(a.units_q), "s"(a.units_r), "s"(a.w[0]),
@@ -51,9 +59,9 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
   const int row0 = (int)blockIdx.y * (MT * 16);
   const int M = min(a.M - row0, MT * 16), KT = a.KT;
   const int wg = (int)blockIdx.x;
-  const int u0 = wg * a.units_q + min(wg, a.units_r);
-  const int nu = a.units_q + (wg < a.units_r ? 1 : 0);
-  const int max_u = a.units_q + (a.units_r ? 1 : 0);
+  const int u0 = (wg * a.units_q + min(wg, a.units_r)) * (PSEQ ? 2 : 1);
+  const int nu = (a.units_q + (wg < a.units_r ? 1 : 0)) * (PSEQ ? 2 : 1);
+  const int max_u = (a.units_q + (a.units_r ? 1 : 0)) * (PSEQ ? 2 : 1);
   const bool has_res = a.residual != nullptr;
   GEMV_STAMP(0);
 
@@ -74,6 +82,10 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
   // thread t: (unit t >> 9 for MT = 2, row, column) covers 16*MT rows x 16 columns per unit
   constexpr int OPU = MT * 256;  // outputs per unit
   auto seg_of = [&](int unit, void*& out, const void*& bias, int& ld, int& col0) {
+    if (PSEQ) {  // (plain launches only: no bias) unit = 2*block + {0: gate, 1: up}; only the up unit's tile is stored
+      out = a.seg[0].out, bias = nullptr, ld = a.seg[0].out_ld, col0 = (unit >> 1) * 16;
+      return;
+    }
     const bool s1 = a.nseg > 1 && NS == 1 && unit >= a.seg[1].unit_start, s2 = a.nseg > 2 && NS == 1 && unit >= a.seg[2].unit_start;
     out = s2 ? a.seg[2].out : (s1 ? a.seg[1].out : a.seg[0].out);
     bias = s2 ? a.seg[2].bias : (s1 ? a.seg[1].bias : a.seg[0].bias);
@@ -128,7 +140,9 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
   const int gsh = a.gsh;
   const int mperm = ((nn & 7) << 3) + (nn >> 3);
   auto issue = [&](int ui, int ti, u32x4 (&w)[NS], uint32_t (&sc)[NS], uint32_t (&zp)[AWQ ? NS : 1]) {
-    const int unit = u0 + min(ui, nu - 1);
+    const int unit_l = u0 + min(ui, nu - 1);
+    const int unit = PSEQ ? unit_l >> 1 : unit_l;   // the 16-column block inside its tensor
+    const bool up = PSEQ && (unit_l & 1);           // (wave-uniform: scalar selects of the kernel arguments, no indexed access)
     const int kt = min(wave + GW_WAVES * ti, KT - 1);
     const int grp = (kt * 128) >> gsh;
     const int col = a.marlin ? ((unit >> 2) << 6) + ((unit & 3) << 1) + mperm : unit * a.s_unit_stride + nn;
@@ -136,9 +150,12 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
     const int64_t zi = (int64_t)grp * a.z_grp_stride + unit * a.z_unit_stride + (nn >> 3);
 #pragma unroll
     for (int b = 0; b < NS; b++) {
-      w[b] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.w[b]) + ((size_t)unit * KT + kt) * 64 + lane);
-      sc[b] = reinterpret_cast<const uint32_t*>(a.scales[b])[si >> 1];
-      if (AWQ) zp[AWQ ? b : 0] = a.zeros[b][zi];
+      const void* wp = PSEQ ? (up ? a.w[1] : a.w[0]) : a.w[b];
+      const void* sp = PSEQ ? (up ? a.scales[1] : a.scales[0]) : a.scales[b];
+      const uint32_t* zq = PSEQ ? (up ? a.zeros[1] : a.zeros[0]) : a.zeros[b];
+      w[b] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp) + ((size_t)unit * KT + kt) * 64 + lane);
+      sc[b] = reinterpret_cast<const uint32_t*>(sp)[si >> 1];
+      if (AWQ) zp[AWQ ? b : 0] = zq[zi];
     }
   };
 #pragma unroll
@@ -336,6 +353,10 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
         v = sl * v2;
       }
       if (has_res) v = rnd_dt<DT>(v) + DT::to_f32(ress[ui * OPU + tid]);
+      if (PSEQ && (ui & 1)) {  // the up unit: its gate value was parked by THIS thread one unit ago (u0 is even)
+        const float gt = DT::to_f32(outs[(ui - 1) * OPU + tid]);
+        v = rnd_dt<DT>(gt / (1.0f + expf(-gt))) * v;
+      }
       outs[ui * OPU + tid] = DT::from_f32(v);
     }
     GEMV_STAMP(10 + 3 * min(ui, 1));
@@ -345,7 +366,7 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
   // ---- everything is stored after the stream has ended
   for (int idx = tid; idx < nu * OPU; idx += GW_THREADS) {
     const int ui = idx / OPU, rem = idx - ui * OPU, row = rem >> 4, col = rem & 15;
-    if (row >= M) continue;
+    if (row >= M || (PSEQ && !(ui & 1))) continue;
     void* o_;
     const void* b_;
     int ld_, c0;

@@ -421,41 +421,48 @@ static int gemv_w_max_rows() {
 }
 // unit distribution of a launch: up to 32 rows = kernel E's (one workgroup per CU); above, `rb` row blocks of 32 rows x `grid`
 // column groups, about one workgroup per CU in total, at most GW_MAX_UNITS units per workgroup
-static void gemv_w_plan(int M, int n_units, int* grid, int* rb, int* q, int* r) {
-  if (M <= 32) {
+// (gate/up pairs of 17+ rows run as PSEQ launches, gemv_q4w.cuh: n_units counts pairs, a pair is two units of the workgroup)
+static void gemv_w_plan(int ns, int M, int n_units, bool plain, int* grid, int* rb, int* q, int* r) {
+  const int rows = 32, max_units = (plain ? GW_MAX_UNITS_PLAIN : GW_MAX_UNITS) / (ns == 2 && M > 16 ? 2 : 1);
+  if (M <= rows) {
     *rb = 1;
     vra_gemv_s_plan(n_units, grid, q, r);
     return;
   }
-  *rb = (M + 31) / 32;
+  *rb = (M + rows - 1) / rows;
   int cg = num_cus() / *rb;
   if (cg < 1) cg = 1;
-  const int need = (n_units + GW_MAX_UNITS - 1) / GW_MAX_UNITS;
+  const int need = (n_units + max_units - 1) / max_units;
   if (cg < need) cg = need;
   if (cg > n_units) cg = n_units;
   *grid = cg, *q = n_units / cg, *r = n_units % cg;
 }
-bool vra_gemv_w_fits(int ns, int M, int K, int group_size, int n_units, bool has_res) {
+bool vra_gemv_w_fits(int ns, int M, int K, int group_size, int n_units, bool has_res, bool has_bias) {
   static const char* off = getenv("VRA_NO_GEMV_W");
   if (off && off[0] == '1') return false;
-  if (M < 5 || M > (ns == 1 ? gemv_w_max_rows() : 32) || K % 128 || K > 4096) return false;
-  if (ns == 2 && M > 16) return false;  // pair x two m-tiles: 8 accumulator tiles + a 4-slot pair ring beside 128 fragment registers spill inside the loop: kernel C
+  static const char* pair_env = getenv("VRA_GEMV_W_PAIR_MAX_ROWS");  // tuning aid: 16 puts 17+-row gate/up launches back on kernels C / D
+  const int pair_max = pair_env ? atoi(pair_env) : gemv_w_max_rows();
+  if (M < 5 || M > (ns == 1 ? gemv_w_max_rows() : (pair_max > 16 ? pair_max : 16)) || K % 128 || K > 4096) return false;
   const int g = group_size > 0 && group_size < K ? group_size : K;
   if (g < K && (g < 128 || (g & (g - 1)))) return false;
   if (n_units < num_cus() / 2) return false;
+  const bool plain = !has_res && !has_bias;
   int grid, rb, q, r;
-  gemv_w_plan(M, n_units, &grid, &rb, &q, &r);
-  const int mu = q + (r ? 1 : 0);
+  gemv_w_plan(ns, M, n_units, plain, &grid, &rb, &q, &r);
+  const bool pseq = ns == 2 && M > 16;
+  if (pseq && !plain) return false;  // (the sequential pair form carries no bias / residual: kernels C / D)
+  const int mu = (q + (r ? 1 : 0)) * (pseq ? 2 : 1);
+  if (mu > (plain ? GW_MAX_UNITS_PLAIN : GW_MAX_UNITS)) return false;
   // row blocks only while all of them run at once: with a second round of workgroups (q/k/v at 200+ rows: 336..384 workgroups)
   // the launch measured no faster than kernels B / D (tools/short_prefill_gemm_times.py: 48.9 against 51.3 us at 200 rows, 49.8
   // against 41.2 at 256)
   if (rb > 1 && grid * rb > num_cus()) return false;
-  return mu <= GW_MAX_UNITS && gemv_q4w_lds_bytes(ns, M > 16 ? 2 : 1, mu, has_res) <= (size_t)kMaxDynLds;
+  return gemv_q4w_lds_bytes(pseq ? 1 : ns, M > 16 ? 2 : 1, mu, has_res) <= (size_t)kMaxDynLds;
 }
-template <class DT, int NS, int MT, bool AWQ, bool NORM>
+template <class DT, int NS, int MT, bool AWQ, bool NORM, bool PSEQ = false>
 static void launch_gemv_w_n(GemvSArgs a, hipStream_t st) {
   static uint64_t attr_devs = 0;
-  auto kern = gemv_q4w_kernel<DT, NS, MT, AWQ, NORM>;
+  auto kern = gemv_q4w_kernel<DT, NS, MT, AWQ, NORM, PSEQ>;
   if (!dev_seen(attr_devs)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
     dev_mark(attr_devs);
@@ -463,8 +470,9 @@ static void launch_gemv_w_n(GemvSArgs a, hipStream_t st) {
   a.KT = a.K / 128;
   a.TPW = GW_TPW;
   int grid, rb;
-  gemv_w_plan(a.M, a.n_units, &grid, &rb, &a.units_q, &a.units_r);
-  const size_t lds = gemv_q4w_lds_bytes(NS, MT, a.units_q + (a.units_r ? 1 : 0), a.residual != nullptr);
+  const bool plain = !a.residual && !a.seg[0].bias && !(a.nseg > 1 && a.seg[1].bias) && !(a.nseg > 2 && a.seg[2].bias);
+  gemv_w_plan(PSEQ ? 2 : NS, a.M, a.n_units, plain, &grid, &rb, &a.units_q, &a.units_r);
+  const size_t lds = gemv_q4w_lds_bytes(NS, MT, (a.units_q + (a.units_r ? 1 : 0)) * (PSEQ ? 2 : 1), a.residual != nullptr);
   a.dbg = 0;
 #ifdef VRA_GEMV_TS
   a.ts = vra_gemv_ts_buf();
@@ -487,6 +495,15 @@ void vra_launch_gemv_w(GemvSArgs a, int ns, int group_size, bool awq, int dtype,
     return;
   }
   const bool bf = dtype == VRA_BF16, two = a.M > 16;
+  if (ns == 2 && two) {  // gate/up pair of 17+ rows: alternating gate / up units of the single-stream two-m-tile kernel (PSEQ)
+    if (!a.norm_w) {
+      vra_set_error("gemv_w: the sequential pair form is built with the fused RMSNorm only");
+      return;
+    }
+    if (awq) bf ? launch_gemv_w_n<BF16, 1, 2, true, true, true>(a, st) : launch_gemv_w_n<F16, 1, 2, true, true, true>(a, st);
+    else bf ? launch_gemv_w_n<BF16, 1, 2, false, true, true>(a, st) : launch_gemv_w_n<F16, 1, 2, false, true, true>(a, st);
+    return;
+  }
 #define VRA_W(NS_, AWQ_)                                                                                   \
   do {                                                                                                     \
     if (bf) two ? launch_gemv_w_v<BF16, NS_, 2, AWQ_>(a, st) : launch_gemv_w_v<BF16, NS_, 1, AWQ_>(a, st);  \
@@ -866,7 +883,8 @@ static bool check_gemm_shape(const char* who, int m, int k, int n, int group_siz
 static bool gemv_s_direct(int ns, const void* in, const void* w0, const void* sc0, const void* qz0, const void* w1, const void* sc1, const void* qz1,
                           const void* bias, const void* residual, void* out, int m, int k, int n, int group_size, int is_awq, int scales_layout,
                           int dtype, int64_t stream, const void* norm_w = nullptr, float eps = 0.f) {
-  const bool use_w = n % 16 == 0 && vra_gemv_w_fits(ns, m, k, group_size, n / 16, residual != nullptr);
+  const bool use_w = n % 16 == 0 && vra_gemv_w_fits(ns, m, k, group_size, n / 16, residual != nullptr, bias != nullptr) &&
+                     !(ns == 2 && m > 16 && !norm_w);  // (the 17+-row pair form of kernel W exists with the fused norm only)
   if (n % 16 || !(use_w || vra_gemv_s_fits(ns, m, k, group_size, n / 16, norm_w != nullptr))) return false;
   const bool grouped = group_size > 0 && group_size < k;
   if (scales_layout == VRA_SCALES_MARLIN && (!grouped || n % 64)) return false;  // channel-wise permutation: converted copy (rowmajor_scales)

@@ -673,7 +673,8 @@ bool Model::gemv_s_ok(int which, int M) const {
   int K, units, ns;
   bool norm;
   gemv_s_shape(L, which, &K, &units, &ns, &norm);
-  return vra_gemv_s_fits(ns, M, K, mc_.group_size, units, norm) || vra_gemv_w_fits(ns, M, K, mc_.group_size, units, which == 1 || which == 3);
+  return vra_gemv_s_fits(ns, M, K, mc_.group_size, units, norm) || vra_gemv_w_fits(ns, M, K, mc_.group_size, units, which == 1 || which == 3,
+                         which == 0 ? (L.q.bias || L.k.bias || L.v.bias) : (which == 2 ? (L.gate.bias || L.up.bias) : (which == 1 ? L.o.bias != nullptr : L.down.bias != nullptr)));
 }
 // the argument block of decode GEMV `which` of layer l (shared by the single launch and the two-phase launch)
 void Model::gemv_s_args(int l, int which, int M, void* out, const void* residual, GemvSArgs* ap, int* nsp) {
