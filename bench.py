@@ -348,6 +348,21 @@ def spawn_ranks(n):
     return max(abs(p.wait()) for p in procs)
 
 
+def tp_rank_algorithmic_bytes(cfg, world, M):
+    """SURVEY §8(d) per GEMM — K*N/2 (packed int4) + (K/g)*N*2 (scales) + (K/g)*N/2 (zeros) + M*K*2 + M*N*2, as
+    Model::gemm_algorithmic_bytes counts them — over ONE rank's shard (column-parallel q/k/v/gate/up: N / world, kv heads
+    replicated below one per rank; row-parallel o/down: K / world) + the unsharded bf16 lm_head (llama.rs:226-245)"""
+    H, I, D, L = cfg["hidden_size"], cfg["intermediate_size"], cfg["head_dim"], cfg["num_layers"]
+    hq, g = cfg["num_heads"] // world, cfg.get("group_size", 128)
+    hkv = cfg["num_kv_heads"] // world if cfg["num_kv_heads"] >= world else 1
+
+    def one(K, N):
+        return K * N // 2 + (K // g) * N * 2 + (K // g) * N // 2 + M * K * 2 + M * N * 2
+
+    layer = one(H, hq * D) + 2 * one(H, hkv * D) + one(hq * D, H) + 2 * one(H, I // world) + one(I // world, H)
+    return L * layer + cfg["vocab_size"] * H * 2 + M * H * 2 + M * cfg["vocab_size"] * 4
+
+
 def tp_main(a):
     """ONE tensor-parallel engine over a.tp ranks (runner processes; shared GPU => one-shot IPC transport, own GPUs => RCCL +
     one-shot): decode tokens/s of the TP engine on the Llama-3-70B shape scaled to the rank count, or of --model."""
@@ -359,15 +374,33 @@ def tp_main(a):
                   use_graph=not a.no_graph, seed=1234) as tp:
         load_s = time.perf_counter() - t0
         res = tp.timed_decode(make_prompts(a.batch, a.prompt_len, cfg["vocab_size"]), a.warmup, a.steps)
+        transport = tp.transport
     ms = max(r[0] for r in res)
+    # A21: at temperature 0 every rank must have produced the same tokens (rank-ordered f32 sums in the one-shot all-reduce, RCCL's
+    # own determinism above the one-shot size) — asserted, not assumed
+    identical = all(r[1] == res[0][1] for r in res)
+    if not identical:
+        raise SystemExit(f"bench.py --tp {a.tp}: the ranks disagree on the generated tokens (A21): " + json.dumps([r[1][0][:8] for r in res]))
     from vllm_rs_amd import _lib
     ngpu = min(a.tp, max(1, _lib.load().vra_device_count()))  # fewer devices than ranks: the ranks SHARE device 0 (functional run, time-sliced)
+    rank_bytes = tp_rank_algorithmic_bytes(cfg, a.tp, a.batch)
+    own_gpus = ngpu == a.tp
+    step_s = ms / a.steps / 1e3
     print(json.dumps({"metric": f"decode tokens/sec, {a.model} TP={a.tp}", "value": a.batch * a.steps / (ms / 1e3), "unit": "tokens/s",
-                      "n_gpus": ngpu if ngpu == a.tp else 1, "ranks": a.tp,
+                      "n_gpus": ngpu if own_gpus else 1, "ranks": a.tp,
                       "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms / a.steps, "higher_is_better": True, "scaling": "strong",
                       "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-                      "config": {"workload": f"{a.model} shape, int4 g128, tensor parallel over {a.tp} ranks ({tp.transport} transport), batch {a.batch}, "
-                                             f"prompt {a.prompt_len}, {a.steps} generated tokens" + ("" if ngpu == a.tp else "; all ranks time-share ONE GPU"), "load_s": load_s}}))
+                      "tokens_identical_across_ranks": identical,
+                      # per RANK: the bytes one rank's GEMMs + lm_head must read per decode step, over the step time (valid as a
+                      # roofline fraction only when every rank has its own GPU; time-shared ranks are marked)
+                      "roofline": {"bound": "hbm", "kernel": "one rank's decode step (int4 GEMV family of its shard + the unsharded lm_head)",
+                                   "achieved": rank_bytes / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": rank_bytes / step_s / 1e9 / HBM_PEAK_GBS if own_gpus else None, "traffic": None,
+                                   "algorithmic_bytes_per_rank_per_step": rank_bytes,
+                                   "note": None if own_gpus else f"{a.tp} ranks time-share one GPU: achieved is per rank of the shared device, frac not meaningful"},
+                      "config": {"workload": f"{a.model} shape, int4 g128, tensor parallel over {a.tp} ranks ({transport} transport: one-shot all-reduce up to 1 MiB "
+                                             f"per message, RCCL above — chosen by message size), batch {a.batch}, "
+                                             f"prompt {a.prompt_len}, {a.steps} generated tokens" + ("" if own_gpus else "; all ranks time-share ONE GPU"), "load_s": load_s}}))
 
 
 def main():
@@ -388,10 +421,16 @@ def main():
     from vllm_rs_amd import _lib
     from vllm_rs_amd import engine as E
     L = _lib.load()
+    # the ranks meet BEFORE anything touches a device: a node that is short of GPUs is reported by every rank after the whole
+    # job has assembled (and the CPU test of the 8-rank launch exercises spawn + rendezvous without a GPU)
+    dist = NodeRendezvous(rank, world) if world > 1 else None
+    if dist is not None:
+        dist.barrier()
+        if rank == 0:
+            print(f"bench.py: rendezvous of {world} ranks complete", file=sys.stderr, flush=True)
     if L.vra_device_count() <= local_rank:
         raise SystemExit(f"bench.py needs {world} GPU(s): no HIP device for rank {local_rank} (the product has no CPU fallback)")
     L.vra_set_device(local_rank)
-    dist = NodeRendezvous(rank, world) if world > 1 else None
 
     def sync():  # barrier + device synchronisation on both sides of the timed region
         L.vra_device_sync()

@@ -69,7 +69,8 @@ void marlin_awq_4bit_f16(const void* in, const int32_t* qweight, const void* sca
                          int32_t n, const void* workspace, int32_t group_size, int64_t stream);
 /* replaces ffi::gemm_half_q_half_alt — src/utils/gptq.rs:182-195 (NOTE n before k). Plain GPTQ:
  * qweight [k/8, n] u32 (checkpoint layout), qzeros [k/g, n/8] u32 (stored z-1), scales [k/g, n] f16
- * row-major, g_idx [k] i32 (may be NULL = k/g), bits must be 4, f16 activations only. */
+ * row-major, g_idx [k] i32 (may be NULL = k/g), f16 activations only.  bits = 4, or 8 (wna16.rs:154-176 sends every
+ * non-Marlin checkpoint here): qweight [k/4, n], qzeros [k/g, n/4], four values per word, zero = stored + 1 as well. */
 void gemm_half_q_half_alt(const void* in, const uint32_t* qweight, const uint32_t* qzeros,
                           const void* scales, const int32_t* g_idx, void* out, int32_t m, int32_t n,
                           int32_t k, int32_t bits, int64_t stream);
@@ -191,6 +192,15 @@ void vra_paged_attention_decode(void* out, const void* q, const void* k_cache, c
                                 int32_t block_size, int32_t max_blocks_per_seq,
                                 int32_t max_context_len, float scale, float softcap,
                                 void* workspace, int32_t dtype, int32_t kv_dtype, int64_t stream);
+/* the same with PagedAttention::new's `sliding_window` (attention.rs:607-616; Mistral-type LlamaForCausalLM checkpoints,
+ * utils/mod.rs:1842-1856): > 0: a query at position p attends the keys p-W+1 .. p (the additive form is vra_causal_mask's
+ * j <= i && i - j < W); 0 = off = the function above.  KV tiles in front of the window are not read. */
+void vra_paged_attention_decode_sw(void* out, const void* q, const void* k_cache, const void* v_cache,
+                                   const uint32_t* block_tables, const uint32_t* context_lens,
+                                   int32_t batch, int32_t q_heads, int32_t kv_heads, int32_t head_dim,
+                                   int32_t block_size, int32_t max_blocks_per_seq,
+                                   int32_t max_context_len, float scale, float softcap, int32_t sliding_window,
+                                   void* workspace, int32_t dtype, int32_t kv_dtype, int64_t stream);
 /* prefill half: causal varlen attention. q [T,Hq,D] with cu_seqlens_q [B+1] u32.
  * If block_tables != NULL keys/values are read from the paged cache (context_lens[b] tokens,
  * query i of sequence b sits at position context_lens[b]-len_q(b)+i) — this covers chunked prefill
@@ -204,6 +214,15 @@ void vra_paged_attention_prefill(void* out, const void* q, const void* k, const 
                                  int32_t q_heads, int32_t kv_heads, int32_t head_dim,
                                  int32_t block_size, int32_t max_blocks_per_seq, float scale,
                                  float softcap, int32_t dtype, int32_t kv_dtype, int64_t stream);
+/* ... with a sliding window (see vra_paged_attention_decode_sw) */
+void vra_paged_attention_prefill_sw(void* out, const void* q, const void* k, const void* v,
+                                    const void* k_cache, const void* v_cache,
+                                    const uint32_t* block_tables, const uint32_t* context_lens,
+                                    const uint32_t* cu_seqlens_q, const uint32_t* cu_seqlens_k,
+                                    int32_t batch, int32_t total_q, int32_t max_seqlen_q,
+                                    int32_t q_heads, int32_t kv_heads, int32_t head_dim,
+                                    int32_t block_size, int32_t max_blocks_per_seq, float scale,
+                                    float softcap, int32_t sliding_window, int32_t dtype, int32_t kv_dtype, int64_t stream);
 /* Fused decode step of one layer's attention front half, ONE launch for what the reference issues as
  * FusedRope::apply_inplace + reshape_and_cache + PagedAttention::forward (attention.rs:745-820): rotary on q
  * and k (NeoX pairing, tables [n_pos, head_dim/2] in the model dtype), scatter of the rotated k and of v

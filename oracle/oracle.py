@@ -325,7 +325,7 @@ def reshape_and_cache(k, v, kc, vc, slots, BS, dt, kv_dt=None):
     lib().orc_reshape_and_cache_kv(_p(k), _p(v), _p(kc), _p(vc), _p(slots), T, Hkv, D, BS, dt, dt if kv_dt is None else kv_dt)
 
 
-def paged_attention(q, kc, vc, block_tables, context_lens, cu_q, Hkv, BS, scale, dt, softcap=0.0, kv_dt=None):
+def paged_attention(q, kc, vc, block_tables, context_lens, cu_q, Hkv, BS, scale, dt, softcap=0.0, kv_dt=None, sliding_window=0):
     q = _c(q)
     Tq, Hq, D = q.shape
     block_tables = _c(block_tables, np.uint32)
@@ -333,8 +333,8 @@ def paged_attention(q, kc, vc, block_tables, context_lens, cu_q, Hkv, BS, scale,
     cu_q = _c(cu_q, np.uint32)
     B, max_blocks = block_tables.shape
     out = np.empty(q.shape, np_dt(dt))
-    lib().orc_paged_attention_kv(_p(out), _p(q), _p(kc), _p(vc), _p(block_tables), _p(context_lens), _p(cu_q), B, Hq, Hkv,
-                                 D, BS, max_blocks, C.c_float(scale), C.c_float(softcap), dt, dt if kv_dt is None else kv_dt)
+    lib().orc_paged_attention_kv_sw(_p(out), _p(q), _p(kc), _p(vc), _p(block_tables), _p(context_lens), _p(cu_q), B, Hq, Hkv,
+                                    D, BS, max_blocks, C.c_float(scale), C.c_float(softcap), int(sliding_window), dt, dt if kv_dt is None else kv_dt)
     return out
 
 

@@ -624,10 +624,22 @@ void orc_paged_attention(void* out, const void* q, const void* kc, const void* v
                          float scale, float softcap, int dt) {
   orc_paged_attention_kv(out, q, kc, vc, block_tables, context_lens, cu_q, B, Hq, Hkv, D, BS, max_blocks, scale, softcap, dt, dt);
 }
+void orc_paged_attention_kv_sw(void* out, const void* q, const void* kc, const void* vc,
+                               const uint32_t* block_tables, const uint32_t* context_lens,
+                               const uint32_t* cu_q, int B, int Hq, int Hkv, int D, int BS, int max_blocks,
+                               float scale, float softcap, int sliding_window, int dt, int kv_dt);
 void orc_paged_attention_kv(void* out, const void* q, const void* kc, const void* vc,
                             const uint32_t* block_tables, const uint32_t* context_lens,
                             const uint32_t* cu_q, int B, int Hq, int Hkv, int D, int BS, int max_blocks,
                             float scale, float softcap, int dt, int kv_dt) {
+  orc_paged_attention_kv_sw(out, q, kc, vc, block_tables, context_lens, cu_q, B, Hq, Hkv, D, BS, max_blocks, scale, softcap, 0, dt, kv_dt);
+}
+/* sliding_window > 0 (PagedAttention::new, attention.rs:607-616): the query at position pos attends the keys
+ * max(0, pos - W + 1) .. pos (attention_rs::mask::causal_mask: j <= i && i - j < W, orc_causal_mask above); 0 = off */
+void orc_paged_attention_kv_sw(void* out, const void* q, const void* kc, const void* vc,
+                               const uint32_t* block_tables, const uint32_t* context_lens,
+                               const uint32_t* cu_q, int B, int Hq, int Hkv, int D, int BS, int max_blocks,
+                               float scale, float softcap, int sliding_window, int dt, int kv_dt) {
   /* Same arithmetic as the plain loops (scores, softmax and P.V in double, keys in ascending order); the keys and values
    * of one (sequence, kv head) are widened to double once and the (query head, query row) pairs run in parallel, so that a
    * 32k-token context (BASELINE config 5) is a matter of seconds on the host cores. */
@@ -657,11 +669,12 @@ void orc_paged_attention_kv(void* out, const void* q, const void* kc, const void
         for (int gi = 0; gi < G; gi++)
           for (int i = 0; i < lq; i++) {
             int h = hk * G + gi;
-            int pos = ctx - lq + i; /* attends keys 0..pos */
+            int pos = ctx - lq + i; /* attends keys j0..pos (j0 = 0 without a sliding window) */
+            int j0 = sliding_window > 0 && pos - sliding_window + 1 > 0 ? pos - sliding_window + 1 : 0;
             int64_t qb = ((int64_t)(q0 + i) * Hq + h) * D;
             for (int d = 0; d < D; d++) qd[d] = (double)ld(q, qb + d, dt);
             double mx = -1e300;
-            for (int j = 0; j <= pos; j++) {
+            for (int j = j0; j <= pos; j++) {
               const double* kr = Kd + (size_t)j * D;
               double sv = 0.0;
               for (int d = 0; d < D; d++) sv += qd[d] * kr[d];
@@ -671,12 +684,12 @@ void orc_paged_attention_kv(void* out, const void* q, const void* kc, const void
               if (sv > mx) mx = sv;
             }
             double den = 0.0;
-            for (int j = 0; j <= pos; j++) {
+            for (int j = j0; j <= pos; j++) {
               sc[j] = exp(sc[j] - mx);
               den += sc[j];
             }
             for (int d = 0; d < D; d++) acc[d] = 0.0;
-            for (int j = 0; j <= pos; j++) {
+            for (int j = j0; j <= pos; j++) {
               const double* vr = Vd + (size_t)j * D;
               const double pj = sc[j];
               for (int d = 0; d < D; d++) acc[d] += pj * vr[d];

@@ -75,6 +75,46 @@ def test_bench_gpus_n_spawns_its_own_ranks(tmp_path):
     assert p.returncode != 0 and "--gpus 4 but the launcher started 2" in p.stderr
 
 
+def test_bench_gpus_8_spawns_eight_ranks_that_rendezvous():
+    """the 8-GPU run must work first time.  `python bench.py --gpus 8` starts eight ranks of itself; they meet on the
+    node-local rendezvous socket BEFORE anything touches a device (rank 0 says so), then — here, without GPUs — every rank stops at
+    the device check with its own rank in the message"""
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "VRA_BENCH_RDZV"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--no-extras"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode != 0
+    assert "rendezvous of 8 ranks complete" in p.stderr, p.stderr[-2000:]
+    for r in range(8):
+        assert f"no HIP device for rank {r}" in p.stderr, p.stderr[-2000:]
+
+
+def test_bench_aggregation_eight_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 8, 29613, q)) for r in range(8)]
+    [p.start() for p in procs]
+    t, value = q.get(timeout=300)
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert t == pytest.approx(0.5 + 0.25 * 7) and value == pytest.approx(4 * 10 * 8 / (0.5 + 0.25 * 7))
+
+
+def test_bench_tp8_fails_loudly_without_gpus_and_counts_a_rank_s_bytes():
+    """`bench.py --tp 8 --model llama3-70b` has no CPU fallback; the per-rank roofline bytes of its JSON line follow SURVEY §8(d)"""
+    import subprocess
+    import bench
+    from vllm_rs_amd import engine as E
+    b = bench.tp_rank_algorithmic_bytes(dict(E.LLAMA3_70B), 8, 1)
+    layer_w = (8192 * 1024 + 2 * 8192 * 128 + 1024 * 8192 + 3 * 8192 * 3584) // 2  # packed int4 bytes of one rank's layer
+    assert 80 * layer_w < b - 128256 * 8192 * 2 < 80 * layer_w * 1.05  # + scales / zeros / activations: a few percent
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--tp", "8", "--model", "llama3-70b", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "needs a GPU" in (p.stderr + p.stdout), (p.stderr + p.stdout)[-1500:]
+
+
 def _shard_cols(q, rank, world):
     """column parallel: packed tensors are stored [in, out] so the OUTPUT dim is dim 1 (wna16.rs:35-40);
     qzeros in units of 8 columns."""

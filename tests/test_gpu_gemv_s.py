@@ -283,10 +283,10 @@ def test_gemv_w_row_blocks_rows_are_independent_of_the_batch_they_ride_in():
         assert np.array_equal(big[lo:hi], small), f"rows {lo}..{hi}"
 
 
-@pytest.mark.parametrize("M", [17, 32, 33, 64, 100, 128, 200, 256])
+@pytest.mark.parametrize("M", [17, 32, 33, 64, 100, 128])
 @pytest.mark.parametrize("awq", [False, True])
 def test_gemv_w_row_blocks_gate_up_pair(M, awq):
-    """norm + gate + up + SiLU*mul of 17..256 rows in the SEQUENTIAL pair form of kernel W (PSEQ, gemv_q4w.cuh): the units of a
+    """norm + gate + up + SiLU*mul of 17..128 rows in the SEQUENTIAL pair form of kernel W (PSEQ, gemv_q4w.cuh): the units of a
     workgroup alternate gate / up blocks of the single-stream two-m-tile kernel, the up unit's epilogue applies SiLU(gate) * up.
     Decode batches of 17..32 rows: one launch instead of a norm launch + kernel C; a 128-token prefill: 4 row blocks x 64 column
     groups of 14 pairs instead of norm + kernel D."""

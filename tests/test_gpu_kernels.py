@@ -175,6 +175,28 @@ def test_gemm_half_q_half_alt(gs, with_g_idx):
     assert_close_dt(got, ref, F16, name="gptq alt", abs_floor=2e-3)
 
 
+@pytest.mark.parametrize("gs,with_g_idx", [(128, True), (64, False)])
+def test_gemm_half_q_half_alt_8bit(gs, with_g_idx):
+    """8-bit plain GPTQ through the same symbol (utils/mod.rs:1313, wna16.rs:154-176): four values per word, zero = stored + 1"""
+    M, K, N = 5, 256, 128
+    r = rng(8 + gs)
+    G = K // gs
+    idx = r.integers(0, 256, size=(K, N), dtype=np.uint8)
+    zeros = r.integers(100, 156, size=(G, N), dtype=np.uint8)  # stored value (z-1), near the middle of the range as real checkpoints have it
+    scales = orc.to_dt((0.0005 + 0.002 * r.random((G, N))).astype(np.float32), F16)
+    qw = np.zeros((K // 4, N), np.uint32)
+    for k in range(K):
+        qw[k // 4] |= idx[k].astype(np.uint32) << (8 * (k % 4))
+    qz = np.zeros((G, N // 4), np.uint32)
+    for n in range(N):
+        qz[:, n // 4] |= zeros[:, n].astype(np.uint32) << (8 * (n % 4))
+    x = rand_dt(r, (M, K), F16)
+    g_idx = ops.dev((np.arange(K) // gs).astype(np.int32)) if with_g_idx else None
+    out = ops.gptq_matmul(ops.dev(x), ops.dev(qw), ops.dev(scales), ops.dev(qz), g_idx, None, 8, gs, False, M, K, N, F16)
+    ref = orc.wna16_gemm(x, idx, (zeros.astype(np.int32) + 1).astype(np.uint8), scales, gs, F16)
+    assert_close_dt(out.numpy(np.uint16, (M, N)), ref, F16, name="gptq alt 8-bit", abs_floor=2e-3)
+
+
 @pytest.mark.parametrize("M", [1, 4, 8, 20, 32])
 @pytest.mark.parametrize("out_f32", [False, True])
 def test_dense_gemm(M, out_f32):
@@ -499,6 +521,51 @@ def test_attention_prefill(Hq, Hkv, D, paged):
         out = pa.forward_prefill(ops.dev(q), Tq, max(lens_q), ops.dev(cu_q), len(lens_q), k=ops.dev(s["k"]), v=ops.dev(s["v"]), cu_k=ops.dev(cu_k))
         ref = orc.varlen_attention(q, s["k"], s["v"], cu_q, cu_k, D ** -0.5, dt)
     assert_close_dt(out.numpy(np.uint16, (Tq, Hq, D)), ref, dt, max_ulp=2.0, max_mismatch_frac=0.5, name="prefill attention", abs_floor=3e-3)
+
+
+@pytest.mark.parametrize("W", [1, 32, 100, 4096])
+@pytest.mark.parametrize("ctxs,ws", [([1, 31, 33, 200], False), ([1000, 77], False), ([3000, 2049], True)])
+def test_paged_attention_decode_sliding_window(W, ctxs, ws):
+    """PagedAttention::new(.., sliding_window, ..) (attention.rs:607-616): the query at position ctx-1 attends the last W keys; tiles
+    in front of the window are skipped (and may hold anything: they are poisoned here), a window wider than the context is a no-op"""
+    Hq, Hkv, D, BS, dt = 32, 8, 128, 64, BF16
+    r = rng(W + sum(ctxs))
+    s = _paged_setup(r, ctxs, Hkv, D, BS, dt, NB=128)
+    pa = ops.PagedAttention(Hq, D, D ** -0.5, Hkv, BS, dt, sliding_window=W)
+    pa.reshape_and_cache(ops.dev(s["k"]), ops.dev(s["v"]), s["kc"], s["vc"], ops.dev(s["slots"]), len(s["slots"]))
+    B = s["B"]
+    q = rand_dt(r, (B, Hq, D), dt)
+    cl = np.array(ctxs, np.uint32)
+    wsb = ops.DevBuf(ops.lib().vra_paged_attention_decode_workspace_bytes(B, Hq, D, max(ctxs))) if ws else None
+    out = pa.forward_decode(ops.dev(q), s["kc"], s["vc"], ops.dev(s["bt"]), ops.dev(cl), B, s["max_blocks"], max(ctxs), wsb)
+    ref = orc.paged_attention(q, s["kc_ref"], s["vc_ref"], s["bt"], cl, None, Hkv, BS, D ** -0.5, dt, sliding_window=W)
+    assert_close_dt(out.numpy(np.uint16, (B, Hq, D)), ref, dt, max_ulp=2.0, max_mismatch_frac=0.5, name=f"decode attention, window {W}", abs_floor=3e-3)
+    if W >= max(ctxs):  # no-op window: the very same bits as the plain entry point
+        plain = ops.PagedAttention(Hq, D, D ** -0.5, Hkv, BS, dt).forward_decode(ops.dev(q), s["kc"], s["vc"], ops.dev(s["bt"]), ops.dev(cl), B,
+                                                                                 s["max_blocks"], max(ctxs), wsb)
+        assert np.array_equal(out.numpy(np.uint16, (B, Hq, D)), plain.numpy(np.uint16, (B, Hq, D)))
+
+
+@pytest.mark.parametrize("W", [1, 16, 50, 300])
+@pytest.mark.parametrize("Hq,Hkv,D", [(8, 2, 128), (4, 4, 64)])
+def test_attention_prefill_sliding_window(W, Hq, Hkv, D):
+    """causal varlen prefill over the paged cache (with cached prefixes) under a sliding window: query at position p sees p-W+1 .. p"""
+    BS, dt = 64, BF16
+    r = rng(Hq * 3 + D + W)
+    lens_q = [5, 70, 1, 133]
+    prefix = [0, 64, 130, 40]
+    ctxs = [a + b for a, b in zip(lens_q, prefix)]
+    s = _paged_setup(r, ctxs, Hkv, D, BS, dt)
+    pa = ops.PagedAttention(Hq, D, D ** -0.5, Hkv, BS, dt, sliding_window=W)
+    cu_q = np.concatenate([[0], np.cumsum(lens_q)]).astype(np.uint32)
+    Tq = int(cu_q[-1])
+    q = rand_dt(r, (Tq, Hq, D), dt)
+    cl = np.array(ctxs, np.uint32)
+    pa.reshape_and_cache(ops.dev(s["k"]), ops.dev(s["v"]), s["kc"], s["vc"], ops.dev(s["slots"]), len(s["slots"]))
+    out = pa.forward_prefill(ops.dev(q), Tq, max(lens_q), ops.dev(cu_q), len(lens_q), k_cache=s["kc"], v_cache=s["vc"],
+                             block_tables=ops.dev(s["bt"]), context_lens=ops.dev(cl), max_blocks=s["max_blocks"])
+    ref = orc.paged_attention(q, s["kc_ref"], s["vc_ref"], s["bt"], cl, cu_q, Hkv, BS, D ** -0.5, dt, sliding_window=W)
+    assert_close_dt(out.numpy(np.uint16, (Tq, Hq, D)), ref, dt, max_ulp=2.0, max_mismatch_frac=0.5, name=f"prefill attention, window {W}", abs_floor=3e-3)
 
 
 def test_causal_mask_and_cast():

@@ -359,3 +359,26 @@ def test_rope_tables_dynamic_and_yarn_bit_exact_host_vs_oracle_and_numpy_kat():
             ms = f32((0.1 * np.log(fac, dtype=f32) + 1.0 if fac > 1 else 1.0)) * f32(rs.get("attn_factor", 1.0))
         ang = (np.arange(n, dtype=f32)[:, None] * inv[None, :]).astype(f32)
         assert np.abs(np.cos(ang) * ms - c).max() < 2e-3 and np.abs(np.sin(ang) * ms - s_).max() < 2e-3, rs  # |d angle| ~ 4096 * 1e-7 rad
+
+
+def test_oracle_paged_attention_sliding_window_matches_the_additive_mask():
+    """attention.rs:607-616 + mask.rs:18-54: the windowed paged attention == softmax((q k^T) * scale + causal_mask(L, W)) v, row by row"""
+    r = np.random.default_rng(3)
+    Hq, Hkv, D, BS, L, W = 4, 2, 64, 64, 90, 17
+    k = orc.to_bf16(r.standard_normal((L, Hkv, D)).astype(np.float32))
+    v = orc.to_bf16(r.standard_normal((L, Hkv, D)).astype(np.float32))
+    q = orc.to_bf16(r.standard_normal((L, Hq, D)).astype(np.float32))
+    kc, vc = np.zeros((2, Hkv, BS, D), np.uint16), np.zeros((2, Hkv, D, BS), np.uint16)
+    orc.reshape_and_cache(k, v, kc, vc, np.arange(L, dtype=np.int64), BS, 0)
+    bt = np.array([[0, 1]], np.uint32)
+    got = orc.from_bf16(orc.paged_attention(q, kc, vc, bt, np.array([L], np.uint32), np.array([0, L], np.uint32), Hkv, BS, D ** -0.5, 0, sliding_window=W))
+    mask = orc.from_bf16(orc.causal_mask(L, W, 0)).astype(np.float64)
+    kf, vf, qf = orc.from_bf16(k).astype(np.float64), orc.from_bf16(v).astype(np.float64), orc.from_bf16(q).astype(np.float64)
+    for h in range(Hq):
+        s_ = qf[:, h] @ kf[:, h // 2].T * D ** -0.5 + mask
+        p_ = np.exp(s_ - s_.max(-1, keepdims=True))
+        ref = (p_ / p_.sum(-1, keepdims=True)) @ vf[:, h // 2]
+        assert np.abs(got[:, h] - ref).max() < 2e-2
+    full = orc.from_bf16(orc.paged_attention(q, kc, vc, bt, np.array([L], np.uint32), np.array([0, L], np.uint32), Hkv, BS, D ** -0.5, 0))
+    wide = orc.from_bf16(orc.paged_attention(q, kc, vc, bt, np.array([L], np.uint32), np.array([0, L], np.uint32), Hkv, BS, D ** -0.5, 0, sliding_window=L))
+    assert np.array_equal(full, wide)

@@ -111,6 +111,10 @@ def load():
          c_f32, c_f32, P, c_i32, c_i32, c_i64)
     _sig(lib, "vra_paged_attention_prefill", None, P, P, P, P, P, P, P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32,
          c_i32, c_i32, c_i32, c_f32, c_f32, c_i32, c_i32, c_i64)
+    _sig(lib, "vra_paged_attention_decode_sw", None, P, P, P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
+         c_f32, c_f32, c_i32, P, c_i32, c_i32, c_i64)
+    _sig(lib, "vra_paged_attention_prefill_sw", None, P, P, P, P, P, P, P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32,
+         c_i32, c_i32, c_i32, c_f32, c_f32, c_i32, c_i32, c_i32, c_i64)
     _sig(lib, "vra_rope_cache_attention_decode", None, P, P, P, P, P, P, P, P, P, P, P, P, c_i32, c_i32, c_i32, c_i32,
          c_i32, c_i32, c_i32, c_f32, P, c_i32, c_i32, c_i64)
     _sig(lib, "vra_causal_mask", None, P, c_i32, c_i32, c_i32, c_i64)

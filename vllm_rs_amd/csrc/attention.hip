@@ -47,6 +47,9 @@ struct PagedAttnArgs {
   int nsplit;
   float* ws_o;   // [B, Hq, nsplit, D]
   float* ws_ml;  // [B, Hq, nsplit, 2]
+  // PagedAttention::new(.., sliding_window, ..) (attention.rs:607-616): > 0: a query at position p sees the keys p-W+1 .. p
+  // (attention_rs::mask::causal_mask as restated by vra_causal_mask: j <= i && i - j < W); 0: off
+  int sliding_window;
 };
 
 template <class DT, int D, bool KV8>
@@ -89,9 +92,10 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_kernel(const PagedAttnA
     row_valid = rq < G;
     tile_first_pos = tile_last_pos = ctx - 1;
     const int ntiles = (ctx + 31) >> 5;
+    const int t_lo = a.sliding_window > 0 ? max(ctx - a.sliding_window, 0) >> 5 : 0;  // tiles in front of the window are not walked
     // split across workgroups (nsplit) then across the 4 waves
-    const int per_split = (ntiles + a.nsplit - 1) / a.nsplit;
-    const int s0 = min(ntiles, split * per_split), s1 = min(ntiles, s0 + per_split);
+    const int per_split = (ntiles - t_lo + a.nsplit - 1) / a.nsplit;
+    const int s0 = min(ntiles, t_lo + split * per_split), s1 = min(ntiles, s0 + per_split);
     const int n_s = s1 - s0;
     kv_w0 = s0 + (n_s * wave) / PA_WAVES;
     kv_w1 = s0 + (n_s * (wave + 1)) / PA_WAVES;
@@ -107,10 +111,11 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_kernel(const PagedAttnA
     row_valid = qtok < lq;
     tile_first_pos = ctx - lq + i0;
     tile_last_pos = ctx - lq + min(i0 + 15, lq - 1);
-    kv_w0 = 0;
+    kv_w0 = a.sliding_window > 0 ? max(tile_first_pos - a.sliding_window + 1, 0) >> 5 : 0;
     kv_w1 = (tile_last_pos >> 5) + 1;
   }
   const int row_pos = a.decode ? ctx - 1 : (row_valid ? ctx - lq + qtok : -1);
+  const int sw = a.sliding_window;
 
   // ---- Q fragments (B operand of K·Qᵀ): lane (row rq, octet oct)
   s16x8 qf[DJ];
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attn_kernel(const PagedAttnA
       float x = (e < 4 ? s0[e] : s1[e - 4]);
       if (a.softcap > 0.f) x = a.softcap * tanhf(x * a.scale / a.softcap) * 1.44269504088896f;
       else x *= a.scale_log2e;
-      if (tok > row_pos || tok >= ctx) x = -INFINITY;
+      if (tok > row_pos || tok >= ctx || (sw > 0 && row_pos - tok >= sw)) x = -INFINITY;
       sv[e] = x;
       tmax = fmaxf(tmax, x);
     }
@@ -739,6 +744,15 @@ extern "C" void vra_paged_attention_decode(void* out, const void* q, const void*
                                            int32_t q_heads, int32_t kv_heads, int32_t head_dim, int32_t block_size,
                                            int32_t max_blocks_per_seq, int32_t max_context_len, float scale, float softcap,
                                            void* workspace, int32_t dtype, int32_t kv_dtype, int64_t stream) {
+  vra_paged_attention_decode_sw(out, q, k_cache, v_cache, block_tables, context_lens, batch, q_heads, kv_heads, head_dim, block_size,
+                                max_blocks_per_seq, max_context_len, scale, softcap, 0, workspace, dtype, kv_dtype, stream);
+}
+extern "C" void vra_paged_attention_decode_sw(void* out, const void* q, const void* k_cache, const void* v_cache,
+                                              const uint32_t* block_tables, const uint32_t* context_lens, int32_t batch,
+                                              int32_t q_heads, int32_t kv_heads, int32_t head_dim, int32_t block_size,
+                                              int32_t max_blocks_per_seq, int32_t max_context_len, float scale, float softcap,
+                                              int32_t sliding_window, void* workspace, int32_t dtype, int32_t kv_dtype, int64_t stream) {
+  VRA_CHECK_ARG(sliding_window >= 0, "vra_paged_attention_decode: sliding_window must be >= 0 (0 = off)");
   VRA_CHECK_ARG(dtype == VRA_BF16 || dtype == VRA_F16, "vra_paged_attention_decode: dtype must be bf16/f16");
   if (!kv_dtype_ok("vra_paged_attention_decode", dtype, kv_dtype)) return;
   VRA_CHECK_ARG(block_size % 32 == 0, "vra_paged_attention_decode: block_size must be a multiple of 32");
@@ -761,7 +775,9 @@ extern "C" void vra_paged_attention_decode(void* out, const void* q, const void*
   a.scale_log2e = scale * 1.44269504088896f;
   a.softcap = softcap;
   a.decode = 1;
-  a.nsplit = workspace ? decode_nsplit(batch, kv_heads, max_context_len) : 1;
+  a.sliding_window = sliding_window;
+  // (the split decision counts the tiles that are walked: a window shorter than the context shortens every chain)
+  a.nsplit = workspace ? decode_nsplit(batch, kv_heads, sliding_window > 0 && sliding_window + 31 < max_context_len ? sliding_window + 31 : max_context_len) : 1;
   a.ws_o = static_cast<float*>(workspace);
   a.ws_ml = a.ws_o ? a.ws_o + (size_t)batch * q_heads * a.nsplit * head_dim : nullptr;
   dim3 grid(a.nsplit, kv_heads, batch);
@@ -788,7 +804,18 @@ extern "C" void vra_paged_attention_prefill(void* out, const void* q, const void
                                             int32_t total_q, int32_t max_seqlen_q, int32_t q_heads, int32_t kv_heads,
                                             int32_t head_dim, int32_t block_size, int32_t max_blocks_per_seq, float scale,
                                             float softcap, int32_t dtype, int32_t kv_dtype, int64_t stream) {
+  vra_paged_attention_prefill_sw(out, q, k, v, k_cache, v_cache, block_tables, context_lens, cu_seqlens_q, cu_seqlens_k, batch, total_q,
+                                 max_seqlen_q, q_heads, kv_heads, head_dim, block_size, max_blocks_per_seq, scale, softcap, 0, dtype, kv_dtype,
+                                 stream);
+}
+extern "C" void vra_paged_attention_prefill_sw(void* out, const void* q, const void* k, const void* v, const void* k_cache,
+                                               const void* v_cache, const uint32_t* block_tables, const uint32_t* context_lens,
+                                               const uint32_t* cu_seqlens_q, const uint32_t* cu_seqlens_k, int32_t batch,
+                                               int32_t total_q, int32_t max_seqlen_q, int32_t q_heads, int32_t kv_heads,
+                                               int32_t head_dim, int32_t block_size, int32_t max_blocks_per_seq, float scale,
+                                               float softcap, int32_t sliding_window, int32_t dtype, int32_t kv_dtype, int64_t stream) {
   (void)total_q;
+  VRA_CHECK_ARG(sliding_window >= 0, "vra_paged_attention_prefill: sliding_window must be >= 0 (0 = off)");
   VRA_CHECK_ARG(dtype == VRA_BF16 || dtype == VRA_F16, "vra_paged_attention_prefill: dtype must be bf16/f16");
   if (!kv_dtype_ok("vra_paged_attention_prefill", dtype, kv_dtype)) return;
   VRA_CHECK_ARG(block_tables || kv_dtype == dtype, "vra_paged_attention_prefill: contiguous k/v are in the activation dtype");
@@ -822,7 +849,9 @@ extern "C" void vra_paged_attention_prefill(void* out, const void* q, const void
   a.softcap = softcap;
   a.decode = 0;
   a.nsplit = 1;
-  if (block_tables && (head_dim == 128 || head_dim == 64) && (block_size & (block_size - 1)) == 0 && !getenv("VRA_NO_PREFILL_TILED")) {
+  a.sliding_window = sliding_window;
+  // (a sliding window runs on the generic kernel below — mask + skipped tiles; the LDS-tiled kernel is the full-causal fast path)
+  if (sliding_window == 0 && block_tables && (head_dim == 128 || head_dim == 64) && (block_size & (block_size - 1)) == 0 && !getenv("VRA_NO_PREFILL_TILED")) {
     // the LDS-tiled prefill kernel (attn_prefill.cuh); 2 row tiles per wave once that still leaves >= 2 workgroups per CU
     PrefillAttnArgs p = {};
     p.out = out, p.q = q, p.kc = k_cache, p.vc = v_cache;

@@ -1197,6 +1197,9 @@ extern "C" void marlin_awq_4bit_f16(const void* in, const int32_t* qweight, cons
 // gemm_half_q_half_alt: plain GPTQ checkpoint layout, f16 only (src/utils/gptq.rs:181-198).  Not a
 // hot path (sym=false / odd group sizes): one thread block per 64 columns, straight from the
 // checkpoint layout, zero = stored+1, g_idx honoured (desc_act), f32 accumulate, one rounding.
+// BITS = 4 | 8 (wna16.rs:154-176 routes every non-Marlin checkpoint here, bits included: 32 / BITS values per word along k in
+// qweight [k * BITS / 32, n], along n in qzeros [k/g, n * BITS / 32], zero = stored + 1 in both widths)
+template <int BITS>
 __global__ __launch_bounds__(256) void gptq_alt_kernel(const uint16_t* __restrict__ x, const uint32_t* __restrict__ qw,
                                                        const uint32_t* __restrict__ qz, const uint16_t* __restrict__ sc,
                                                        const int32_t* __restrict__ g_idx, uint16_t* __restrict__ out,
@@ -1207,16 +1210,18 @@ __global__ __launch_bounds__(256) void gptq_alt_kernel(const uint16_t* __restric
   const int n = blockIdx.x * 64 + c, m = blockIdx.y;
   float acc = 0.f;
   if (n < N) {
-    const int rows = K >> 3;
+    constexpr int PW = 32 / BITS;  // values per word
+    constexpr uint32_t MASK = (1u << BITS) - 1u;
+    const int rows = K / PW;
     for (int r = ks; r < rows; r += 4) {
       uint32_t w = qw[(size_t)r * N + n];
 #pragma unroll
-      for (int e = 0; e < 8; e++) {
-        int k = r * 8 + e;
+      for (int e = 0; e < PW; e++) {
+        int k = r * PW + e;
         int grp = g_idx ? g_idx[k] : k / group_size;
         float s = F16::to_f32(sc[(size_t)grp * N + n]);
-        int z = (int)((qz[(size_t)grp * (N >> 3) + (n >> 3)] >> (4 * (n & 7))) & 0xFu) + 1;
-        float wv = (float)((int)((w >> (4 * e)) & 0xFu) - z) * s;  // exact (q - z)*s, one rounding at the output
+        int z = (int)((qz[(size_t)grp * (N / PW) + (n / PW)] >> (BITS * (n % PW))) & MASK) + 1;
+        float wv = (float)((int)((w >> (BITS * e)) & MASK) - z) * s;  // exact (q - z)*s, one rounding at the output
         acc += F16::to_f32(x[(size_t)m * K + k]) * wv;
       }
     }
@@ -1229,7 +1234,7 @@ extern "C" void gemm_half_q_half_alt(const void* in, const uint32_t* qweight, co
                                      const int32_t* g_idx, void* out, int32_t m, int32_t n, int32_t k, int32_t bits,
                                      int64_t stream) {
   VRA_CHECK_ARG(in && qweight && qzeros && scales && out, "gemm_half_q_half_alt: null pointer");
-  VRA_CHECK_ARG(bits == 4, "gemm_half_q_half_alt: only 4-bit supported (bits=%d)", bits);
+  VRA_CHECK_ARG(bits == 4 || bits == 8, "gemm_half_q_half_alt: 4- or 8-bit GPTQ only (bits=%d)", bits);
   VRA_CHECK_ARG(k % 8 == 0 && n % 8 == 0, "gemm_half_q_half_alt: k,n must be multiples of 8");
   // The reference's signature carries no group size: with g_idx (every GPTQ checkpoint has one, and wna16.rs:127-148 always
   // passes it on this path) the group of a row is g_idx[k].  Without it the group size is read off the EXTENT of the scales
@@ -1247,7 +1252,8 @@ extern "C" void gemm_half_q_half_alt(const void* in, const uint32_t* qweight, co
     }
   }
   dim3 grid((n + 63) / 64, m);
-  gptq_alt_kernel<<<grid, 256, 0, as_stream(stream)>>>((const uint16_t*)in, qweight, qzeros, (const uint16_t*)scales, g_idx, (uint16_t*)out, m, n, k, group);
+  if (bits == 8) gptq_alt_kernel<8><<<grid, 256, 0, as_stream(stream)>>>((const uint16_t*)in, qweight, qzeros, (const uint16_t*)scales, g_idx, (uint16_t*)out, m, n, k, group);
+  else gptq_alt_kernel<4><<<grid, 256, 0, as_stream(stream)>>>((const uint16_t*)in, qweight, qzeros, (const uint16_t*)scales, g_idx, (uint16_t*)out, m, n, k, group);
 }
 
 // NormX::forward + QLinear::forward in one call (others.rs:11-29 in front of wna16.rs:263-306): out = rmsnorm(in)·W (+ bias).

@@ -94,7 +94,7 @@ def marlin_weight_repack(qweight_dev, shape, bits=4, is_awq=False):
 def gptq_matmul(x, qweight, scale, qzeros, g_idx, workspace, bits, group_size, is_awq, m, k, n, dtype=BF16):
     """gptq_matmul (src/utils/gptq.rs:243-263) → marlin_* when `workspace` is given, else
     gemm_half_q_half_alt. All tensors are DevBufs; returns the output DevBuf [m, n]."""
-    assert bits == 4
+    assert bits == 4 or (bits == 8 and workspace is None)
     out = DevBuf(m * n * 2)
     L = lib()
     if workspace is not None:
@@ -238,8 +238,9 @@ class FusedRope:
 class PagedAttention:
     """attention_rs::PagedAttention (attention.rs:607-616,808-820): new(heads, D, scale, kv_heads, …)."""
 
-    def __init__(self, num_heads, head_dim, scale, num_kv_heads, block_size=64, dtype=BF16, softcap=0.0, fp8_kvcache=False):
+    def __init__(self, num_heads, head_dim, scale, num_kv_heads, block_size=64, dtype=BF16, softcap=0.0, fp8_kvcache=False, sliding_window=0):
         self.Hq, self.D, self.scale, self.Hkv, self.BS, self.dtype, self.softcap = num_heads, head_dim, scale, num_kv_heads, block_size, dtype, softcap
+        self.sliding_window = int(sliding_window or 0)  # PagedAttention::new(.., sliding_window, ..), attention.rs:607-616
         self.kv_dtype = 3 if fp8_kvcache else dtype   # VRA_FP8_E4M3 (PagedAttention::new(.., fp8_kvcache), attention.rs:607-616)
 
     def reshape_and_cache(self, k, v, k_cache, v_cache, slot_mapping, tokens):
@@ -250,9 +251,10 @@ class PagedAttention:
     def forward_decode(self, q, k_cache, v_cache, block_tables, context_lens, batch, max_blocks, max_context_len,
                        workspace=None):
         out = DevBuf(batch * self.Hq * self.D * 2)
-        lib().vra_paged_attention_decode(out.ptr, _ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(block_tables),
-                                         _ptr(context_lens), batch, self.Hq, self.Hkv, self.D, self.BS, max_blocks,
-                                         max_context_len, self.scale, self.softcap, _ptr(workspace), self.dtype, self.kv_dtype, 0)
+        lib().vra_paged_attention_decode_sw(out.ptr, _ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(block_tables),
+                                            _ptr(context_lens), batch, self.Hq, self.Hkv, self.D, self.BS, max_blocks,
+                                            max_context_len, self.scale, self.softcap, self.sliding_window, _ptr(workspace), self.dtype,
+                                            self.kv_dtype, 0)
         check_error()
         return out
 
@@ -270,9 +272,9 @@ class PagedAttention:
     def forward_prefill(self, q, total_q, max_seqlen_q, cu_q, batch, k=None, v=None, cu_k=None, k_cache=None,
                         v_cache=None, block_tables=None, context_lens=None, max_blocks=0):
         out = DevBuf(total_q * self.Hq * self.D * 2)
-        lib().vra_paged_attention_prefill(out.ptr, _ptr(q), _ptr(k), _ptr(v), _ptr(k_cache), _ptr(v_cache),
-                                          _ptr(block_tables), _ptr(context_lens), _ptr(cu_q), _ptr(cu_k), batch, total_q,
-                                          max_seqlen_q, self.Hq, self.Hkv, self.D, self.BS, max_blocks, self.scale,
-                                          self.softcap, self.dtype, self.kv_dtype, 0)
+        lib().vra_paged_attention_prefill_sw(out.ptr, _ptr(q), _ptr(k), _ptr(v), _ptr(k_cache), _ptr(v_cache),
+                                             _ptr(block_tables), _ptr(context_lens), _ptr(cu_q), _ptr(cu_k), batch, total_q,
+                                             max_seqlen_q, self.Hq, self.Hkv, self.D, self.BS, max_blocks, self.scale,
+                                             self.softcap, self.sliding_window, self.dtype, self.kv_dtype, 0)
         check_error()
         return out
