@@ -256,6 +256,21 @@ def test_dense_gemm_argmax(M, K, N, dt):
         assert np.array_equal(toks, np.argmax(got, axis=-1))
 
 
+def test_dense_gemm_argmax_hand_off_stress_over_all_xcds():
+    """the last-arriver reduction of the fused lm_head argmax rests on an ISA-level ordering argument (gemv.cuh: agent-scope
+    candidate stores acknowledged at vmcnt(0), a returning counter RMW) instead of a release / acquire pair: 200
+    back-to-back launches over every CU of all 8 XCDs, x changing every launch (the candidates of the previous launch are stale
+    in the workspace), every token checked against the argmax of the logits of the same launch"""
+    M, K, N, dt = 4, 1024, 128256, BF16
+    r = rng(99)
+    w = ops.dev(rand_dt(r, (N, K), dt, 0.05))
+    f = ops.DenseGemmArgmax()
+    for it in range(200):
+        x = rand_dt(r, (M, K), dt)
+        logits, toks = f(ops.dev(x), w, None, M, K, N, dt)
+        assert np.array_equal(toks, np.argmax(logits.numpy(np.float32, (M, N)), axis=-1)), it
+
+
 # ---------------------------------------------------------------- norms / elementwise
 @pytest.mark.parametrize("dt", [BF16, F16])
 @pytest.mark.parametrize("T,H", [(1, 4096), (7, 2048), (33, 3584)])

@@ -388,8 +388,18 @@ __global__ __launch_bounds__(GEMV_THREADS, 4) void gemv_kernel(const GemvArgs a)
       for (int d = 8; d > 0; d >>= 1) am_best = gemv_am_max(am_best, gemv_am_shfl_xor(am_best, d));
       if (tid < 16 * M && (tid & 15) == 0)
         __hip_atomic_store(a.am_ws + (size_t)(tid >> 4) * gridDim.x + blockIdx.x, am_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      // no fences (an agent-scope release walks the whole L2 once per workgroup: measured +150 us per launch): the candidate is a
-      // write-through store, complete at vmcnt(0); the counter and the candidate loads below are device-scope accesses too
+      // No C++-level release / acquire pair, on purpose: an agent-scope release is `buffer_wbl2 sc1` — it walks the whole
+      // L2 once per workgroup: measured +150 us per launch.  The ordering rests on the ISA instead, and only on these four facts:
+      //   (1) the candidate store, the counter RMW and the candidate loads are ALL agent-scope atomics (sc1): they are performed
+      //       at the memory side of the XCD L2s, never served from or parked in a non-coherent line (one 8-byte word each: no tearing);
+      //   (2) `s_waitcnt vmcnt(0)` returns once the write-through store has been ACKNOWLEDGED by that coherence point (gfx9 counts
+      //       stores in vmcnt; the asm statement is opaque to hipcc, so it can neither be dropped nor moved — the guide's known
+      //       failure is the compiler-generated wait behind a fence, which this is not);
+      //   (3) the barrier below orders every thread's acknowledged store before thread 0's RMW; the RMW's returned value orders the
+      //       last workgroup's loads behind every other workgroup's RMW (a returning atomic is complete when its value is back);
+      //   (4) the workspace belongs to ONE Model and one stream: launches that share it are stream-ordered (the counter is re-armed
+      //       by the last workgroup before the kernel ends).
+      // tests/test_gpu_kernels.py::test_dense_gemm_argmax_hand_off_stress_over_all_xcds: 200 launches over all CUs, fresh x each.
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) {

@@ -62,7 +62,11 @@ TINYLLAMA = dict(arch="llama", hidden_size=2048, intermediate_size=5632, num_lay
 class Engine:
     def __init__(self, cfg, *, block_size=64, max_num_seqs=32, max_model_len=0, num_gpu_blocks=0, kv_fraction=0.0,
                  prefill_chunk=8192, enable_prefix_cache=False, use_graph=True, tp_rank=0, tp_world_size=1, device=0,
-                 seed=1234, comm=None, fp8_kvcache=False, cpu_mem_fold=0.2, swap_cooling_ms=0, min_tokens_left_for_swap=0):
+                 seed=1234, comm=None, fp8_kvcache=False, cpu_mem_fold=0.0, swap_cooling_ms=0, min_tokens_left_for_swap=0):
+        # cpu_mem_fold: CPU swap space as a fraction of the KV blocks, PINNED per layer at finalize.  0 (no swap space: preempted
+        # sequences are recomputed) unless the caller asks — the reference's default 0.2 (kvcache_allocator.rs:317) is applied where
+        # the reference's ENGINE plans CPU block ids, i.e. on the runner-IPC path (runner_ipc.py, host/runner_main.cpp); as the
+        # package-wide default it pinned 13 GB of host memory per 8192-block engine
         self.L = _lib.load()
         if self.L.vra_device_count() <= 0:
             raise RuntimeError("vllm_rs_amd.Engine needs a GPU: no HIP device visible (there is no CPU fallback)")
@@ -249,7 +253,7 @@ class HostEngine:
     Needs no GPU; used by the CPU parity tests of scheduler.rs / block_manager.rs / runner.rs behaviour."""
 
     def __init__(self, cfg, *, num_gpu_blocks, block_size=64, max_num_seqs=32, max_model_len=0, prefill_chunk=8192,
-                 enable_prefix_cache=False, cpu_mem_fold=0.2, swap_cooling_ms=0, min_tokens_left_for_swap=0):
+                 enable_prefix_cache=False, cpu_mem_fold=0.0, swap_cooling_ms=0, min_tokens_left_for_swap=0):
         self.L = _lib.load()
         self.mc = model_config(cfg)
         self.ec = EngineConfig(block_size=block_size, max_num_seqs=max_num_seqs, max_model_len=max_model_len,

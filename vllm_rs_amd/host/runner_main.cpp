@@ -614,10 +614,16 @@ int main(int argc, char** argv) {
       vra_engine_config neg = in.ec;
       econfig_from_json(*uml, &neg);
       if (neg.block_size != in.ec.block_size) die("UsableMemoryLeft: block_size differs from Init.econfig");
+      // the reference replaces the whole EngineConfig (*econfig = ecfg, runner.rs:225); what vra_engine_update_config does not carry
+      // over was fixed when the model was built from Init.econfig (the cache element type, the sampler seed): it must not differ
+      if (neg.fp8_kvcache != in.ec.fp8_kvcache) die("UsableMemoryLeft: fp8_kvcache differs from Init.econfig (the model was built with Init's)");
+      if (neg.seed != in.ec.seed) die("UsableMemoryLeft: seed differs from Init.econfig");
       if (vra_engine_update_config(eng, &neg) != 0) die(std::string("update_config: ") + vra_engine_last_error(eng));
       in.ec.num_gpu_blocks = neg.num_gpu_blocks, in.ec.max_num_seqs = neg.max_num_seqs, in.ec.max_model_len = neg.max_model_len;
     } else {
-      fprintf(stderr, "vra_runner: expected UsableMemoryLeft after the first InitAck (%s); keeping Init.econfig\n", jerr.c_str());
+      // the frame has been consumed: answering it with the second InitAck would leave the engine waiting on a step that never gets
+      // its reply — a peer that does not follow engine.rs:355-378 is a protocol error, reported and fatal
+      die("expected UsableMemoryLeft(EngineConfig) as JSON after the first InitAck (engine.rs:355-378)" + (jerr.empty() ? std::string() : ": " + jerr));
     }
   }
   if (in.ec.block_size <= 0) die("econfig.block_size must be positive");
