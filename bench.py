@@ -118,12 +118,38 @@ def pmc_traffic(kernel):
     with a library built from these very sources (the source hash, and the .so hash of that build, are stored next to the
     counters): a kernel change can never leave a stale number in the line."""
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc.json")))
-        if pmc.get("src_sha16") != src_sha16() and pmc.get("lib_sha16") != lib_sha16():
+        pmc = load_pmc()
+        if pmc is None:
             return None
         if kernel == "family":  # the four launches of a layer: norm+qkv, o_proj, down (<..,1,..>) and the gate/up pair (<..,2,..>)
             return 3 * pmc["kernels"]["gemv_q4s_kernel<BF16,1,false>"]["hbm_bytes_per_launch"] + pmc["kernels"]["gemv_q4s_kernel<BF16,2,false>"]["hbm_bytes_per_launch"]
         return pmc["kernels"][kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
+def load_pmc():
+    """the committed counter / trace pass of this round (profiles/r04_pmc.json, tools/summarise_profiles.py) — only if it was taken
+    with a library built from these very sources"""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc.json")))
+    except Exception:
+        return None
+    if pmc.get("src_sha16") != src_sha16() and pmc.get("lib_sha16") != lib_sha16():
+        return None
+    return pmc
+
+
+def in_situ_family():
+    """the dequant-GEMV family INSIDE the decode step: average launch durations of the two kernel-E instantiations in
+    the rocprofv3 kernel trace of the eager bs-1 step (profiles/r04_decode_bs1_kernel_trace.txt) — 3 launches of <BF16,1,false> and
+    one of <BF16,2,false> per layer — next to the isolated-launch figure bench.py times itself"""
+    pmc = load_pmc()
+    try:
+        t = pmc["in_situ_decode_bs1_kernel_trace"]
+        us = 3 * t["gemv_q4s_kernel<BF16,1,false>"]["avg_us"] + t["gemv_q4s_kernel<BF16,2,false>"]["avg_us"]
+        return {"us_per_layer": us, "GBps": 113475584 / us / 1e3, "frac": 113475584 / us / 1e3 / HBM_PEAK_GBS,
+                "source": "profiles/r04_decode_bs1_kernel_trace.txt (rocprofv3 --kernel-trace of the eager step, same sources)"}
     except Exception:
         return None
 
@@ -489,6 +515,7 @@ def main():
                             "time_dominant_launch": {"name": dom_name, "kernel": dom["kernel"], "GBps": dom["GBps"], "frac": dom["GBps"] / HBM_PEAK_GBS,
                                                      "avg_launch_ms": dom["ms"], "algorithmic_bytes_per_launch": dom["bytes"],
                                                      "traffic": pmc_traffic(dom["kernel"]) if a.batch == 1 else None},
+                            "in_situ_family": in_situ_family() if a.batch == 1 else None,
                             "family": per, "family_GBps": tot_b / tot_ms / 1e6, "family_frac": tot_b / tot_ms / 1e6 / HBM_PEAK_GBS,
                             "family_ms_per_token": tot_ms * cfg["num_layers"], "lib_sha16": lib_sha16(), "src_sha16": src_sha16()}
         # ---------------- bs=32 decode
@@ -503,7 +530,7 @@ def main():
                 per32[name] = {"ms": ms, "bytes": b, "GBps": b / ms / 1e6}
                 b32 += b
                 ms32 += ms
-            line["roofline_bs32"] = {"bound": "hbm", "kernel": "dequant-GEMM family at 32 rows (gemv_q4w_kernel qkv / o_proj, gemm_q4_kernel gate/up / down)",
+            line["roofline_bs32"] = {"bound": "hbm", "kernel": "dequant-GEMM family at 32 rows (gemv_q4w_kernel: norm+qkv, o_proj, norm+gate/up in its sequential pair form; gemm_q4_kernel: down)",
                                      "achieved": b32 / ms32 / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b32 / ms32 / 1e6 / HBM_PEAK_GBS,
                                      "family": per32, "family_ms_per_step": ms32 * cfg["num_layers"], "step_ms": dt32 * 1e3 / 64}
         # ---------------- the KV term ("also ctx in {1k, 8k}"): decode at long contexts

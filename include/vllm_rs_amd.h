@@ -375,6 +375,12 @@ typedef struct vra_model_config {
    * (beta_fast 32, beta_slow 1, attn_factor 1, extrapolation_factor 1). */
   int32_t rope_dynamic_alpha;
   double rope_yarn_beta_fast, rope_yarn_beta_slow, rope_yarn_attn_factor, rope_yarn_extrapolation_factor;
+  /* appended in round 4: the reference keeps original_max_position_embeddings (or max_position_embeddings / factor)
+   * as f64 for the llama3 wavelengths and the dynamic table (rotary_emb.rs:150-164) — > 0: used instead of the truncated
+   * rope_original_max_position; and it honours an EXPLICIT 0 in a yarn field: bit i of rope_yarn_explicit (0 beta_fast, 1 beta_slow,
+   * 2 attn_factor, 3 extrapolation_factor) = "the field was given, take it as it is" (0 in the field then means 0, not the default) */
+  double rope_original_max_position_f;
+  int32_t rope_yarn_explicit;
 } vra_model_config;
 
 typedef struct vra_engine_config {

@@ -30,6 +30,10 @@ def model_config(cfg):
                                        (cfg["max_position_embeddings"] / rs["factor"] if rs.get("factor") else cfg["max_position_embeddings"])),
         rope_dynamic_alpha=int("alpha" in rs), rope_yarn_beta_fast=rs.get("beta_fast", 32.0), rope_yarn_beta_slow=rs.get("beta_slow", 1.0),
         rope_yarn_attn_factor=rs.get("attn_factor", 1.0), rope_yarn_extrapolation_factor=rs.get("extrapolation_factor", 1.0),
+        # (the f64 the reference keeps, rotary_emb.rs:150-164; and which yarn fields were given explicitly: an explicit 0 is honoured)
+        rope_original_max_position_f=float(rs.get("original_max_position_embeddings") or
+                                           (cfg["max_position_embeddings"] / rs["factor"] if rs.get("factor") else cfg["max_position_embeddings"])),
+        rope_yarn_explicit=sum(1 << i for i, k in enumerate(("beta_fast", "beta_slow", "attn_factor", "extrapolation_factor")) if k in rs),
         attention_bias=int(bool(cfg.get("attention_bias"))), quant_method=QUANT[cfg.get("quant_method")],
         bits=4, group_size=cfg.get("group_size", 128), dtype=cfg.get("dtype", BF16),
         tie_word_embeddings=int(bool(cfg.get("tie_word_embeddings"))))

@@ -33,7 +33,8 @@ extern "C" int64_t vra_kv_plan_num_blocks(const vra_model_config* mc, const vra_
 extern "C" int32_t vra_rope_table_rows(const vra_model_config* mc) {
   if (mc->rope_scaling_type == 4) return (int32_t)(uint32_t)((float)mc->max_position_embeddings * (float)mc->rope_factor);
   if (mc->rope_scaling_type == 3 && !mc->rope_dynamic_alpha) {
-    const double omax = mc->rope_original_max_position > 0 ? mc->rope_original_max_position : mc->max_position_embeddings;
+    const double omax = mc->rope_original_max_position_f > 0.0 ? mc->rope_original_max_position_f
+                                                                 : (mc->rope_original_max_position > 0 ? mc->rope_original_max_position : mc->max_position_embeddings);
     return (int32_t)(uint32_t)(omax * mc->rope_factor);
   }
   return mc->max_position_embeddings;
@@ -46,7 +47,8 @@ extern "C" int32_t vra_rope_table_rows(const vra_model_config* mc) {
 extern "C" void vra_rope_tables_f32(const vra_model_config* mc, int32_t n_pos, float* h_cos, float* h_sin) {
   const int rot = mc->head_dim, half = rot / 2;
   std::vector<float> inv(half);
-  const double omax = mc->rope_original_max_position > 0 ? mc->rope_original_max_position : mc->max_position_embeddings;
+  const double omax = mc->rope_original_max_position_f > 0.0 ? mc->rope_original_max_position_f
+                                                               : (mc->rope_original_max_position > 0 ? mc->rope_original_max_position : mc->max_position_embeddings);
   double theta = mc->rope_theta;
   float mscale = 1.0f;
   if (mc->rope_scaling_type == 3) {  // "dynamic" (rotary_emb.rs:281-333)
@@ -77,10 +79,12 @@ extern "C" void vra_rope_tables_f32(const vra_model_config* mc, int32_t n_pos, f
     }
   } else if (mc->rope_scaling_type == 4) {  // "yarn" (YarnRotaryEmbedding::new_yarn, rotary_emb.rs:482-540): everything in f32
     const float base = (float)mc->rope_theta, factor = (float)mc->rope_factor;
-    const float beta_fast = mc->rope_yarn_beta_fast != 0.0 ? (float)mc->rope_yarn_beta_fast : 32.0f;
-    const float beta_slow = mc->rope_yarn_beta_slow != 0.0 ? (float)mc->rope_yarn_beta_slow : 1.0f;
-    const float attn_factor = mc->rope_yarn_attn_factor != 0.0 ? (float)mc->rope_yarn_attn_factor : 1.0f;
-    const float extrapolation = mc->rope_yarn_extrapolation_factor != 0.0 ? (float)mc->rope_yarn_extrapolation_factor : 1.0f;
+    // (0 in a field = the reference's default, unless the caller marked the field as explicitly given: rope_yarn_explicit)
+    const int ex = mc->rope_yarn_explicit;
+    const float beta_fast = (ex & 1) || mc->rope_yarn_beta_fast != 0.0 ? (float)mc->rope_yarn_beta_fast : 32.0f;
+    const float beta_slow = (ex & 2) || mc->rope_yarn_beta_slow != 0.0 ? (float)mc->rope_yarn_beta_slow : 1.0f;
+    const float attn_factor = (ex & 4) || mc->rope_yarn_attn_factor != 0.0 ? (float)mc->rope_yarn_attn_factor : 1.0f;
+    const float extrapolation = (ex & 8) || mc->rope_yarn_extrapolation_factor != 0.0 ? (float)mc->rope_yarn_extrapolation_factor : 1.0f;
     auto corr_dim = [&](float num_rot) {  // yarn_find_correction_dim
       return ((float)rot * logf((float)(size_t)omax / (num_rot * 2.0f * 3.14159265358979323846f))) / (2.0f * logf(base));
     };

@@ -141,6 +141,9 @@ static bool init_from_json(const std::string& text, Init* out, std::string* err)
       // rotary_emb.rs:150-164: the key, else max_position_embeddings / factor, else max_position_embeddings
       mc.rope_original_max_position = rs->has("original_max_position_embeddings") ? (int)rs->i64("original_max_position_embeddings", 0)
                                       : (rs->has("factor") ? (int)((double)mc.max_position_embeddings / rs->num("factor", 1.0)) : mc.max_position_embeddings);
+      mc.rope_original_max_position_f = rs->has("original_max_position_embeddings") ? rs->num("original_max_position_embeddings", 0.0)
+                                        : (rs->has("factor") ? (double)mc.max_position_embeddings / rs->num("factor", 1.0) : (double)mc.max_position_embeddings);
+      mc.rope_yarn_explicit = (rs->has("beta_fast") ? 1 : 0) | (rs->has("beta_slow") ? 2 : 0) | (rs->has("attn_factor") ? 4 : 0) | (rs->has("extrapolation_factor") ? 8 : 0);
       mc.rope_yarn_beta_fast = rs->num("beta_fast", 32.0), mc.rope_yarn_beta_slow = rs->num("beta_slow", 1.0);
       mc.rope_yarn_attn_factor = rs->num("attn_factor", 1.0), mc.rope_yarn_extrapolation_factor = rs->num("extrapolation_factor", 1.0);
     }
