@@ -77,6 +77,11 @@ struct GemvArgs {
   uint32_t* am_out;
   unsigned long long* am_ws;
   unsigned long long* ts;  // VRA_GEMV_TS builds: [grid][32] wall-clock stamps of wave 0
+  // dense launches: seg[].w is the TILE-MAJOR copy vra_dense_tile_weights makes (u32x4 word ((nb*KT + kt)*4 + l)*64 + lane holds row
+  // nb*16 + nn, columns kt*128 + l*32 + oct*8 ..: the MFMA operand order, one contiguous KiB per wave load) instead of row-major
+  // [n, K].  A row-major wave load touches 16 rows x 64 bytes — half a 128-byte line of 16 different lines, the other halves by the
+  // next load: the 1 GB lm_head streamed at 5.5 TB/s in that form whatever the ring depth (a plain contiguous read: 6.75)
+  int dense_tiled;
 };
 #ifdef VRA_GEMV_TS
 #define GEMV_STAMP(i)                                                     \
@@ -220,9 +225,12 @@ __global__ __launch_bounds__(GEMV_THREADS, 4) void gemv_kernel(const GemvArgs a)
             }
           } else {
             const int n = min(nb * 16 + nn, sg.n - 1);
-            const u32x4* wp = reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(sg.w) + (size_t)n * K) + oct;
+            // (one pointer, scalar-selected stride: the row-major and the tile-major form differ in base and step only)
+            const u32x4* wp = a.dense_tiled ? reinterpret_cast<const u32x4*>(sg.w) + ((size_t)nb * KT + kt) * 256 + lane
+                                            : reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(sg.w) + (size_t)n * K) + oct + kt * 16;
+            const int lstep = a.dense_tiled ? 64 : 4;
 #pragma unroll
-            for (int l = 0; l < 4; l++) w[u][b][INT4 ? 0 : l] = __builtin_nontemporal_load(wp + kt * 16 + l * 4);
+            for (int l = 0; l < 4; l++) w[u][b][INT4 ? 0 : l] = __builtin_nontemporal_load(wp + l * lstep);
           }
         } else {
           // no such k-tile for this wave: zero weights / zero scales contribute exactly 0 and keep the

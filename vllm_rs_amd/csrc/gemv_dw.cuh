@@ -28,6 +28,7 @@ struct GemvDWArgs {
   int out_ld, out_f32;
   int M, K, KT;
   int n_units, units_q, units_r;  // workgroup b owns units_q (+1 if b < units_r) units starting at b*units_q + min(b, units_r)
+  int dense_tiled;  // w is the tile-major copy of vra_dense_tile_weights (gemv.cuh GemvArgs::dense_tiled)
 };
 
 static inline size_t gemv_dw_lds_bytes(int mt, int max_units) {
@@ -57,9 +58,11 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_dw_kernel(const GemvDWArgs a)
   auto issue = [&](int g, u32x4 (&w)[4]) {
     const int ui = min(g >> 2, nu - 1), ti = g & 3;  // steps past the end re-read the last unit (never consumed)
     const int kt = min(wave + GW_WAVES * ti, KT - 1);
-    const uint16_t* p = static_cast<const uint16_t*>(a.w) + (size_t)((u0 + ui) * 16 + nn) * K + kt * 128 + oct * 8;
+    const u32x4* p = a.dense_tiled ? reinterpret_cast<const u32x4*>(a.w) + ((size_t)(u0 + ui) * KT + kt) * 256 + lane
+                                   : reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.w) + (size_t)((u0 + ui) * 16 + nn) * K + kt * 128 + oct * 8);
+    const int jstep = a.dense_tiled ? 64 : 4;
 #pragma unroll
-    for (int j = 0; j < 4; j++) w[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + j * 32));
+    for (int j = 0; j < 4; j++) w[j] = __builtin_nontemporal_load(p + j * jstep);
   };
   issue(0, wb[0]);
   issue(1, wb[1]);

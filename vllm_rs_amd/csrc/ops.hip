@@ -162,6 +162,25 @@ extern "C" void vra_embedding(const uint32_t* ids, const void* table, void* out,
   if (tokens <= 0) return;
   gather_rows_kernel<<<tokens, 256, 0, as_stream(stream)>>>(ids, (const unsigned char*)table, (unsigned char*)out, tokens, hidden * es, (uint32_t)vocab);
 }
+// dense [N, K] 16-bit row-major -> tile-major (gemv.cuh GemvArgs::dense_tiled): one 16-byte word per thread
+__global__ void dense_tile_kernel(const u32x4* __restrict__ in, u32x4* __restrict__ out, int N, int K) {
+  const int KT = K >> 7;
+  const int64_t total = (int64_t)(N >> 4) * KT * 256;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63), l = (int)((i >> 6) & 3);
+    const int64_t t = i >> 8;
+    const int kt = (int)(t % KT), nb = (int)(t / KT);
+    const int nn = lane & 15, oct = lane >> 4;
+    out[i] = in[((int64_t)(nb * 16 + nn) * K + kt * 128 + l * 32 + oct * 8) >> 3];
+  }
+}
+void vra_dense_tile_weights(const void* w_rowmajor, void* out_tiled, int32_t n, int32_t k, int64_t stream) {
+  VRA_CHECK_ARG(n % 16 == 0 && k % 128 == 0, "vra_dense_tile_weights: need n %% 16 == 0 and k %% 128 == 0");
+  const int64_t total = (int64_t)n * k / 8;
+  int grid = (int)((total + 255) / 256);
+  if (grid > 16384) grid = 16384;
+  dense_tile_kernel<<<grid, 256, 0, as_stream(stream)>>>((const u32x4*)w_rowmajor, (u32x4*)out_tiled, n, k);
+}
 void vra_embedding_bump(const uint32_t* ids, const void* table, void* out, int32_t tokens, int32_t hidden, int32_t vocab, int32_t dtype,
                         uint32_t* bump, int64_t stream) {
   size_t es = dtype == VRA_F32 ? 4 : 2;

@@ -38,5 +38,7 @@ size_t vra_qkv_attn_granule_bytes(int max_rows, int Hq, int Hkv, int D);
 // vra_embedding + one increment of *bump (the forward's epoch word) in the same launch
 void vra_embedding_bump(const uint32_t* ids, const void* table, void* out, int32_t tokens, int32_t hidden, int32_t vocab, int32_t dtype,
                         uint32_t* bump, int64_t stream);
+// dense [n, k] 16-bit row-major -> the tile-major copy the dense GEMV kernels stream one contiguous KiB per wave load from
+void vra_dense_tile_weights(const void* w_rowmajor, void* out_tiled, int32_t n, int32_t k, int64_t stream);
 // longest context the fused launch takes (tuning knob VRA_QKV_ATTN_MAX_CTX; 0 switches the fused launch off)
 int vra_qkv_attn_max_ctx();

@@ -381,6 +381,18 @@ bool Model::finalize_weights() {
     return false;
   }
   if (!build_decode_streams()) return false;
+  // the lm_head also in tile-major form for the decode GEMV kernels (one contiguous KiB per wave load instead of 16 half lines:
+  // gemv.cuh GemvArgs::dense_tiled); the row-major tensor stays for the embedding gather of tied models and the prefill GEMM
+  static const char* lt_env = getenv("VRA_LM_HEAD_TILED");
+  if (!(lt_env && lt_env[0] == '0') && !lm_head_.quant && lm_head_.N % 16 == 0 && lm_head_.K % 128 == 0 && !lm_head_tiled_) {
+    if (!(lm_head_tiled_ = dalloc((size_t)lm_head_.N * lm_head_.K * es_))) return false;
+    vra_dense_tile_weights(lm_head_.w, lm_head_tiled_, lm_head_.N, lm_head_.K, 0);
+    if (const char* e = vra_last_error(); e && e[0]) {
+      error = std::string("lm_head tiling: ") + e;
+      vra_clear_error();
+      return false;
+    }
+  }
   finalized_ = hipDeviceSynchronize() == hipSuccess;
   return finalized_;
 }
@@ -950,7 +962,8 @@ bool Model::forward(const InputMetadata& md, int64_t stream, uint32_t* tokens) {
   if (!(rows >= 4 && vra_gemv_dw_fits(rows, H, lm_head_.N)) && vra_gemv_fits(false, 1, rows, H, -1)) {
     GemvArgs a = {};
     a.nseg = 1;
-    a.seg[0] = GemvSeg{lm_head_.w, nullptr, nullptr, nullptr, logits_, lm_head_.N, lm_head_.N, 0};
+    a.seg[0] = GemvSeg{lm_head_tiled_ ? lm_head_tiled_ : lm_head_.w, nullptr, nullptr, nullptr, logits_, lm_head_.N, lm_head_.N, 0};
+    a.dense_tiled = lm_head_tiled_ ? 1 : 0;
     a.x = xin;
     a.x_ld = H;
     a.norm_w = final_norm_;
@@ -967,7 +980,7 @@ bool Model::forward(const InputMetadata& md, int64_t stream, uint32_t* tokens) {
   } else if (vra_gemv_dw_fits(rows, H, lm_head_.N)) {  // 9..32 rows: final norm + lm_head in one launch (gemv_dw.cuh)
     GemvDWArgs a = {};
     a.x = xin, a.x_ld = H, a.norm_w = final_norm_, a.eps = mc_.rms_norm_eps;
-    a.w = lm_head_.w, a.out = logits_, a.out_ld = lm_head_.N, a.out_f32 = 1;
+    a.w = lm_head_tiled_ ? lm_head_tiled_ : lm_head_.w, a.dense_tiled = lm_head_tiled_ ? 1 : 0, a.out = logits_, a.out_ld = lm_head_.N, a.out_f32 = 1;
     a.M = rows, a.K = H, a.n_units = lm_head_.N / 16;
     vra_launch_gemv_dw(a, dt_, stream);
   } else {

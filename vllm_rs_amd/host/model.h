@@ -132,6 +132,7 @@ class Model {
   void* embed_ = nullptr;
   void* final_norm_ = nullptr;
   QLinear lm_head_;
+  void* lm_head_tiled_ = nullptr;  // tile-major copy of the lm_head (csrc/gemv.cuh GemvArgs::dense_tiled), made at finalize
   std::vector<LayerWeights> layers_;
   void* cos_ = nullptr;
   void* sin_ = nullptr;
