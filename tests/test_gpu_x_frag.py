@@ -1,0 +1,96 @@
+"""GPU: "fragment-order h" (DESIGN.md §3.1b).  At decode steps of 5..32 sequences the producers of the hidden state (embedding
+gather, o_proj on kernel W, down_proj on kernel C) and the decode attention write their output a second time in kernel W's MFMA
+operand order, and the kernel-W consumers (norm + q/k/v, o_proj, norm + gate/up) load x from that copy with one contiguous KiB per
+wave load.  It is a change of ADDRESSES only: the same 16-bit values reach the same MFMA lanes, so logits and the KV cache must be
+bit-identical with `vra_debug_set_x_frag(0)` and `(1)` — for every row count of the range (ragged last m-tile, 16 / 17 rows), both
+checkpoint formats, bias, both dtypes, head dims 64 / 128, eager and graph replay."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from tests.test_gpu_engine import F16, build, check_logits, prefill_inputs, simple_tables, small_cfg
+from vllm_rs_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+CFGS = {
+    "llama3_8b_widths": small_cfg(hidden_size=4096, intermediate_size=14336, num_layers=2, num_heads=32, num_kv_heads=8, head_dim=128,
+                                  vocab_size=2048, rope_theta=500000.0, max_position_embeddings=2048),
+    "small_gptq": small_cfg(max_position_embeddings=2048),
+    "small_f16": small_cfg(dtype=F16, max_position_embeddings=2048),
+    "small_awq_bias": small_cfg(arch="qwen2", quant_method="awq", attention_bias=True, num_heads=8, num_kv_heads=2, head_dim=64, hidden_size=512,
+                                max_position_embeddings=2048),
+    "qwen2_7b_widths": small_cfg(arch="qwen2", attention_bias=True, hidden_size=3584, intermediate_size=18944, num_layers=1, num_heads=28,
+                                 num_kv_heads=4, head_dim=128, vocab_size=2048, quant_method="awq", rope_theta=1e6, rms_norm_eps=1e-6,
+                                 max_position_embeddings=2048),
+}
+
+
+def _decode_inputs(seqs, bt):
+    ids = np.array([s[-1] for s in seqs], np.uint32)
+    pos = np.array([len(s) - 1 for s in seqs], np.int64)
+    slots = np.array([int(bt[b, (len(s) - 1) // 64]) * 64 + (len(s) - 1) % 64 for b, s in enumerate(seqs)], np.int64)
+    ctx = np.array([len(s) for s in seqs], np.uint32)
+    return ids, pos, slots, ctx
+
+
+@pytest.mark.parametrize("name", list(CFGS))
+@pytest.mark.parametrize("B", [5, 8, 15, 16, 17, 24, 31, 32])
+def test_fragment_order_h_is_bit_identical_to_row_major(name, B):
+    cfg = CFGS[name]
+    lib = _lib.load()
+    r = np.random.default_rng(B)
+    lens = [int(n) for n in r.integers(3, 150, size=B)]
+    lens[0] = 300  # one sequence on the split-KV path of the decode attention
+    nblk = sum((n + 8 + 63) // 64 for n in lens) + 2
+    eng, oracle = build(cfg, seed=5, max_num_seqs=32, num_gpu_blocks=nblk)
+    try:
+        prompts = [r.integers(0, cfg["vocab_size"], size=n).tolist() for n in lens]
+        bt = simple_tables([len(p) + 8 for p in prompts])
+        ids, pos, slots, ctx, cu = prefill_inputs(prompts, bt)
+        ref = oracle.forward(ids, pos, slots, bt, ctx, cu)
+        eng.forward_raw(ids, pos, slots, bt, ctx, cu)
+        seqs = [list(p) for p in prompts]
+        tok = orc.argmax_f32(ref)
+        for step in range(2):
+            for s, t in zip(seqs, tok):
+                s.append(int(t))
+            ids, pos, slots, ctx = _decode_inputs(seqs, bt)
+            lib.vra_debug_set_x_frag(0)
+            rows = eng.forward_raw(ids, pos, slots, bt, ctx, None)
+            lib.vra_debug_set_x_frag(1)
+            frag = eng.forward_raw(ids, pos, slots, bt, ctx, None)
+            again = eng.forward_raw(ids, pos, slots, bt, ctx, None)
+            assert np.array_equal(frag.view(np.uint32), rows.view(np.uint32)), f"{name} B={B} step {step}: fragment-order h changed the logits"
+            assert np.array_equal(frag.view(np.uint32), again.view(np.uint32)), f"{name} B={B} step {step}: not reproducible"
+            ref = oracle.forward(ids, pos, slots, bt, ctx, None)
+            check_logits(frag, ref, f"{name} B={B} fragment-order h step {step}", cfg["dtype"], max_ulps=5.0)
+            tok = orc.argmax_f32(ref)
+    finally:
+        lib.vra_debug_set_x_frag(1)
+        eng.close()
+
+
+def test_a_step_outside_5_to_32_rows_after_a_fragment_step_reads_row_major():
+    """the fragment copy only exists for 5..32-row steps: a 4-row step (kernel E) and a 33-row step (row blocks) right after a
+    32-row one must not pick up a stale fragment buffer"""
+    cfg = CFGS["small_gptq"]
+    lib = _lib.load()
+    lib.vra_debug_set_x_frag(1)
+    r = np.random.default_rng(0)
+    lens = [int(n) for n in r.integers(3, 60, size=33)]
+    eng, oracle = build(cfg, seed=9, max_num_seqs=40, num_gpu_blocks=sum((n + 8 + 63) // 64 for n in lens) + 2)
+    try:
+        prompts = [r.integers(0, cfg["vocab_size"], size=n).tolist() for n in lens]
+        bt = simple_tables([len(p) + 8 for p in prompts])
+        ids, pos, slots, ctx, cu = prefill_inputs(prompts, bt)
+        ref = oracle.forward(ids, pos, slots, bt, ctx, cu)
+        eng.forward_raw(ids, pos, slots, bt, ctx, cu)
+        seqs = [list(p) + [int(t)] for p, t in zip(prompts, orc.argmax_f32(ref))]
+        for n in (32, 4, 33, 20, 1):
+            ids, pos, slots, ctx = _decode_inputs(seqs[:n], bt[:n])
+            got = eng.forward_raw(ids, pos, slots, bt[:n], ctx, None)
+            ref = oracle.forward(ids, pos, slots, bt[:n], ctx, None)
+            check_logits(got, ref, f"{n} rows after a fragment step", cfg["dtype"], max_ulps=5.0)
+    finally:
+        eng.close()

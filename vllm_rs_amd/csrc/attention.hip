@@ -360,8 +360,13 @@ struct FusedDecodeArgs {
   int nsplit;
   float* ws_o;   // [B, Hq, nsplit, D]
   float* ws_ml;  // [B, Hq, nsplit, 2]
+  uint16_t* out_frag;  // sequences 0..31 also in kernel W's fragment order (gemv_q4s.cuh GemvSArgs::x_frag: the o_proj launch's x), or null
   unsigned long long* ts;  // VRA_ATTN_TS builds: per-workgroup wall-clock stamps
 };
+// element (row m < 32, column c) of a [rows, K] activation in kernel W's fragment order (16-bit index)
+__device__ __forceinline__ size_t vra_frag_index16(int m, int c) {
+  return ((size_t)((((c >> 7) * 2 + (m >> 4)) * 4 + ((c >> 5) & 3)) * 64 + ((c >> 3) & 3) * 16 + (m & 15))) * 8 + (c & 7);
+}
 
 template <class DT, int D, bool KV8>
 __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const FusedDecodeArgs a) {
@@ -665,7 +670,9 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
         a.ws_ml[(((size_t)b * a.Hq + head) * a.nsplit + split) * 2 + 1] = L;
       }
     } else {
-      static_cast<uint16_t*>(a.out)[((size_t)b * a.Hq + head) * D + d] = DT::from_f32(L > 0.f ? acc / L : 0.f);
+      const uint16_t ov = DT::from_f32(L > 0.f ? acc / L : 0.f);
+      static_cast<uint16_t*>(a.out)[((size_t)b * a.Hq + head) * D + d] = ov;
+      if (a.out_frag && b < 32) a.out_frag[vra_frag_index16(b, head * D + d)] = ov;
     }
   }
   FD_STAMP(11);
@@ -673,7 +680,7 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
 
 // second pass for split-KV decode: merge nsplit partials per (b, head)
 template <class DT, int D>
-__global__ void paged_attn_merge_kernel(uint16_t* out, const float* ws_o, const float* ws_ml, int Hq, int nsplit) {
+__global__ void paged_attn_merge_kernel(uint16_t* out, const float* ws_o, const float* ws_ml, int Hq, int nsplit, uint16_t* out_frag = nullptr) {
   const int b = blockIdx.y, head = blockIdx.x, d = threadIdx.x;
   const size_t base = ((size_t)b * Hq + head) * nsplit;
   float M = -INFINITY;
@@ -685,7 +692,9 @@ __global__ void paged_attn_merge_kernel(uint16_t* out, const float* ws_o, const 
     L += ws_ml[(base + s) * 2 + 1] * f;
     acc += ws_o[(base + s) * D + d] * f;
   }
-  out[((size_t)b * Hq + head) * D + d] = DT::from_f32(L > 0.f ? acc / L : 0.f);
+  const uint16_t ov = DT::from_f32(L > 0.f ? acc / L : 0.f);
+  out[((size_t)b * Hq + head) * D + d] = ov;
+  if (out_frag && b < 32) out_frag[vra_frag_index16(b, head * D + d)] = ov;
 }
 
 static int decode_nsplit(int batch, int kv_heads, int max_context_len) {
@@ -895,6 +904,11 @@ extern "C" void vra_paged_attention_prefill_sw(void* out, const void* q, const v
   else launch_attn<F16>(a, head_dim, kv_dtype == VRA_FP8_E4M3, grid, as_stream(stream));
 }
 
+void vra_rope_cache_attention_decode_frag(void* out, const void* q, const void* k, const void* v, void* k_cache, void* v_cache, const void* cos,
+                                          const void* sin, const int64_t* positions, const int64_t* slot_mapping, const uint32_t* block_tables,
+                                          const uint32_t* context_lens, int32_t batch, int32_t q_heads, int32_t kv_heads, int32_t head_dim,
+                                          int32_t block_size, int32_t max_blocks_per_seq, int32_t max_context_len, float scale, void* workspace,
+                                          int32_t dtype, int32_t kv_dtype, void* out_frag, int64_t stream);
 extern "C" void vra_rope_cache_attention_decode(void* out, const void* q, const void* k, const void* v, void* k_cache, void* v_cache,
                                                 const void* cos, const void* sin, const int64_t* positions,
                                                 const int64_t* slot_mapping, const uint32_t* block_tables,
@@ -902,6 +916,17 @@ extern "C" void vra_rope_cache_attention_decode(void* out, const void* q, const 
                                                 int32_t kv_heads, int32_t head_dim, int32_t block_size,
                                                 int32_t max_blocks_per_seq, int32_t max_context_len, float scale,
                                                 void* workspace, int32_t dtype, int32_t kv_dtype, int64_t stream) {
+  vra_rope_cache_attention_decode_frag(out, q, k, v, k_cache, v_cache, cos, sin, positions, slot_mapping, block_tables, context_lens, batch, q_heads,
+                                       kv_heads, head_dim, block_size, max_blocks_per_seq, max_context_len, scale, workspace, dtype, kv_dtype, nullptr,
+                                       stream);
+}
+// internal (native runtime): the same launch, the output ALSO in kernel W's fragment order (rows 0..31, K = q_heads * head_dim, a
+// multiple of 128) for the o_proj launch that follows
+void vra_rope_cache_attention_decode_frag(void* out, const void* q, const void* k, const void* v, void* k_cache, void* v_cache, const void* cos,
+                                          const void* sin, const int64_t* positions, const int64_t* slot_mapping, const uint32_t* block_tables,
+                                          const uint32_t* context_lens, int32_t batch, int32_t q_heads, int32_t kv_heads, int32_t head_dim,
+                                          int32_t block_size, int32_t max_blocks_per_seq, int32_t max_context_len, float scale, void* workspace,
+                                          int32_t dtype, int32_t kv_dtype, void* out_frag, int64_t stream) {
   VRA_CHECK_ARG(dtype == VRA_BF16 || dtype == VRA_F16, "vra_rope_cache_attention_decode: dtype must be bf16/f16");
   if (!kv_dtype_ok("vra_rope_cache_attention_decode", dtype, kv_dtype)) return;
   VRA_CHECK_ARG(out && q && k && v && k_cache && v_cache && cos && sin && positions && slot_mapping && block_tables && context_lens,
@@ -936,6 +961,7 @@ extern "C" void vra_rope_cache_attention_decode(void* out, const void* q, const 
   a.nsplit = workspace ? decode_nsplit(batch, kv_heads, max_context_len) : 1;
   a.ws_o = static_cast<float*>(workspace);
   a.ws_ml = a.ws_o ? a.ws_o + (size_t)batch * q_heads * a.nsplit * head_dim : nullptr;
+  a.out_frag = (q_heads * head_dim) % 128 == 0 ? static_cast<uint16_t*>(out_frag) : nullptr;
   dim3 grid(a.nsplit, kv_heads, batch);
   hipStream_t st = as_stream(stream);
   const bool kv8 = kv_dtype == VRA_FP8_E4M3;
@@ -954,7 +980,7 @@ extern "C" void vra_rope_cache_attention_decode(void* out, const void* q, const 
 #undef VRA_FD
   if (a.nsplit > 1) {
     dim3 mg(q_heads, batch);
-#define VRA_MERGE(DT, DD) paged_attn_merge_kernel<DT, DD><<<mg, DD, 0, st>>>((uint16_t*)out, a.ws_o, a.ws_ml, q_heads, a.nsplit)
+#define VRA_MERGE(DT, DD) paged_attn_merge_kernel<DT, DD><<<mg, DD, 0, st>>>((uint16_t*)out, a.ws_o, a.ws_ml, q_heads, a.nsplit, a.out_frag)
     if (dtype == VRA_BF16) {
       if (head_dim == 128) VRA_MERGE(BF16, 128);
       else VRA_MERGE(BF16, 64);

@@ -46,6 +46,10 @@ struct GemmCArgs {
   uint32_t* counters;  // arrival flags, 16 words apart, one per (item, row tile, slice): zero on entry, zero on exit
   uint32_t* err;       // scratch error word: set when a slice wait timed out (vra_scratch_error)
   unsigned long long* ts;  // VRA_GEMV_TS builds: [grid.z][grid.x][32] wall-clock stamps (compute wave 0: 0..15, producer wave 0: 16..31)
+  // single-segment 16-bit launches of up to 32 rows: the outputs ALSO go to this buffer in kernel W's fragment order (gemv_q4w.cuh
+  // x_frag: u32x4 word ((kt*2 + mt)*4 + j)*64 + oct*16 + nn = row mt*16 + nn, columns kt*128 + j*32 + oct*8 .. +7) — the next
+  // launch that consumes them as x then fetches one contiguous KiB per wave load instead of 16 half lines
+  void* out_frag;
 };
 #ifdef VRA_GEMV_TS
 #define GC_STAMP(i)                                                                                   \
@@ -249,7 +253,10 @@ __global__ __launch_bounds__(GC_THREADS) void gemm_q4_kernel(const GemmCArgs a) 
         *reinterpret_cast<f32x4*>(op) = f32x4{rnd_dt<DT>(o8[0]), rnd_dt<DT>(o8[1]), rnd_dt<DT>(o8[2]), rnd_dt<DT>(o8[3])};
         *reinterpret_cast<f32x4*>(op + 4) = f32x4{rnd_dt<DT>(o8[4]), rnd_dt<DT>(o8[5]), rnd_dt<DT>(o8[6]), rnd_dt<DT>(o8[7])};
       } else {
-        *reinterpret_cast<u32x4*>(static_cast<uint16_t*>(sg.out) + (size_t)m * sg.out_ld + n) = pack8<DT>(o8);
+        const u32x4 pk = pack8<DT>(o8);
+        *reinterpret_cast<u32x4*>(static_cast<uint16_t*>(sg.out) + (size_t)m * sg.out_ld + n) = pk;
+        if (a.out_frag && m < 32)
+          static_cast<u32x4*>(a.out_frag)[(size_t)((((n >> 7) * 2 + (m >> 4)) * 4 + ((n >> 5) & 3)) * 64) + ((n >> 3) & 3) * 16 + (m & 15)] = pk;
       }
     }
   };

@@ -71,6 +71,12 @@ struct GemvSArgs {
   // (unit * 16 + column) / 2 — the consumer workgroup of the SAME launch polls the tags instead of waiting for a flag
   void* gran;
   int gran_ld;
+  // kernel W, launches of up to 32 rows: x in FRAGMENT order (u32x4 word ((kt*2 + mt)*4 + j)*64 + lane = row mt*16 + nn, columns
+  // kt*128 + j*32 + oct*8 .. +7 — what the producing launch left beside the row-major tensor): one contiguous KiB per wave load;
+  // and the same for the outputs of a single-segment launch (the next consumer's x).  tools/xload_probe.hip: 256 KB per CU in 1.0
+  // instead of 2.5 us
+  const void* x_frag;
+  void* out_frag;
 };
 
 static inline size_t gemv_q4s_lds_bytes(int ns, int tpw, int max_units, int xrows = 4) {

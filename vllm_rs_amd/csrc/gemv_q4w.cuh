@@ -42,7 +42,8 @@ static inline size_t gemv_q4w_lds_bytes(int ns, int mt, int max_units, bool has_
 // is an ordinary single-stream unit over two m-tiles (every fragment feeds two MFMAs), the gate result waits in the LDS output
 // tile of its unit and the up unit's epilogue applies SiLU(gate) * up — the arithmetic of the pair kernel, rounding for rounding.
 // units_q / units_r count PAIRS.
-template <class DT, int NS, int MT, bool AWQ, bool NORM, bool PSEQ = false>
+// XF: x comes from a.x_frag (fragment order, launches of up to 32 rows: GemvSArgs::x_frag); compile time, as NORM
+template <class DT, int NS, int MT, bool AWQ, bool NORM, bool PSEQ = false, bool XF = false>
 __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a) {
   static_assert(!PSEQ || (NS == 1 && MT == 2), "PSEQ is the single-stream two-m-tile kernel over alternating gate / up units");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -181,14 +182,17 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
       // the L1 served them at half rate; any row stride that is an odd multiple of 16..64 bytes measured 2.3..2.8 µs faster
       // per launch at 32 rows, and this is that effect without touching the layout)
 #pragma unroll
-      for (int j = 0; j < 4; j++) xf[ti][j][mt] = *reinterpret_cast<const u32x4*>(xr + (j ^ (nn & 1)) * 32);
+      for (int j = 0; j < 4; j++) {
+        if constexpr (XF) xf[ti][j][mt] = static_cast<const u32x4*>(a.x_frag)[(size_t)(((kt * 2 + mt) * 4 + j) * 64) + lane];
+        else xf[ti][j][mt] = *reinterpret_cast<const u32x4*>(xr + (j ^ (nn & 1)) * 32);
+      }
     }
   }
 
   __builtin_amdgcn_sched_barrier(0);
   GEMV_STAMP(2);
   if (has_res || any_bias) stage_epilogue_operands();
-  if (nn & 1) {
+  if (!XF && (nn & 1)) {
 #pragma unroll
     for (int ti = 0; ti < GW_TPW; ti++)
 #pragma unroll
@@ -372,6 +376,15 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
     int ld_, c0;
     seg_of(u0 + ui, o_, b_, ld_, c0);
     static_cast<uint16_t*>(o_)[(size_t)(row0 + row) * ld_ + c0 + col] = outs[idx];
+  }
+  if (a.out_frag && !PSEQ && gridDim.y == 1) {  // the same outputs in fragment order: 8 columns = one 16-byte word
+    for (int i8 = tid; i8 < nu * OPU / 8; i8 += GW_THREADS) {
+      const int idx = i8 * 8, ui = idx / OPU, rem = idx - ui * OPU, row = rem >> 4, col = rem & 15;
+      if (row >= M) continue;
+      const int n = (u0 + ui) * 16 + col;  // (single-segment launch: the launch-wide column is the output column)
+      static_cast<u32x4*>(a.out_frag)[(size_t)((((n >> 7) * 2 + (row >> 4)) * 4 + ((n >> 5) & 3)) * 64) + ((n >> 3) & 3) * 16 + (row & 15)] =
+          *reinterpret_cast<const u32x4*>(outs + idx);
+    }
   }
   GEMV_STAMP(15);
 }

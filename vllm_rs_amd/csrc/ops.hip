@@ -146,14 +146,21 @@ extern "C" void vra_silu_mul(const void* gate, const void* up, void* out, int64_
 // ---------------------------------------------------------------- row gathers
 __global__ __launch_bounds__(256) void gather_rows_kernel(const uint32_t* __restrict__ idx, const unsigned char* __restrict__ table,
                                                           unsigned char* __restrict__ out, int rows, size_t row_bytes,
-                                                          uint32_t n_table_rows, uint32_t* __restrict__ bump = nullptr) {
+                                                          uint32_t n_table_rows, uint32_t* __restrict__ bump = nullptr,
+                                                          u32x4* __restrict__ frag = nullptr) {
   const int r = blockIdx.x;
   if (bump && r == 0 && threadIdx.x == 0) *bump += 1u;  // the forward's epoch word (qkv_attn.h): one writer, read by LATER launches
   uint32_t src = idx[r];
   if (src >= n_table_rows) src = n_table_rows - 1;  // clamp (the reference would fault)
   const u32x4* s = reinterpret_cast<const u32x4*>(table + (size_t)src * row_bytes);
   u32x4* d = reinterpret_cast<u32x4*>(out + (size_t)r * row_bytes);
-  for (size_t i = threadIdx.x; i < row_bytes / 16; i += blockDim.x) d[i] = s[i];
+  for (size_t i = threadIdx.x; i < row_bytes / 16; i += blockDim.x) {
+    const u32x4 v = s[i];
+    d[i] = v;
+    // rows 0..31 also in kernel W's fragment order (GemvSArgs::x_frag; 16-bit rows, hidden % 128 == 0: 16-byte chunk i = columns
+    // i*8 .. +7 = k-tile i >> 4, k-step (i >> 2) & 3, octet i & 3)
+    if (frag && r < 32) frag[(((i >> 4) * 2 + (size_t)(r >> 4)) * 4 + ((i >> 2) & 3)) * 64 + (i & 3) * 16 + (r & 15)] = v;
+  }
 }
 extern "C" void vra_embedding(const uint32_t* ids, const void* table, void* out, int32_t tokens, int32_t hidden,
                               int32_t vocab, int32_t dtype, int64_t stream) {
@@ -182,11 +189,13 @@ void vra_dense_tile_weights(const void* w_rowmajor, void* out_tiled, int32_t n, 
   dense_tile_kernel<<<grid, 256, 0, as_stream(stream)>>>((const u32x4*)w_rowmajor, (u32x4*)out_tiled, n, k);
 }
 void vra_embedding_bump(const uint32_t* ids, const void* table, void* out, int32_t tokens, int32_t hidden, int32_t vocab, int32_t dtype,
-                        uint32_t* bump, int64_t stream) {
+                        uint32_t* bump, void* frag, int64_t stream) {
   size_t es = dtype == VRA_F32 ? 4 : 2;
   VRA_CHECK_ARG((hidden * es) % 16 == 0, "vra_embedding: row bytes must be a multiple of 16");
   if (tokens <= 0) return;
-  gather_rows_kernel<<<tokens, 256, 0, as_stream(stream)>>>(ids, (const unsigned char*)table, (unsigned char*)out, tokens, hidden * es, (uint32_t)vocab, bump);
+  if (es != 2 || hidden % 128) frag = nullptr;
+  gather_rows_kernel<<<tokens, 256, 0, as_stream(stream)>>>(ids, (const unsigned char*)table, (unsigned char*)out, tokens, hidden * es, (uint32_t)vocab, bump,
+                                                            (u32x4*)frag);
 }
 extern "C" void vra_index_select_rows(const void* x, const uint32_t* idx, void* out, int32_t n_idx, int32_t hidden,
                                       int32_t dtype, int64_t stream) {

@@ -36,8 +36,9 @@ void vra_launch_qkv_attn(GemvSArgs a, QkvAttnTail t, void* gran, int group_size,
 // bytes of the granule buffer for up to `max_rows` rows of q|k|v
 size_t vra_qkv_attn_granule_bytes(int max_rows, int Hq, int Hkv, int D);
 // vra_embedding + one increment of *bump (the forward's epoch word) in the same launch
+// (+ rows 0..31 in kernel W's fragment order into `frag`, GemvSArgs::x_frag, when frag != null)
 void vra_embedding_bump(const uint32_t* ids, const void* table, void* out, int32_t tokens, int32_t hidden, int32_t vocab, int32_t dtype,
-                        uint32_t* bump, int64_t stream);
+                        uint32_t* bump, void* frag, int64_t stream);
 // dense [n, k] 16-bit row-major -> the tile-major copy the dense GEMV kernels stream one contiguous KiB per wave load from
 void vra_dense_tile_weights(const void* w_rowmajor, void* out_tiled, int32_t n, int32_t k, int64_t stream);
 // longest context the fused launch takes (tuning knob VRA_QKV_ATTN_MAX_CTX; 0 switches the fused launch off)

@@ -459,10 +459,13 @@ bool vra_gemv_w_fits(int ns, int M, int K, int group_size, int n_units, bool has
   if (rb > 1 && grid * rb > num_cus()) return false;
   return gemv_q4w_lds_bytes(pseq ? 1 : ns, M > 16 ? 2 : 1, mu, has_res) <= (size_t)kMaxDynLds;
 }
-template <class DT, int NS, int MT, bool AWQ, bool NORM, bool PSEQ = false>
+template <class DT, int NS, int MT, bool AWQ, bool NORM, bool PSEQ = false, bool XF = false>
 static void launch_gemv_w_n(GemvSArgs a, hipStream_t st) {
+  if constexpr (!XF) {  // fragment-order x (rows <= 32 only): the same launch, other x loads
+    if (a.x_frag && a.M <= 32 && a.nseg >= 1) return launch_gemv_w_n<DT, NS, MT, AWQ, NORM, PSEQ, true>(a, st);
+  }
   static uint64_t attr_devs = 0;
-  auto kern = gemv_q4w_kernel<DT, NS, MT, AWQ, NORM, PSEQ>;
+  auto kern = gemv_q4w_kernel<DT, NS, MT, AWQ, NORM, PSEQ, XF>;
   if (!dev_seen(attr_devs)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
     dev_mark(attr_devs);

@@ -21,6 +21,17 @@ static int g_fused_qkv_attn = [] {
   return e ? atoi(e) : 0;
 }();
 extern "C" void vra_debug_set_fused_qkv_attn(int on) { g_fused_qkv_attn = on; }
+// VRA_X_FRAG=0 / vra_debug_set_x_frag(0): steps of 5..32 rows read h row-major in kernel W (no fragment-order copy)
+static int g_x_frag = [] {
+  const char* e = getenv("VRA_X_FRAG");
+  return e ? atoi(e) : 1;
+}();
+extern "C" void vra_debug_set_x_frag(int on) { g_x_frag = on; }
+void vra_rope_cache_attention_decode_frag(void* out, const void* q, const void* k, const void* v, void* k_cache, void* v_cache, const void* cos,
+                                          const void* sin, const int64_t* positions, const int64_t* slot_mapping, const uint32_t* block_tables,
+                                          const uint32_t* context_lens, int32_t batch, int32_t q_heads, int32_t kv_heads, int32_t head_dim,
+                                          int32_t block_size, int32_t max_blocks_per_seq, int32_t max_context_len, float scale, void* workspace,
+                                          int32_t dtype, int32_t kv_dtype, void* out_frag, int64_t stream);  // csrc/attention.hip
 
 namespace vra {
 
@@ -431,6 +442,14 @@ bool Model::init_buffers(int max_tokens, int max_seqs) {
   const size_t gb = vra_qkv_attn_granule_bytes(4, hq_, hkv_, mc_.head_dim);
   if (!(qkv_gran_ = dalloc(gb)) || hipMemset(qkv_gran_, 0, gb) != hipSuccess) return false;
   if (!(epoch_ = (uint32_t*)dalloc(64)) || hipMemset(epoch_, 0, 64) != hipSuccess) return false;
+  if (H % 128 == 0) {
+    const size_t fb = (size_t)(H / 128) * 2 * 4096;
+    if (!(hfrag_ = dalloc(fb)) || hipMemset(hfrag_, 0, fb) != hipSuccess) return false;
+  }
+  if ((hq_ * mc_.head_dim) % 128 == 0) {
+    const size_t fb = (size_t)(hq_ * mc_.head_dim / 128) * 2 * 4096;
+    if (!(afrag_ = dalloc(fb)) || hipMemset(afrag_, 0, fb) != hipSuccess) return false;
+  }
   return build_decode_step();
 }
 
@@ -447,9 +466,26 @@ static bool take_err(std::string& error, const char* where) {
   return false;
 }
 
-bool Model::linear(const QLinear& l0, const void* x, void* out, int M, const void* residual, int64_t stream, bool with_bias) {
+bool Model::linear(const QLinear& l0, const void* x, void* out, int M, const void* residual, int64_t stream, bool with_bias, void* out_frag,
+                   bool* wrote_frag) {
   QLinear l = l0;
   if (!with_bias) l.bias = nullptr;
+  if (wrote_frag) *wrote_frag = false;
+  // down_proj of a 5..32-row step on kernel C, leaving its outputs in fragment order as well (the dispatch order of vra_wna16_gemm:
+  // kernels E / W and A first — they do not take this shape —, then C)
+  if (l.quant && out_frag && M >= 5 && M <= 32 && l.N % 16 == 0 && !vra_gemv_s_fits(1, M, l.K, mc_.group_size, l.N / 16, false) &&
+      !vra_gemv_w_fits(1, M, l.K, mc_.group_size, l.N / 16, residual != nullptr, l.bias != nullptr) && !vra_gemv_fits(true, 1, M, l.K, mc_.group_size) &&
+      vra_gemm_q4_fits(1, M, l.K, mc_.group_size)) {
+    GemmCArgs c = {};
+    c.nseg = 1;
+    c.seg[0] = GemvSeg{l.w, l.scales, l.qzeros, l.bias, out, l.N, l.N, 0};
+    c.x = x, c.x_ld = l.K, c.residual = residual, c.res_ld = l.N;
+    c.M = M, c.K = l.K, c.group_size = mc_.group_size, c.n_blocks = l.N / 16;
+    c.out_frag = out_frag;
+    vra_launch_gemm_q4(c, l.awq && l.qzeros != nullptr, dt_, stream);
+    if (wrote_frag) *wrote_frag = true;
+    return !take_err(error, "linear (kernel C)");
+  }
   if (l.quant) {
     vra_wna16_gemm(x, l.w, l.scales, l.qzeros, l.bias, residual, out, M, l.K, l.N, mc_.group_size, l.awq ? 1 : 0,
                    VRA_SCALES_ROWMAJOR, dt_, stream);
@@ -755,12 +791,13 @@ bool Model::qkv_attn(int l, const InputMetadata& md, int64_t stream) {
   vra_launch_qkv_attn(a, t, qkv_gran_, mc_.group_size, L.q.awq, dt_, mc_.head_dim, stream);
   return !take_err(error, "qkv_attn");
 }
-bool Model::gemv_s(int l, int which, int M, void* out, const void* residual, int64_t stream) {
+bool Model::gemv_s(int l, int which, int M, void* out, const void* residual, int64_t stream, const void* x_frag, void* out_frag) {
   if (!gemv_s_ok(which, M)) return false;
   const LayerWeights& L = layers_[l];
   GemvSArgs a;
   int ns;
   gemv_s_args(l, which, M, out, residual, &a, &ns);
+  if (M > 4 && M <= 32) a.x_frag = x_frag, a.out_frag = out_frag;  // kernel W only (1..4 rows: kernel E reads and writes row-major)
   if (M > 4) vra_launch_gemv_w(a, ns, mc_.group_size, L.q.awq, dt_, stream);  // kernel W: 5..32 rows, K <= 4096
   else vra_launch_gemv_s(a, ns, mc_.group_size, L.q.awq, dt_, stream);
   return !take_err(error, "gemv_s");
@@ -901,7 +938,10 @@ bool Model::forward(const InputMetadata& md, int64_t stream, uint32_t* tokens) {
   const int kv_dt = ec_.fp8_kvcache ? VRA_FP8_E4M3 : dt_;
   error.clear();
   // embed_forward (llama.rs:260-267)
-  vra_embedding_bump(md.input_ids, embed_, h_, T, H, mc_.vocab_size, dt_, epoch_, stream);  // (+ the forward's epoch word: qkv_attn.h)
+  // (+ the forward's epoch word: qkv_attn.h; + steps of 5..32 rows: h also in kernel W's fragment order, GemvSArgs::x_frag)
+  const bool use_frag = g_x_frag && hfrag_ && T > 4 && T <= 32 && world_ == 1;
+  vra_embedding_bump(md.input_ids, embed_, h_, T, H, mc_.vocab_size, dt_, epoch_, use_frag ? hfrag_ : nullptr, stream);
+  hfrag_ok_ = use_frag;
   // decode of 1..2 sequences at short contexts: all layers in ONE persistent launch (csrc/decode_step.hip)
   const bool one_launch = !md.is_prefill && B == T && decode_step_ok(T, md.max_context_len);
   if (one_launch && !launch_decode_phases(md, 0, mc_.num_layers * DP_PHASES_PER_LAYER, stream)) return false;
@@ -910,9 +950,10 @@ bool Model::forward(const InputMetadata& md, int64_t stream, uint32_t* tokens) {
     // ---- attention block (llama.rs:115-126): norm -> q,k,v -> rope -> cache + attention -> o_proj (+ residual)
     const QLinear qkv[3] = {L.q, L.k, L.v};
     void* outs[3] = {q_, k_, v_};
+    bool attn_frag = false;  // the attention output of this layer also exists in fragment order (afrag_)
     const bool fused_attn = g_fused_qkv_attn && qkv_attn(l, md, stream);
     if (!fused_attn && !error.empty()) return false;
-    if (!fused_attn && !gemv_s(l, 0, T, nullptr, nullptr, stream)) {
+    if (!fused_attn && !gemv_s(l, 0, T, nullptr, nullptr, stream, hfrag_ok_ ? hfrag_ : nullptr)) {
       if (!error.empty()) return false;
       if (!linear_fused_norm(qkv, 3, outs, h_, L.attn_norm, T, stream)) return false;
     }
@@ -925,9 +966,10 @@ bool Model::forward(const InputMetadata& md, int64_t stream, uint32_t* tokens) {
                                   nullptr, B, T, md.max_seqlen_q, hq_, hkv_, D, ec_.block_size, md.max_blocks, scale, 0.f, dt_, kv_dt, stream);
     } else {
       // decode: RoPE + KV write + paged attention in ONE launch (three in the reference, attention.rs:745-820)
-      vra_rope_cache_attention_decode(attn_, q_, k_, v_, kc_[l], vc_[l], cos_, sin_, md.positions, md.slot_mapping, md.block_tables,
-                                      md.context_lens, B, hq_, hkv_, D, ec_.block_size, md.max_blocks, md.max_context_len, scale,
-                                      attn_ws_, dt_, kv_dt, stream);
+      attn_frag = use_frag && afrag_ && B == T;
+      vra_rope_cache_attention_decode_frag(attn_, q_, k_, v_, kc_[l], vc_[l], cos_, sin_, md.positions, md.slot_mapping, md.block_tables,
+                                           md.context_lens, B, hq_, hkv_, D, ec_.block_size, md.max_blocks, md.max_context_len, scale,
+                                           attn_ws_, dt_, kv_dt, attn_frag ? afrag_ : nullptr, stream);
     }
     if (take_err(error, "attention")) return false;
     if (world_ > 1) {
@@ -936,17 +978,28 @@ bool Model::forward(const InputMetadata& md, int64_t stream, uint32_t* tokens) {
       if (!gemv_s(l, 1, T, tmp_, nullptr, stream) && (!error.empty() || !linear(L.o, attn_, tmp_, T, nullptr, stream, false))) return false;
       vra_all_reduce_fused(comm_, tmp_, h_, L.o.bias, h_, T, H, dt_, stream);
       if (take_err(error, "all_reduce(o_proj)")) return false;
-    } else if (!error.empty() || (!gemv_s(l, 1, T, h_, h_, stream) && (!error.empty() || !linear(L.o, attn_, h_, T, h_, stream)))) {
-      return false;
+    } else {
+      // o_proj writes h: on kernel W (5..32 rows) also its fragment-order copy; any other kernel leaves the copy stale
+      if (!error.empty()) return false;
+      const bool w_o = gemv_s(l, 1, T, h_, h_, stream, attn_frag ? afrag_ : nullptr, use_frag ? hfrag_ : nullptr);
+      if (!error.empty()) return false;
+      hfrag_ok_ = use_frag && w_o;
+      if (!w_o && !linear(L.o, attn_, h_, T, h_, stream)) return false;
     }
     // ---- MLP block (llama.rs:127-130)
-    if (!gemv_s(l, 2, T, nullptr, nullptr, stream) && (!error.empty() || !gate_up(L, h_, L.ffn_norm, act_, T, stream))) return false;
+    if (!gemv_s(l, 2, T, nullptr, nullptr, stream, hfrag_ok_ ? hfrag_ : nullptr) && (!error.empty() || !gate_up(L, h_, L.ffn_norm, act_, T, stream))) return false;
     if (world_ > 1) {
       if (!gemv_s(l, 3, T, tmp_, nullptr, stream) && (!error.empty() || !linear(L.down, act_, tmp_, T, nullptr, stream, false))) return false;
       vra_all_reduce_fused(comm_, tmp_, h_, L.down.bias, h_, T, H, dt_, stream);
       if (take_err(error, "all_reduce(down_proj)")) return false;
-    } else if (!error.empty() || (!gemv_s(l, 3, T, h_, h_, stream) && (!error.empty() || !linear(L.down, act_, h_, T, h_, stream)))) {
-      return false;
+    } else {
+      // down_proj writes h: kernel E at 1..4 rows (no copy), kernel C with the fragment-order copy at 5..32, anything else: stale
+      if (!error.empty()) return false;
+      const bool e_d = gemv_s(l, 3, T, h_, h_, stream);
+      if (!error.empty()) return false;
+      bool wrote = false;
+      if (!e_d && !linear(L.down, act_, h_, T, h_, stream, true, use_frag ? hfrag_ : nullptr, &wrote)) return false;
+      hfrag_ok_ = use_frag && wrote;
     }
   }
   // last token of every sequence (llama.rs:306-310), final norm, lm_head -> f32 (llama.rs:311-320)

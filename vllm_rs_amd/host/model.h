@@ -107,14 +107,15 @@ class Model {
  private:
   void* dalloc(size_t bytes);
   bool qlinear_synth(QLinear& l, int K, int N, bool bias, uint64_t seed);
-  bool linear(const QLinear& l, const void* x, void* out, int M, const void* residual, int64_t stream, bool with_bias = true);
+  bool linear(const QLinear& l, const void* x, void* out, int M, const void* residual, int64_t stream, bool with_bias = true, void* out_frag = nullptr,
+              bool* wrote_frag = nullptr);
   bool linear_fused_norm(const QLinear* ls, int nl, void* const* outs, const void* x, const void* norm_w, int M, int64_t stream);
   bool gate_up(const LayerWeights& L, const void* x, const void* norm_w, void* act, int M, int64_t stream);
   bool build_decode_streams();
   bool build_decode_step();  // descriptor table of the persistent decode step (needs weights, buffers and the KV cache)
   // kernel E launch of one decode GEMV of layer `l` (which: 0 norm+q/k/v, 1 o_proj, 2 norm+gate/up+SiLU*mul, 3 down);
   // false = shape not covered (the caller takes the general path).  `out`/`residual` as for linear().
-  bool gemv_s(int l, int which, int M, void* out, const void* residual, int64_t stream);
+  bool gemv_s(int l, int which, int M, void* out, const void* residual, int64_t stream, const void* x_frag = nullptr, void* out_frag = nullptr);
   bool gemv_s_ok(int which, int M) const;
   void gemv_s_args(int l, int which, int M, void* out, const void* residual, ::GemvSArgs* a, int* ns);
   vra_model_config mc_;
@@ -149,6 +150,12 @@ class Model {
   // fused q/k/v + attention decode launch (csrc/qkv_attn.hip): the q|k|v granules of a step and the forward's epoch word
   void* qkv_gran_ = nullptr;
   uint32_t* epoch_ = nullptr;
+  // the hidden state of a step of up to 32 rows in kernel W's fragment order (csrc/gemv_q4s.cuh GemvSArgs::x_frag), written beside
+  // h_ by the launches that produce it (embedding, o_proj on kernel W, down_proj on kernel C) and read by the norm + q/k/v and
+  // norm + gate/up launches of kernel W; hfrag_ok_: the copy matches h_ (false after any other writer of h_)
+  void* hfrag_ = nullptr;
+  bool hfrag_ok_ = false;
+  void* afrag_ = nullptr;  // the decode attention's output of a 5..32-sequence step in fragment order (o_proj's x on kernel W)
   bool qkv_attn(int l, const InputMetadata& md, int64_t stream);  // false = not covered (error empty) or failed (error set)
   // persistent decode step
   void* dp_layers_ = nullptr;     // device: DPLayer[num_layers]
