@@ -303,3 +303,42 @@ def test_gemv_w_row_blocks_gate_up_pair(M, awq):
     # (as test_gemv_w_gate_up_pair, over up to 3.7 M outputs instead of 230 k: gate and up each carry a possible 1-ulp flip and SiLU's
     # slope stretches the gate's — one output in 1.4 M reached 4.x ulp at 100 rows: 6)
     assert_close_dt(out.numpy(np.uint16, (M, N)), orc.silu_mul(g, u, BF16), BF16, max_ulp=6.0, max_mismatch_frac=0.05, name="gemv_w row blocks gate/up", abs_floor=8e-3)
+
+
+# ---------------------------------------------------------------------------------------------
+# kernel W, K > 4096 (down_proj): K slices across workgroups — the slices' f32 partial tiles meet through memory and the last slice
+# of a unit group sums them in slice order.  Slice shapes: 14336 = 4 x 28 tiles (waves 4..7 hold three), 18944 = 4 x 30 + 28
+# (uneven last slice, 51 unit groups, 4 or 5 units each), 11008 = 2 x 29 + 28, 8192 = 2 x 32, 5632 = 2 x 22 (two waves hold two tiles)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M", [5, 16, 17, 32])
+@pytest.mark.parametrize("K,N", [(14336, 4096), (18944, 3584), (11008, 4096), (8192, 8192), (5632, 2048)])
+def test_gemv_w_k_slices_gptq_real_widths(M, K, N):
+    r = rng(M * 13 + K + N)
+    q = make_quant(r, K, N, 128, BF16, False)
+    x = rand_dt(r, (M, K), BF16)
+    tiled, sc = _tiled(q), ops.dev(q["scales"])
+    out = ops.wna16_gemm(ops.dev(x), tiled, sc, None, M, K, N, 128)
+    ref = orc.wna16_gemm(x, q["idx"], None, q["scales"], 128, BF16)
+    got = out.numpy(np.uint16, (M, N))
+    assert_close_dt(got, ref, BF16, name=f"gemv_w k-slices M={M} K={K} N={N}", abs_floor=4e-3)
+    for _ in range(3):  # fixed slice order: bitwise stable from launch to launch, flags back at zero
+        again = ops.wna16_gemm(ops.dev(x), tiled, sc, None, M, K, N, 128).numpy(np.uint16, (M, N))
+        assert np.array_equal(got, again)
+    assert ops.lib().vra_take_device_error() == 0
+
+
+@pytest.mark.parametrize("M", [7, 32])
+@pytest.mark.parametrize("dt,awq,gs,layout", [(BF16, True, 128, 0), (F16, True, 128, 1), (F16, False, 128, 0), (BF16, False, 256, 0), (BF16, True, -1, 0)])
+def test_gemv_w_k_slices_formats_bias_residual_in_place(M, dt, awq, gs, layout):
+    K, N = 18944, 3584
+    r = rng(M + gs + layout * 3 + awq + 300)
+    q = make_quant(r, K, N, gs, dt, awq)
+    x, bias, res = rand_dt(r, (M, K), dt), rand_dt(r, (N,), dt), rand_dt(r, (M, N), dt)
+    sc = orc.marlin_permute_scales(q["scales"], grouped=True) if layout == 1 else q["scales"]
+    out = ops.wna16_gemm(ops.dev(x), _tiled(q, awq), ops.dev(sc), ops.dev(q["qzeros"]) if awq else None, M, K, N, gs, awq, layout, ops.dev(bias), ops.dev(res),
+                         dtype=dt)
+    ref = orc.wna16_gemm(x, q["idx"], q["zeros"], q["scales"], gs, dt, bias, res)
+    g0 = orc.from_dt(orc.wna16_gemm(x, q["idx"], q["zeros"], q["scales"], gs, dt), dt)
+    mag = np.maximum(np.abs(g0), np.abs(g0 + orc.from_dt(bias, dt)[None, :]))
+    assert_close_dt(out.numpy(np.uint16, (M, N)), ref, dt, max_ulp=2.0, name=f"gemv_w k-slices formats dt={dt} awq={awq} gs={gs} layout={layout}", mag=mag)
+    assert ops.lib().vra_take_device_error() == 0

@@ -25,7 +25,8 @@ void vra_launch_gemv_s(GemvSArgs a, int ns, int group_size, bool awq, int dtype,
 void vra_scales_to_unit_major(const void* scales, void* out, int G, int N, int unit0, int64_t stream);
 void vra_zeros_to_unit_major(const uint32_t* zeros, uint32_t* out, int G, int N, int unit0, int64_t stream);
 // kernel W (gemv_q4w.cuh): int4, 5..32 rows, K <= 4096, same argument block and unit distribution as kernel E
-bool vra_gemv_w_fits(int ns, int M, int K, int group_size, int n_units, bool has_res, bool has_bias = false);
+// (norm_or_segments: the launch carries a fused RMSNorm or more than one output segment — not available in the K-sliced form, K > 4096)
+bool vra_gemv_w_fits(int ns, int M, int K, int group_size, int n_units, bool has_res, bool has_bias = false, bool norm_or_segments = false);
 void vra_launch_gemv_w(GemvSArgs a, int ns, int group_size, bool awq, int dtype, int64_t stream);
 // kernel W, dense (gemv_dw.cuh): 16-bit [N, K] weights, 4..32 rows, K <= 4096 (the lm_head of decode batches); a.norm_w != null
 // fuses the RMSNorm.  The launcher fills KT and the unit distribution.

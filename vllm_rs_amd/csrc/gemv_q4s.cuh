@@ -77,6 +77,15 @@ struct GemvSArgs {
   // instead of 2.5 us
   const void* x_frag;
   void* out_frag;
+  // kernel W, K > 4096 (down_proj of 5..32 rows): K SLICES across workgroups.  Workgroup (slice z, unit group g) = blockIdx.x
+  // z * kz_groups + g holds the x fragments of k-tiles z*ktz .. (the last slice may be shorter) and streams those tiles of its
+  // group's units; the f32 partial tiles of slices 0..kz-2 travel through `slabs` ([z][unit][rows x 16] f32, write-through
+  // stores), every slice raises its flag (`counters`, 16 words apart, zero on entry and on exit), and the LAST slice of a group
+  // — the only workgroups that wait — sums them in slice order and runs the epilogue (the exchange of kernel C, gemm_q4.cuh)
+  int kz, ktz, kz_groups;
+  float* slabs;
+  uint32_t* counters;
+  uint32_t* err;
 };
 
 static inline size_t gemv_q4s_lds_bytes(int ns, int tpw, int max_units, int xrows = 4) {

@@ -24,8 +24,9 @@
 #define GW_THREADS (GW_WAVES * 64)
 #define GW_TPW 4  // k-tiles per wave and unit: w + 8*ti (K <= 4096)
 
-static inline size_t gemv_q4w_lds_bytes(int ns, int mt, int max_units, bool has_res) {
+static inline size_t gemv_q4w_lds_bytes(int ns, int mt, int max_units, bool has_res, bool kz = false) {
   size_t b = (size_t)2 * GW_WAVES * ns * mt * 1024;           // double-buffered partial tiles
+  if (kz) b += (size_t)max_units * mt * 16 * 16 * 4;          // K-sliced launches: the workgroup's f32 partial tiles
   b += (size_t)GW_WAVES * 32 * 4;                              // Σx² partials [wave][32 rows]
   b += (size_t)GW_WAVES * GW_TPW * 32 * 4;                     // Σx per (wave, tile, row)
   b += (size_t)max_units * mt * 16 * 16 * 2;                   // finished outputs (16-bit), stored after the stream
@@ -43,9 +44,11 @@ static inline size_t gemv_q4w_lds_bytes(int ns, int mt, int max_units, bool has_
 // tile of its unit and the up unit's epilogue applies SiLU(gate) * up — the arithmetic of the pair kernel, rounding for rounding.
 // units_q / units_r count PAIRS.
 // XF: x comes from a.x_frag (fragment order, launches of up to 32 rows: GemvSArgs::x_frag); compile time, as NORM
-template <class DT, int NS, int MT, bool AWQ, bool NORM, bool PSEQ = false, bool XF = false>
+// KZ: K > 4096 as K slices across workgroups (GemvSArgs::kz; single stream, no fused norm — a slice does not see whole rows)
+template <class DT, int NS, int MT, bool AWQ, bool NORM, bool PSEQ = false, bool XF = false, bool KZ = false>
 __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a) {
   static_assert(!PSEQ || (NS == 1 && MT == 2), "PSEQ is the single-stream two-m-tile kernel over alternating gate / up units");
+  static_assert(!KZ || (NS == 1 && !NORM && !PSEQ), "K slices: single stream, no fused RMSNorm");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int D = GW_TPW;  // ring slot = the wave's tile index within a unit (w + 8*ti)
   asm volatile("" ::"s"(a.x), "s"(a.x_ld), "s"(a.norm_w), "s"(a.K), "s"(a.M), "s"(a.KT), "s"(a.gsh), "s"(a.units_q), "s"(a.units_r), "s"(a.w[0]),
@@ -59,7 +62,10 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
   // per row block (L2 / MALL hits), the x of a workgroup stays at 16*MT rows, and nothing meets across workgroups
   const int row0 = (int)blockIdx.y * (MT * 16);
   const int M = min(a.M - row0, MT * 16), KT = a.KT;
-  const int wg = (int)blockIdx.x;
+  const int zi = KZ ? (int)blockIdx.x / a.kz_groups : 0;                    // K slice
+  const int wg = KZ ? (int)blockIdx.x - zi * a.kz_groups : (int)blockIdx.x;  // unit group
+  const int kt0 = KZ ? zi * a.ktz : 0, KTL = KZ ? min(a.ktz, KT - kt0) : KT;  // this workgroup's k-tiles: kt0 .. kt0 + KTL - 1
+  const bool owner = !KZ || zi == a.kz - 1;                                  // runs the epilogue and stores
   const int u0 = (wg * a.units_q + min(wg, a.units_r)) * (PSEQ ? 2 : 1);
   const int nu = (a.units_q + (wg < a.units_r ? 1 : 0)) * (PSEQ ? 2 : 1);
   const int max_u = (a.units_q + (a.units_r ? 1 : 0)) * (PSEQ ? 2 : 1);
@@ -73,6 +79,8 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
   off += (size_t)GW_WAVES * 32 * 4;
   float* xsum = reinterpret_cast<float*>(smem + off) + (size_t)wave * GW_TPW * 32;  // this wave's [4 tiles][32 rows]
   off += (size_t)GW_WAVES * GW_TPW * 32 * 4;
+  float* outf = reinterpret_cast<float*>(smem + off);  // KZ: [unit][MT*16 rows][16 cols] f32 partial tiles of this slice
+  if (KZ) off += (size_t)max_u * MT * 256 * 4;
   uint16_t* outs = reinterpret_cast<uint16_t*>(smem + off);  // [unit][MT*16 rows][16 cols]
   off += (size_t)max_u * MT * 256 * 2;
   uint16_t* ress = reinterpret_cast<uint16_t*>(smem + off);
@@ -87,6 +95,9 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
       out = a.seg[0].out, bias = nullptr, ld = a.seg[0].out_ld, col0 = (unit >> 1) * 16;
       return;
     }
+    // (`unit` is wave-uniform at every call — the callers pass it through readfirstlane: with a per-lane unit hipcc selected the
+    // ADDRESS of the segment field inside the kernel-argument block and fetched it with a VECTOR load, each followed by a vmcnt(0)
+    // that also waited for the weight ring: ~0.5 us per unit of a launch with a residual, tools/gemv_w_ts.py)
     const bool s1 = a.nseg > 1 && NS == 1 && unit >= a.seg[1].unit_start, s2 = a.nseg > 2 && NS == 1 && unit >= a.seg[2].unit_start;
     out = s2 ? a.seg[2].out : (s1 ? a.seg[1].out : a.seg[0].out);
     bias = s2 ? a.seg[2].bias : (s1 ? a.seg[1].bias : a.seg[0].bias);
@@ -104,7 +115,7 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
       const int idx = tid + it * GW_THREADS;
       e_res[it] = e_b0[it] = e_b1[it] = 0;
       if (idx < nu * OPU) {
-        const int ui = idx / OPU, rem = idx - ui * OPU, row = rem >> 4, col = rem & 15;
+        const int ui = __builtin_amdgcn_readfirstlane(idx / OPU), rem = idx - ui * OPU, row = rem >> 4, col = rem & 15;  // (OPU is a multiple of 64)
         void* o_;
         const void* b_;
         int ld_, c0;
@@ -140,28 +151,34 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
   uint32_t zb[D][AWQ ? NS : 1];
   const int gsh = a.gsh;
   const int mperm = ((nn & 7) << 3) + (nn >> 3);
+  // every ring load is (buffer resource of the tensor, ONE per-lane offset fixed for the launch, a scalar offset for the unit / tile /
+  // scale group): no per-load 64-bit VALU address arithmetic — the loop is bound by VALU issue (tools/gemv_w_ts.py, isa_mix.py)
+  const uint32_t vo_w = (uint32_t)lane * 16u;
+  const uint32_t vo_s = (uint32_t)((a.marlin ? mperm : nn) >> 1) * 4u;  // the 32-bit word that holds the lane's 16-bit scale
+  const uint32_t vo_z = (uint32_t)(nn >> 3) * 4u;
   auto issue = [&](int ui, int ti, u32x4 (&w)[NS], uint32_t (&sc)[NS], uint32_t (&zp)[AWQ ? NS : 1]) {
     const int unit_l = u0 + min(ui, nu - 1);
     const int unit = PSEQ ? unit_l >> 1 : unit_l;   // the 16-column block inside its tensor
     const bool up = PSEQ && (unit_l & 1);           // (wave-uniform: scalar selects of the kernel arguments, no indexed access)
-    const int kt = min(wave + GW_WAVES * ti, KT - 1);
+    const int kt = kt0 + min(wave + GW_WAVES * ti, KTL - 1);
     const int grp = (kt * 128) >> gsh;
-    const int col = a.marlin ? ((unit >> 2) << 6) + ((unit & 3) << 1) + mperm : unit * a.s_unit_stride + nn;
-    const int64_t si = (int64_t)grp * a.s_grp_stride + col;
-    const int64_t zi = (int64_t)grp * a.z_grp_stride + unit * a.z_unit_stride + (nn >> 3);
+    const int ucol = a.marlin ? ((unit >> 2) << 6) + ((unit & 3) << 1) : unit * a.s_unit_stride;  // (even)
+    const uint32_t so_w = (uint32_t)(unit * KT + kt) * 1024u;
+    const uint32_t so_s = (uint32_t)(grp * a.s_grp_stride + ucol) * 2u;
+    const uint32_t so_z = (uint32_t)(grp * a.z_grp_stride + unit * a.z_unit_stride) * 4u;
 #pragma unroll
     for (int b = 0; b < NS; b++) {
       const void* wp = PSEQ ? (up ? a.w[1] : a.w[0]) : a.w[b];
       const void* sp = PSEQ ? (up ? a.scales[1] : a.scales[0]) : a.scales[b];
       const uint32_t* zq = PSEQ ? (up ? a.zeros[1] : a.zeros[0]) : a.zeros[b];
-      w[b] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp) + ((size_t)unit * KT + kt) * 64 + lane);
-      sc[b] = reinterpret_cast<const uint32_t*>(sp)[si >> 1];
-      if (AWQ) zp[AWQ ? b : 0] = zq[zi];
+      w[b] = __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wp), 0, 0x7FFFFFF0, 0x00020000), vo_w, so_w, 2);  // nt
+      sc[b] = __builtin_amdgcn_raw_buffer_load_b32(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(sp), 0, 0x7FFFFFF0, 0x00020000), vo_s, so_s, 0);
+      if (AWQ) zp[AWQ ? b : 0] = __builtin_amdgcn_raw_buffer_load_b32(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(zq), 0, 0x7FFFFFF0, 0x00020000), vo_z, so_z, 0);
     }
   };
 #pragma unroll
   for (int ti = 0; ti < GW_TPW; ti++) issue(0, ti, wb[ti], sb[ti], zb[ti]);
-  if (has_res || any_bias) request_epilogue_operands();
+  if ((has_res || any_bias) && owner) request_epilogue_operands();
   GEMV_STAMP(1);
 
   __builtin_amdgcn_sched_barrier(0);  // (phase boundaries are scheduling barriers: hipcc otherwise interleaves the phases for
@@ -173,7 +190,7 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
   for (int ti = 0; ti < GW_TPW; ti++) {
     // (a wave without this k-tile re-reads the last one: its scale is zeroed in the main loop and its Σx² share below — a
     // select on the loaded fragments would double their registers)
-    const int kt = min(wave + GW_WAVES * ti, KT - 1);
+    const int kt = kt0 + min(wave + GW_WAVES * ti, KTL - 1);
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
       const uint16_t* xr = static_cast<const uint16_t*>(a.x) + (size_t)(row0 + min(mt * 16 + nn, M - 1)) * a.x_ld + kt * 128 + oct * 8;
@@ -191,7 +208,7 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
 
   __builtin_amdgcn_sched_barrier(0);
   GEMV_STAMP(2);
-  if (has_res || any_bias) stage_epilogue_operands();
+  if ((has_res || any_bias) && owner) stage_epilogue_operands();
   if (!XF && (nn & 1)) {
 #pragma unroll
     for (int ti = 0; ti < GW_TPW; ti++)
@@ -303,17 +320,18 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
       for (int mt = 0; mt < MT; mt++) acc[b][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ti = 0; ti < GW_TPW; ti++) {
-      const bool valid = wave + GW_WAVES * ti < KT;
+      const bool valid = wave + GW_WAVES * ti < KTL;
 #pragma unroll
       for (int b = 0; b < NS; b++) {  // stream by stream: only the MT accumulators of one stream's tile are live at a time
-        f32x4 ag[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++) ag[mt] = vra_zero_acc();
+        f32x4 ag[MT];  // (every chain STARTS with the C = 0 form of the MFMA: no accumulator is zeroed on the VALU)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           const s16x8 bf = magic_word<DT>(wb[ti][b][j]);  // dequantised ONCE for all m-tiles
 #pragma unroll
-          for (int mt = 0; mt < MT; mt++) DT::mfma(ag[mt], __builtin_bit_cast(s16x8, xf[ti][j][mt]), bf);
+          for (int mt = 0; mt < MT; mt++) {
+            if (j == 0) DT::mfma0(ag[mt], __builtin_bit_cast(s16x8, xf[ti][j][mt]), bf);
+            else DT::mfma(ag[mt], __builtin_bit_cast(s16x8, xf[ti][j][mt]), bf);
+          }
         }
         VRA_MFMA_DRAIN();
         float s = DT::to_f32((uint16_t)(shalf ? sb[ti][b] >> 16 : sb[ti][b]));
@@ -347,29 +365,88 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
         v += rf[((((w * NS + 0) * MT + mt) * 64) + dl) * 4 + r];
         if (NS == 2) v2 += rf[((((w * NS + 1) * MT + mt) * 64) + dl) * 4 + r];
       }
-      const float bias = DT::to_f32(biass[(ui * NS + 0) * 16 + col]);
-      v = rnd_dt<DT>(v);
-      if (any_bias) v = rnd_dt<DT>(v + bias);  // (a segment without a bias was staged as +0: adding it changes nothing but the sign of -0)
-      if (NS == 2) {
-        v2 = rnd_dt<DT>(v2);
-        if (a.seg[1].bias) v2 = rnd_dt<DT>(v2 + DT::to_f32(biass[(ui * NS + 1) * 16 + col]));
-        const float sl = rnd_dt<DT>(v / (1.0f + expf(-v)));
-        v = sl * v2;
+      if constexpr (KZ) {  // the slice's partial tile waits in LDS; exchange and epilogue run after the stream
+        outf[ui * OPU + tid] = v;
+      } else {
+        const float bias = DT::to_f32(biass[(ui * NS + 0) * 16 + col]);
+        v = rnd_dt<DT>(v);
+        if (any_bias) v = rnd_dt<DT>(v + bias);  // (a segment without a bias was staged as +0: adding it changes nothing but the sign of -0)
+        if (NS == 2) {
+          v2 = rnd_dt<DT>(v2);
+          if (a.seg[1].bias) v2 = rnd_dt<DT>(v2 + DT::to_f32(biass[(ui * NS + 1) * 16 + col]));
+          const float sl = rnd_dt<DT>(v / (1.0f + expf(-v)));
+          v = sl * v2;
+        }
+        if (has_res) v = rnd_dt<DT>(v) + DT::to_f32(ress[ui * OPU + tid]);
+        if (PSEQ && (ui & 1)) {  // the up unit: its gate value was parked by THIS thread one unit ago (u0 is even)
+          const float gt = DT::to_f32(outs[(ui - 1) * OPU + tid]);
+          v = rnd_dt<DT>(gt / (1.0f + expf(-gt))) * v;
+        }
+        outs[ui * OPU + tid] = DT::from_f32(v);
       }
-      if (has_res) v = rnd_dt<DT>(v) + DT::to_f32(ress[ui * OPU + tid]);
-      if (PSEQ && (ui & 1)) {  // the up unit: its gate value was parked by THIS thread one unit ago (u0 is even)
-        const float gt = DT::to_f32(outs[(ui - 1) * OPU + tid]);
-        v = rnd_dt<DT>(gt / (1.0f + expf(-gt))) * v;
-      }
-      outs[ui * OPU + tid] = DT::from_f32(v);
     }
     GEMV_STAMP(10 + 3 * min(ui, 1));
   }
   __syncthreads();
   GEMV_STAMP(14);
+  if constexpr (KZ) {
+    // ---- the K slices of a unit group meet through memory (kernel C's exchange, gemm_q4.cuh: the XCDs' L2s are not coherent,
+    // so partials leave as write-through stores, every slice raises its own flag line once they are acknowledged, and the last
+    // slice polls the flags, sums the slabs with agent-scope loads in slice order — deterministic — and resets the flags).
+    // Only owners wait and there are kz_groups < CUs of them: some non-owner is always resident and never waits.
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a.slabs, 0, 0x7FFFFFF0, 0x00020000);
+    uint32_t* fl = a.counters + (size_t)wg * a.kz * 16;
+    const int n4 = nu * OPU / 4;
+    if (!owner) {
+      for (int i4 = tid; i4 < n4; i4 += GW_THREADS) {
+        const int idx = i4 * 4, ui = idx / OPU, rem = idx - ui * OPU;
+        const f32x4 pv = *reinterpret_cast<const f32x4*>(outf + idx);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pv), srs, (uint32_t)(((zi * a.n_units + u0 + ui) * OPU + rem) * 4), 0, 16);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // write-through stores: acknowledged by memory
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(fl + zi * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      GEMV_STAMP(15);
+      return;
+    }
+    if (tid < a.kz - 1) {
+      const uint64_t t0 = __builtin_readcyclecounter();
+      while (__hip_atomic_load(fl + tid * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        __builtin_amdgcn_s_sleep(1);
+        if (__builtin_readcyclecounter() - t0 > (1ull << 31)) {  // never hang the device on a lost slice
+          __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+      __hip_atomic_store(fl + tid * 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    GEMV_STAMP(7);
+    constexpr int ZMAX = 7;  // other slices (kz <= 8): all their loads in flight at once
+    for (int i4 = tid; i4 < n4; i4 += GW_THREADS) {
+      const int idx = i4 * 4, ui = idx / OPU, rem = idx - ui * OPU, col = rem & 15;
+      u32x4 pz[ZMAX];
+#pragma unroll
+      for (int z = 0; z < ZMAX; z++)
+        pz[z] = __builtin_amdgcn_raw_buffer_load_b128(srs, (uint32_t)(((min(z, a.kz - 2) * a.n_units + u0 + ui) * OPU + rem) * 4), 0, 16);
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int z = 0; z < ZMAX; z++)
+        if (z < a.kz - 1) v += __builtin_bit_cast(f32x4, pz[z]);
+      v += *reinterpret_cast<const f32x4*>(outf + idx);
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        float t = rnd_dt<DT>(v[e]);
+        if (any_bias) t = rnd_dt<DT>(t + DT::to_f32(biass[ui * 16 + col + e]));
+        if (has_res) t = rnd_dt<DT>(t) + DT::to_f32(ress[idx + e]);
+        outs[idx + e] = DT::from_f32(t);
+      }
+    }
+    __syncthreads();
+  }
   // ---- everything is stored after the stream has ended
   for (int idx = tid; idx < nu * OPU; idx += GW_THREADS) {
-    const int ui = idx / OPU, rem = idx - ui * OPU, row = rem >> 4, col = rem & 15;
+    const int ui = __builtin_amdgcn_readfirstlane(idx / OPU), rem = idx - ui * OPU, row = rem >> 4, col = rem & 15;
     if (row >= M || (PSEQ && !(ui & 1))) continue;
     void* o_;
     const void* b_;
@@ -377,11 +454,11 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
     seg_of(u0 + ui, o_, b_, ld_, c0);
     static_cast<uint16_t*>(o_)[(size_t)(row0 + row) * ld_ + c0 + col] = outs[idx];
   }
-  if (a.out_frag && !PSEQ && gridDim.y == 1) {  // the same outputs in fragment order: 8 columns = one 16-byte word
+  if (a.out_frag && gridDim.y == 1) {  // the same outputs in fragment order: 8 columns = one 16-byte word
     for (int i8 = tid; i8 < nu * OPU / 8; i8 += GW_THREADS) {
       const int idx = i8 * 8, ui = idx / OPU, rem = idx - ui * OPU, row = rem >> 4, col = rem & 15;
-      if (row >= M) continue;
-      const int n = (u0 + ui) * 16 + col;  // (single-segment launch: the launch-wide column is the output column)
+      if (row >= M || (PSEQ && !(ui & 1))) continue;
+      const int n = (PSEQ ? (u0 + ui) >> 1 : u0 + ui) * 16 + col;  // (single-segment launch: the launch-wide column is the output column)
       static_cast<u32x4*>(a.out_frag)[(size_t)((((n >> 7) * 2 + (row >> 4)) * 4 + ((n >> 5) & 3)) * 64) + ((n >> 3) & 3) * 16 + (row & 15)] =
           *reinterpret_cast<const u32x4*>(outs + idx);
     }

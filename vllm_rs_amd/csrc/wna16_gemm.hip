@@ -437,9 +437,34 @@ static void gemv_w_plan(int ns, int M, int n_units, bool plain, int* grid, int* 
   if (cg > n_units) cg = n_units;
   *grid = cg, *q = n_units / cg, *r = n_units % cg;
 }
-bool vra_gemv_w_fits(int ns, int M, int K, int group_size, int n_units, bool has_res, bool has_bias) {
+// K > 4096 (down_proj, 5..32 rows): kz K slices of at most 32 k-tiles (what 8 waves hold as x fragments), kz_groups = CUs / kz
+// unit groups; workgroup (z, g) = blockIdx.x z * groups + g — the owners (z = kz - 1) carry the highest ids and start last
+static bool gemv_w_kz_plan(int K, int n_units, int* kz, int* ktz, int* groups) {
+  const int KT = K / 128, per = GW_WAVES * GW_TPW;
+  const int z = (KT + per - 1) / per;
+  if (z < 2 || z > 8) return false;
+  const int g = num_cus() / z;
+  if (g < 1 || n_units < g) return false;
+  const int t = (KT + z - 1) / z;
+  if ((z - 1) * t >= KT) return false;  // every slice holds at least one tile
+  *kz = z, *ktz = t, *groups = g;
+  return true;
+}
+bool vra_gemv_w_fits(int ns, int M, int K, int group_size, int n_units, bool has_res, bool has_bias, bool norm_or_segments) {
   static const char* off = getenv("VRA_NO_GEMV_W");
   if (off && off[0] == '1') return false;
+  if (K > 4096) {
+    static const char* kz_off = getenv("VRA_GEMV_W_KZ");  // tuning aid: 0 puts down_proj of 5..32 rows back on kernel C
+    if ((kz_off && kz_off[0] == '0') || ns != 1 || norm_or_segments || M < 5 || M > 32 || K % 128) return false;
+    const int g = group_size > 0 && group_size < K ? group_size : K;
+    if (g < K && (g < 128 || (g & (g - 1)))) return false;
+    int kz, ktz, groups;
+    if (!gemv_w_kz_plan(K, n_units, &kz, &ktz, &groups)) return false;
+    const int mu = (n_units + groups - 1) / groups, mt = M > 16 ? 2 : 1;
+    if (mu > GW_MAX_UNITS) return false;
+    if ((size_t)kz * n_units * mt * 256 * 4 > vra_scratch_slab_bytes() || (size_t)groups * kz * 16 > vra_scratch_counter_count()) return false;
+    return gemv_q4w_lds_bytes(1, mt, mu, has_res, true) <= (size_t)kMaxDynLds;
+  }
   static const char* pair_env = getenv("VRA_GEMV_W_PAIR_MAX_ROWS");  // tuning aid: 16 puts 17+-row gate/up launches back on kernels C / D
   const int pair_max = pair_env ? atoi(pair_env) : gemv_w_max_rows();
   if (M < 5 || M > (ns == 1 ? gemv_w_max_rows() : (pair_max > 16 ? pair_max : 16)) || K % 128 || K > 4096) return false;
@@ -484,6 +509,35 @@ static void launch_gemv_w_n(GemvSArgs a, hipStream_t st) {
 #endif
   kern<<<dim3(grid, rb), GW_THREADS, lds, st>>>(a);
 }
+template <class DT, int MT, bool AWQ, bool XF>
+static void launch_gemv_w_kz(GemvSArgs a, hipStream_t st) {
+  static uint64_t attr_devs = 0;
+  auto kern = gemv_q4w_kernel<DT, 1, MT, AWQ, false, false, XF, true>;
+  if (!dev_seen(attr_devs)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+    dev_mark(attr_devs);
+  }
+  a.KT = a.K / 128;
+  a.TPW = GW_TPW;
+  if (a.norm_w || a.nseg != 1 || !gemv_w_kz_plan(a.K, a.n_units, &a.kz, &a.ktz, &a.kz_groups)) {
+    vra_set_error("gemv_w: K = %d needs the K-sliced form (single segment, no fused norm, 2..8 slices)", a.K);
+    return;
+  }
+  a.units_q = a.n_units / a.kz_groups, a.units_r = a.n_units % a.kz_groups;
+  a.slabs = vra_scratch_slabs(), a.counters = vra_scratch_counters(), a.err = vra_scratch_error_word();
+  if (!a.slabs || !a.counters) {
+    vra_set_error("gemv_w: scratch not initialised (vra_scratch_init)");
+    return;
+  }
+  const size_t lds = gemv_q4w_lds_bytes(1, MT, a.units_q + (a.units_r ? 1 : 0), a.residual != nullptr, true);
+  a.dbg = 0;
+#ifdef VRA_GEMV_TS
+  a.ts = vra_gemv_ts_buf();
+#else
+  a.ts = nullptr;
+#endif
+  kern<<<dim3(a.kz * a.kz_groups, 1), GW_THREADS, lds, st>>>(a);
+}
 template <class DT, int NS, int MT, bool AWQ>
 static void launch_gemv_w_v(const GemvSArgs& a, hipStream_t st) {
   if (a.norm_w) launch_gemv_w_n<DT, NS, MT, AWQ, true>(a, st);
@@ -498,6 +552,27 @@ void vra_launch_gemv_w(GemvSArgs a, int ns, int group_size, bool awq, int dtype,
     return;
   }
   const bool bf = dtype == VRA_BF16, two = a.M > 16;
+  if (a.K > 4096) {  // K slices across workgroups (down_proj)
+    if (ns != 1 || a.M > 32) {
+      vra_set_error("gemv_w: K = %d takes single-stream launches of up to 32 rows", a.K);
+      return;
+    }
+    const bool xf = a.x_frag != nullptr;
+#define VRA_WKZ(DT_, MT_)                                                                                                                     \
+  do {                                                                                                                                        \
+    if (awq) xf ? launch_gemv_w_kz<DT_, MT_, true, true>(a, st) : launch_gemv_w_kz<DT_, MT_, true, false>(a, st);                              \
+    else xf ? launch_gemv_w_kz<DT_, MT_, false, true>(a, st) : launch_gemv_w_kz<DT_, MT_, false, false>(a, st);                                \
+  } while (0)
+    if (bf) {
+      if (two) VRA_WKZ(BF16, 2);
+      else VRA_WKZ(BF16, 1);
+    } else {
+      if (two) VRA_WKZ(F16, 2);
+      else VRA_WKZ(F16, 1);
+    }
+#undef VRA_WKZ
+    return;
+  }
   if (ns == 2 && two) {  // gate/up pair of 17+ rows: alternating gate / up units of the single-stream two-m-tile kernel (PSEQ)
     if (!a.norm_w) {
       vra_set_error("gemv_w: the sequential pair form is built with the fused RMSNorm only");
@@ -887,7 +962,9 @@ static bool gemv_s_direct(int ns, const void* in, const void* w0, const void* sc
                           const void* bias, const void* residual, void* out, int m, int k, int n, int group_size, int is_awq, int scales_layout,
                           int dtype, int64_t stream, const void* norm_w = nullptr, float eps = 0.f) {
   const bool use_w = n % 16 == 0 && vra_gemv_w_fits(ns, m, k, group_size, n / 16, residual != nullptr, bias != nullptr) &&
-                     !(ns == 2 && m > 16 && !norm_w);  // (the 17+-row pair form of kernel W exists with the fused norm only)
+                     !(ns == 2 && m > 16 && !norm_w) &&  // (the 17+-row pair form of kernel W exists with the fused norm only)
+                     !(k > 4096 && norm_w);              // (K slices do not see whole rows: no fused norm)
+  // (this entry point: one output segment)
   if (n % 16 || !(use_w || vra_gemv_s_fits(ns, m, k, group_size, n / 16, norm_w != nullptr))) return false;
   const bool grouped = group_size > 0 && group_size < k;
   if (scales_layout == VRA_SCALES_MARLIN && (!grouped || n % 64)) return false;  // channel-wise permutation: converted copy (rowmajor_scales)

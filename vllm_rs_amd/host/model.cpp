@@ -446,6 +446,10 @@ bool Model::init_buffers(int max_tokens, int max_seqs) {
     const size_t fb = (size_t)(H / 128) * 2 * 4096;
     if (!(hfrag_ = dalloc(fb)) || hipMemset(hfrag_, 0, fb) != hipSuccess) return false;
   }
+  if (inter_ % 128 == 0) {
+    const size_t fb = (size_t)(inter_ / 128) * 2 * 4096;
+    if (!(actfrag_ = dalloc(fb)) || hipMemset(actfrag_, 0, fb) != hipSuccess) return false;
+  }
   if ((hq_ * mc_.head_dim) % 128 == 0) {
     const size_t fb = (size_t)(hq_ * mc_.head_dim / 128) * 2 * 4096;
     if (!(afrag_ = dalloc(fb)) || hipMemset(afrag_, 0, fb) != hipSuccess) return false;
@@ -722,7 +726,8 @@ bool Model::gemv_s_ok(int which, int M) const {
   bool norm;
   gemv_s_shape(L, which, &K, &units, &ns, &norm);
   return vra_gemv_s_fits(ns, M, K, mc_.group_size, units, norm) || vra_gemv_w_fits(ns, M, K, mc_.group_size, units, which == 1 || which == 3,
-                         which == 0 ? (L.q.bias || L.k.bias || L.v.bias) : (which == 2 ? (L.gate.bias || L.up.bias) : (which == 1 ? L.o.bias != nullptr : L.down.bias != nullptr)));
+                         which == 0 ? (L.q.bias || L.k.bias || L.v.bias) : (which == 2 ? (L.gate.bias || L.up.bias) : (which == 1 ? L.o.bias != nullptr : L.down.bias != nullptr)),
+                         norm || which == 0);
 }
 // the argument block of decode GEMV `which` of layer l (shared by the single launch and the two-phase launch)
 void Model::gemv_s_args(int l, int which, int M, void* out, const void* residual, GemvSArgs* ap, int* nsp) {
@@ -987,7 +992,8 @@ bool Model::forward(const InputMetadata& md, int64_t stream, uint32_t* tokens) {
       if (!w_o && !linear(L.o, attn_, h_, T, h_, stream)) return false;
     }
     // ---- MLP block (llama.rs:127-130)
-    if (!gemv_s(l, 2, T, nullptr, nullptr, stream, hfrag_ok_ ? hfrag_ : nullptr) && (!error.empty() || !gate_up(L, h_, L.ffn_norm, act_, T, stream))) return false;
+    const bool w_gu = gemv_s(l, 2, T, nullptr, nullptr, stream, hfrag_ok_ ? hfrag_ : nullptr, use_frag ? actfrag_ : nullptr);
+    if (!w_gu && (!error.empty() || !gate_up(L, h_, L.ffn_norm, act_, T, stream))) return false;
     if (world_ > 1) {
       if (!gemv_s(l, 3, T, tmp_, nullptr, stream) && (!error.empty() || !linear(L.down, act_, tmp_, T, nullptr, stream, false))) return false;
       vra_all_reduce_fused(comm_, tmp_, h_, L.down.bias, h_, T, H, dt_, stream);
@@ -995,9 +1001,9 @@ bool Model::forward(const InputMetadata& md, int64_t stream, uint32_t* tokens) {
     } else {
       // down_proj writes h: kernel E at 1..4 rows (no copy), kernel C with the fragment-order copy at 5..32, anything else: stale
       if (!error.empty()) return false;
-      const bool e_d = gemv_s(l, 3, T, h_, h_, stream);
+      const bool e_d = gemv_s(l, 3, T, h_, h_, stream, use_frag && w_gu && actfrag_ ? actfrag_ : nullptr, use_frag ? hfrag_ : nullptr);
       if (!error.empty()) return false;
-      bool wrote = false;
+      bool wrote = e_d && T > 4;  // (kernel W, K-sliced: writes the fragment copy; kernel E at 1..4 rows does not)
       if (!e_d && !linear(L.down, act_, h_, T, h_, stream, true, use_frag ? hfrag_ : nullptr, &wrote)) return false;
       hfrag_ok_ = use_frag && wrote;
     }
@@ -1050,7 +1056,10 @@ bool Model::forward(const InputMetadata& md, int64_t stream, uint32_t* tokens) {
 bool Model::launch_gemm(int which, int layer, int M, int64_t stream) {
   if (layer < 0 || layer >= mc_.num_layers || M < 1 || M > max_tokens_) return false;
   const LayerWeights& L = layers_[layer];
-  if (gemv_s(layer, which, M, which == 1 || which == 3 ? tmp_ : nullptr, which == 1 || which == 3 ? h_ : nullptr, stream)) return true;
+  // (5..32 rows: x in fragment order where the forward pass reads it that way — the timing does not depend on the values)
+  const bool xf = g_x_frag && M > 4 && M <= 32 && world_ == 1;
+  const void* x_frag = !xf ? nullptr : (which == 1 ? afrag_ : (which == 3 ? actfrag_ : hfrag_));
+  if (gemv_s(layer, which, M, which == 1 || which == 3 ? tmp_ : nullptr, which == 1 || which == 3 ? h_ : nullptr, stream, x_frag)) return true;
   if (!error.empty()) return false;
   switch (which) {
     case 0: {

@@ -155,6 +155,7 @@ class Model {
   // norm + gate/up launches of kernel W; hfrag_ok_: the copy matches h_ (false after any other writer of h_)
   void* hfrag_ = nullptr;
   bool hfrag_ok_ = false;
+  void* actfrag_ = nullptr;  // SiLU(gate) * up of a 5..32-row step in fragment order (down_proj's x on the K-sliced kernel W)
   void* afrag_ = nullptr;  // the decode attention's output of a 5..32-sequence step in fragment order (o_proj's x on kernel W)
   bool qkv_attn(int l, const InputMetadata& md, int64_t stream);  // false = not covered (error empty) or failed (error set)
   // persistent decode step
