@@ -76,5 +76,10 @@ int main(int argc, char** argv) {
   run<2, false>("4096x256 D2", bufs, nbuf, bytes, 4096, 256, out, it);
   run<1, true>("8192x256 D1 nt", bufs, nbuf, bytes, 8192, 256, out, it);
   run<4, true>("1 buf 512x512 D4 nt", bufs, 1, bytes, 512, 512, out, it);
+  // kernel W's shape: one 8-wave workgroup per CU, a 4-deep ring of 1 KiB tiles per wave
+  run<2, true>("256x512 D2 nt (W/2)", bufs, nbuf, bytes, 256, 512, out, it);
+  run<4, true>("256x512 D4 nt (W)", bufs, nbuf, bytes, 256, 512, out, it);
+  run<8, true>("256x512 D8 nt (2W)", bufs, nbuf, bytes, 256, 512, out, it);
+  run<16, true>("256x512 D16 nt (4W)", bufs, nbuf, bytes, 256, 512, out, it);
   return 0;
 }

@@ -152,18 +152,33 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
   uint32_t zb[D][AWQ ? NS : 1];
   const int gsh = a.gsh;
   const int mperm = ((nn & 7) << 3) + (nn >> 3);  // marlin: column r = (unit&3)*16 + nn sits at (r&7)*8 + (r>>3) of its 64
+  // every ring load is (buffer resource of the tensor, ONE per-lane offset fixed for the launch, a scalar offset for the unit / tile /
+  // scale group): no per-load 64-bit VALU address arithmetic.  The stream phase of this kernel is bound by VALU issue, not by HBM
+  // (tools/stream_shape_probe.hip: the same loads without any compute run at 7.8 TB/s; isa_mix.py: 48 VALU instructions per KiB tile
+  // before this change, 29 of them the int4 -> bf16 conversion itself)
+  const uint32_t vo_w = (uint32_t)lane * 16u;
+  const uint32_t vo_s = (uint32_t)((a.marlin ? mperm : nn) >> 1) * 4u;  // the 32-bit word that holds the lane's 16-bit scale
+  const uint32_t vo_z = (uint32_t)(nn >> 3) * 4u;
+  __amdgpu_buffer_rsrc_t rw[NS], rs[NS], rz[AWQ ? NS : 1];
+#pragma unroll
+  for (int b = 0; b < NS; b++) {
+    rw[b] = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w[b]), 0, 0x7FFFFFF0, 0x00020000);
+    rs[b] = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.scales[b]), 0, 0x7FFFFFF0, 0x00020000);
+    if (AWQ) rz[AWQ ? b : 0] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a.zeros[b]), 0, 0x7FFFFFF0, 0x00020000);
+  }
   auto issue = [&](int ui, int ti, u32x4 (&w)[NS], uint32_t (&sc)[NS], uint32_t (&zp)[AWQ ? NS : 1]) {
     const int unit = u0 + ui;
     const int kt = min(wave + 16 * ti, KT - 1);
     const int grp = (kt * 128) >> gsh;
-    const int col = a.marlin ? ((unit >> 2) << 6) + ((unit & 3) << 1) + mperm : unit * a.s_unit_stride + nn;
-    const int64_t si = (int64_t)grp * a.s_grp_stride + col;
-    const int64_t zi = (int64_t)grp * a.z_grp_stride + unit * a.z_unit_stride + (nn >> 3);
+    const int ucol = a.marlin ? ((unit >> 2) << 6) + ((unit & 3) << 1) : unit * a.s_unit_stride;  // (even)
+    const uint32_t so_w = (uint32_t)(unit * KT + kt) * 1024u;
+    const uint32_t so_s = (uint32_t)(grp * a.s_grp_stride + ucol) * 2u;
+    const uint32_t so_z = (uint32_t)(grp * a.z_grp_stride + unit * a.z_unit_stride) * 4u;
 #pragma unroll
     for (int b = 0; b < NS; b++) {
-      w[b] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.w[b]) + ((size_t)unit * KT + kt) * 64 + lane);
-      sc[b] = reinterpret_cast<const uint32_t*>(a.scales[b])[si >> 1];  // the word holding the scale; its half is a per-lane constant
-      if (AWQ) zp[AWQ ? b : 0] = a.zeros[b][zi];
+      w[b] = __builtin_amdgcn_raw_buffer_load_b128(rw[b], vo_w, so_w, 2);  // nt
+      sc[b] = __builtin_amdgcn_raw_buffer_load_b32(rs[b], vo_s, so_s, 0);  // the word holding the scale; its half is a per-lane constant
+      if (AWQ) zp[AWQ ? b : 0] = __builtin_amdgcn_raw_buffer_load_b32(rz[AWQ ? b : 0], vo_z, so_z, 0);
     }
   };
   int iu = 0, it = 0;  // issue cursor, clamped to the last step
@@ -272,9 +287,14 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
         const bool valid = wave + 16 * ct < KT;
         const unsigned char* xp = xfrag + (size_t)ct * TLS;
         f32x4 ag[NS];
+        // (all LDS reads of the step go out first: with one read in front of each MFMA pair hipcc waited lgkmcnt(0) four times per step)
+        u32x4 xv[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) xv[j] = *reinterpret_cast<const u32x4*>(xp + j * 64);
+        const f32x4 sx = *reinterpret_cast<const f32x4*>(xw + (size_t)ct * TLS + XR * 272);  // Σx of rows 0..3 over this tile
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          const s16x8 xf = __builtin_bit_cast(s16x8, *reinterpret_cast<const u32x4*>(xp + j * 64));
+          const s16x8 xf = __builtin_bit_cast(s16x8, xv[j]);
 #pragma unroll
           for (int b = 0; b < NS; b++) {
             if (j == 0) DT::mfma0(ag[b], xf, magic_word<DT>(wb[r][b][j]));  // C = 0: no accumulator to clear
@@ -282,7 +302,6 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
           }
         }
         VRA_MFMA_DRAIN();
-        const f32x4 sx = *reinterpret_cast<const f32x4*>(xw + (size_t)ct * TLS + XR * 272);  // Σx of rows 0..3 over this tile
 #pragma unroll
         for (int b = 0; b < NS; b++) {
           float s = DT::to_f32((uint16_t)(shalf ? sb[r][b] >> 16 : sb[r][b]));
