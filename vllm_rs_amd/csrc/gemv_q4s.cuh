@@ -93,7 +93,10 @@ static inline size_t gemv_q4s_lds_bytes(int ns, int tpw, int max_units, int xrow
 }
 
 #define GS_MIN_WAVES_PER_SIMD 4
-#define GS_RING_PAIR 2  // ring depth (tile-steps of 2 KiB) of the gate/up pair stream (measured: 2 beats 1 by 2 % of the decode step)
+#ifndef GS_RING_PAIR
+#define GS_RING_PAIR 2
+#endif
+// GS_RING_PAIR: ring depth (tile-steps of 2 KiB) of the gate/up pair stream (measured: 2 beats 1 by 2 % of the decode step)
 // Variants that were built, parity-green, measured and REMOVED in round 3 (their numbers: DESIGN.md §3.1): two 16-wave
 // workgroups per CU (GS_OCC2), rotating wave priorities, the ring issued before the x loads, waiting for x before the first
 // HBM load, a tail prefetch of the next launch's first tiles, and the two-phase launches joined by a grid barrier
@@ -211,7 +214,7 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
       const int ti = t0 + i;
       if (ti < TPW) {
         const bool valid = wave + 16 * ti < KT;
-        if (!valid) xv[i] = u32x4{0u, 0u, 0u, 0u};  // a wave without this k-tile: zero slice (and zeroed scales below)
+        if (!valid) xv[i] = u32x4{0u, 0u, 0u, 0u};  // a wave without this k-tile: zero slice (its partial sums are exactly 0)
         unsigned char* tp = xw + (size_t)ti * TLS;
         *reinterpret_cast<u32x4*>(tp + srg + nn * 16) = xv[i];
         if (norm) {
@@ -284,7 +287,6 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
 #pragma unroll
     for (int r = 0; r < D; r++) {
       if (s0 + r < S) {
-        const bool valid = wave + 16 * ct < KT;
         const unsigned char* xp = xfrag + (size_t)ct * TLS;
         f32x4 ag[NS];
         // (all LDS reads of the step go out first: with one read in front of each MFMA pair hipcc waited lgkmcnt(0) four times per step)
@@ -305,7 +307,7 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
 #pragma unroll
         for (int b = 0; b < NS; b++) {
           float s = DT::to_f32((uint16_t)(shalf ? sb[r][b] >> 16 : sb[r][b]));
-          s = valid ? s : 0.f;
+          // (a wave without this k-tile holds a ZERO x slice — ag and Σx are exactly 0 and the clamped tile's scale is finite: nothing to mask)
           const float zc = AWQ ? CB + (float)((zb[r][AWQ ? b : 0] >> zsh) & 0xFu) : CB + 8.f;
 #pragma unroll
           for (int e = 0; e < 4; e++) acc[b][e] = fmaf(s, fmaf(-zc, sx[e], ag[b][e]), acc[b][e]);
