@@ -18,6 +18,7 @@
 #include "common.cuh"
 #include "kvcache.cuh"
 #include "attn_prefill.cuh"
+#include "attn_launch.h"
 
 #define PA_THREADS 256
 #define PA_WAVES 4
@@ -904,11 +905,6 @@ extern "C" void vra_paged_attention_prefill_sw(void* out, const void* q, const v
   else launch_attn<F16>(a, head_dim, kv_dtype == VRA_FP8_E4M3, grid, as_stream(stream));
 }
 
-void vra_rope_cache_attention_decode_frag(void* out, const void* q, const void* k, const void* v, void* k_cache, void* v_cache, const void* cos,
-                                          const void* sin, const int64_t* positions, const int64_t* slot_mapping, const uint32_t* block_tables,
-                                          const uint32_t* context_lens, int32_t batch, int32_t q_heads, int32_t kv_heads, int32_t head_dim,
-                                          int32_t block_size, int32_t max_blocks_per_seq, int32_t max_context_len, float scale, void* workspace,
-                                          int32_t dtype, int32_t kv_dtype, void* out_frag, int64_t stream);
 extern "C" void vra_rope_cache_attention_decode(void* out, const void* q, const void* k, const void* v, void* k_cache, void* v_cache,
                                                 const void* cos, const void* sin, const int64_t* positions,
                                                 const int64_t* slot_mapping, const uint32_t* block_tables,

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "../csrc/attn_launch.h"
 #include "../csrc/decode_step.h"
 #include "../csrc/gemm_launch.h"
 #include "../csrc/qkv_attn.h"
@@ -27,12 +28,6 @@ static int g_x_frag = [] {
   return e ? atoi(e) : 1;
 }();
 extern "C" void vra_debug_set_x_frag(int on) { g_x_frag = on; }
-void vra_rope_cache_attention_decode_frag(void* out, const void* q, const void* k, const void* v, void* k_cache, void* v_cache, const void* cos,
-                                          const void* sin, const int64_t* positions, const int64_t* slot_mapping, const uint32_t* block_tables,
-                                          const uint32_t* context_lens, int32_t batch, int32_t q_heads, int32_t kv_heads, int32_t head_dim,
-                                          int32_t block_size, int32_t max_blocks_per_seq, int32_t max_context_len, float scale, void* workspace,
-                                          int32_t dtype, int32_t kv_dtype, void* out_frag, int64_t stream);  // csrc/attention.hip
-
 namespace vra {
 
 Model::Model(const vra_model_config& mc, const vra_engine_config& ec) : mc_(mc), ec_(ec) {
