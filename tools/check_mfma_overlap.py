@@ -7,6 +7,11 @@ For every v_mfma in the given .s files:
       read or write the destination registers (the inline-asm form is invisible to hipcc's hazard
       recogniser, so the code places VRA_MFMA_DRAIN() = `s_nop 7; s_nop 4` itself).
 Exit status 1 if any violation is found (the Makefile fails the build).
+
+Also a performance lint (round 4): (3) no kernel may fetch KERNEL ARGUMENTS with vector loads.  A struct field selected under a
+per-lane index (`a.seg[i].out` with i varying across lanes) makes hipcc select the field's ADDRESS inside the kernel-argument block
+(s[0:1]) and read it with global_load — followed by `s_waitcnt vmcnt(0)`, which also waits for every weight tile in flight: a full HBM
+round trip per occurrence.  Wave-uniform indices (readfirstlane) give scalar selects and s_loads.
 """
 import re
 import sys
@@ -91,14 +96,45 @@ def check(path):
     return total, bad
 
 
+KERNARG_VEC = re.compile(r"v_lshl_add_u64\s+v\[\d+:\d+\],\s*s\[0:1\]|global_load_\w+\s+\S+,\s*v\d+,\s*s\[0:1\]")
+
+
+# tolerated: the peer-pointer table of the one-shot all-reduce is indexed by the thread on purpose (one load per launch); the
+# prologue of kernel B and the epilogue wave of kernel A (int4) — both off the decode path since kernels E / W — pay one round trip
+KERNARG_VEC_OK = ("oneshot_all_reduce_kernel", "gemm_skinny_kernel", "gemv_q4_kernel")
+SDST = re.compile(r"^s_\w+\s+(s\[(\d+):(\d+)\]|s(\d+))(?=[,\s]|$)")
+
+
+def check_kernarg_vector_loads(path):
+    """s[0:1] holds the kernel-argument pointer from entry until something else is written to it"""
+    bad = 0
+    for fn, body in instrs(path):
+        n = 0
+        for t in body:
+            if KERNARG_VEC.search(t):
+                n += 1
+            m = SDST.match(t)
+            if m and not t.startswith(("s_cmp", "s_cbranch", "s_waitcnt", "s_nop", "s_barrier", "s_bitcmp")):
+                lo, hi = (int(m.group(2)), int(m.group(3))) if m.group(2) is not None else (int(m.group(4)), int(m.group(4)))
+                if lo <= 1 and hi >= 0:
+                    break  # s0 / s1 rewritten: no longer the kernel-argument pointer
+        if n and any(k in fn for k in KERNARG_VEC_OK):
+            print(f"[note: kernel arguments fetched with {n} vector loads, tolerated] {fn}", file=sys.stderr)
+        elif n:
+            bad += n
+            print(f"[kernel arguments fetched with {n} vector loads] {fn}", file=sys.stderr)
+    return bad
+
+
 def main(paths):
-    T = B = 0
+    T = B = K = 0
     for p in paths:
         t, b = check(p)
         T += t
         B += b
-    print(f"check_mfma_overlap: {T} MFMA instructions, {B} violations")
-    return 1 if B else 0
+        K += check_kernarg_vector_loads(p)
+    print(f"check_mfma_overlap: {T} MFMA instructions, {B} violations" + (f", {K} vector loads of kernel arguments" if K else ""))
+    return 1 if B or K else 0
 
 
 if __name__ == "__main__":

@@ -350,7 +350,11 @@ __global__ __launch_bounds__(GEMV_THREADS, 4) void gemv_kernel(const GemvArgs a)
       __syncthreads();
       const int nout = a.silu_dual ? 16 * M : NBW * 16 * M;
       for (int idx = tid; idx < nout; idx += GEMV_THREADS) {
-        const int nl = idx & 15, m = (idx >> 4) % M, b = idx / (16 * M);
+        // (b: the tensor of a multi-block item.  This kernel is launched with NBW = 1, or NBW = 2 as the gate/up PAIR whose epilogue
+        // covers 16*M outputs: b is 0 either way — and must be a constant here: under a per-lane b hipcc selected the ADDRESS of
+        // a.seg[b] inside the kernel-argument block and fetched its fields with vector loads + vmcnt(0), a memory round trip per
+        // work item, 31 per workgroup of the lm_head launch; tools/check_mfma_overlap.py now fails the build on that pattern)
+        const int nl = idx & 15, m = (idx >> 4) % M, b = NBW <= 2 ? 0 : idx / (16 * M);
         const int rl = (nl >> 2) * 16 + m, rr = nl & 3;  // D layout: row = (lane>>4)*4 + reg, col = lane&15
         float v = 0.f, v2 = 0.f;
 #pragma unroll
