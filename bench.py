@@ -488,6 +488,13 @@ def main():
                    "batch_per_gpu": a.batch},
         "gpu_ms_per_step_events": ms_events / a.steps,
     }
+    if not a.no_graph:
+        # what the GPU alone needs for this step: the same decode graph replayed back to back, no upload / download / host work
+        # in between (vra_engine_bench_replay); ms_per_step minus this is what the host loop adds per step
+        rp = eng.bench_replay(64)
+        line["step_overhead"] = {"gpu_ms_per_step_graph_replay_only": rp, "host_loop_ms_per_step": dt * 1e3 / a.steps - rp,
+                                 "note": "replay-only = the step's hipGraph launched 64x back to back with frozen metadata; the timed region above runs the full loop "
+                                         "(schedule, one upload, graph launch, downloads of tokens and error word, wait, commit) per step"}
 
     if rank == 0 and not a.no_extras:
         # ---------------- roofline of the dequant-GEMM family at the headline batch: every launch of the four GEMV shapes of a

@@ -253,8 +253,9 @@ void vra_dense_gemm(const void* x, const void* w, const void* bias, void* out, i
 /* logits.argmax(-1) (logits_processor.rs:67-70): first maximal index per row. */
 void vra_argmax_f32(const float* logits, uint32_t* out, int32_t rows, int32_t cols, int64_t stream);
 /* lm_head + greedy sampling as one launch (llama.rs:311-320 followed by logits_processor.rs:67-70): f32 logits as
- * vra_dense_gemm(..., VRA_F32) AND tokens[m] = first maximal index of row m.  Up to 8 rows the tokens come out of the GEMV
- * itself (per-workgroup candidates, the last workgroup to arrive reduces them); beyond that it is the two launches.
+ * vra_dense_gemm(..., VRA_F32) AND tokens[m] = first maximal index of row m.  Up to 8 rows (kernel A) and at 4..32 rows
+ * with k <= 4096 (the dense W kernel) the tokens come out of the GEMV launch itself (per-workgroup candidates, the last
+ * workgroup to arrive reduces them); anything else is the two launches.
  * `workspace`: vra_dense_gemm_argmax_workspace_bytes() bytes, zeroed ONCE by the caller, one per concurrent stream. */
 int64_t vra_dense_gemm_argmax_workspace_bytes(void);
 void vra_dense_gemm_argmax(const void* x, const void* w, const void* bias, float* logits, uint32_t* tokens, void* workspace,
@@ -540,6 +541,9 @@ int32_t vra_engine_forward_raw(void* eng, const uint32_t* h_ids, const int64_t* 
  * running batch back to back (graph replay when enabled) and returns elapsed ms measured with HIP
  * events on the engine stream; tokens are sampled and appended exactly as in vra_engine_step. */
 double vra_engine_timed_decode(void* eng, int32_t steps);
+/* measurement aid: the decode graph of the most recent step replayed `steps` times back to back with that step's metadata left in
+ * place (no upload / download / host work in between; engine state untouched); returns ms per replay, -1 without a graph. */
+double vra_engine_bench_replay(void* eng, int32_t steps);
 /* tensor parallel: attach a communicator (vra_comm_create and/or vra_comm_ipc_begin/connect) before finalize;
  * the communicator stays caller-owned and must outlive the engine */
 int32_t vra_engine_set_comm(void* eng, void* comm);

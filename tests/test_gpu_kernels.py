@@ -233,9 +233,11 @@ def test_dense_gemm_decode_batches(M, K, N, dt, with_bias):
 
 
 @pytest.mark.parametrize("dt", [BF16, F16])
-@pytest.mark.parametrize("M,K,N", [(1, 4096, 128256), (2, 2048, 32000), (3, 512, 2048), (8, 1024, 4112), (12, 1024, 4096)])
+@pytest.mark.parametrize("M,K,N", [(1, 4096, 128256), (2, 2048, 32000), (3, 512, 2048), (8, 1024, 4112), (12, 1024, 4096),
+                                   (9, 1024, 32000), (16, 512, 4096), (17, 2048, 16384), (31, 1024, 4112), (32, 4096, 32000)])
 def test_dense_gemm_argmax(M, K, N, dt):
-    """the greedy token out of the lm_head launch (kernel A's last-arriver reduction, <= 8 rows; two launches beyond) ==
+    """the greedy token out of the lm_head launch (kernel A's last-arriver reduction at <= 8 rows, the dense W kernel's at 4..32
+    rows where it fits — round 4 —, two launches otherwise) ==
     vra_argmax_f32 of the logits the same launch wrote == the oracle's first maximal index; exact ties (duplicated weight
     rows, the maximum planted at chosen columns) resolve to the smaller index; the workspace re-arms itself between launches"""
     r = rng(M * 7 + K + N)
@@ -266,6 +268,19 @@ def test_dense_gemm_argmax_hand_off_stress_over_all_xcds():
     w = ops.dev(rand_dt(r, (N, K), dt, 0.05))
     f = ops.DenseGemmArgmax()
     for it in range(200):
+        x = rand_dt(r, (M, K), dt)
+        logits, toks = f(ops.dev(x), w, None, M, K, N, dt)
+        assert np.array_equal(toks, np.argmax(logits.numpy(np.float32, (M, N)), axis=-1)), it
+
+
+def test_dense_gemm_argmax_dense_w_hand_off_stress():
+    """the same hand-off out of the dense W kernel (gemv_dw.cuh, 9..32 rows: one workgroup per CU, 32 rows of candidates): 100
+    back-to-back launches at the Llama-3 vocabulary, x changing every launch, every token against the logits of its launch"""
+    M, K, N, dt = 32, 1024, 128256, BF16
+    r = rng(98)
+    w = ops.dev(rand_dt(r, (N, K), dt, 0.05))
+    f = ops.DenseGemmArgmax()
+    for it in range(100):
         x = rand_dt(r, (M, K), dt)
         logits, toks = f(ops.dev(x), w, None, M, K, N, dt)
         assert np.array_equal(toks, np.argmax(logits.numpy(np.float32, (M, N)), axis=-1)), it

@@ -216,6 +216,7 @@ def load():
     _sig(lib, "vra_engine_release_request", None, P, c_i64)
     _sig(lib, "vra_engine_forward_raw", c_i32, P, P, P, P, c_i32, c_i32, P, c_i32, P, P, c_i32, P)
     _sig(lib, "vra_engine_timed_decode", C.c_double, P, c_i32)
+    _sig(lib, "vra_engine_bench_replay", C.c_double, P, c_i32)
     _sig(lib, "vra_engine_set_comm", c_i32, P, P)
     _sig(lib, "vra_engine_bench_gemm", C.c_double, P, c_i32, c_i32, c_i32)
     _sig(lib, "vra_engine_gemm_bytes", c_i64, P, c_i32, c_i32)

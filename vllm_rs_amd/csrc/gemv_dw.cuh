@@ -29,6 +29,11 @@ struct GemvDWArgs {
   int M, K, KT;
   int n_units, units_q, units_r;  // workgroup b owns units_q (+1 if b < units_r) units starting at b*units_q + min(b, units_r)
   int dense_tiled;  // w is the tile-major copy of vra_dense_tile_weights (gemv.cuh GemvArgs::dense_tiled)
+  // fused greedy argmax (f32 output, grid * M <= GEMV_AM_COUNTER): the hand-off of gemv.cuh — per-workgroup candidate keys
+  // [M][grid] in am_ws, the arrival counter at am_ws[GEMV_AM_COUNTER], the last workgroup to arrive writes am_out[m] (first
+  // maximal index of the logits this launch wrote, as vra_argmax_f32) and re-arms the counter
+  uint32_t* am_out;
+  unsigned long long* am_ws;
 };
 
 static inline size_t gemv_dw_lds_bytes(int mt, int max_units) {
@@ -186,13 +191,47 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_dw_kernel(const GemvDWArgs a)
   __syncthreads();
   // ---- everything is stored after the stream has ended (bias and the roundings of the other dense kernels: the sum is rounded
   // to the model dtype, the bias added, rounded again; an f32 output carries the same value widened)
+  // (OPU divides GW_THREADS: a thread holds the same row / column of every unit it stores — its argmax candidate is a register)
+  unsigned long long am_best = 0ull;
   for (int idx = tid; idx < nu * OPU; idx += GW_THREADS) {
     const int ui = idx / OPU, rem = idx - ui * OPU, row = rem >> 4, col = rem & 15;
     if (row >= M) continue;
     const int n = (u0 + ui) * 16 + col;
     float v = rnd_dt<DT>(outs[idx]);
     if (a.bias) v = rnd_dt<DT>(v + DT::to_f32(static_cast<const uint16_t*>(a.bias)[n]));
+    if (a.am_out) am_best = gemv_am_max(am_best, gemv_am_key(v, (uint32_t)n));
     if (a.out_f32) static_cast<float*>(a.out)[(size_t)row * a.out_ld + n] = v;
     else static_cast<uint16_t*>(a.out)[(size_t)row * a.out_ld + n] = DT::from_f32(v);
+  }
+  if (a.am_out) {  // uniform.  The ordering argument is gemv.cuh's (agent-scope candidate stores acknowledged at vmcnt(0), a
+                   // returning counter RMW); `part` (the norm prologue's table) is free by now
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>(part);  // [32 groups of 16 threads]
+    uint32_t* flag = reinterpret_cast<uint32_t*>(cand + 32);
+#pragma unroll
+    for (int d = 8; d > 0; d >>= 1) am_best = gemv_am_max(am_best, gemv_am_shfl_xor(am_best, d));
+    if ((tid & 15) == 0) cand[tid >> 4] = am_best;
+    __syncthreads();
+    if (tid < M) {  // MT = 2: group g holds row g; MT = 1: groups g and g + 16 hold row g (threads t and t + 256 store alternate units)
+      const unsigned long long b = MT == 2 ? cand[tid] : gemv_am_max(cand[tid], cand[tid + 16]);
+      __hip_atomic_store(a.am_ws + (size_t)tid * gridDim.x + blockIdx.x, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const uint32_t old = __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(a.am_ws + GEMV_AM_COUNTER), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *flag = old == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (*flag) {  // the last workgroup to arrive: wave w reduces rows w, w + 8, ..
+      for (int row = wave; row < M; row += GW_WAVES) {
+        unsigned long long b = 0ull;
+        for (int c = lane; c < (int)gridDim.x; c += 64)
+          b = gemv_am_max(b, __hip_atomic_load(a.am_ws + (size_t)row * gridDim.x + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) b = gemv_am_max(b, gemv_am_shfl_xor(b, d));
+        if (lane == 0) a.am_out[row] = 0xffffffffu - (uint32_t)b;
+      }
+      if (tid == 0) __hip_atomic_store(reinterpret_cast<uint32_t*>(a.am_ws + GEMV_AM_COUNTER), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }

@@ -1158,6 +1158,10 @@ static void launch_gemv_dw_n(GemvDWArgs a, hipStream_t st) {
   int grid;
   vra_gemv_s_plan(a.n_units, &grid, &a.units_q, &a.units_r);
   const size_t lds = gemv_dw_lds_bytes(MT, a.units_q + (a.units_r ? 1 : 0));
+  if (a.am_out && (!a.am_ws || !a.out_f32 || (size_t)grid * a.M > (size_t)GEMV_AM_COUNTER)) {
+    vra_set_error("gemv_dw: fused argmax needs a workspace, f32 logits and grid * M <= %d (grid %d, M %d)", GEMV_AM_COUNTER, grid, a.M);
+    return;
+  }
   kern<<<grid, GW_THREADS, lds, st>>>(a);
 }
 void vra_launch_gemv_dw(GemvDWArgs a, int dtype, int64_t stream) {
@@ -1229,6 +1233,14 @@ extern "C" void vra_dense_gemm_argmax(const void* x, const void* w, const void* 
     a.am_out = tokens;
     a.am_ws = static_cast<unsigned long long*>(workspace);
     vra_launch_gemv(a, false, dtype, stream);
+    return;
+  }
+  if (!vra_gemv_fits(false, 1, m, k, -1) && vra_gemv_dw_fits(m, k, n)) {  // 4..32 rows: the dense W kernel, same hand-off
+    GemvDWArgs a = {};
+    a.x = x, a.x_ld = k, a.w = w, a.bias = bias, a.out = logits, a.out_ld = n, a.out_f32 = 1;
+    a.M = m, a.K = k, a.n_units = n / 16;
+    a.am_out = tokens, a.am_ws = static_cast<unsigned long long*>(workspace);
+    vra_launch_gemv_dw(a, dtype, stream);
     return;
   }
   vra_dense_gemm(x, w, bias, logits, m, k, n, dtype, VRA_F32, stream);

@@ -233,6 +233,10 @@ class Engine:
     def timed_decode(self, steps):
         return self.L.vra_engine_timed_decode(self.h, steps)
 
+    def bench_replay(self, steps):
+        """ms per replay of the last step's decode graph, back to back, no host work in between (measurement aid)"""
+        return self.L.vra_engine_bench_replay(self.h, steps)
+
     def bench_gemm(self, which, m, iters):
         return self.L.vra_engine_bench_gemm(self.h, which, m, iters)
 

@@ -81,6 +81,7 @@ class Engine {
   uint32_t* h_tokens_ = nullptr;
   uint32_t* h_err_ = nullptr;  // pinned copy of the device error words (split-K exchange, one-shot all-reduce), read every step
   std::map<int64_t, hipGraphExec_t> graphs_;
+  hipGraphExec_t last_graph_ = nullptr;  // the decode graph of the most recent step (vra_engine_bench_replay)
   bool prepared_ = false;
   int64_t planned_blocks_ = 0;
   // ---- sampling (ModelRunner::sample, runner.rs:1390-1570): strategy cached at prefill from the first sequence (A3)
@@ -441,6 +442,7 @@ class Engine {
         if (ge) {
           if (hipGraphLaunch(ge, stream_) != hipSuccess) return fail("hipGraphLaunch failed");
           launched = true;
+          last_graph_ = ge;
         }
       }
       if (!launched) {
@@ -1102,6 +1104,29 @@ extern "C" double vra_engine_timed_decode(void* e, int32_t steps) {
   (void)hipEventDestroy(a);
   (void)hipEventDestroy(b);
   return ms;
+}
+
+// Measurement aid (bench.py `step_overhead`): the decode graph of the most recent step launched `steps` times back to back with the
+// metadata of that step left in place — no upload, no download, no host work between replays (each replay rewrites the same KV slot
+// and the same token: engine state is untouched).  ms per replay = what the GPU needs for a step; vra_engine_timed_decode minus this
+// is what the host loop (upload, launch, two downloads, wake-up, scheduler) adds per step: 9–13 us at bs 1
+// (profiles/r04_ab_step_host_loop.txt — where a single download and a polling wait were also measured: no gain, not kept).
+extern "C" double vra_engine_bench_replay(void* e, int32_t steps) {
+  auto* en = static_cast<Engine*>(e);
+  if (!en->last_graph_ || steps <= 0) return -1.0;
+  hipEvent_t a, b;
+  (void)hipEventCreate(&a);
+  (void)hipEventCreate(&b);
+  (void)hipGraphLaunch(en->last_graph_, en->stream_);
+  (void)hipEventRecord(a, en->stream_);
+  for (int i = 0; i < steps; i++) (void)hipGraphLaunch(en->last_graph_, en->stream_);
+  (void)hipEventRecord(b, en->stream_);
+  (void)hipEventSynchronize(b);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, a, b);
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  return (double)ms / steps;
 }
 
 // roofline leg of bench.py: average launch duration of one decode-shaped GEMM kernel family,

@@ -1036,6 +1036,11 @@ bool Model::forward(const InputMetadata& md, int64_t stream, uint32_t* tokens) {
     a.x = xin, a.x_ld = H, a.norm_w = final_norm_, a.eps = mc_.rms_norm_eps;
     a.w = lm_head_tiled_ ? lm_head_tiled_ : lm_head_.w, a.dense_tiled = lm_head_tiled_ ? 1 : 0, a.out = logits_, a.out_ld = lm_head_.N, a.out_f32 = 1;
     a.M = rows, a.K = H, a.n_units = lm_head_.N / 16;
+    static const char* dwam_env = getenv("VRA_DW_ARGMAX");  // tuning aid: 0 = separate argmax launch behind the dense W kernel
+    if (tokens && !(dwam_env && atoi(dwam_env) == 0)) {  // the greedy tokens out of the same launch (as at <= 8 rows above)
+      a.am_out = tokens, a.am_ws = argmax_ws_;
+      tokens = nullptr;
+    }
     vra_launch_gemv_dw(a, dt_, stream);
   } else {
     vra_rms_norm(xin, final_norm_, xn_, rows, H, mc_.rms_norm_eps, dt_, stream);
