@@ -550,7 +550,8 @@ int32_t vra_engine_set_comm(void* eng, void* comm);
 /* roofline leg of bench.py: average duration (ms) of ONE launch of a decode-shaped GEMM kernel
  * family at m rows, rotating over all layers' weights so nothing is cache resident, measured with
  * HIP events on the engine stream. which: 0 = norm+q/k/v, 1 = o_proj(+residual),
- * 2 = norm+gate/up+SiLU·mul, 3 = down(+residual).  vra_engine_gemm_bytes = SURVEY §8(d)
+ * 2 = norm+gate/up+SiLU·mul, 3 = down(+residual), 4 = final norm + lm_head (+ greedy tokens; m <= max_num_seqs, one
+ * tensor: nothing to rotate over — 1 GB does not stay cache resident either).  vra_engine_gemm_bytes = SURVEY §8(d)
  * algorithmic bytes of that launch. */
 double vra_engine_bench_gemm(void* eng, int32_t which, int32_t m, int32_t iters);
 int64_t vra_engine_gemm_bytes(const void* eng, int32_t which, int32_t m);

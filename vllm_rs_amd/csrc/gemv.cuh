@@ -23,6 +23,9 @@
 #define GEMV_THREADS 512
 #define GEMV_WAVES 8
 #define GEMV_MAX_SEG 3
+#ifndef GEMV_DENSE_NBUF
+#define GEMV_DENSE_NBUF 3  // ring depth (sub-steps of 4 KiB per wave) of the dense single-tensor stream (the lm_head)
+#endif
 #define GEMV_AM_MAX_GRID 2048
 #define GEMV_AM_COUNTER (8 * GEMV_AM_MAX_GRID)
 // (value, index) -> one u64 whose unsigned order is "larger value first, then smaller index"; NaN orders below everything
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(GEMV_THREADS, 4) void gemv_kernel(const GemvArgs a)
 
   // register ring of NBUF sub-steps: a buffer is refilled (for the sub-step NBUF ahead) right after it
   // has been consumed, so NBUF*UK*NBW KiB per wave are in flight all the time and nothing is copied
-  constexpr int NBUF = (!INT4 && NBW == 2) ? 2 : 3;  // (the dense gate/up pair holds 8 x 16 B per lane and sub-step: two sub-steps fit the 128 VGPRs)
+  constexpr int NBUF = (!INT4 && NBW == 2) ? 2 : (!INT4 ? GEMV_DENSE_NBUF : 3);  // (the dense gate/up pair holds 8 x 16 B per lane and sub-step: two sub-steps fit the 128 VGPRs)
   u32x4 wbuf[NBUF][UK][NBW][LPT];
   u32x2 sbuf[NBUF][UK][NBW][NSC];
   uint32_t zbuf[NBUF][UK][NBW][NZP];

@@ -429,6 +429,7 @@ bool Model::init_buffers(int max_tokens, int max_seqs) {
     return false;
   const size_t am_bytes = ((size_t)GEMV_AM_COUNTER + 8) * 8;
   if (!(argmax_ws_ = (unsigned long long*)dalloc(am_bytes)) || hipMemset(argmax_ws_, 0, am_bytes) != hipSuccess) return false;
+  if (!(bench_tokens_ = (uint32_t*)dalloc((size_t)max_seqs * 4))) return false;  // launch_gemm(4, ..): the lm_head microbenchmark's tokens
   if (mc_.quant_method == 0) {
     if (!(gate_ = dalloc(T * inter_ * es_)) || !(up_ = dalloc(T * inter_ * es_))) return false;
   }
@@ -1011,6 +1012,12 @@ bool Model::forward(const InputMetadata& md, int64_t stream, uint32_t* tokens) {
     xin = last_;
     rows = B;
   }
+  return lm_head(xin, rows, tokens, stream);
+}
+
+// final norm + lm_head -> f32 logits (llama.rs:311-320) and, when `tokens` is given, the greedy tokens (logits_processor.rs:67-70)
+bool Model::lm_head(const void* xin, int rows, uint32_t* tokens, int64_t stream) {
+  const int H = mc_.hidden_size;
   // 1..3 rows: kernel A (x in LDS); 4..32 rows: the dense W kernel where it fits (measured 0.6 % of the step faster than kernel A at 4..7
   // rows, equal at 1..2), else kernel A / kernel B behind a norm launch
   if (!(rows >= 4 && vra_gemv_dw_fits(rows, H, lm_head_.N)) && vra_gemv_fits(false, 1, rows, H, -1)) {
@@ -1055,6 +1062,7 @@ bool Model::forward(const InputMetadata& md, int64_t stream, uint32_t* tokens) {
 // ---------------------------------------------------------------------------------------------
 bool Model::launch_gemm(int which, int layer, int M, int64_t stream) {
   if (layer < 0 || layer >= mc_.num_layers || M < 1 || M > max_tokens_) return false;
+  if (which == 4) return M <= max_seqs_ && lm_head(h_, M, bench_tokens_, stream);  // final norm + lm_head (+ greedy tokens), the decode form
   const LayerWeights& L = layers_[layer];
   // (5..32 rows: x in fragment order where the forward pass reads it that way — the timing does not depend on the values)
   const bool xf = g_x_frag && M > 4 && M <= 32 && world_ == 1;
@@ -1087,6 +1095,7 @@ int64_t Model::gemm_algorithmic_bytes(int which, int M) const {
     case 1: return one(L.o);
     case 2: return one(L.gate) + one(L.up);
     case 3: return one(L.down);
+    case 4: return one(lm_head_) + (int64_t)M * lm_head_.N * 2;  // f32 logits: M*N*4 instead of M*N*2
     default: return 0;
   }
 }

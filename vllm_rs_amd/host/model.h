@@ -102,6 +102,7 @@ class Model {
   // microbenchmark hooks (bench.py roofline leg): launch one decode-shaped GEMM of layer `layer`
   // which: 0 qkv(fused norm) 1 o_proj 2 gate_up 3 down 4 lm_head ; M rows
   bool launch_gemm(int which, int layer, int M, int64_t stream);
+  bool lm_head(const void* xin, int rows, uint32_t* tokens, int64_t stream);
   int64_t gemm_algorithmic_bytes(int which, int M) const;
 
  private:
@@ -146,6 +147,7 @@ class Model {
   void *h_ = nullptr, *xn_ = nullptr, *q_ = nullptr, *k_ = nullptr, *v_ = nullptr, *attn_ = nullptr, *act_ = nullptr,
        *tmp_ = nullptr, *gate_ = nullptr, *up_ = nullptr, *last_ = nullptr, *attn_ws_ = nullptr;
   float* logits_ = nullptr;
+  uint32_t* bench_tokens_ = nullptr;
   unsigned long long* argmax_ws_ = nullptr;  // kernel A's candidate keys + arrival counter (gemv.cuh)
   // fused q/k/v + attention decode launch (csrc/qkv_attn.hip): the q|k|v granules of a step and the forward's epoch word
   void* qkv_gran_ = nullptr;
