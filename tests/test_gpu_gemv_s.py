@@ -327,7 +327,28 @@ def test_gemv_w_k_slices_gptq_real_widths(M, K, N):
     assert ops.lib().vra_take_device_error() == 0
 
 
-@pytest.mark.parametrize("M", [7, 32])
+@pytest.mark.parametrize("M", [33, 64, 96, 150])
+@pytest.mark.parametrize("K,N", [(14336, 4096), (18944, 3584), (8192, 8192)])
+def test_gemv_w_k_slices_in_row_blocks(M, K, N):
+    """down_proj of short prefills (33..96 and 129..160 rows, round 4): the K-sliced launch in row blocks of 32 rows (blockIdx.y),
+    every row block with its own slabs and flags; a row of such a launch is bit-identical to the same row of a 32-row launch"""
+    r = rng(M * 17 + K + N)
+    q = make_quant(r, K, N, 128, BF16, False)
+    x = rand_dt(r, (M, K), BF16)
+    tiled, sc = _tiled(q), ops.dev(q["scales"])
+    got = ops.wna16_gemm(ops.dev(x), tiled, sc, None, M, K, N, 128).numpy(np.uint16, (M, N))
+    ref = orc.wna16_gemm(x, q["idx"], None, q["scales"], 128, BF16)
+    assert_close_dt(got, ref, BF16, name=f"gemv_w k-slices in row blocks M={M} K={K} N={N}", abs_floor=4e-3)
+    for _ in range(2):  # fixed slice order per row block: bitwise stable, flags back at zero
+        assert np.array_equal(got, ops.wna16_gemm(ops.dev(x), tiled, sc, None, M, K, N, 128).numpy(np.uint16, (M, N)))
+    r0 = ((M - 1) // 32) * 32  # the last (possibly ragged) row block as a launch of its own
+    one = ops.wna16_gemm(ops.dev(np.ascontiguousarray(x[r0:])), tiled, sc, None, M - r0, K, N, 128).numpy(np.uint16, (M - r0, N))
+    if M - r0 >= 17:  # (same m-tile count: 17..32 rows run the two-m-tile kernel as the row blocks do)
+        assert np.array_equal(got[r0:], one)
+    assert ops.lib().vra_take_device_error() == 0
+
+
+@pytest.mark.parametrize("M", [7, 32, 64, 150])
 @pytest.mark.parametrize("dt,awq,gs,layout", [(BF16, True, 128, 0), (F16, True, 128, 1), (F16, False, 128, 0), (BF16, False, 256, 0), (BF16, True, -1, 0)])
 def test_gemv_w_k_slices_formats_bias_residual_in_place(M, dt, awq, gs, layout):
     K, N = 18944, 3584

@@ -117,6 +117,10 @@ static ScratchSet* scratch_for_current_device(bool create) {
   void* p = nullptr;
   if (!s.slabs) {
     if (hipMalloc(&p, kSlabBytes) != hipSuccess) return nullptr;
+    {
+      const char* poison = getenv("VRA_POISON_ALLOC");  // debugging aid (host/model.cpp): slabs start as NaN instead of whatever was there
+      if (poison && poison[0] == '1') (void)hipMemset(p, 0xFF, kSlabBytes);
+    }
     s.slabs = (float*)p;
   }
   if (!s.counters) {

@@ -70,6 +70,11 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
   const int nu = (a.units_q + (wg < a.units_r ? 1 : 0)) * (PSEQ ? 2 : 1);
   const int max_u = (a.units_q + (a.units_r ? 1 : 0)) * (PSEQ ? 2 : 1);
   const bool has_res = a.residual != nullptr;
+  // K slices in ROW BLOCKS (33..128 rows, down_proj of short prefills): the owner takes bias and residual straight from memory in its
+  // exchange loop instead of carrying them in registers through the stream (EPI_IT bounds the units of a workgroup to GW_MAX_UNITS;
+  // a row-blocked launch gives a workgroup up to GW_MAX_UNITS_PLAIN units); slabs and flags get a row-block index
+  const int rbi = (int)blockIdx.y;
+  const bool late_epi = KZ && gridDim.y > 1;
   GEMV_STAMP(0);
 
   // ---- LDS carve-up
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
   };
 #pragma unroll
   for (int ti = 0; ti < GW_TPW; ti++) issue(0, ti, wb[ti], sb[ti], zb[ti]);
-  if ((has_res || any_bias) && owner) request_epilogue_operands();
+  if ((has_res || any_bias) && owner && !late_epi) request_epilogue_operands();
   GEMV_STAMP(1);
 
   __builtin_amdgcn_sched_barrier(0);  // (phase boundaries are scheduling barriers: hipcc otherwise interleaves the phases for
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
 
   __builtin_amdgcn_sched_barrier(0);
   GEMV_STAMP(2);
-  if ((has_res || any_bias) && owner) stage_epilogue_operands();
+  if ((has_res || any_bias) && owner && !late_epi) stage_epilogue_operands();
   if (!XF && (nn & 1)) {
 #pragma unroll
     for (int ti = 0; ti < GW_TPW; ti++)
@@ -395,13 +400,14 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
     // slice polls the flags, sums the slabs with agent-scope loads in slice order — deterministic — and resets the flags).
     // Only owners wait and there are kz_groups < CUs of them: some non-owner is always resident and never waits.
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a.slabs, 0, 0x7FFFFFF0, 0x00020000);
-    uint32_t* fl = a.counters + (size_t)wg * a.kz * 16;
+    uint32_t* fl = a.counters + (size_t)(rbi * a.kz_groups + wg) * a.kz * 16;
+    const int zbase = rbi * a.kz;  // slab index of this row block's slice 0
     const int n4 = nu * OPU / 4;
     if (!owner) {
       for (int i4 = tid; i4 < n4; i4 += GW_THREADS) {
         const int idx = i4 * 4, ui = idx / OPU, rem = idx - ui * OPU;
         const f32x4 pv = *reinterpret_cast<const f32x4*>(outf + idx);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pv), srs, (uint32_t)(((zi * a.n_units + u0 + ui) * OPU + rem) * 4), 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pv), srs, (uint32_t)((((zbase + zi) * a.n_units + u0 + ui) * OPU + rem) * 4), 0, 16);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // write-through stores: acknowledged by memory
       __syncthreads();
@@ -428,7 +434,14 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
       u32x4 pz[ZMAX];
 #pragma unroll
       for (int z = 0; z < ZMAX; z++)
-        pz[z] = __builtin_amdgcn_raw_buffer_load_b128(srs, (uint32_t)(((min(z, a.kz - 2) * a.n_units + u0 + ui) * OPU + rem) * 4), 0, 16);
+        pz[z] = __builtin_amdgcn_raw_buffer_load_b128(srs, (uint32_t)((((zbase + min(z, a.kz - 2)) * a.n_units + u0 + ui) * OPU + rem) * 4), 0, 16);
+      // (row-blocked launches: bias and residual of the 4 outputs straight from memory — single segment: column = unit * 16 + col)
+      u32x2 lres = {0u, 0u}, lbias = {0u, 0u};
+      if (late_epi) {
+        const int row = rem >> 4, n = (u0 + ui) * 16 + col;
+        if (has_res && row < M) lres = *reinterpret_cast<const u32x2*>(static_cast<const uint16_t*>(a.residual) + (size_t)(row0 + row) * a.res_ld + n);
+        if (any_bias) lbias = *reinterpret_cast<const u32x2*>(static_cast<const uint16_t*>(a.seg[0].bias) + n);
+      }
       f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int z = 0; z < ZMAX; z++)
@@ -437,8 +450,10 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
 #pragma unroll
       for (int e = 0; e < 4; e++) {
         float t = rnd_dt<DT>(v[e]);
-        if (any_bias) t = rnd_dt<DT>(t + DT::to_f32(biass[ui * 16 + col + e]));
-        if (has_res) t = rnd_dt<DT>(t) + DT::to_f32(ress[idx + e]);
+        const uint16_t bv = late_epi ? (uint16_t)(lbias[e >> 1] >> (16 * (e & 1))) : biass[ui * 16 + col + e];
+        const uint16_t rv = late_epi ? (uint16_t)(lres[e >> 1] >> (16 * (e & 1))) : (has_res ? ress[idx + e] : (uint16_t)0);
+        if (any_bias) t = rnd_dt<DT>(t + DT::to_f32(bv));
+        if (has_res) t = rnd_dt<DT>(t) + DT::to_f32(rv);
         outs[idx + e] = DT::from_f32(t);
       }
     }

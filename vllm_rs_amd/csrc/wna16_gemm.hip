@@ -439,11 +439,21 @@ static void gemv_w_plan(int ns, int M, int n_units, bool plain, int* grid, int* 
 }
 // K > 4096 (down_proj, 5..32 rows): kz K slices of at most 32 k-tiles (what 8 waves hold as x fragments), kz_groups = CUs / kz
 // unit groups; workgroup (z, g) = blockIdx.x z * groups + g — the owners (z = kz - 1) carry the highest ids and start last
-static bool gemv_w_kz_plan(int K, int n_units, int* kz, int* ktz, int* groups) {
+// Round 4 (last part): 33..128 rows (down_proj of short prefills) as `rb` row blocks of 32 rows in blockIdx.y, each with its own slabs
+// and flags; groups = CUs / (kz * rb), so the whole launch is still one round of workgroups
+static int gemv_w_kz_max_rows() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("VRA_GEMV_W_KZ_MAX_ROWS");  // tuning aid: 32 puts down_proj of short prefills back on kernel D
+    v = e ? atoi(e) : 160;
+  }
+  return v;
+}
+static bool gemv_w_kz_plan(int K, int n_units, int rb, int* kz, int* ktz, int* groups) {
   const int KT = K / 128, per = GW_WAVES * GW_TPW;
   const int z = (KT + per - 1) / per;
-  if (z < 2 || z > 8) return false;
-  const int g = num_cus() / z;
+  if (z < 2 || z > 8 || rb < 1) return false;
+  const int g = num_cus() / (z * rb);
   if (g < 1 || n_units < g) return false;
   const int t = (KT + z - 1) / z;
   if ((z - 1) * t >= KT) return false;  // every slice holds at least one tile
@@ -455,14 +465,20 @@ bool vra_gemv_w_fits(int ns, int M, int K, int group_size, int n_units, bool has
   if (off && off[0] == '1') return false;
   if (K > 4096) {
     static const char* kz_off = getenv("VRA_GEMV_W_KZ");  // tuning aid: 0 puts down_proj of 5..32 rows back on kernel C
-    if ((kz_off && kz_off[0] == '0') || ns != 1 || norm_or_segments || M < 5 || M > 32 || K % 128) return false;
+    if ((kz_off && kz_off[0] == '0') || ns != 1 || norm_or_segments || M < 5 || M > std::max(32, gemv_w_kz_max_rows()) || K % 128) return false;
     const int g = group_size > 0 && group_size < K ? group_size : K;
     if (g < K && (g < 128 || (g & (g - 1)))) return false;
     int kz, ktz, groups;
-    if (!gemv_w_kz_plan(K, n_units, &kz, &ktz, &groups)) return false;
+    const int rb = (M + 31) / 32;
+    // which row counts: measured against kernel D (+ its row-sum pass) on the Llama-3-8B down projection, us per launch
+    // (profiles/r04_ab_kernel_w_k_slices_row_blocks.txt): 64 rows 38.6 -> 25.5, 96 rows 49.3 -> 36.4, 160 rows 77.7 -> 50.9 — but
+    // 128 rows 36.4 -> 39.6 and 200 rows 57.0 -> 65.6 (two / four full 64-row tiles per column block are kernel D's good cases)
+    static const char* any_rb = getenv("VRA_GEMV_W_KZ_ANY_RB");  // tuning aid: 1 = every row-block count up to the row limit
+    if (rb > 3 && rb != 5 && !(any_rb && any_rb[0] == '1')) return false;
+    if (!gemv_w_kz_plan(K, n_units, rb, &kz, &ktz, &groups)) return false;
     const int mu = (n_units + groups - 1) / groups, mt = M > 16 ? 2 : 1;
-    if (mu > GW_MAX_UNITS) return false;
-    if ((size_t)kz * n_units * mt * 256 * 4 > vra_scratch_slab_bytes() || (size_t)groups * kz * 16 > vra_scratch_counter_count()) return false;
+    if (mu > (rb > 1 ? GW_MAX_UNITS_PLAIN : GW_MAX_UNITS)) return false;  // (row blocks: epilogue operands straight from memory, gemv_q4w.cuh)
+    if ((size_t)rb * kz * n_units * mt * 256 * 4 > vra_scratch_slab_bytes() - ((size_t)16 << 20) || (size_t)rb * groups * kz * 16 > vra_scratch_counter_count()) return false;
     return gemv_q4w_lds_bytes(1, mt, mu, has_res, true) <= (size_t)kMaxDynLds;
   }
   static const char* pair_env = getenv("VRA_GEMV_W_PAIR_MAX_ROWS");  // tuning aid: 16 puts 17+-row gate/up launches back on kernels C / D
@@ -519,7 +535,8 @@ static void launch_gemv_w_kz(GemvSArgs a, hipStream_t st) {
   }
   a.KT = a.K / 128;
   a.TPW = GW_TPW;
-  if (a.norm_w || a.nseg != 1 || !gemv_w_kz_plan(a.K, a.n_units, &a.kz, &a.ktz, &a.kz_groups)) {
+  const int rb = (a.M + 31) / 32;
+  if (a.norm_w || a.nseg != 1 || !gemv_w_kz_plan(a.K, a.n_units, rb, &a.kz, &a.ktz, &a.kz_groups)) {
     vra_set_error("gemv_w: K = %d needs the K-sliced form (single segment, no fused norm, 2..8 slices)", a.K);
     return;
   }
@@ -536,7 +553,7 @@ static void launch_gemv_w_kz(GemvSArgs a, hipStream_t st) {
 #else
   a.ts = nullptr;
 #endif
-  kern<<<dim3(a.kz * a.kz_groups, 1), GW_THREADS, lds, st>>>(a);
+  kern<<<dim3(a.kz * a.kz_groups, rb), GW_THREADS, lds, st>>>(a);
 }
 template <class DT, int NS, int MT, bool AWQ>
 static void launch_gemv_w_v(const GemvSArgs& a, hipStream_t st) {
@@ -553,11 +570,11 @@ void vra_launch_gemv_w(GemvSArgs a, int ns, int group_size, bool awq, int dtype,
   }
   const bool bf = dtype == VRA_BF16, two = a.M > 16;
   if (a.K > 4096) {  // K slices across workgroups (down_proj)
-    if (ns != 1 || a.M > 32) {
-      vra_set_error("gemv_w: K = %d takes single-stream launches of up to 32 rows", a.K);
+    if (ns != 1 || a.M > std::max(32, gemv_w_kz_max_rows())) {
+      vra_set_error("gemv_w: K = %d takes single-stream launches of up to %d rows", a.K, std::max(32, gemv_w_kz_max_rows()));
       return;
     }
-    const bool xf = a.x_frag != nullptr;
+    const bool xf = a.x_frag != nullptr && a.M <= 32;
 #define VRA_WKZ(DT_, MT_)                                                                                                                     \
   do {                                                                                                                                        \
     if (awq) xf ? launch_gemv_w_kz<DT_, MT_, true, true>(a, st) : launch_gemv_w_kz<DT_, MT_, true, false>(a, st);                              \

@@ -62,6 +62,10 @@ void* Model::dalloc(size_t bytes) {
     return nullptr;
   }
   allocs_.push_back(p);
+  // debugging aid: VRA_POISON_ALLOC=1 fills every buffer with 0xFF bytes (NaN as bf16 / f16 / f32) before its first use — a kernel
+  // that consumes memory nobody wrote then shows up as NaN logits instead of depending on what the allocator handed out
+  static const char* poison = getenv("VRA_POISON_ALLOC");
+  if (poison && poison[0] == '1') (void)hipMemset(p, 0xFF, bytes ? bytes : 16);
   return p;
 }
 
