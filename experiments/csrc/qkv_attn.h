@@ -3,7 +3,7 @@
 #pragma once
 #include <stdint.h>
 
-#include "gemv_q4s.cuh"
+#include "gemv_q4s.cuh"  // (vllm_rs_amd/csrc, on the include path of the EXPERIMENTS build)
 
 struct QkvAttnTail {
   const uint32_t* epoch;  // device word, bumped once per forward BEFORE this launch (vra_embedding_bump): granule tags are
@@ -35,11 +35,6 @@ bool vra_qkv_attn_fits(int M, int K, int group_size, int n_units, int Hq, int Hk
 void vra_launch_qkv_attn(GemvSArgs a, QkvAttnTail t, void* gran, int group_size, bool awq, int dtype, int D, int64_t stream);
 // bytes of the granule buffer for up to `max_rows` rows of q|k|v
 size_t vra_qkv_attn_granule_bytes(int max_rows, int Hq, int Hkv, int D);
-// vra_embedding + one increment of *bump (the forward's epoch word) in the same launch
-// (+ rows 0..31 in kernel W's fragment order into `frag`, GemvSArgs::x_frag, when frag != null)
-void vra_embedding_bump(const uint32_t* ids, const void* table, void* out, int32_t tokens, int32_t hidden, int32_t vocab, int32_t dtype,
-                        uint32_t* bump, void* frag, int64_t stream);
-// dense [n, k] 16-bit row-major -> the tile-major copy the dense GEMV kernels stream one contiguous KiB per wave load from
-void vra_dense_tile_weights(const void* w_rowmajor, void* out_tiled, int32_t n, int32_t k, int64_t stream);
+// (vra_embedding_bump, which bumps the forward's epoch word, is declared in vllm_rs_amd/csrc/gemm_launch.h)
 // longest context the fused launch takes (tuning knob VRA_QKV_ATTN_MAX_CTX; 0 switches the fused launch off)
 int vra_qkv_attn_max_ctx();

@@ -36,3 +36,11 @@ void vra_launch_gemv_dw(GemvDWArgs a, int dtype, int64_t stream);
 // GemmDArgs::xsum set skips its own row-sum pass
 float* vra_gemm_q4_big_xsum_table(int M, int K);
 void vra_rms_norm_xsum(const void* x, const void* weight, void* out, float* xsum, int tokens, int hidden, float eps, int dtype, int64_t stream);
+
+// ---- internal helpers of ops.hip / wna16_gemm.hip used by the native runtime
+// vra_embedding + one increment of *bump (null: none; the forward's epoch word of the experiments build) in the same launch
+// (+ rows 0..31 in kernel W's fragment order into `frag`, GemvSArgs::x_frag, when frag != null)
+void vra_embedding_bump(const uint32_t* ids, const void* table, void* out, int32_t tokens, int32_t hidden, int32_t vocab, int32_t dtype,
+                        uint32_t* bump, void* frag, int64_t stream);
+// dense [n, k] 16-bit row-major -> the tile-major copy the dense GEMV kernels stream one contiguous KiB per wave load from
+void vra_dense_tile_weights(const void* w_rowmajor, void* out_tiled, int32_t n, int32_t k, int64_t stream);

@@ -13,7 +13,9 @@
 #include <thread>
 #include <memory>
 
-#include "../csrc/decode_step.h"
+#ifdef VRA_EXPERIMENTS
+#include "decode_step.h"
+#endif
 #include "../csrc/scratch.h"
 #include "core.h"
 #include "model.h"
@@ -456,15 +458,19 @@ class Engine {
     if (dev_err && hipMemcpyAsync(h_err_, dev_err, 4, hipMemcpyDeviceToHost, stream_) != hipSuccess) return fail("error-word download failed");
     uint32_t* comm_err = comm_ ? vra_comm_error_word(comm_) : nullptr;
     if (comm_err && hipMemcpyAsync(h_err_ + 1, comm_err, 4, hipMemcpyDeviceToHost, stream_) != hipSuccess) return fail("error-word download failed");
+#ifdef VRA_EXPERIMENTS
     uint32_t* step_err = vra_decode_step_error_word();
     if (step_err && hipMemcpyAsync(h_err_ + 2, step_err, 4, hipMemcpyDeviceToHost, stream_) != hipSuccess) return fail("error-word download failed");
+#endif
     if (hipStreamSynchronize(stream_) != hipSuccess) return fail(std::string("stream error: ") + hipGetErrorString(hipGetLastError()));
+#ifdef VRA_EXPERIMENTS
     if (h_err_[2]) {
       const uint32_t code = h_err_[2];
       h_err_[2] = 0;
       vra_decode_step_reset();
       return fail("persistent decode step: a wait timed out on the device (code " + std::to_string(code) + "; results of this step are invalid)");
     }
+#endif
     if (h_err_[1]) {
       h_err_[1] = 0;
       (void)hipMemsetAsync(comm_err, 0, 4, stream_);
@@ -1058,12 +1064,15 @@ extern "C" int32_t vra_engine_forward_raw(void* e, const uint32_t* h_ids, const 
   uint32_t* comm_err = en->comm_ ? vra_comm_error_word(en->comm_) : nullptr;
   if (dev_err) (void)hipMemcpyAsync(en->h_err_, dev_err, 4, hipMemcpyDeviceToHost, en->stream_);
   if (comm_err) (void)hipMemcpyAsync(en->h_err_ + 1, comm_err, 4, hipMemcpyDeviceToHost, en->stream_);
+#ifdef VRA_EXPERIMENTS
   uint32_t* step_err = vra_decode_step_error_word();
   if (step_err) (void)hipMemcpyAsync(en->h_err_ + 2, step_err, 4, hipMemcpyDeviceToHost, en->stream_);
+#endif
   if (hipStreamSynchronize(en->stream_) != hipSuccess) {
     en->error = "stream error in forward_raw";
     return -1;
   }
+#ifdef VRA_EXPERIMENTS
   if (step_err && en->h_err_[2]) {
     const uint32_t code = en->h_err_[2];
     en->h_err_[2] = 0;
@@ -1071,6 +1080,7 @@ extern "C" int32_t vra_engine_forward_raw(void* e, const uint32_t* h_ids, const 
     en->error = "persistent decode step: a wait timed out on the device (code " + std::to_string(code) + "; results of this forward are invalid)";
     return -1;
   }
+#endif
   if (comm_err && en->h_err_[1]) {
     en->h_err_[1] = 0;
     (void)hipMemsetAsync(comm_err, 0, 4, en->stream_);

@@ -7,12 +7,15 @@
 #include <string.h>
 
 #include "../csrc/attn_launch.h"
-#include "../csrc/decode_step.h"
 #include "../csrc/gemm_launch.h"
-#include "../csrc/qkv_attn.h"
 #include "../csrc/scratch.h"
 #include "host_utils.h"
+#ifdef VRA_EXPERIMENTS  // `make EXPERIMENTS=1` (libvra_experiments.so): the kernels that lost their A/B, /experiments/csrc
+#include "decode_step.h"
+#include "qkv_attn.h"
+#endif
 
+#ifdef VRA_EXPERIMENTS
 // The fused decode launch of csrc/qkv_attn.hip (norm + q/k/v + RoPE + KV write + attention) is OPT-IN: measured at parity with the
 // two launches (kernel E, then decode_attn_fused_kernel [+ merge]) — bs 1 1.737 / 1.743 against 1.743 / 1.743 ms per step on
 // one box — and a spin wait inside a kernel is not taken for nothing.  VRA_FUSED_QKV_ATTN=1 or
@@ -22,6 +25,7 @@ static int g_fused_qkv_attn = [] {
   return e ? atoi(e) : 0;
 }();
 extern "C" void vra_debug_set_fused_qkv_attn(int on) { g_fused_qkv_attn = on; }
+#endif
 // VRA_X_FRAG=0 / vra_debug_set_x_frag(0): steps of 5..32 rows read h row-major in kernel W (no fragment-order copy)
 static int g_x_frag = [] {
   const char* e = getenv("VRA_X_FRAG");
@@ -419,7 +423,11 @@ bool Model::init_kv_cache(int num_blocks) {
     (void)hipMemset(vc_[l], 0, per);
   }
   if (hipDeviceSynchronize() != hipSuccess) return false;
+#ifdef VRA_EXPERIMENTS
   return build_decode_step();
+#else
+  return true;
+#endif
 }
 
 bool Model::init_buffers(int max_tokens, int max_seqs) {
@@ -439,9 +447,11 @@ bool Model::init_buffers(int max_tokens, int max_seqs) {
   }
   const size_t ws = vra_paged_attention_decode_workspace_bytes(max_seqs, hq_, mc_.head_dim, vra_rope_table_rows(&mc_));
   if (!(attn_ws_ = dalloc(ws))) return false;
+#ifdef VRA_EXPERIMENTS
   const size_t gb = vra_qkv_attn_granule_bytes(4, hq_, hkv_, mc_.head_dim);
   if (!(qkv_gran_ = dalloc(gb)) || hipMemset(qkv_gran_, 0, gb) != hipSuccess) return false;
   if (!(epoch_ = (uint32_t*)dalloc(64)) || hipMemset(epoch_, 0, 64) != hipSuccess) return false;
+#endif
   if (H % 128 == 0) {
     const size_t fb = (size_t)(H / 128) * 2 * 4096;
     if (!(hfrag_ = dalloc(fb)) || hipMemset(hfrag_, 0, fb) != hipSuccess) return false;
@@ -454,7 +464,14 @@ bool Model::init_buffers(int max_tokens, int max_seqs) {
     const size_t fb = (size_t)(hq_ * mc_.head_dim / 128) * 2 * 4096;
     if (!(afrag_ = dalloc(fb)) || hipMemset(afrag_, 0, fb) != hipSuccess) return false;
   }
+  // (hipMemset of device memory may return before the fill has run: nothing of this may still be pending when the engine's
+  // non-blocking stream starts its first forward)
+  if (hipDeviceSynchronize() != hipSuccess) return false;
+#ifdef VRA_EXPERIMENTS
   return build_decode_step();
+#else
+  return true;
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -776,7 +793,8 @@ void Model::gemv_s_args(int l, int which, int M, void* out, const void* residual
       break;
   }
 }
-// decode steps of 1..4 sequences: norm + q/k/v + RoPE + KV write + attention in ONE launch (csrc/qkv_attn.hip)
+#ifdef VRA_EXPERIMENTS
+// decode steps of 1..4 sequences: norm + q/k/v + RoPE + KV write + attention in ONE launch (experiments/csrc/qkv_attn.hip)
 bool Model::qkv_attn(int l, const InputMetadata& md, int64_t stream) {
   const int M = md.n_tokens;
   if (md.is_prefill || md.n_seqs != M || M > 4 || !gemv_s_ok(0, M) || l >= 255 || !qkv_gran_) return false;
@@ -796,6 +814,7 @@ bool Model::qkv_attn(int l, const InputMetadata& md, int64_t stream) {
   vra_launch_qkv_attn(a, t, qkv_gran_, mc_.group_size, L.q.awq, dt_, mc_.head_dim, stream);
   return !take_err(error, "qkv_attn");
 }
+#endif
 bool Model::gemv_s(int l, int which, int M, void* out, const void* residual, int64_t stream, const void* x_frag, void* out_frag) {
   if (!gemv_s_ok(which, M)) return false;
   const LayerWeights& L = layers_[l];
@@ -808,8 +827,9 @@ bool Model::gemv_s(int l, int which, int M, void* out, const void* residual, int
   return !take_err(error, "gemv_s");
 }
 
+#ifdef VRA_EXPERIMENTS
 // ---------------------------------------------------------------------------------------------
-// persistent decode step (csrc/decode_step.hip)
+// persistent decode step (experiments/csrc/decode_step.hip)
 // ---------------------------------------------------------------------------------------------
 bool Model::build_decode_step() {
   if (dp_layers_ || !finalized_ || !h_ || kc_.empty() || world_ > 1 || mc_.quant_method == 0) return true;  // (not an error: the step keeps its launches)
@@ -925,6 +945,7 @@ bool Model::launch_decode_phases(const InputMetadata& md, int ph0, int ph1, int6
   vra_launch_decode_step(a, dt_, layers_[0].q.awq, ec_.fp8_kvcache != 0, mc_.head_dim, stream);
   return !take_err(error, "decode step");
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // forward
@@ -947,16 +968,24 @@ bool Model::forward(const InputMetadata& md, int64_t stream, uint32_t* tokens) {
   const bool use_frag = g_x_frag && hfrag_ && T > 4 && T <= 32 && world_ == 1;
   vra_embedding_bump(md.input_ids, embed_, h_, T, H, mc_.vocab_size, dt_, epoch_, use_frag ? hfrag_ : nullptr, stream);
   hfrag_ok_ = use_frag;
-  // decode of 1..2 sequences at short contexts: all layers in ONE persistent launch (csrc/decode_step.hip)
+#ifdef VRA_EXPERIMENTS
+  // decode of 1..2 sequences at short contexts: all layers in ONE persistent launch (experiments/csrc/decode_step.hip)
   const bool one_launch = !md.is_prefill && B == T && decode_step_ok(T, md.max_context_len);
   if (one_launch && !launch_decode_phases(md, 0, mc_.num_layers * DP_PHASES_PER_LAYER, stream)) return false;
+#else
+  const bool one_launch = false;
+#endif
   for (int l = one_launch ? mc_.num_layers : 0; l < mc_.num_layers; l++) {
     const LayerWeights& L = layers_[l];
     // ---- attention block (llama.rs:115-126): norm -> q,k,v -> rope -> cache + attention -> o_proj (+ residual)
     const QLinear qkv[3] = {L.q, L.k, L.v};
     void* outs[3] = {q_, k_, v_};
     bool attn_frag = false;  // the attention output of this layer also exists in fragment order (afrag_)
+#ifdef VRA_EXPERIMENTS
     const bool fused_attn = g_fused_qkv_attn && qkv_attn(l, md, stream);
+#else
+    const bool fused_attn = false;
+#endif
     if (!fused_attn && !error.empty()) return false;
     if (!fused_attn && !gemv_s(l, 0, T, nullptr, nullptr, stream, hfrag_ok_ ? hfrag_ : nullptr)) {
       if (!error.empty()) return false;

@@ -14,7 +14,6 @@
 #include "../../include/vllm_rs_amd.h"
 
 struct GemvSArgs;  // csrc/gemv_q4s.cuh
-struct DPStepArgs;  // csrc/decode_step.h
 
 namespace vra {
 
