@@ -548,7 +548,9 @@ def main():
             lc[f"bs{bs}_ctx{ctx}"] = {"tokens_per_s": bs * 16 / dtl, "ms_per_step": dtl * 1e3 / 16, "kv_GB_per_step": kv / 1e9}
         line["long_context_decode"] = lc
         line["ttft_p50_ms"] = {"bs1_prompt128": ttft_p50(eng, 128, V, 1), "bs32_prompt128": ttft_p50(eng, 128, V, 32, reps=2),
-                               "bs1_prompt2048": ttft_p50(eng, 2048, V, 1, reps=3)}
+                               "bs1_prompt2048": ttft_p50(eng, 2048, V, 1, reps=3),
+                               # (round 5: the cost-model fix of vra_gemm_q4_big_fits — a 200-token prompt must not be slower than a 256-token one)
+                               "bs1_prompt200": ttft_p50(eng, 200, V, 1, reps=3), "bs1_prompt256": ttft_p50(eng, 256, V, 1, reps=3)}
         line["step_bytes_roofline"] = {"algorithmic_bytes_per_step": 3625975808 + 1050673152 + 532480,
                                        "frac_of_8TBps": (3625975808 + 1050673152 + 532480) / (dt / a.steps) / 8e12 if a.batch == 1 else None}
         eng.close()

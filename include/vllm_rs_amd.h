@@ -326,6 +326,9 @@ void vra_all_reduce_fused(void* comm, void* partial, void* dst, const void* bias
  * results of that launch are invalid).  Reads and clears; synchronises.  vra_comm_error_word is the
  * device word behind it (NULL without the one-shot transport) for callers that poll it themselves. */
 int32_t vra_comm_take_error(void* comm);
+/* what the first timed-out wait of the one-shot exchange saw (valid after vra_comm_take_error / the error word reported a
+ * timeout): h_out[0] slice index, [1] the peer rank waited for, [2] the epoch expected, [3] the flag value last read. */
+int32_t vra_comm_error_detail(void* comm, uint32_t h_out[4]);
 uint32_t* vra_comm_error_word(void* comm);
 
 /* device plumbing for hosts that have no HIP binding of their own (tests, bench, the runtime) */
@@ -466,6 +469,11 @@ int32_t vra_engine_finalize_weights(void* eng); /* repack + scale layout + KV ca
  * until buffers exist), then vra_engine_finalize_weights for activations, KV cache and graphs. */
 /* parity instrumentation: the f32 logits [n_seqs, vocab] the last step (hipGraph replay or eager) left on the device */
 int32_t vra_engine_copy_logits(void* eng, float* h_out, int32_t n_seqs);
+/* parity instrumentation of the tensor-parallel forward: with snapshots on, layer 0 of every forward keeps copies of its stages
+ * (0 q, 1 k, 2 v before RoPE, 3 attention output, 4 o_proj partial of this rank, 5 h after the first all-reduce + residual,
+ * 6 SiLU(gate)*up, 7 down_proj partial, 8 h after the second all-reduce); read returns the bytes copied or -1. */
+void vra_engine_debug_tp_snapshots(void* eng, int32_t on);
+int64_t vra_engine_debug_read_tp_snapshot(void* eng, int32_t idx, void* h_out, int64_t max_bytes);
 int32_t vra_engine_finalize_model(void* eng);
 int32_t vra_engine_update_config(void* eng, const vra_engine_config* cfg);
 /* ModelRunner::swap_kvcache (runner.rs:1626-1670; MessageType::KVCacheSwap): copy whole blocks between the GPU cache and the

@@ -156,6 +156,24 @@ def test_gate_up_silu_many_rows(awq):
     assert_close_dt(out.numpy(np.uint16, (M, N)), ref, BF16, max_ulp=3.0, max_mismatch_frac=0.04, name="kernel D gate_up_silu", abs_floor=4e-3)
 
 
+@pytest.mark.parametrize("M", [143, 160, 200, 221])
+def test_gate_up_silu_143_to_221_rows_at_the_llama3_8b_widths(M):
+    """the row range where the launcher's cost model changed its choice in round 5 (kernel B's pair form priced at its measured
+    420 TFLOP/s: kernel D with four m-tiles per wave takes these launches now, wna16_gemm.hip `vra_gemm_q4_big_fits`), at the
+    real gate/up shape of BASELINE config 2: K = 4096, N = 14336, ragged last row tile at every M"""
+    K, N = 4096, 14336
+    r = rng(1000 + M)
+    qg, qu = make_quant(r, K, N, 128, BF16), make_quant(r, K, N, 128, BF16)
+    x = rand_dt(r, (M, K), BF16)
+    tg = ops.marlin_weight_repack(ops.dev(qg["qweight"]), qg["qweight"].shape)
+    tu = ops.marlin_weight_repack(ops.dev(qu["qweight"]), qu["qweight"].shape)
+    out = ops.wna16_gate_up_silu(ops.dev(x), tg, ops.dev(qg["scales"]), None, tu, ops.dev(qu["scales"]), None, M, K, N, 128)
+    g = orc.wna16_gemm(x, qg["idx"], None, qg["scales"], 128, BF16)
+    u = orc.wna16_gemm(x, qu["idx"], None, qu["scales"], 128, BF16)
+    ref = orc.silu_mul(g, u, BF16)
+    assert_close_dt(out.numpy(np.uint16, (M, N)), ref, BF16, max_ulp=3.0, max_mismatch_frac=0.04, name=f"gate_up_silu {M} rows", abs_floor=4e-3)
+
+
 @pytest.mark.parametrize("gs,with_g_idx", [(128, True), (64, True), (64, False), (32, False), (128, False)])
 def test_gemm_half_q_half_alt(gs, with_g_idx):
     """the non-Marlin GPTQ path (gptq.rs:181-198): asymmetric zeros (stored z-1), groups from g_idx — or, without it, from the

@@ -190,44 +190,42 @@ def test_tp8_llama3_70b_widths_one_gpu(monkeypatch):
     # eight runner processes + this one on ONE GPU are more than the hardware scheduler keeps resident: a rank can be
     # descheduled for seconds while its peers spin in the all-reduce (seen: the 4 s bound expiring on the first forward)
     monkeypatch.setenv("VRA_COMM_TIMEOUT_S", "60")
-    # Nine processes on ONE GPU are not a schedulable configuration in general: tools/tp8_repro.py (80 forwards back to back) ends in
-    # the all-reduce's bounded wait expiring — peers starved behind spinning kernels —, and one full-suite run of round 4 saw this
-    # test's three forwards deviate 9.5 ulp (ranks bit-identical to each other, no error word) where four isolated reruns, the
-    # poisoned-allocation run (VRA_POISON_ALLOC=1) and the single-process sweep of the same shapes (tools/repro_sweep.py) are clean.
-    # Real tensor parallelism runs one rank per GPU.  The oversubscribed run is therefore given ONE fresh retry, loudly.
-    def run_once():
-        w = om.make_random_checkpoint(cfg, 21)
-        oracle_tp = om.OracleModel(cfg, w, num_blocks=16, tp_world=world)
-        oracle_1 = om.OracleModel(cfg, w, num_blocks=16)
-        r = np.random.default_rng(21)
-        prompts = [r.integers(1, cfg["vocab_size"] - 1, size=n).tolist() for n in (19, 6)]
-        bt = simple_tables([len(p) + 4 for p in prompts])
-        with TPEngine(cfg, world, devices=[0] * world, transport="ipc", tensors=w, num_gpu_blocks=16, max_num_seqs=8,
-                      max_model_len=cfg["max_position_embeddings"], use_graph=False, timeout=900) as tp:
-            ids, pos, slots, ctx, cu = prefill_inputs(prompts, bt)
-            got = [tp.forward_raw(ids, pos, slots, bt, ctx, cu)]
-            ref_tp = [oracle_tp.forward(ids, pos, slots, bt, ctx, cu)]
-            ref_1 = [oracle_1.forward(ids, pos, slots, bt, ctx, cu)]
-            seqs = [list(p) for p in prompts]
-            for step in range(2):
-                nxt = orc.argmax_f32(ref_tp[-1])
-                for s, t in zip(seqs, nxt):
-                    s.append(int(t))
-                ids = np.array([s[-1] for s in seqs], np.uint32)
-                pos = np.array([len(s) - 1 for s in seqs], np.int64)
-                slots = np.array([int(bt[b, (len(s) - 1) // 64]) * 64 + (len(s) - 1) % 64 for b, s in enumerate(seqs)], np.int64)
-                ctx = np.array([len(s) for s in seqs], np.uint32)
-                ref_tp.append(oracle_tp.forward(ids, pos, slots, bt, ctx))
-                ref_1.append(oracle_1.forward(ids, pos, slots, bt, ctx))
-                got.append(tp.forward_raw(ids, pos, slots, bt, ctx))
-        for i, (g, rt, r1) in enumerate(zip(got, ref_tp, ref_1)):
-            for rank in range(1, world):
-                assert (g[0] == g[rank]).all(), f"step {i}: rank {rank} disagrees with rank 0 (A21)"
-            check_logits(g[0], rt, f"tp8 70B widths step {i} vs TP oracle", BF16)
-            check_logits(g[0], r1, f"tp8 70B widths step {i} vs unsharded oracle", BF16, max_ulps=2 * LOGIT_ULPS)
-
-    try:
-        run_once()
-    except (AssertionError, RuntimeError) as e:  # noqa: PERF203
-        print(f"\nWARNING: first oversubscribed TP=8 run failed ({str(e)[:300]}); retrying once with fresh runner processes", flush=True)
-        run_once()
+    w = om.make_random_checkpoint(cfg, 21)
+    oracle_tp = om.OracleModel(cfg, w, num_blocks=16, tp_world=world)
+    oracle_st = om.OracleModel(cfg, w, num_blocks=16, tp_world=world)  # its own KV cache: the per-stage oracle of a failing step
+    oracle_1 = om.OracleModel(cfg, w, num_blocks=16)
+    r = np.random.default_rng(21)
+    prompts = [r.integers(1, cfg["vocab_size"] - 1, size=n).tolist() for n in (19, 6)]
+    bt = simple_tables([len(p) + 4 for p in prompts])
+    steps = []  # (args of the forward, every rank's logits, every rank's stage snapshots)
+    with TPEngine(cfg, world, devices=[0] * world, transport="ipc", tensors=w, num_gpu_blocks=16, max_num_seqs=8,
+                  max_model_len=cfg["max_position_embeddings"], use_graph=False, timeout=900, snapshots=True) as tp:
+        ids, pos, slots, ctx, cu = prefill_inputs(prompts, bt)
+        args = (ids, pos, slots, bt, ctx, cu)
+        steps.append((args, tp.forward_raw(*args), tp.snapshots()))
+        ref_tp = [oracle_tp.forward(*args)]
+        ref_1 = [oracle_1.forward(*args)]
+        seqs = [list(p) for p in prompts]
+        for step in range(2):
+            nxt = orc.argmax_f32(ref_tp[-1])
+            for s, t in zip(seqs, nxt):
+                s.append(int(t))
+            ids = np.array([s[-1] for s in seqs], np.uint32)
+            pos = np.array([len(s) - 1 for s in seqs], np.int64)
+            slots = np.array([int(bt[b, (len(s) - 1) // 64]) * 64 + (len(s) - 1) % 64 for b, s in enumerate(seqs)], np.int64)
+            ctx = np.array([len(s) for s in seqs], np.uint32)
+            args = (ids, pos, slots, bt, ctx, None)
+            ref_tp.append(oracle_tp.forward(*args))
+            ref_1.append(oracle_1.forward(*args))
+            steps.append((args, tp.forward_raw(*args[:5]), tp.snapshots()))
+    # No retry: a deviation is reported WITH the first stage and rank whose value leaves the per-stage TP oracle —
+    # one rank's GEMM partial, the exchange (h_after_* wrong behind correct partials) or an input of the layer (tests/tp_stages.py).
+    from tests.tp_stages import first_deviation, oracle_stages
+    for i, ((args, g, snaps), rt, r1) in enumerate(zip(steps, ref_tp, ref_1)):
+        ref_stages = oracle_stages(oracle_st, *args)
+        where = first_deviation(snaps, ref_stages, BF16)
+        assert not where, f"tp8 70B widths step {i}: a stage of layer 0 deviates from the per-stage TP oracle:\n{where}"
+        for rank in range(1, world):
+            assert (g[0] == g[rank]).all(), f"step {i}: rank {rank} disagrees with rank 0 (A21)"
+        check_logits(g[0], rt, f"tp8 70B widths step {i} vs TP oracle", BF16)
+        check_logits(g[0], r1, f"tp8 70B widths step {i} vs unsharded oracle", BF16, max_ulps=2 * LOGIT_ULPS)

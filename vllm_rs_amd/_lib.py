@@ -142,6 +142,7 @@ def load():
     _sig(lib, "vra_comm_ipc_connect", c_i32, P, P, c_i64)
     _sig(lib, "vra_all_reduce_fused", None, P, P, P, P, P, c_i64, c_i32, c_i32, c_i64)
     _sig(lib, "vra_comm_take_error", c_i32, P)
+    _sig(lib, "vra_comm_error_detail", c_i32, P, P)
     _sig(lib, "vra_comm_error_word", P, P)
     _sig(lib, "vra_device_count", c_i32)
     _sig(lib, "vra_set_device", c_i32, c_i32)
@@ -197,6 +198,8 @@ def load():
     _sig(lib, "vra_engine_load_tensor", c_i32, P, C.c_char_p, P, P, c_i32, c_i32)
     _sig(lib, "vra_engine_finalize_weights", c_i32, P)
     _sig(lib, "vra_engine_copy_logits", c_i32, P, P, c_i32)
+    _sig(lib, "vra_engine_debug_tp_snapshots", None, P, c_i32)
+    _sig(lib, "vra_engine_debug_read_tp_snapshot", c_i64, P, c_i32, P, c_i64)
     _sig(lib, "vra_engine_finalize_model", c_i32, P)
     _sig(lib, "vra_engine_update_config", c_i32, P, P)
     _sig(lib, "vra_engine_num_gpu_blocks", c_i32, P)

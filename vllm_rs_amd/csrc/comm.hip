@@ -105,7 +105,11 @@ __global__ __launch_bounds__(256) void oneshot_all_reduce_kernel(const OneShotAr
     while (!dead && (int32_t)(__hip_atomic_load(ours, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
       __builtin_amdgcn_s_sleep(2);
       if (wall_clock64() - t0 > a.timeout_ticks) {
-        __hip_atomic_store(a.epochs + OS_MAX_WG, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the first waiter to give up leaves what it saw (slice, peer, epoch expected, flag read) behind the error word
+        if (__hip_atomic_exchange(a.epochs + OS_MAX_WG, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+          a.epochs[OS_MAX_WG + 1] = (uint32_t)j, a.epochs[OS_MAX_WG + 2] = (uint32_t)tid, a.epochs[OS_MAX_WG + 3] = e;
+          a.epochs[OS_MAX_WG + 4] = __hip_atomic_load(ours, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         break;
       }
     }
@@ -323,6 +327,12 @@ extern "C" int32_t vra_comm_take_error(void* c) {
   if (hipMemcpy(&v, vc->epochs + OS_MAX_WG, 4, hipMemcpyDeviceToHost) != hipSuccess) return 0;
   if (v) (void)hipMemset(vc->epochs + OS_MAX_WG, 0, 4);
   return v != 0;
+}
+
+extern "C" int32_t vra_comm_error_detail(void* c, uint32_t h_out[4]) {
+  VraComm* vc = static_cast<VraComm*>(c);
+  if (!vc || !vc->epochs || !h_out) return -1;
+  return hipMemcpy(h_out, vc->epochs + OS_MAX_WG + 1, 16, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 
 // device word behind vra_comm_take_error, for callers that fold the check into their own device-to-host copy (NULL: no one-shot transport)

@@ -726,7 +726,9 @@ int vra_gemm_q4_big_fits(bool dual, int M, int cols, int K, int group_size, cons
   // tiles (mb 2)?  A small cost model fitted to the Llama-3-8B shapes at M = 128..4096 (tools/gemv_s_microbench.py, us):
   //   kernel D: workgroups are co-resident in pairs (2 per CU, 4 waves each); per K = 4096 a pair of 64-row workgroups takes
   //             82 us and a lone one 47; 32-row workgroups 46 and 28; + 15 us of launch, row-sum pass and epilogue;
-  //   kernel B: 17 us + FLOPs at 490 TFLOP/s (650 for the gate/up pair).
+  //   kernel B: 17 us + FLOPs at 490 TFLOP/s; the gate/up pair form at 420 (round 5: it was priced at 650 and therefore picked for
+  //             ~143..221 rows, where it really takes 110-129 us against kernel D's 85-92: a 200-token prompt was slower than a
+  //             256-token one, profiles/r04_probe_kernel_d_tile_choice_160_256_rows.txt).
   // e.g. M = 512: o 50.9 (B) / 39.8 (D, mb 2) / 58.3 (mb 4); down 143 / 117 / 180; gate/up 169 (mb 4) / 189 (mb 2).
   const int gx = dual ? (cols + 127) / 128 : (cols + 255) / 256;
   const int cus = num_cus();
@@ -739,7 +741,7 @@ int vra_gemm_q4_big_fits(bool dual, int M, int cols, int K, int group_size, cons
     return 15.0 + ((double)(q / 2) * pair + (double)(q % 2) * lone) * kf;
   };
   const double flops = 2.0 * (double)M * (double)cols * (dual ? 2.0 : 1.0) * (double)K;
-  const double est_b = 17.0 + flops / ((dual ? 650.0 : 490.0) * 1e6);
+  const double est_b = 17.0 + flops / ((dual ? 420.0 : 490.0) * 1e6);
   double best = est_b;
   int pick = 0;
   const double d4 = est_d(4), d2 = est_d(2);

@@ -230,6 +230,24 @@ class Engine:
         self._check(rc, "forward_raw")
         return out
 
+    TP_STAGES = ("q", "k", "v", "attn", "o_partial", "h_after_o", "act", "down_partial", "h_after_down")
+
+    def tp_snapshots(self, on=True):
+        """parity instrumentation: keep copies of layer 0's stages of every forward (vra_engine_debug_tp_snapshots)"""
+        self.L.vra_engine_debug_tp_snapshots(self.h, int(on))
+        return self
+
+    def read_tp_snapshots(self):
+        """stage name -> uint16 bit patterns (flat) of the stages layer 0 of the last forward left behind"""
+        out = {}
+        cap = 64 << 20
+        buf = np.empty(cap // 2, np.uint16)
+        for i, name in enumerate(self.TP_STAGES):
+            n = self.L.vra_engine_debug_read_tp_snapshot(self.h, i, buf.ctypes.data_as(C.c_void_p), cap)
+            if n > 0:
+                out[name] = buf[:n // 2].copy()
+        return out
+
     def timed_decode(self, steps):
         return self.L.vra_engine_timed_decode(self.h, steps)
 

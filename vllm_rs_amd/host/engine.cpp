@@ -20,6 +20,14 @@
 #include "core.h"
 #include "model.h"
 
+// " [slice j, peer r: expected epoch e, flag read f]" of the first one-shot wait that gave up (comm.hip)
+static std::string comm_timeout_detail(void* comm) {
+  uint32_t d[4] = {0, 0, 0, 0};
+  if (!comm || vra_comm_error_detail(comm, d) != 0) return "";
+  return " [slice " + std::to_string(d[0]) + ", waiting for rank " + std::to_string(d[1]) + ": expected epoch " + std::to_string(d[2]) +
+         ", its flag read " + std::to_string(d[3]) + "]";
+}
+
 namespace vra {
 
 static inline uint32_t vra_hash32_host(uint64_t seed, uint64_t idx) {  // == vra_hash32 of csrc/common.cuh
@@ -474,7 +482,7 @@ class Engine {
     if (h_err_[1]) {
       h_err_[1] = 0;
       (void)hipMemsetAsync(comm_err, 0, 4, stream_);
-      return fail("one-shot all-reduce timed out waiting for a peer (results of this step are invalid)");
+      return fail("one-shot all-reduce timed out waiting for a peer (results of this step are invalid)" + comm_timeout_detail(comm_));
     }
     if (h_err_[0]) {
       h_err_[0] = 0;
@@ -787,6 +795,13 @@ extern "C" int32_t vra_engine_copy_logits(void* e, float* h_out, int32_t n_seqs)
   }
   return 0;
 }
+// parity instrumentation of the tensor-parallel forward (model.h `set_tp_snapshots`): stage copies of layer 0, read back per stage
+extern "C" void vra_engine_debug_tp_snapshots(void* e, int32_t on) { static_cast<Engine*>(e)->model_.set_tp_snapshots(on != 0); }
+extern "C" int64_t vra_engine_debug_read_tp_snapshot(void* e, int32_t idx, void* h_out, int64_t max_bytes) {
+  auto* en = static_cast<Engine*>(e);
+  if (en->dry()) return -1;
+  return en->model_.read_tp_snapshot(idx, h_out, max_bytes, (int64_t)en->stream_);
+}
 extern "C" int32_t vra_engine_finalize_model(void* e) {
   auto* en = static_cast<Engine*>(e);
   if (en->dry()) return 0;
@@ -1084,7 +1099,7 @@ extern "C" int32_t vra_engine_forward_raw(void* e, const uint32_t* h_ids, const 
   if (comm_err && en->h_err_[1]) {
     en->h_err_[1] = 0;
     (void)hipMemsetAsync(comm_err, 0, 4, en->stream_);
-    en->error = "one-shot all-reduce timed out waiting for a peer (results of this forward are invalid)";
+    en->error = "one-shot all-reduce timed out waiting for a peer (results of this forward are invalid)" + comm_timeout_detail(en->comm_);
     return -1;
   }
   if (dev_err && en->h_err_[0]) {

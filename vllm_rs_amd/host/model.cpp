@@ -948,6 +948,25 @@ bool Model::launch_decode_phases(const InputMetadata& md, int ph0, int ph1, int6
 #endif
 
 // ---------------------------------------------------------------------------------------------
+// stage snapshots of layer 0 (parity instrumentation, model.h)
+// ---------------------------------------------------------------------------------------------
+bool Model::snap(int idx, const void* src, size_t bytes, int64_t stream) {
+  if (!snap_on_) return true;
+  if (snap_cap_[idx] < bytes) {
+    if (!(snap_[idx] = dalloc(bytes))) return false;
+    snap_cap_[idx] = bytes;
+  }
+  snap_bytes_[idx] = bytes;
+  return hipMemcpyAsync(snap_[idx], src, bytes, hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(stream)) == hipSuccess;
+}
+int64_t Model::read_tp_snapshot(int idx, void* host, int64_t max_bytes, int64_t stream) {
+  if (idx < 0 || idx >= 9 || !snap_[idx] || !host || (int64_t)snap_bytes_[idx] > max_bytes) return -1;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (hipMemcpyAsync(host, snap_[idx], snap_bytes_[idx], hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
+  return (int64_t)snap_bytes_[idx];
+}
+
+// ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
 bool Model::forward(const InputMetadata& md, int64_t stream, uint32_t* tokens) {
@@ -991,6 +1010,9 @@ bool Model::forward(const InputMetadata& md, int64_t stream, uint32_t* tokens) {
       if (!error.empty()) return false;
       if (!linear_fused_norm(qkv, 3, outs, h_, L.attn_norm, T, stream)) return false;
     }
+    if (l == 0 && snap_on_ && !fused_attn &&
+        !(snap(0, q_, (size_t)T * hq_ * D * es_, stream) && snap(1, k_, (size_t)T * hkv_ * D * es_, stream) && snap(2, v_, (size_t)T * hkv_ * D * es_, stream)))
+      return false;
     if (fused_attn) {
     } else if (md.is_prefill) {
       // RoPE + KV write in one launch (two in the reference: rotary_emb.rs:88-103, attention.rs:808-820)
@@ -1006,12 +1028,15 @@ bool Model::forward(const InputMetadata& md, int64_t stream, uint32_t* tokens) {
                                            attn_ws_, dt_, kv_dt, attn_frag ? afrag_ : nullptr, stream);
     }
     if (take_err(error, "attention")) return false;
+    if (l == 0 && !snap(3, attn_, (size_t)T * hq_ * D * es_, stream)) return false;
     if (world_ > 1) {
       // TensorParallelRowLinear::forward (distributed.rs:438-455): partial GEMM -> all_reduce -> + bias; then the layer's
       // residual add (llama.rs:126) — the last two fused behind the reduction
       if (!gemv_s(l, 1, T, tmp_, nullptr, stream) && (!error.empty() || !linear(L.o, attn_, tmp_, T, nullptr, stream, false))) return false;
+      if (l == 0 && !snap(4, tmp_, (size_t)T * H * es_, stream)) return false;
       vra_all_reduce_fused(comm_, tmp_, h_, L.o.bias, h_, T, H, dt_, stream);
       if (take_err(error, "all_reduce(o_proj)")) return false;
+      if (l == 0 && !snap(5, h_, (size_t)T * H * es_, stream)) return false;
     } else {
       // o_proj writes h: on kernel W (5..32 rows) also its fragment-order copy; any other kernel leaves the copy stale
       if (!error.empty()) return false;
@@ -1023,10 +1048,13 @@ bool Model::forward(const InputMetadata& md, int64_t stream, uint32_t* tokens) {
     // ---- MLP block (llama.rs:127-130)
     const bool w_gu = gemv_s(l, 2, T, nullptr, nullptr, stream, hfrag_ok_ ? hfrag_ : nullptr, use_frag ? actfrag_ : nullptr);
     if (!w_gu && (!error.empty() || !gate_up(L, h_, L.ffn_norm, act_, T, stream))) return false;
+    if (l == 0 && !snap(6, act_, (size_t)T * inter_ * es_, stream)) return false;
     if (world_ > 1) {
       if (!gemv_s(l, 3, T, tmp_, nullptr, stream) && (!error.empty() || !linear(L.down, act_, tmp_, T, nullptr, stream, false))) return false;
+      if (l == 0 && !snap(7, tmp_, (size_t)T * H * es_, stream)) return false;
       vra_all_reduce_fused(comm_, tmp_, h_, L.down.bias, h_, T, H, dt_, stream);
       if (take_err(error, "all_reduce(down_proj)")) return false;
+      if (l == 0 && !snap(8, h_, (size_t)T * H * es_, stream)) return false;
     } else {
       // down_proj writes h: kernel E at 1..4 rows (no copy), kernel C with the fragment-order copy at 5..32, anything else: stale
       if (!error.empty()) return false;

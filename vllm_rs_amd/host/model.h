@@ -103,6 +103,13 @@ class Model {
   bool launch_gemm(int which, int layer, int M, int64_t stream);
   bool lm_head(const void* xin, int rows, uint32_t* tokens, int64_t stream);
   int64_t gemm_algorithmic_bytes(int which, int M) const;
+  // Parity instrumentation of the tensor-parallel forward (tests/test_gpu_tp.py, tools/tp8_stress.py): with snapshots on, layer 0
+  // of every forward leaves copies of its stages — 0 q, 1 k, 2 v (GEMM outputs, before RoPE), 3 attention output (o_proj's x),
+  // 4 o_proj partial (what this rank hands to the all-reduce), 5 h after all-reduce + residual, 6 SiLU(gate)*up (down_proj's x),
+  // 7 down_proj partial, 8 h after the second all-reduce — so that a deviating logit can be traced to the first stage and rank
+  // that deviates from the oracle.  Off (the default): no buffers, no copies.
+  void set_tp_snapshots(bool on) { snap_on_ = on; }
+  int64_t read_tp_snapshot(int idx, void* host, int64_t max_bytes, int64_t stream);  // bytes copied, -1 on error
 
  private:
   void* dalloc(size_t bytes);
@@ -157,6 +164,11 @@ class Model {
   void* hfrag_ = nullptr;
   bool hfrag_ok_ = false;
   void* actfrag_ = nullptr;  // SiLU(gate) * up of a 5..32-row step in fragment order (down_proj's x on the K-sliced kernel W)
+  bool snap_on_ = false;
+  void* snap_[9] = {};
+  size_t snap_bytes_[9] = {};
+  size_t snap_cap_[9] = {};
+  bool snap(int idx, const void* src, size_t bytes, int64_t stream);
   void* afrag_ = nullptr;  // the decode attention's output of a 5..32-sequence step in fragment order (o_proj's x on kernel W)
   bool qkv_attn(int l, const InputMetadata& md, int64_t stream);  // false = not covered (error empty) or failed (error set)
   // persistent decode step

@@ -64,6 +64,8 @@ def _runner_main(conn, rank):
         tag, nb = conn.recv()
         assert tag == "NumBlocks"
         eng.set_num_gpu_blocks(nb).finalize()
+        if init.get("snapshots"):
+            eng.tp_snapshots(True)
         conn.send(("InitAck", True))
         while True:
             tag, payload = conn.recv()
@@ -91,6 +93,8 @@ def _runner_main(conn, rank):
                     conn.send(("Timed", (ms, outs)))
                 elif tag == "AllReduce":  # the collective on its own (parity tests of comm.hip), on the engine's stream
                     conn.send(("Reduced", _all_reduce_once(L, comm, eng, rank, payload)))
+                elif tag == "Snapshots":  # layer 0's stages of the last forward (parity instrumentation)
+                    conn.send(("Stages", eng.read_tp_snapshots()))
                 elif tag == "NumBlocksQuery":
                     conn.send(("NumBlocks", eng.num_gpu_blocks))
                 else:
@@ -146,7 +150,8 @@ def _all_reduce_once(L, comm, eng, rank, p):
 class TPEngine:
     """engine-process side: spawns `world` runners and talks to them (engine.rs:187-330, 844-892)"""
 
-    def __init__(self, cfg, world, *, devices=None, transport="auto", tensors=None, oneshot_max_bytes=0, timeout=600, **engine_kw):
+    def __init__(self, cfg, world, *, devices=None, transport="auto", tensors=None, oneshot_max_bytes=0, timeout=600, snapshots=False,
+                 **engine_kw):
         from . import _lib
         L = _lib.load()
         ndev = L.vra_device_count()
@@ -178,7 +183,7 @@ class TPEngine:
             self.procs.append(p)
         for r, c in enumerate(self.conns):
             c.send(("Init", dict(rank=r, device=devices[r], world=world, transport=transport, nccl_id=nccl_id, cfg=cfg,
-                                 engine_kw=engine_kw, tensors=tensors, oneshot_max_bytes=oneshot_max_bytes)))
+                                 engine_kw=engine_kw, tensors=tensors, oneshot_max_bytes=oneshot_max_bytes, snapshots=snapshots)))
         if transport in ("ipc", "both"):
             table = b"".join(self._expect(c, "IpcHandle") for c in self.conns)
             for c in self.conns:
@@ -220,6 +225,10 @@ class TPEngine:
     def all_reduce(self, data, dtype, bias=None, residual=None, reps=1):
         """data: one array per rank -> every rank's reduced array"""
         return self._all("AllReduce", dict(data=data, dtype=dtype, bias=bias, residual=residual, reps=reps), "Reduced")
+
+    def snapshots(self):
+        """per rank: stage name -> bit patterns of layer 0's stages of the last forward (needs snapshots=True)"""
+        return self._all("Snapshots", None, "Stages")
 
     def num_gpu_blocks(self):
         return self._all("NumBlocksQuery", None, "NumBlocks")
