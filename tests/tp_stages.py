@@ -46,9 +46,11 @@ def oracle_stages(o, ids, positions, slot_mapping, block_tables, context_lens, c
 STAGE_ORDER = ("q", "k", "v", "attn", "o_partial", "h_after_o", "act", "down_partial", "h_after_down")
 
 
-def first_deviation(got_ranks, ref_ranks, dt, max_ulps=2.0):
-    """-> text naming, per rank, the first stage whose values leave the oracle by more than `max_ulps` storage ulps of the stage's
-    own magnitude (one ulp of slack beyond the exact product's rounding: summation order), or '' when every stage agrees"""
+def first_deviation(got_ranks, ref_ranks, dt, max_ulps=8.0, common_ulps=2.0, common_frac=0.005):
+    """-> text naming, per rank, the first stage that leaves the oracle, or '' when every stage agrees.  A stage agrees when no value
+    is off by more than `max_ulps` storage ulps of the stage's own magnitude and at most `common_frac` of its values by more than
+    `common_ulps`: single flipped roundings travel (a 1-ulp flip of gate or up moves SiLU(gate)*up by up to ~3 ulp, seen on
+    hardware: 1 of 7168 values), a wrong tile / stale slab / missing K slice moves many values by far more."""
     bits = 8 if dt == 0 else 11
     lines = []
     for r, (g, f) in enumerate(zip(got_ranks, ref_ranks)):
@@ -59,8 +61,8 @@ def first_deviation(got_ranks, ref_ranks, dt, max_ulps=2.0):
             scale = max(float(np.abs(b).max()), 1e-30)
             ulp = 2.0 ** (np.floor(np.log2(scale)) - (bits - 1))
             d = np.abs(a - b) / ulp
-            if float(d.max()) > max_ulps:
-                bad = np.flatnonzero(d > max_ulps)
+            if float(d.max()) > max_ulps or float((d > common_ulps).mean()) > common_frac:
+                bad = np.flatnonzero(d > common_ulps)
                 lines.append(f"rank {r}: first deviating stage '{n}': {bad.size} of {d.size} values off by up to {float(d.max()):.1f} ulp "
                              f"(flat indices {bad[:6].tolist()}..{int(bad[-1])})")
                 break

@@ -3,7 +3,7 @@ tests/test_gpu_tp.py::test_tp8_llama3_70b_widths_one_gpu — run REPS prefill an
 forward compared with the TP ORACLE (not only with the first run), and on a deviation traced to the first rank and stage of layer 0
 that leaves the per-stage oracle (tests/tp_stages.py).  A forward that fails loudly (bounded wait expired) is reported with the
 waiter's view (slice, peer, epoch expected, flag read) and the session goes on with fresh runner processes.
-    python tools/tp8_stress.py [reps] [sessions] [wall-clock budget s]"""
+    python tools/tp8_stress.py [reps] [sessions] [wall-clock budget s] [hardware queues per runner, cycled over the sessions: e.g. 1,4]"""
 import sys, time, numpy as np
 sys.path.insert(0, '.')
 from oracle import model as om
@@ -13,6 +13,7 @@ from vllm_rs_amd.runner import TPEngine
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 25
 SESSIONS = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 BUDGET = float(sys.argv[3]) if len(sys.argv) > 3 else 420.0
+HWQ = (sys.argv[4] if len(sys.argv) > 4 else "1").split(",")
 BF16 = 0
 
 
@@ -40,6 +41,9 @@ def main():
         if time.time() - t_start > BUDGET:
             break
         t0 = time.time()
+        import os
+        os.environ["VRA_TP_SHARED_HW_QUEUES"] = HWQ[sess % len(HWQ)]
+        print(f"# session {sess}: GPU_MAX_HW_QUEUES={HWQ[sess % len(HWQ)]} in every runner", flush=True)
         try:
             with TPEngine(cfg, world, devices=[0] * world, transport="ipc", tensors=w, num_gpu_blocks=16, max_num_seqs=8, max_model_len=512, use_graph=False, timeout=300, snapshots=True) as tp:
                 print(f"# session {sess}: 8 runners up after {time.time() - t0:.0f} s", flush=True)
@@ -52,7 +56,9 @@ def main():
                         stats["forwards"] += 1
                         same = all(np.array_equal(g[k].view(np.uint32), g[0].view(np.uint32)) for k in range(world))
                         try:
-                            check_logits(g[0], ref, f"{name} rep {rep}", BF16)
+                            import contextlib, io
+                            with contextlib.redirect_stdout(io.StringIO()):
+                                check_logits(g[0], ref, f"{name} rep {rep}", BF16)
                             ok = True
                         except AssertionError as e:
                             ok = False
@@ -64,7 +70,8 @@ def main():
                     print(f"# session {sess} {name}: {REPS} forwards in {time.time() - t1:.1f} s", flush=True)
         except (RuntimeError, TimeoutError) as e:
             stats["loud"] += 1
-            print(f"session {sess}: LOUD failure after {time.time() - t0:.0f} s: {str(e)[-700:]}", flush=True)
+            stats.setdefault("loud_sessions", []).append((sess, HWQ[sess % len(HWQ)]))
+            print(f"session {sess}: LOUD failure after {time.time() - t0:.0f} s: {str(e)[-2500:]}", flush=True)
     print("tp8_stress:", stats, f"({time.time() - t_start:.0f} s)")
 
 

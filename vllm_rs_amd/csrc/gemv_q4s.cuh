@@ -15,8 +15,8 @@
 //   * x never crosses waves: a wave needs only the x slices of ITS k-tiles.  It loads them itself (one 16-byte load per lane
 //     covers 4 rows x 128 columns), parks them in a wave-private LDS region (row-major, one octet of padding per row: the
 //     MFMA A-fragment reads of 4 rows are 4 banks apart) together with the per-tile sums Σx of the zero-point fix-up.  With
-//     a fused RMSNorm the ONLY cross-wave step of the prologue is the 16 x 4 table of partial Σx² (one barrier); every wave
-//     then normalises its own slices in place.
+//     a fused RMSNorm there is NO cross-wave step either (round 5): every wave forms Σx² of the whole rows itself — on the
+//     matrix cores, from M*K/512 extra cache-hit loads per lane — and normalises its slices straight from registers.
 //   * partial tiles of all units meet in LDS ONCE, behind the single barrier at the end of the stream; the first
 //     units*64 threads then add the 16 wave partials in fixed order and run the fused epilogue (bias, SiLU·mul, residual);
 //     bias / residual were requested before the weight stream started.
@@ -93,6 +93,9 @@ static inline size_t gemv_q4s_lds_bytes(int ns, int tpw, int max_units, int xrow
 }
 
 #define GS_MIN_WAVES_PER_SIMD 4
+#ifndef GS_RING_EARLY
+#define GS_RING_EARLY 0
+#endif
 #ifndef GS_RING_PAIR
 #define GS_RING_PAIR 2
 #endif
@@ -125,7 +128,7 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
   // ---- LDS carve-up
   constexpr int TLS = XR * 272 + 16;  // bytes per tile
   unsigned char* xw = smem + (size_t)wave * TPW * TLS;  // this wave's x slices
-  float* part = reinterpret_cast<float*>(smem + (size_t)GS_WAVES * TPW * TLS);  // [16 waves][4 rows] Σx²
+  // (256 bytes behind the x slices held the 16 x 4 table of partial Σx² until round 5; the layout of `red` is unchanged)
   f32x4* red = reinterpret_cast<f32x4*>(smem + (size_t)GS_WAVES * TPW * TLS + 256);  // [unit][NS][wave][16 lanes]
 
   // ---- epilogue operands of the threads that will finish the outputs (requested before the weight stream starts):
@@ -198,69 +201,130 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
   const int srg = (XR == 4 ? oct : min(oct, XR - 1)) * 272;
   const bool norm = a.norm_w != nullptr;
   const uint16_t* xrow = static_cast<const uint16_t*>(a.x) + (size_t)min(oct, M - 1) * a.x_ld + nn * 8;
-  const uint16_t* nwp = static_cast<const uint16_t*>(a.norm_w) + nn * 8;
-  u32x4 nr[GS_NORM_TPW];
-  float ss = 0.f;
-  for (int t0 = 0; t0 < TPW; t0 += 4) {
-    u32x4 xv[4];
+  auto fill_ring = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int kt = min(wave + 16 * min(t0 + i, TPW - 1), KT - 1);
-      xv[i] = *reinterpret_cast<const u32x4*>(xrow + (size_t)kt * 128);
-      if (norm && t0 == 0) nr[i] = *reinterpret_cast<const u32x4*>(nwp + (size_t)kt * 128);  // (norm => TPW <= 4)
+    for (int r = 0; r < D; r++) {
+      issue(iu, it, wb[r], sb[r], zb[r]);
+      advance_issue();
     }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  if (!norm) {
+    for (int t0 = 0; t0 < TPW; t0 += 4) {
+      u32x4 xv[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int ti = t0 + i;
-      if (ti < TPW) {
-        const bool valid = wave + 16 * ti < KT;
-        if (!valid) xv[i] = u32x4{0u, 0u, 0u, 0u};  // a wave without this k-tile: zero slice (its partial sums are exactly 0)
-        unsigned char* tp = xw + (size_t)ti * TLS;
-        *reinterpret_cast<u32x4*>(tp + srg + nn * 16) = xv[i];
-        if (norm) {
-          float f[8];
-          unpack8<DT>(xv[i], f);
+      for (int i = 0; i < 4; i++) {
+        const int kt = min(wave + 16 * min(t0 + i, TPW - 1), KT - 1);
+        xv[i] = *reinterpret_cast<const u32x4*>(xrow + (size_t)kt * 128);
+      }
 #pragma unroll
-          for (int e = 0; e < 8; e++) ss += f[e] * f[e];
-        } else {
+      for (int i = 0; i < 4; i++) {
+        const int ti = t0 + i;
+        if (ti < TPW) {
+          const bool valid = wave + 16 * ti < KT;
+          if (!valid) xv[i] = u32x4{0u, 0u, 0u, 0u};  // a wave without this k-tile: zero slice (its partial sums are exactly 0)
+          unsigned char* tp = xw + (size_t)ti * TLS;
+          *reinterpret_cast<u32x4*>(tp + srg + nn * 16) = xv[i];
           const float s8 = row16_sum(octet_sum<DT>(xv[i]));
           if (nn == 0) reinterpret_cast<float*>(tp + XR * 272)[oct] = s8;
         }
       }
     }
-  }
-  GEMV_STAMP(16);
-
-  // the ring is filled right behind the x loads (in order per wave: x first); the staging below overlaps the first HBM round trip
+    GEMV_STAMP(16);
+    // the ring is filled right behind the x loads (in order per wave: x first); the staging above overlaps nothing of it
+    fill_ring();
+    GEMV_STAMP(1);
+  } else {
+    // Fused RMSNorm (round 5): NO cross-wave step.  Rounds 1-4 let every wave sum the squares of ITS slices, met at a workgroup
+    // barrier for the 16 x 4 table of partial sums, then read its slices back from LDS to normalise them: the timeline
+    // (profiles/r02_timeline_kernel_e.txt) shows x in LDS at 0.99 us, the barrier released at 2.31, the slices normalised at 2.96 —
+    // 1.3 us of waiting for the slowest of 16 waves.  Now every wave forms the sum of squares of the WHOLE rows by itself: M*K/512
+    // extra 16-byte loads per lane (L1 / L2 hits: the 16 waves of the CU read the same 8 KB per row) and as many MFMAs — with
+    // A = B = the loaded fragment the matrix core returns X·Xᵀ, whose diagonal holds the sums of squares of the 16 "pseudo-rows"
+    // a fragment is made of (16-bit x 16-bit products are exact in f32) — then normalises its slices straight from registers.
+    // Arithmetic contract unchanged: x̂ = round(x · rstd · g) exactly as before (others.rs:11-29); only the order in which the
+    // f32 sum of squares is formed differs (rstd moves in its last bit at most: the same in every wave and workgroup).
+    u32x4 xv[GS_NORM_TPW], nr[GS_NORM_TPW];
+    const uint16_t* nwp = static_cast<const uint16_t*>(a.norm_w) + nn * 8;
 #pragma unroll
-  for (int r = 0; r < D; r++) {
-    issue(iu, it, wb[r], sb[r], zb[r]);
-    advance_issue();
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  GEMV_STAMP(1);
-
-  if (norm) {
-    // Σx² of the rows: every wave contributes the partial sums of its slices, fixed order
-    const float rsum = row16_sum(ss);
-    if (nn == 0) part[wave * 4 + oct] = rsum;
-    __syncthreads();
+    for (int i = 0; i < GS_NORM_TPW; i++) {  // (norm => TPW <= GS_NORM_TPW)
+      const int kt = min(wave + 16 * min(i, TPW - 1), KT - 1);
+      xv[i] = *reinterpret_cast<const u32x4*>(xrow + (size_t)kt * 128);
+      nr[i] = *reinterpret_cast<const u32x4*>(nwp + (size_t)kt * 128);
+    }
+    // pseudo-row nn of a fragment belongs to row slot nn >> psh (1, 2 or 4 slots for M = 1, 2, 3..4 rows; slot s holds row
+    // min(s, M-1)) and is its part pi; chunk c of a row = elements ((c*P + pi)*32 + oct*8 .. +7): P*64 contiguous bytes per slot
+    const int psh = M == 1 ? 4 : (M == 2 ? 3 : 2), P = 1 << psh;
+    const int slot = nn >> psh, pi = nn & (P - 1);
+    const int NC = (a.K + P * 32 - 1) / (P * 32);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (uint32_t)(((M - 1) * a.x_ld + a.K) * 2), 0x00020000);
+    const uint32_t fo_row = (uint32_t)(min(slot, M - 1) * a.x_ld) * 2u;
+    auto load_chunks = [&](int c0, u32x4 (&fr)[8]) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int el = ((c0 + j) * P + pi) * 32 + oct * 8;
+        fr[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, el < a.K ? fo_row + (uint32_t)el * 2u : 0x7FFFFFF0u, 0, 0);  // past the row: out of range = 0
+      }
+    };
+    f32x4 sq;
+    auto square_chunks = [&](const u32x4 (&fr)[8], const bool first) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const s16x8 f = __builtin_bit_cast(s16x8, fr[j]);
+        if (first && j == 0) DT::mfma0(sq, f, f);  // C = 0: no accumulator to clear
+        else DT::mfma(sq, f, f);
+      }
+    };
+    {
+      u32x4 fr[8];
+      load_chunks(0, fr);
+      GEMV_STAMP(16);
+#if GS_RING_EARLY
+      fill_ring();  // (A/B: the ring on its way while x is still in flight — x is older, so its wait leaves the ring outstanding)
+#endif
+      square_chunks(fr, true);
+    }
+    for (int c0 = 8; c0 < NC; c0 += 8) {  // M > 1 or K > 4096: further groups of 8 chunks
+      u32x4 fr[8];
+      load_chunks(c0, fr);
+      square_chunks(fr, false);
+    }
+#if !GS_RING_EARLY
+    // the ring goes out once x has arrived (an earlier ring measured slower in round 3: the CU's vector-memory path returns in
+    // order, and the HBM loads of the first waves stood in front of the L2 hits the later waves were waiting for)
+    fill_ring();
+#endif
+    GEMV_STAMP(1);
+    VRA_MFMA_DRAIN();
+    // lane (oct, nn) holds D[4*oct + e][nn], e = 0..3: the diagonal entry of pseudo-row nn sits in the lanes with nn >> 2 == oct
+    const int de = nn & 3;
+    float dv = de == 0 ? sq[0] : (de == 1 ? sq[1] : (de == 2 ? sq[2] : sq[3]));
+    dv = (nn >> 2) == oct ? dv : 0.f;
+    float tot = 0.f;  // Σx² of this staging lane's row min(oct, M-1); fixed order: 16-lane rows by DPP, then rows 0..3
+#pragma unroll
+    for (int sl = 0; sl < 4; sl++) {
+      if (sl < M) {
+        const float v = row16_sum(slot == sl ? dv : 0.f);
+        const float t = ((__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0)) +
+                          __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16))) +
+                         __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32))) +
+                        __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+        tot = min(oct, M - 1) == sl ? t : tot;
+      }
+    }
     GEMV_STAMP(18);
-    float tot = 0.f;
-#pragma unroll
-    for (int w = 0; w < GS_WAVES; w++) tot += part[w * 4 + oct];
     const float rstd = 1.0f / sqrtf(tot / (float)a.K + a.eps);
 #pragma unroll
     for (int ti = 0; ti < GS_NORM_TPW; ti++) {
       if (ti < TPW) {
         unsigned char* tp = xw + (size_t)ti * TLS;
-        const u32x4 raw = *reinterpret_cast<const u32x4*>(tp + srg + nn * 16);
         float f[8], g[8];
-        unpack8<DT>(raw, f);
+        unpack8<DT>(xv[ti], f);
         unpack8<DT>(nr[ti], g);
 #pragma unroll
         for (int e = 0; e < 8; e++) f[e] = f[e] * rstd * g[e];
-        const u32x4 v = pack8<DT>(f);
+        u32x4 v = pack8<DT>(f);
+        if (wave + 16 * ti >= KT) v = u32x4{0u, 0u, 0u, 0u};  // a wave without this k-tile: zero slice (its partial sums are exactly 0)
         *reinterpret_cast<u32x4*>(tp + srg + nn * 16) = v;
         const float s8 = row16_sum(octet_sum<DT>(v));  // over the ROUNDED values the MFMA will see
         if (nn == 0) reinterpret_cast<float*>(tp + XR * 272)[oct] = s8;

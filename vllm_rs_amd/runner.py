@@ -34,6 +34,13 @@ def _runner_main(conn, rank):
         from .engine import Engine
         tag, init = conn.recv()
         assert tag == "Init"
+        if init.get("shared_device"):
+            # Ranks that SHARE a GPU (the single-GPU stand-in of the TP tests): every HIP process opens up to four hardware queues;
+            # nine processes oversubscribe the device's queue slots, the scheduler then has to rotate queues — and a queue whose
+            # kernel spins in the one-shot exchange waiting for a peer does not yield: the peer's queue can stay unmapped until the
+            # bounded wait expires (tools/tp8_stress.py: "expected epoch 26, its flag read 25" after 62 clean forwards).  One
+            # hardware queue per runner keeps all ranks' queues mapped at once.  Real TP (one rank per GPU) is not affected.
+            os.environ.setdefault("GPU_MAX_HW_QUEUES", init.get("hw_queues", "1"))
         L = _lib.load()
         dev, world = init["device"], init["world"]
         L.vra_set_device(dev)
@@ -183,7 +190,8 @@ class TPEngine:
             self.procs.append(p)
         for r, c in enumerate(self.conns):
             c.send(("Init", dict(rank=r, device=devices[r], world=world, transport=transport, nccl_id=nccl_id, cfg=cfg,
-                                 engine_kw=engine_kw, tensors=tensors, oneshot_max_bytes=oneshot_max_bytes, snapshots=snapshots)))
+                                 engine_kw=engine_kw, tensors=tensors, oneshot_max_bytes=oneshot_max_bytes, snapshots=snapshots,
+                                 shared_device=shared, hw_queues=os.environ.get("VRA_TP_SHARED_HW_QUEUES", "1"))))
         if transport in ("ipc", "both"):
             table = b"".join(self._expect(c, "IpcHandle") for c in self.conns)
             for c in self.conns:
@@ -207,9 +215,26 @@ class TPEngine:
         return payload
 
     def _all(self, tag, payload, reply):
+        """broadcast, then collect EVERY rank's answer before judging them: when a step fails, what each rank saw (which peer it
+        waited for, at which epoch) is the evidence — the first rank's error alone hides the waiting graph"""
         for c in self.conns:
             c.send((tag, payload))
-        return [self._expect(c, reply) for c in self.conns]
+        got, errs = [], []
+        for r, c in enumerate(self.conns):
+            if not c.poll(self.timeout):
+                errs.append(f"rank {r}: no answer within {self.timeout}s")
+                got.append(None)
+                continue
+            t, pl = c.recv()
+            if t != reply:
+                errs.append(f"rank {r}: {pl.strip().splitlines()[-1] if t == 'Error' and isinstance(pl, str) else f'expected {reply}, got {t}'}")
+                got.append(None)
+            else:
+                got.append(pl)
+        if errs:
+            ok = [r for r, g in enumerate(got) if g is not None]
+            raise RuntimeError("runner error(s) in " + tag + ":\n" + "\n".join(errs) + (f"\n(ranks {ok} answered normally)" if ok else ""))
+        return got
 
     def forward_raw(self, *args):
         """-> the f32 logits of every rank (A21: they must be identical)"""
