@@ -138,6 +138,13 @@ void vra_wna16_dequant(const void* qweight_tiled, const void* scales, const void
  * out[t,:] = x[t,:] * rsqrt(mean(x²)+eps) * w, f32 math, one rounding. */
 void vra_rms_norm(const void* x, const void* weight, void* out, int32_t tokens, int32_t hidden,
                   float eps, int32_t dtype, int64_t stream);
+/* q_norm / k_norm of Attention::forward_ext (src/models/layers/attention.rs:538-601,713-735; Qwen3-style checkpoints), IN PLACE on
+ * q [tokens, q_heads, head_dim] and k [tokens, kv_heads, head_dim], before the rotary embedding.  full_dim == 0: one RMSNorm per
+ * (token, head) over head_dim channels, weights [head_dim] (attention.rs:724-731); full_dim != 0: one RMSNorm per token over the
+ * whole row, weights [q_heads * head_dim] / [kv_heads * head_dim] (`full_dim_qk_norm`, attention.rs:714-722; under tensor
+ * parallelism the caller passes its shard of the weight, attention.rs:567-590). */
+void vra_qk_rms_norm(void* q, void* k, const void* q_weight, const void* k_weight, int32_t tokens, int32_t q_heads, int32_t kv_heads,
+                     int32_t head_dim, int32_t full_dim, float eps, int32_t dtype, int64_t stream);
 /* residual add + norm: h = round(x + residual) written to `h_out`, out = rmsnorm(h).
  * Equivalent to llama.rs:126-128 `(attn_output + residual)` followed by the next norm. */
 void vra_add_rms_norm(const void* x, const void* residual, const void* weight, void* h_out,
@@ -359,7 +366,7 @@ float vra_event_elapsed_ms(void* start, void* stop); /* syncs on `stop` */
 /* Model/engine configuration — the fields of `Config` (src/utils/config.rs:218-255),
  * `QuantConfig` (:735-757) and `EngineConfig` (:285-328) the hot path consumes. */
 typedef struct vra_model_config {
-  int32_t arch;              /* 0 = LlamaForCausalLM/Mistral (llama.rs), 1 = Qwen2ForCausalLM (qwen3.rs) */
+  int32_t arch;              /* 0 = LlamaForCausalLM/Mistral (llama.rs), 1 = Qwen2ForCausalLM, 2 = Qwen3ForCausalLM (both qwen3.rs) */
   int32_t hidden_size, intermediate_size, num_layers;
   int32_t num_heads, num_kv_heads, head_dim, vocab_size;
   int32_t max_position_embeddings;
@@ -385,6 +392,10 @@ typedef struct vra_model_config {
    * 2 attn_factor, 3 extrapolation_factor) = "the field was given, take it as it is" (0 in the field then means 0, not the default) */
   double rope_original_max_position_f;
   int32_t rope_yarn_explicit;
+  /* appended in round 5 (fills the struct's tail padding: the size is unchanged).  q_norm / k_norm of the attention block
+   * (attention.rs:538-601): 0 none, 1 per head (weights [head_dim]: Qwen3), 2 over the full q / k row (weights [heads * head_dim]).
+   * Loaded checkpoints set it from the shape of `self_attn.q_norm.weight`; synthetic weights follow this field. */
+  int32_t qk_norm;
 } vra_model_config;
 
 typedef struct vra_engine_config {

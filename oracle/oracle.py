@@ -212,12 +212,18 @@ def gemm_wdense(x, w, bias, residual, dt):
     return out
 
 
-def wna16_gemm(x, idx, zeros, scales, group_size, dt, bias=None, residual=None):
+def wna16_gemm(x, idx, zeros, scales, group_size, dt, bias=None, residual=None, row_scale=None):
+    """row_scale [M] f32: the deferred RMSNorm factor, applied to the f32 sums before the output rounding (rms_norm_deferred)"""
     x, idx, zeros, scales, bias, residual = _c(x), _c(idx, np.uint8), _c(zeros, np.uint8), _c(scales), _c(bias), _c(residual)
     M, K = x.shape
     N = idx.shape[1]
     out = np.empty((M, N), np_dt(dt))
-    lib().orc_wna16_gemm(_p(x), _p(idx), _p(zeros), _p(scales), _p(bias), _p(residual), M, K, N, group_size, dt, _p(out))
+    if row_scale is None:
+        lib().orc_wna16_gemm(_p(x), _p(idx), _p(zeros), _p(scales), _p(bias), _p(residual), M, K, N, group_size, dt, _p(out))
+    else:
+        rs = _c(row_scale, np.float32)
+        assert rs.shape == (M,)
+        lib().orc_wna16_gemm_row_scale(_p(x), _p(idx), _p(zeros), _p(scales), _p(bias), _p(residual), _p(rs), M, K, N, group_size, dt, _p(out))
     return out
 
 
@@ -246,6 +252,16 @@ def rms_norm(x, w, eps, dt):
     out = np.empty((T, H), np_dt(dt))
     lib().orc_rms_norm(_p(x), _p(w), T, H, C.c_float(eps), dt, _p(out))
     return out
+
+
+def rms_norm_deferred(x, w, eps, dt):
+    """-> (round(x * w) [T, H], rstd [T] f32): the order of the engine's 1..4-row decode launches (vra_oracle.c orc_rms_norm_deferred)"""
+    x, w = _c(x), _c(w)
+    T, H = x.shape
+    out = np.empty((T, H), np_dt(dt))
+    rstd = np.empty(T, np.float32)
+    lib().orc_rms_norm_deferred(_p(x), _p(w), T, H, C.c_float(eps), dt, _p(out), _p(rstd))
+    return out, rstd
 
 
 def add(a, b, dt):

@@ -345,9 +345,9 @@ void orc_gemm_wdense(const void* x, const void* w, const void* bias, const void*
  * to 16 bits before the MMA — orc_dequant/orc_gemm_wdense above restate that variant; the two differ
  * by < 1 output ulp and the reference's kernel sources are not in the tree to arbitrate.)
  * x [M,K] dt; idx [K,N]; scales [G,N]; zeros [G,N] or NULL. */
-void orc_wna16_gemm(const void* x, const uint8_t* idx, const uint8_t* zeros, const void* scales,
-                    const void* bias, const void* residual, int M, int K, int N, int group_size,
-                    int dt, void* out) {
+static void wna16_gemm_rs(const void* x, const uint8_t* idx, const uint8_t* zeros, const void* scales,
+                          const void* bias, const void* residual, const float* row_scale, int M, int K, int N, int group_size,
+                          int dt, void* out) {
   /* Blocked for the caches (32 columns x 64 rows of accumulators per thread, k outermost inside a block, weights
    * dequantised once per (k, column) and row block); every output is still the SEQUENTIAL sum over k = 0..K-1 in double,
    * i.e. bit-identical to the plain triple loop. */
@@ -382,7 +382,9 @@ void orc_wna16_gemm(const void* x, const uint8_t* idx, const uint8_t* zeros, con
         for (int m = 0; m < mc; m++)
           for (int c = 0; c < nc; c++) {
             int n = n0 + c;
-            float v = rnd((float)acc[m][c], dt);
+            float v = (float)acc[m][c];
+            if (row_scale) v = v * row_scale[m0 + m];  /* the deferred RMSNorm factor, on the f32 dot product (see orc_rms_norm_deferred) */
+            v = rnd(v, dt);
             if (bias) v = rnd(v + ld(bias, n, dt), dt);
             if (residual) v = rnd(v + ld(residual, (int64_t)(m0 + m) * N + n, dt), dt);
             st(out, (int64_t)(m0 + m) * N + n, v, dt);
@@ -390,6 +392,19 @@ void orc_wna16_gemm(const void* x, const uint8_t* idx, const uint8_t* zeros, con
       }
   }
   free(xf);
+}
+void orc_wna16_gemm(const void* x, const uint8_t* idx, const uint8_t* zeros, const void* scales,
+                    const void* bias, const void* residual, int M, int K, int N, int group_size,
+                    int dt, void* out) {
+  wna16_gemm_rs(x, idx, zeros, scales, bias, residual, NULL, M, K, N, group_size, dt, out);
+}
+/* The same product with a per-row f32 factor applied to the f32 sum BEFORE the output rounding:
+ *     out = rnd( row_scale[m] · Σ_k x_k · s_g(k) · (q_k − z_g(k)) )   [+ bias, + residual as above]
+ * — the second, stated order of RMSNorm ∘ GEMV (orc_rms_norm_deferred below). */
+void orc_wna16_gemm_row_scale(const void* x, const uint8_t* idx, const uint8_t* zeros, const void* scales,
+                              const void* bias, const void* residual, const float* row_scale, int M, int K, int N,
+                              int group_size, int dt, void* out) {
+  wna16_gemm_rs(x, idx, zeros, scales, bias, residual, row_scale, M, K, N, group_size, dt, out);
 }
 /* Fast path of the same arithmetic straight from GPTQ-packed words (timed CPU baseline, bs small):
  * qw [K/8,N] u32 (gptq layout), symmetric zero 8, scales [G,N] dt. f32 accumulation. */
@@ -451,6 +466,25 @@ void orc_rms_norm(const void* x, const void* w, int T, int H, float eps, int dt,
     }
     float r = 1.0f / sqrtf((float)(ss / H) + eps);
     for (int i = 0; i < H; i++) st(out, (int64_t)t * H + i, ld(x, (int64_t)t * H + i, dt) * r * ld(w, i, dt), dt);
+  }
+}
+/* RMSNorm with the normalisation factor DEFERRED to the consumer GEMV (round 5; the order of the engine's 1..4-row decode launches,
+ * vllm_rs_amd/csrc/gemv_q4s.cuh): rstd = 1/sqrt(mean(x²) + eps) is one scalar per row and commutes with the matrix product,
+ *     Σ_k (x_k · rstd · g_k) · w_kn  =  rstd · Σ_k (x_k · g_k) · w_kn,
+ * so the kernel stages  out = rnd(x · g)  (ONE rounding per element, as NormX::forward has — of x·g instead of x·rstd·g) without
+ * waiting for the row's sum of squares, and multiplies the f32 dot products by rstd (returned here, f32) before they are rounded.
+ * A stated second variant next to orc_rms_norm (others.rs:11-29 order), like orc_gemm_wdense next to orc_wna16_gemm: the same
+ * error size against the unrounded truth (tests/test_gpu_tolerance.py), another rounding pattern. */
+void orc_rms_norm_deferred(const void* x, const void* w, int T, int H, float eps, int dt, void* out, float* rstd) {
+#pragma omp parallel for
+  for (int t = 0; t < T; t++) {
+    double ss = 0.0;
+    for (int i = 0; i < H; i++) {
+      double v = ld(x, (int64_t)t * H + i, dt);
+      ss += v * v;
+    }
+    rstd[t] = 1.0f / sqrtf((float)(ss / H) + eps);
+    for (int i = 0; i < H; i++) st(out, (int64_t)t * H + i, ld(x, (int64_t)t * H + i, dt) * ld(w, i, dt), dt);
   }
 }
 /* candle `+` (llama.rs:126,130) */

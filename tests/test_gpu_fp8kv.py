@@ -99,11 +99,13 @@ def test_prefill_attention_over_fp8_cache_with_prefix():
 
 
 @pytest.mark.parametrize("dt", [BF16, F16])
-@pytest.mark.parametrize("ctxs", [[1, 40, 65, 0], [300, 129]])
+@pytest.mark.parametrize("ctxs", [[1, 40, 65, 0], [300, 129], [511, 512, 513, 1030], [5000, 2100]])
 def test_fused_decode_with_fp8_cache(dt, ctxs):
     """RoPE + cache write + attention in one launch over an FP8 cache: the new token's K row / V column reach the cache as
     E4M3 bytes (bit-exact) and enter THIS step's attention as the values a later read returns"""
-    Hq, Hkv, D, BS, NB = 8, 2, 128, 64, 32
+    # (round 5: contexts at the split boundaries of the small-batch rule — 512 tokens = 16 tiles: 2 splits, 1024: 4 — and beyond
+    # block 63, where a wave of the latency form re-bases its block-id vector: attention.hip `decode_nsplit`, LAT)
+    Hq, Hkv, D, BS, NB = 8, 2, 128, 64, 128 if max(ctxs) > 400 else 32
     r = rng(sum(ctxs) + dt)
     B = len(ctxs)
     mb = max(max((c + BS - 1) // BS for c in ctxs), 1)
@@ -127,14 +129,15 @@ def test_fused_decode_with_fp8_cache(dt, ctxs):
     q, k, v = rand_dt(r, (B, Hq, D), dt), rand_dt(r, (B, Hkv, D), dt, 2.0), rand_dt(r, (B, Hkv, D), dt, 2.0)
     pos = np.array([max(c - 1, 0) for c in ctxs], np.int64)
     slots = np.array([int(bt[b, (c - 1) // BS]) * BS + (c - 1) % BS if c > 0 else -1 for b, c in enumerate(ctxs)], np.int64)
-    cos, sin = orc.rope_tables(D, 10000.0, 4096)
+    cos, sin = orc.rope_tables(D, 10000.0, 8192)
     cos, sin = orc.to_dt(cos, dt), orc.to_dt(sin, dt)
     cl = np.array(ctxs, np.uint32)
     qr, kr = orc.rope(q, cos, sin, pos, False, dt, dt), orc.rope(k, cos, sin, pos, False, dt, dt)
     orc.reshape_and_cache(kr, v, kc_ref, vc_ref, slots, BS, dt, orc.FP8)
     ref = orc.paged_attention(qr, kc_ref, vc_ref, bt, cl, None, Hkv, BS, D ** -0.5, dt, kv_dt=orc.FP8)
+    wsb = ops.DevBuf(ops.lib().vra_paged_attention_decode_workspace_bytes(B, Hq, D, max(ctxs))) if max(ctxs) > 400 else None
     out = pa.rope_cache_decode(ops.dev(q), ops.dev(k), ops.dev(v), kc, vc, ops.dev(cos), ops.dev(sin), ops.dev(pos), ops.dev(slots),
-                               ops.dev(bt), ops.dev(cl), B, mb, max(ctxs))
+                               ops.dev(bt), ops.dev(cl), B, mb, max(ctxs), wsb)
     got = out.numpy(np.uint16, (B, Hq, D))
     live = [b for b, c in enumerate(ctxs) if c > 0]
     for b, c in enumerate(ctxs):

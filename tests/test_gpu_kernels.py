@@ -487,7 +487,10 @@ def test_paged_attention_decode_split_kv():
 
 @pytest.mark.parametrize("dt", [BF16, F16])
 @pytest.mark.parametrize("Hq,Hkv,D", [(32, 8, 128), (8, 1, 128), (4, 2, 64), (4, 4, 64)])
-@pytest.mark.parametrize("ctxs,ws", [([1], False), ([31, 32, 33, 0], False), ([64, 65, 200, 7], False), ([3000, 2049], True)])
+@pytest.mark.parametrize("ctxs,ws", [([1], False), ([31, 32, 33, 0], False), ([64, 65, 200, 7], False), ([3000, 2049], True),
+                                     # round 5: the split boundaries of the small-batch rule (a split keeps >= 8 tiles: 2 splits from 512
+                                     # tokens, 4 from 1024) and contexts beyond block 63 (the latency form re-bases its block-id vector)
+                                     ([255, 256, 257, 300], True), ([511, 512, 513, 1030], True), ([5000, 2100], True)])
 def test_fused_rope_cache_attention_decode(Hq, Hkv, D, ctxs, ws, dt):
     """one launch == FusedRope + reshape_and_cache + PagedAttention decode (attention.rs:745-820): the history is in the
     cache, the NEW token's q,k,v come in un-rotated; ctx 0 = padded graph lane (slot -1: writes nothing, output 0)."""
@@ -518,7 +521,7 @@ def test_fused_rope_cache_attention_decode(Hq, Hkv, D, ctxs, ws, dt):
     q, k, v = rand_dt(r, (B, Hq, D), dt), rand_dt(r, (B, Hkv, D), dt), rand_dt(r, (B, Hkv, D), dt)
     pos = np.array([max(c - 1, 0) for c in ctxs], np.int64)
     slots = np.array([int(bt[b, (c - 1) // BS]) * BS + (c - 1) % BS if c > 0 else -1 for b, c in enumerate(ctxs)], np.int64)
-    cos, sin = orc.rope_tables(D, 10000.0, 4096)
+    cos, sin = orc.rope_tables(D, 10000.0, 8192)
     cos, sin = orc.to_dt(cos, dt), orc.to_dt(sin, dt)
     cl = np.array(ctxs, np.uint32)
     # ---- oracle: the three-step composition on host copies of the caches

@@ -17,8 +17,11 @@ for bs in %r:
     out["bs%%d_ms_per_step" %% bs] = round(dt * 1e3 / (256 if bs == 1 else 64), 4)
 for m in (1,):
     out["family_us_m%%d" %% m] = [round(eng.bench_gemm(w, m, 320) * 1e3, 2) for w in range(4)]
-lc, _, _ = bench.run_decode(eng, bench.make_prompts(1, 8000, cfg["vocab_size"], seed=8077), 4, 16, L.vra_device_sync)
-out["bs1_ctx8000_ms"] = round(lc * 1e3 / 16, 4)
+for ctx in (1024, 8000):
+    lc, _, _ = bench.run_decode(eng, bench.make_prompts(1, ctx, cfg["vocab_size"], seed=77 + ctx), 4, 16, L.vra_device_sync)
+    out["bs1_ctx%%d_ms" %% ctx] = round(lc * 1e3 / 16, 4)
+lc, _, _ = bench.run_decode(eng, bench.make_prompts(32, 128, cfg["vocab_size"], seed=43), 8, 64, L.vra_device_sync)
+out["bs32_ms"] = round(lc * 1e3 / 64, 4)
 print(json.dumps(out))
 '''
 
@@ -30,8 +33,12 @@ def main():
     for r in range(rounds):
         for lib in libs:
             env = dict(os.environ)
-            if lib != "default":
-                env["VRA_LIB"] = os.path.join(ROOT, "vllm_rs_amd", lib)
+            name, _, evars = lib.partition("@")  # "lib.so@VAR=1,VAR2=x": environment of that child
+            for kv in filter(None, evars.split(",")):
+                k, _, v = kv.partition("=")
+                env[k] = v
+            if name != "default":
+                env["VRA_LIB"] = os.path.join(ROOT, "vllm_rs_amd", name)
             p = subprocess.run([sys.executable, "-c", CHILD % (ROOT, batches)], env=env, capture_output=True, text=True, cwd=ROOT)
             line = p.stdout.strip().splitlines()[-1] if p.stdout.strip() else p.stderr[-400:]
             print(f"round {r} {lib:28s} {line}", flush=True)

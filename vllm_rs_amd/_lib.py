@@ -27,7 +27,7 @@ class ModelConfig(C.Structure):
         ("dtype", c_i32), ("tie_word_embeddings", c_i32),
         ("rope_dynamic_alpha", c_i32), ("rope_yarn_beta_fast", C.c_double), ("rope_yarn_beta_slow", C.c_double),
         ("rope_yarn_attn_factor", C.c_double), ("rope_yarn_extrapolation_factor", C.c_double),
-        ("rope_original_max_position_f", C.c_double), ("rope_yarn_explicit", c_i32),
+        ("rope_original_max_position_f", C.c_double), ("rope_yarn_explicit", c_i32), ("qk_norm", c_i32),
     ]
 
 
@@ -99,6 +99,7 @@ def load():
     _sig(lib, "vra_wna16_unpack_indices", None, P, P, c_i32, c_i32, c_i64)
     _sig(lib, "vra_wna16_dequant", None, P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64)
     _sig(lib, "vra_rms_norm", None, P, P, P, c_i32, c_i32, c_f32, c_i32, c_i64)
+    _sig(lib, "vra_qk_rms_norm", None, P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_i64)
     _sig(lib, "vra_add_rms_norm", None, P, P, P, P, P, c_i32, c_i32, c_f32, c_i32, c_i64)
     _sig(lib, "vra_add", None, P, P, P, c_i64, c_i32, c_i64)
     _sig(lib, "vra_embedding", None, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i64)

@@ -369,10 +369,18 @@ __device__ __forceinline__ size_t vra_frag_index16(int m, int c) {
   return ((size_t)((((c >> 7) * 2 + (m >> 4)) * 4 + ((c >> 5) & 3)) * 64 + ((c >> 3) & 3) * 16 + (m & 15))) * 8 + (c & 7);
 }
 
+// (Round 5 built a "latency form" of this kernel for small grids — the sequence's block ids fetched as one wave-wide load at kernel
+// entry and picked with v_readlane, a wave's first K/V tile requested BEFORE the RoPE prologue, further tiles double-buffered, 240
+// VGPRs — parity-green and SLOWER than this form at every point measured on one box (bs 1: 1.666 against 1.649 ms per step, ctx 1024
+// 1.744 against 1.722, ctx 8000 2.063 against 2.054, bs 32 2.682 against 2.673; profiles/r05_ab_attention_lat.txt): the vector-memory
+// path of a CU returns in order, so the early HBM loads stand in front of the prologue's L2 hits and the chain is no shorter.
+// Removed; what stayed of it: raw loads first / conversion at use, the split rule and the merge kernel below.)
 template <class DT, int D, bool KV8>
 __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const FusedDecodeArgs a) {
   typedef typename KVT<KV8>::elem kv_t;
   constexpr int DJ = D / 32, DT16 = D / 16, HALF = D / 2;
+  constexpr int KR = KV8 ? D / 64 : DJ;  // 16-byte loads of a lane's share of one K row
+  typedef typename std::conditional<KV8, u32x2, u32x4>::type vraw_t;  // a lane's 8 tokens of one V channel as loaded
   __shared__ __attribute__((aligned(16))) float lds_o[FD_WAVES][16][D + 4];
   __shared__ float lds_ml[FD_WAVES][16][2];
   __shared__ __attribute__((aligned(16))) kv_t knew[D];       // the new token's K row in CACHE format (read like a cache row)
@@ -408,7 +416,28 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
     const int T0 = tile << 5;
     return (size_t)b * a.max_blocks + (a.bs_shift >= 0 ? T0 >> a.bs_shift : T0 / a.BS);
   };
-  uint32_t blk_cur = a.block_tables[tile_blk_index(min(kv_w0, max(ntiles - 1, 0)))];
+  auto tile_blk = [&](int tile) -> uint32_t { return a.block_tables[tile_blk_index(tile)]; };
+  const kv_t* kcache = static_cast<const kv_t*>(a.kc);
+  const kv_t* vcache = static_cast<const kv_t*>(a.vc);
+  // the raw loads of one tile (nothing is converted or consumed here: all of them go out back to back)
+  auto load_tile = [&](int tile, uint32_t blk, u32x4 (&kr0)[KR], u32x4 (&kr1)[KR], vraw_t (&vr)[DT16]) {
+    const int T0 = tile << 5;
+    const int off = a.bs_shift >= 0 ? T0 & (a.BS - 1) : T0 % a.BS;
+    const kv_t* krow0 = kcache + (((size_t)blk * a.Hkv + hk) * a.BS + off + krow_tok) * D;
+    const kv_t* krow1 = krow0 + 4 * D;
+    const size_t vbase = (((size_t)blk * a.Hkv + hk) * D) * a.BS + off;
+#pragma unroll
+    for (int i = 0; i < KR; i++) {
+      kr0[i] = *reinterpret_cast<const u32x4*>(krow0 + (KV8 ? oct * (D / 4) + i * 16 : i * 32 + oct * 8));
+      kr1[i] = *reinterpret_cast<const u32x4*>(krow1 + (KV8 ? oct * (D / 4) + i * 16 : i * 32 + oct * 8));
+    }
+    // V: they only depend on the block table; consumed after the softmax
+#pragma unroll
+    for (int t = 0; t < DT16; t++) vr[t] = *reinterpret_cast<const vraw_t*>(vcache + vbase + (size_t)(t * 16 + rq) * a.BS + oct * 8);
+  };
+  uint32_t blk_cur = tile_blk(min(kv_w0, max(ntiles - 1, 0)));
+  u32x4 ka0[KR], ka1[KR];
+  vraw_t va[DT16];
   // ---- new token: rotate k (threads 0 .. D/16-1), copy v (threads 64 .. 64+D/8-1); stage both in LDS
   if (tid < HALF / 8) {
     const uint16_t* kp = static_cast<const uint16_t*>(a.k) + ((size_t)b * a.Hkv + hk) * D;
@@ -515,41 +544,27 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
 #pragma unroll
   for (int t = 0; t < DT16; t++) o[t] = vra_zero_acc();
   float m_run = -INFINITY, l_run = 0.f;
-  const kv_t* kcache = static_cast<const kv_t*>(a.kc);
-  const kv_t* vcache = static_cast<const kv_t*>(a.vc);
-  for (int tile = kv_w0; tile < kv_w1; tile++) {
+  // one tile: QK^T, online softmax, PV on the RAW registers of that tile (converted here: FP8 caches widen to 16 bits)
+  auto compute_tile = [&](int tile, const u32x4 (&kr0)[KR], const u32x4 (&kr1)[KR], const vraw_t (&vr)[DT16]) {
     const int T0 = tile << 5;
-    const uint32_t blk = blk_cur;
-    const int off = a.bs_shift >= 0 ? T0 & (a.BS - 1) : T0 % a.BS;
-    blk_cur = a.block_tables[tile_blk_index(min(tile + 1, ntiles - 1))];  // next tile's block id, in flight during this tile
-    const kv_t* krow0 = kcache + (((size_t)blk * a.Hkv + hk) * a.BS + off + krow_tok) * D;
-    const kv_t* krow1 = krow0 + 4 * D;
-    const size_t vbase = (((size_t)blk * a.Hkv + hk) * D) * a.BS + off;
     const bool has_new = last >= T0 && last < T0 + 32;  // wave-uniform: the tile that holds the new token
     u32x4 k0[DJ], k1[DJ];
     if constexpr (KV8) {
-      u32x4 r0[D / 64], r1[D / 64];  // a lane's D/4 bytes of each row
-#pragma unroll
-      for (int i = 0; i < D / 64; i++) {
-        r0[i] = *reinterpret_cast<const u32x4*>(krow0 + oct * (D / 4) + i * 16);
-        r1[i] = *reinterpret_cast<const u32x4*>(krow1 + oct * (D / 4) + i * 16);
-      }
 #pragma unroll
       for (int j = 0; j < DJ; j++) {
-        k0[j] = vra_unpack_e4m3x8<DT>(u32x2{r0[j >> 1][(j & 1) * 2], r0[j >> 1][(j & 1) * 2 + 1]});
-        k1[j] = vra_unpack_e4m3x8<DT>(u32x2{r1[j >> 1][(j & 1) * 2], r1[j >> 1][(j & 1) * 2 + 1]});
+        k0[j] = vra_unpack_e4m3x8<DT>(u32x2{kr0[j >> 1][(j & 1) * 2], kr0[j >> 1][(j & 1) * 2 + 1]});
+        k1[j] = vra_unpack_e4m3x8<DT>(u32x2{kr1[j >> 1][(j & 1) * 2], kr1[j >> 1][(j & 1) * 2 + 1]});
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < DJ; j++) {
-        k0[j] = kv_load8<DT, KV8>(krow0 + j * 32 + oct * 8);
-        k1[j] = kv_load8<DT, KV8>(krow1 + j * 32 + oct * 8);
-      }
+      for (int j = 0; j < DJ; j++) k0[j] = kr0[j], k1[j] = kr1[j];
     }
-    // V: issue the loads now (they only depend on the block table), consume after the softmax
     u32x4 vfr[DT16];
 #pragma unroll
-    for (int t = 0; t < DT16; t++) vfr[t] = kv_load8<DT, KV8>(vcache + vbase + (size_t)(t * 16 + rq) * a.BS + oct * 8);
+    for (int t = 0; t < DT16; t++) {
+      if constexpr (KV8) vfr[t] = vra_unpack_e4m3x8<DT>(vr[t]);
+      else vfr[t] = vr[t];
+    }
     FD_STAMP(5);
     // the new token's K row comes from LDS (the cache write of split 0 may not be visible yet).  Patched in AFTER the loads:
     // selecting the row POINTER (cache or LDS) made every K load of the loop a flat_load — slower to issue than global_load
@@ -634,6 +649,12 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
       for (int r = 0; r < 4; r++) o[t][r] *= ar[r];
       DT::mfma(o[t], pfrag, __builtin_bit_cast(s16x8, vv));
     }
+  };
+  for (int tile = kv_w0; tile < kv_w1; tile++) {
+    const uint32_t blk = blk_cur;
+    blk_cur = tile_blk(min(tile + 1, ntiles - 1));  // next tile's block id, in flight during this tile
+    load_tile(tile, blk, ka0, ka1, va);
+    compute_tile(tile, ka0, ka1, va);
   }
   FD_STAMP(8);
   VRA_MFMA_DRAIN();
@@ -679,37 +700,70 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
   FD_STAMP(11);
 }
 
-// second pass for split-KV decode: merge nsplit partials per (b, head)
+// second pass for split-KV decode: merge nsplit partials per (b, head).  The (max, sum) pairs of the splits go through LDS once
+// (thread s fetches split s: one round trip instead of a dependent pair per split), the partial rows are fetched eight splits at
+// a time (independent loads, clamped index with weight 0) and added in split order — the same sums in the same order as the
+// one-split-at-a-time loop of rounds 1-4.  nsplit <= 64 <= D.
 template <class DT, int D>
 __global__ void paged_attn_merge_kernel(uint16_t* out, const float* ws_o, const float* ws_ml, int Hq, int nsplit, uint16_t* out_frag = nullptr) {
+  __shared__ float s_m[64], s_l[64];
   const int b = blockIdx.y, head = blockIdx.x, d = threadIdx.x;
   const size_t base = ((size_t)b * Hq + head) * nsplit;
+  if (d < nsplit) {
+    s_m[d] = ws_ml[(base + d) * 2];
+    s_l[d] = ws_ml[(base + d) * 2 + 1];
+  }
+  __syncthreads();
   float M = -INFINITY;
-  for (int s = 0; s < nsplit; s++) M = fmaxf(M, ws_ml[(base + s) * 2]);
+  for (int s = 0; s < nsplit; s++) M = fmaxf(M, s_m[s]);
   const float Ms = M == -INFINITY ? 0.f : M;
   float L = 0.f, acc = 0.f;
-  for (int s = 0; s < nsplit; s++) {
-    const float f = exp2f(ws_ml[(base + s) * 2] - Ms);
-    L += ws_ml[(base + s) * 2 + 1] * f;
-    acc += ws_o[(base + s) * D + d] * f;
+  for (int s0 = 0; s0 < nsplit; s0 += 8) {
+    float o8[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) o8[j] = ws_o[(base + min(s0 + j, nsplit - 1)) * D + d];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      if (s0 + j < nsplit) {
+        const float f = exp2f(s_m[s0 + j] - Ms);
+        L += s_l[s0 + j] * f;
+        acc += o8[j] * f;
+      }
+    }
   }
   const uint16_t ov = DT::from_f32(L > 0.f ? acc / L : 0.f);
   out[((size_t)b * Hq + head) * D + d] = ov;
   if (out_frag && b < 32) out_frag[vra_frag_index16(b, head * D + d)] = ov;
 }
 
+static int num_cus_attn() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+  }
+  return n;
+}
 static int decode_nsplit(int batch, int kv_heads, int max_context_len) {
-  // enough workgroups to cover the chip (256 CUs); each split should keep >= 8 tiles (256 tokens)
   int wg = batch * kv_heads;
   int tiles = (max_context_len + 31) / 32;
   int s = 1;
-  // a split keeps >= 8 tiles (2 per wave) — or >= 4 (one per wave) while there are fewer than 64 workgroups: at bs 1 the
-  // eight (sequence, kv head) workgroups leave the chip idle and the shorter tile chain pays for the merge launch
-  // (bs 1, ctx 130..380: 534 -> 554 tok/s), at bs 32 it does not (3.46 -> 3.54 ms per step), and past 64 workgroups the
-  // wider merge loses (bs 1, ctx 8000: 2.36 -> 2.60 ms with 32 splits instead of 16)
-  static const char* e = getenv("VRA_ATTN_SPLIT_TILES");  // tuning aid: fewest tiles a split keeps (overrides both)
+  static const char* e = getenv("VRA_ATTN_SPLIT_TILES");  // tuning aid: fewest tiles a split keeps (overrides both rules)
   const int forced = e && atoi(e) > 0 ? atoi(e) : 0;
-  while (wg * s < 512 && tiles / (s * 2) >= (forced ? forced : (wg * s < 64 ? 4 : 8)) && s < 64) s *= 2;
+  const int cus = num_cus_attn();
+  if (wg * 2 <= cus) {
+    // Small batches: as many splits as keep the grid within the CUs (one workgroup per CU at most) and leave a split at least
+    // 4 tiles (one per wave).  bs 1: 2 splits from 256 tokens, ... 32 (256 workgroups) at 8k — rounds 1-4 stopped at 64
+    // workgroups because their merge kernel walked the splits one dependent round trip at a time; measured on one box
+    // (profiles/r05_ab_attention_splits.txt): keep 4 beats 2, 8 and 16 at ctx 150..400, 1024 and 8000.
+    const int keep = forced ? forced : 4;
+    while (wg * s * 2 <= cus && tiles / (s * 2) >= keep && s < 64) s *= 2;
+    return s;
+  }
+  // enough workgroups to cover the chip (256 CUs); each split keeps >= 8 tiles (256 tokens): at bs 32 shorter splits do not pay
+  // for the merge launch (3.46 -> 3.54 ms per step), and past 64 workgroups per ... the wider merge loses
+  while (wg * s < 512 && tiles / (s * 2) >= (forced ? forced : 8) && s < 64) s *= 2;
   return s;
 }
 

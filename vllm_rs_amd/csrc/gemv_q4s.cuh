@@ -15,8 +15,8 @@
 //   * x never crosses waves: a wave needs only the x slices of ITS k-tiles.  It loads them itself (one 16-byte load per lane
 //     covers 4 rows x 128 columns), parks them in a wave-private LDS region (row-major, one octet of padding per row: the
 //     MFMA A-fragment reads of 4 rows are 4 banks apart) together with the per-tile sums Σx of the zero-point fix-up.  With
-//     a fused RMSNorm there is NO cross-wave step either (round 5): every wave forms Σx² of the whole rows itself — on the
-//     matrix cores, from M*K/512 extra cache-hit loads per lane — and normalises its slices straight from registers.
+//     a fused RMSNorm there is NO cross-wave step either (round 5): a wave stages round(x · g) and leaves the partial Σx² of its
+//     slices for the end-of-stream reduction; rstd is applied to the f32 dot products in the epilogue (it commutes with the GEMV).
 //   * partial tiles of all units meet in LDS ONCE, behind the single barrier at the end of the stream; the first
 //     units*64 threads then add the 16 wave partials in fixed order and run the fused epilogue (bias, SiLU·mul, residual);
 //     bias / residual were requested before the weight stream started.
@@ -93,9 +93,6 @@ static inline size_t gemv_q4s_lds_bytes(int ns, int tpw, int max_units, int xrow
 }
 
 #define GS_MIN_WAVES_PER_SIMD 4
-#ifndef GS_RING_EARLY
-#define GS_RING_EARLY 0
-#endif
 #ifndef GS_RING_PAIR
 #define GS_RING_PAIR 2
 #endif
@@ -128,7 +125,7 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
   // ---- LDS carve-up
   constexpr int TLS = XR * 272 + 16;  // bytes per tile
   unsigned char* xw = smem + (size_t)wave * TPW * TLS;  // this wave's x slices
-  // (256 bytes behind the x slices held the 16 x 4 table of partial Σx² until round 5; the layout of `red` is unchanged)
+  float* part = reinterpret_cast<float*>(smem + (size_t)GS_WAVES * TPW * TLS);  // [16 waves][4 rows] partial Σx² (fused norm)
   f32x4* red = reinterpret_cast<f32x4*>(smem + (size_t)GS_WAVES * TPW * TLS + 256);  // [unit][NS][wave][16 lanes]
 
   // ---- epilogue operands of the threads that will finish the outputs (requested before the weight stream starts):
@@ -235,15 +232,15 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
     fill_ring();
     GEMV_STAMP(1);
   } else {
-    // Fused RMSNorm (round 5): NO cross-wave step.  Rounds 1-4 let every wave sum the squares of ITS slices, met at a workgroup
-    // barrier for the 16 x 4 table of partial sums, then read its slices back from LDS to normalise them: the timeline
-    // (profiles/r02_timeline_kernel_e.txt) shows x in LDS at 0.99 us, the barrier released at 2.31, the slices normalised at 2.96 —
-    // 1.3 us of waiting for the slowest of 16 waves.  Now every wave forms the sum of squares of the WHOLE rows by itself: M*K/512
-    // extra 16-byte loads per lane (L1 / L2 hits: the 16 waves of the CU read the same 8 KB per row) and as many MFMAs — with
-    // A = B = the loaded fragment the matrix core returns X·Xᵀ, whose diagonal holds the sums of squares of the 16 "pseudo-rows"
-    // a fragment is made of (16-bit x 16-bit products are exact in f32) — then normalises its slices straight from registers.
-    // Arithmetic contract unchanged: x̂ = round(x · rstd · g) exactly as before (others.rs:11-29); only the order in which the
-    // f32 sum of squares is formed differs (rstd moves in its last bit at most: the same in every wave and workgroup).
+    // Fused RMSNorm (round 5): the normalisation factor is applied in the EPILOGUE.  rstd = 1 / sqrt(mean(x²) + eps) is one scalar
+    // per row and commutes with the GEMV:  Σ_k (x_k · rstd · g_k) · w_kn  =  rstd · Σ_k (x_k · g_k) · w_kn.  Rounds 1-4 normalised x
+    // BEFORE the stream, which put a workgroup barrier (the 16 x 4 table of partial Σx²) and a second pass over the wave's slices
+    // between the arrival of x and the first MFMA — profiles/r02_timeline_kernel_e.txt: x in LDS at 0.99 us, barrier released at
+    // 2.31, slices normalised at 2.96.  Now a wave stages x̃ = round(x · g) the moment its slices land, keeps the partial Σx² of
+    // its slices for the end-of-stream reduction that exists anyway (`part`, read behind the final barrier), and the epilogue
+    // multiplies the f32 dot products by rstd before anything is rounded.  One rounding per element of x̃ as before (of x·g instead
+    // of x·rstd·g): the same error size, another rounding pattern — the oracle restates this order as its stated second variant
+    // (oracle/vra_oracle.c orc_rms_norm_deferred / the `row_scale` of orc_wna16_gemm), tests compare against that variant.
     u32x4 xv[GS_NORM_TPW], nr[GS_NORM_TPW];
     const uint16_t* nwp = static_cast<const uint16_t*>(a.norm_w) + nn * 8;
 #pragma unroll
@@ -252,68 +249,7 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
       xv[i] = *reinterpret_cast<const u32x4*>(xrow + (size_t)kt * 128);
       nr[i] = *reinterpret_cast<const u32x4*>(nwp + (size_t)kt * 128);
     }
-    // pseudo-row nn of a fragment belongs to row slot nn >> psh (1, 2 or 4 slots for M = 1, 2, 3..4 rows; slot s holds row
-    // min(s, M-1)) and is its part pi; chunk c of a row = elements ((c*P + pi)*32 + oct*8 .. +7): P*64 contiguous bytes per slot
-    const int psh = M == 1 ? 4 : (M == 2 ? 3 : 2), P = 1 << psh;
-    const int slot = nn >> psh, pi = nn & (P - 1);
-    const int NC = (a.K + P * 32 - 1) / (P * 32);
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (uint32_t)(((M - 1) * a.x_ld + a.K) * 2), 0x00020000);
-    const uint32_t fo_row = (uint32_t)(min(slot, M - 1) * a.x_ld) * 2u;
-    auto load_chunks = [&](int c0, u32x4 (&fr)[8]) {
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const int el = ((c0 + j) * P + pi) * 32 + oct * 8;
-        fr[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, el < a.K ? fo_row + (uint32_t)el * 2u : 0x7FFFFFF0u, 0, 0);  // past the row: out of range = 0
-      }
-    };
-    f32x4 sq;
-    auto square_chunks = [&](const u32x4 (&fr)[8], const bool first) {
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const s16x8 f = __builtin_bit_cast(s16x8, fr[j]);
-        if (first && j == 0) DT::mfma0(sq, f, f);  // C = 0: no accumulator to clear
-        else DT::mfma(sq, f, f);
-      }
-    };
-    {
-      u32x4 fr[8];
-      load_chunks(0, fr);
-      GEMV_STAMP(16);
-#if GS_RING_EARLY
-      fill_ring();  // (A/B: the ring on its way while x is still in flight — x is older, so its wait leaves the ring outstanding)
-#endif
-      square_chunks(fr, true);
-    }
-    for (int c0 = 8; c0 < NC; c0 += 8) {  // M > 1 or K > 4096: further groups of 8 chunks
-      u32x4 fr[8];
-      load_chunks(c0, fr);
-      square_chunks(fr, false);
-    }
-#if !GS_RING_EARLY
-    // the ring goes out once x has arrived (an earlier ring measured slower in round 3: the CU's vector-memory path returns in
-    // order, and the HBM loads of the first waves stood in front of the L2 hits the later waves were waiting for)
-    fill_ring();
-#endif
-    GEMV_STAMP(1);
-    VRA_MFMA_DRAIN();
-    // lane (oct, nn) holds D[4*oct + e][nn], e = 0..3: the diagonal entry of pseudo-row nn sits in the lanes with nn >> 2 == oct
-    const int de = nn & 3;
-    float dv = de == 0 ? sq[0] : (de == 1 ? sq[1] : (de == 2 ? sq[2] : sq[3]));
-    dv = (nn >> 2) == oct ? dv : 0.f;
-    float tot = 0.f;  // Σx² of this staging lane's row min(oct, M-1); fixed order: 16-lane rows by DPP, then rows 0..3
-#pragma unroll
-    for (int sl = 0; sl < 4; sl++) {
-      if (sl < M) {
-        const float v = row16_sum(slot == sl ? dv : 0.f);
-        const float t = ((__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0)) +
-                          __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16))) +
-                         __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32))) +
-                        __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
-        tot = min(oct, M - 1) == sl ? t : tot;
-      }
-    }
-    GEMV_STAMP(18);
-    const float rstd = 1.0f / sqrtf(tot / (float)a.K + a.eps);
+    float ss = 0.f;
 #pragma unroll
     for (int ti = 0; ti < GS_NORM_TPW; ti++) {
       if (ti < TPW) {
@@ -321,15 +257,23 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
         float f[8], g[8];
         unpack8<DT>(xv[ti], f);
         unpack8<DT>(nr[ti], g);
+        const bool valid = wave + 16 * ti < KT;  // a wave without this k-tile: zero slice (its partial sums are exactly 0)
 #pragma unroll
-        for (int e = 0; e < 8; e++) f[e] = f[e] * rstd * g[e];
-        u32x4 v = pack8<DT>(f);
-        if (wave + 16 * ti >= KT) v = u32x4{0u, 0u, 0u, 0u};  // a wave without this k-tile: zero slice (its partial sums are exactly 0)
+        for (int e = 0; e < 8; e++) {
+          ss += valid ? f[e] * f[e] : 0.f;
+          f[e] = valid ? f[e] * g[e] : 0.f;
+        }
+        const u32x4 v = pack8<DT>(f);
         *reinterpret_cast<u32x4*>(tp + srg + nn * 16) = v;
         const float s8 = row16_sum(octet_sum<DT>(v));  // over the ROUNDED values the MFMA will see
         if (nn == 0) reinterpret_cast<float*>(tp + XR * 272)[oct] = s8;
       }
     }
+    const float rsum = row16_sum(ss);  // Σx² of this wave's slices of row min(oct, M-1): met in the epilogue, fixed order
+    if (nn == 0) part[wave * 4 + oct] = rsum;
+    GEMV_STAMP(16);
+    fill_ring();
+    GEMV_STAMP(1);
   }
   GEMV_STAMP(2);
 
@@ -412,6 +356,14 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
     const float e_bias = DT::to_f32((uint16_t)((e_col & 1) ? e_bias_w >> 16 : e_bias_w));
     const float e_bias2 = DT::to_f32((uint16_t)((e_col & 1) ? e_bias2_w >> 16 : e_bias2_w));
     const float e_res = DT::to_f32((uint16_t)((e_res_idx & 1) ? e_res_w >> 16 : e_res_w));
+    if (norm) {  // the deferred normalisation: rstd of row e_m from the 16 waves' partial sums (fixed order), on the f32 dot products
+      float tot = 0.f;
+#pragma unroll
+      for (int w = 0; w < GS_WAVES; w++) tot += part[w * 4 + e_m];
+      const float rstd = 1.0f / sqrtf(tot / (float)a.K + a.eps);
+      v *= rstd;
+      if (NS == 2) v2 *= rstd;
+    }
     v = rnd_dt<DT>(v);
     if (e_biasp) v = rnd_dt<DT>(v + e_bias);
     if (NS == 2) {

@@ -104,6 +104,57 @@ extern "C" void vra_add_rms_norm(const void* x, const void* residual, const void
     rms_norm_kernel<F16, true><<<tokens, 256, 0, as_stream(stream)>>>((const uint16_t*)x, (const uint16_t*)residual, (const uint16_t*)weight, (uint16_t*)h_out, (uint16_t*)out, hidden, eps);
 }
 
+// ---------------------------------------------------------------- q/k-norm (Attention::forward_ext, attention.rs:713-735)
+// Qwen3-style checkpoints carry `q_norm` / `k_norm`: an RMSNorm over every head's head_dim channels of q and k (weight [head_dim],
+// `q.flatten(0, 1)` -> NormX::forward, attention.rs:724-731) — or, when the weight has num_heads * head_dim entries, over the whole
+// q / k row (`full_dim_qk_norm`, attention.rs:714-722, the weight sharded with the heads: attention.rs:567-590) — applied BEFORE the
+// rotary embedding, in place.  Same arithmetic as rms_norm_kernel: f32 sum of squares, rstd = 1 / sqrt(mean + eps), x * rstd * g,
+// one rounding.  Per-head form: 16 lanes per (token, head) row (head_dim <= 128: 8 channels per lane), sums by DPP, q and k rows
+// in ONE launch; the full-dim form is two rows of rms_norm_kernel per token.
+template <class DT>
+__global__ __launch_bounds__(256) void qk_head_norm_kernel(uint16_t* __restrict__ q, uint16_t* __restrict__ k, const uint16_t* __restrict__ qw,
+                                                           const uint16_t* __restrict__ kw, int64_t q_rows, int64_t rows, int D, float eps) {
+  const int tid = threadIdx.x, l16 = tid & 15;
+  const int64_t row = (int64_t)blockIdx.x * 16 + (tid >> 4);
+  const bool act = row < rows && l16 * 8 < D;
+  const bool is_q = row < q_rows;
+  uint16_t* xp = (is_q ? q + row * D : k + (row - q_rows) * D) + l16 * 8;
+  u32x4 v = {0u, 0u, 0u, 0u};
+  if (act) v = *reinterpret_cast<const u32x4*>(xp);
+  float f[8], g[8];
+  unpack8<DT>(v, f);
+  float ss = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; e++) ss += f[e] * f[e];
+  ss = row16_sum(ss);
+  const float rstd = 1.0f / sqrtf(ss / (float)D + eps);
+  if (act) {
+    unpack8<DT>(*reinterpret_cast<const u32x4*>((is_q ? qw : kw) + l16 * 8), g);
+#pragma unroll
+    for (int e = 0; e < 8; e++) f[e] = f[e] * rstd * g[e];
+    *reinterpret_cast<u32x4*>(xp) = pack8<DT>(f);
+  }
+}
+extern "C" void vra_qk_rms_norm(void* q, void* k, const void* q_weight, const void* k_weight, int32_t tokens, int32_t q_heads, int32_t kv_heads,
+                                int32_t head_dim, int32_t full_dim, float eps, int32_t dtype, int64_t stream) {
+  VRA_CHECK_ARG(q && k && q_weight && k_weight, "vra_qk_rms_norm: null pointer");
+  VRA_CHECK_ARG(dtype == VRA_BF16 || dtype == VRA_F16, "vra_qk_rms_norm: dtype must be bf16/f16");
+  VRA_CHECK_ARG(tokens >= 0 && q_heads > 0 && kv_heads > 0, "vra_qk_rms_norm: bad shape");
+  if (tokens == 0) return;
+  if (full_dim) {  // weight [heads * head_dim]: one RMSNorm over the token's whole q (k) row
+    vra_rms_norm(q, q_weight, q, tokens, q_heads * head_dim, eps, dtype, stream);
+    vra_rms_norm(k, k_weight, k, tokens, kv_heads * head_dim, eps, dtype, stream);
+    return;
+  }
+  VRA_CHECK_ARG(head_dim % 8 == 0 && head_dim >= 8 && head_dim <= 128, "vra_qk_rms_norm: per-head form needs head_dim %% 8 == 0, <= 128 (got %d)", head_dim);
+  const int64_t q_rows = (int64_t)tokens * q_heads, rows = q_rows + (int64_t)tokens * kv_heads;
+  const unsigned grid = (unsigned)((rows + 15) / 16);
+  if (dtype == VRA_BF16)
+    qk_head_norm_kernel<BF16><<<grid, 256, 0, as_stream(stream)>>>((uint16_t*)q, (uint16_t*)k, (const uint16_t*)q_weight, (const uint16_t*)k_weight, q_rows, rows, head_dim, eps);
+  else
+    qk_head_norm_kernel<F16><<<grid, 256, 0, as_stream(stream)>>>((uint16_t*)q, (uint16_t*)k, (const uint16_t*)q_weight, (const uint16_t*)k_weight, q_rows, rows, head_dim, eps);
+}
+
 // ---------------------------------------------------------------- elementwise
 template <class DT, int OP>  // OP 0: add, 1: silu(a)*b
 __global__ __launch_bounds__(256) void ew_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b,

@@ -18,7 +18,8 @@ def model_config(cfg):
     rs = cfg.get("rope_scaling") or {}
     head_dim = cfg.get("head_dim") or cfg["hidden_size"] // cfg["num_heads"]
     return ModelConfig(
-        arch=1 if cfg.get("arch", "llama") in ("qwen2", 1) else 0,
+        arch={"llama": 0, 0: 0, "qwen2": 1, 1: 1, "qwen3": 2, 2: 2}[cfg.get("arch", "llama")],
+        qk_norm={None: 0, 0: 0, False: 0, "head": 1, 1: 1, True: 1, "full": 2, 2: 2}[cfg.get("qk_norm", 1 if cfg.get("arch") in ("qwen3", 2) else 0)],
         hidden_size=cfg["hidden_size"], intermediate_size=cfg["intermediate_size"], num_layers=cfg["num_layers"],
         num_heads=cfg["num_heads"], num_kv_heads=cfg["num_kv_heads"], head_dim=head_dim, vocab_size=cfg["vocab_size"],
         max_position_embeddings=cfg["max_position_embeddings"], rms_norm_eps=cfg["rms_norm_eps"],

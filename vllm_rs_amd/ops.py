@@ -175,6 +175,13 @@ def rms_norm(x, weight, tokens, hidden, eps, dtype=BF16):
     return out
 
 
+def qk_rms_norm(q, k, q_weight, k_weight, tokens, q_heads, kv_heads, head_dim, full_dim, eps, dtype=BF16):
+    """in place on the device buffers q [tokens, q_heads, head_dim] and k [tokens, kv_heads, head_dim] (attention.rs:713-735)"""
+    lib().vra_qk_rms_norm(_ptr(q), _ptr(k), _ptr(q_weight), _ptr(k_weight), tokens, q_heads, kv_heads, head_dim, int(full_dim), eps, dtype, 0)
+    check_error()
+    return q, k
+
+
 def add_rms_norm(x, residual, weight, tokens, hidden, eps, dtype=BF16):
     h, out = DevBuf(tokens * hidden * 2), DevBuf(tokens * hidden * 2)
     lib().vra_add_rms_norm(_ptr(x), _ptr(residual), _ptr(weight), h.ptr, out.ptr, tokens, hidden, eps, dtype, 0)
