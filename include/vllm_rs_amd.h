@@ -483,6 +483,12 @@ int32_t vra_engine_copy_logits(void* eng, float* h_out, int32_t n_seqs);
 /* parity instrumentation of the tensor-parallel forward: with snapshots on, layer 0 of every forward keeps copies of its stages
  * (0 q, 1 k, 2 v before RoPE, 3 attention output, 4 o_proj partial of this rank, 5 h after the first all-reduce + residual,
  * 6 SiLU(gate)*up, 7 down_proj partial, 8 h after the second all-reduce); read returns the bytes copied or -1. */
+/* parity instrumentation: which fused RMSNorm launches of a step of `rows` rows apply the normalisation factor in their epilogue
+ * (the 1..4-row decode kernel: rstd commutes with the GEMV; bit 0 = norm + q/k/v, bit 1 = norm + gate/up), and the shape predicate
+ * behind it (ns 1 | 2 streams, m rows, K, group size, 16-column units of the launch, fused norm) — the oracle restates the order
+ * the engine runs (oracle/model.py ENGINE_RULE). */
+int32_t vra_engine_norm_deferred(void* eng, int32_t rows);
+int32_t vra_debug_gemv_s_fits(int32_t ns, int32_t m, int32_t k, int32_t group_size, int32_t n_units, int32_t norm);
 void vra_engine_debug_tp_snapshots(void* eng, int32_t on);
 int64_t vra_engine_debug_read_tp_snapshot(void* eng, int32_t idx, void* h_out, int64_t max_bytes);
 int32_t vra_engine_finalize_model(void* eng);

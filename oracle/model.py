@@ -16,6 +16,26 @@ from . import oracle as orc
 
 BF16, F16, F32 = 0, 1, 2
 
+# The engine's decode launches of 1..4 rows apply the RMSNorm factor in the GEMV's epilogue (vllm_rs_amd/csrc/gemv_q4s.cuh: rstd
+# commutes with the product; orc.rms_norm_deferred + the row_scale of orc.wna16_gemm restate that order).  WHICH launches of a step
+# take that kernel is a shape rule of the engine; GPU parity runs install it here (tests/conftest.py, tests/full_depth.py:
+# `vra_debug_gemv_s_fits`, checked against the engine's own report by tests/test_gpu_engine.py) so that the oracle restates the
+# order the engine runs.  None (CPU runs, no engine to compare with): the reference order everywhere (others.rs:11-29).
+ENGINE_RULE = None  # callable(ns, rows, K, group_size, n_units, norm) -> bool
+
+
+def deferred_norm_mask(cfg, T, tp_world=1):
+    """bit 0: norm + q/k/v of a T-row step in the deferred order, bit 1: norm + gate/up (mirror of Model::norm_deferred_mask)"""
+    if ENGINE_RULE is None or T < 1 or T > 4 or cfg.get("quant_method") not in ("gptq", "awq"):
+        return 0
+    H, D, gs = cfg["hidden_size"], cfg["head_dim"], cfg.get("group_size", 128)
+    hq = cfg["num_heads"] // tp_world
+    hkv = max(1, cfg["num_kv_heads"] // tp_world)
+    inter = cfg["intermediate_size"] // tp_world
+    if (hq * D) % 16 or (hkv * D) % 16 or inter % 16 or H % 16:
+        return 0
+    return (1 if ENGINE_RULE(1, T, H, gs, (hq + 2 * hkv) * D // 16, 1) else 0) | (2 if ENGINE_RULE(2, T, H, gs, inter // 16, 1) else 0)
+
 
 class Linear:
     def __init__(self, w, prefix, cfg):
@@ -50,9 +70,10 @@ class Linear:
                                   self.gs, self.dt, None, None)
         return orc.dense_gemm(x, np.ascontiguousarray(self.w[:, k0:k1]), None, self.dt, self.dt)
 
-    def __call__(self, x, residual=None):
+    def __call__(self, x, residual=None, row_scale=None):
         if self.quant:
-            return orc.wna16_gemm(x, self.idx, self.zeros, self.scales, self.gs, self.dt, self.bias, residual)
+            return orc.wna16_gemm(x, self.idx, self.zeros, self.scales, self.gs, self.dt, self.bias, residual, row_scale)
+        assert row_scale is None, "the deferred norm order exists for the int4 decode kernel only"
         out = orc.dense_gemm(x, self.w, self.bias, self.dt, self.dt)
         return orc.add(out, residual, self.dt) if residual is not None else out
 
@@ -94,7 +115,8 @@ class OracleModel:
                 q=Linear(weights, p + "self_attn.q_proj", cfg), k=Linear(weights, p + "self_attn.k_proj", cfg),
                 v=Linear(weights, p + "self_attn.v_proj", cfg), o=Linear(weights, p + "self_attn.o_proj", cfg),
                 gate=Linear(weights, p + "mlp.gate_proj", cfg), up=Linear(weights, p + "mlp.up_proj", cfg),
-                down=Linear(weights, p + "mlp.down_proj", cfg)))
+                down=Linear(weights, p + "mlp.down_proj", cfg),
+                q_norm=weights.get(p + "self_attn.q_norm.weight"), k_norm=weights.get(p + "self_attn.k_norm.weight")))
         self.embed = weights["model.embed_tokens.weight"]
         self.final_norm = weights["model.norm.weight"]
         self.lm_head = weights.get("lm_head.weight", self.embed)
@@ -111,6 +133,24 @@ class OracleModel:
             out = orc.add(out, np.broadcast_to(lin.bias, out.shape).copy(), self.dt)
         return orc.add(out, residual, self.dt)
 
+    def qk_norm(self, L, q, k):
+        """q_norm / k_norm of Attention::forward_ext (attention.rs:713-735), before the rotary embedding: per head over head_dim
+        (weight [head_dim], attention.rs:724-731) or over the whole q / k row (weight [heads * head_dim], `full_dim_qk_norm`,
+        attention.rs:714-722).  One RMSNorm each, one rounding (NormX::forward: f32 inside, cast back)."""
+        wq, wk = L.get("q_norm"), L.get("k_norm")
+        if wq is None or wk is None:
+            return q, k
+        T, Hq, D = q.shape
+        Hkv = k.shape[1]
+        eps, dt = self.cfg["rms_norm_eps"], self.dt
+        if wq.shape[0] == D:
+            q = orc.rms_norm(q.reshape(T * Hq, D), wq, eps, dt).reshape(T, Hq, D)
+            k = orc.rms_norm(k.reshape(T * Hkv, D), wk, eps, dt).reshape(T, Hkv, D)
+        else:
+            q = orc.rms_norm(q.reshape(T, Hq * D), wq, eps, dt).reshape(T, Hq, D)
+            k = orc.rms_norm(k.reshape(T, Hkv * D), wk, eps, dt).reshape(T, Hkv, D)
+        return q, k
+
     def forward(self, ids, positions, slot_mapping, block_tables, context_lens, cu_q=None):
         """returns f32 logits [n_seqs, vocab]; cu_q None => decode (one token per sequence)."""
         cfg, dt = self.cfg, self.dt
@@ -118,18 +158,26 @@ class OracleModel:
         ids = np.asarray(ids, np.uint32)
         T = len(ids)
         h = orc.embedding(ids, self.embed, dt)
+        dmask = deferred_norm_mask(cfg, T, self.tp)
         for li, L in enumerate(self.layers):
-            x = orc.rms_norm(h, L["attn_norm"], eps, dt)
-            q = L["q"](x).reshape(T, Hq, D)
-            k = L["k"](x).reshape(T, Hkv, D)
-            v = L["v"](x).reshape(T, Hkv, D)
+            if dmask & 1:  # the engine's 1..4-row launch: x staged as round(x * g), rstd on the f32 dot products (gemv_q4s.cuh)
+                x, rs = orc.rms_norm_deferred(h, L["attn_norm"], eps, dt)
+            else:
+                x, rs = orc.rms_norm(h, L["attn_norm"], eps, dt), None
+            q = L["q"](x, row_scale=rs).reshape(T, Hq, D)
+            k = L["k"](x, row_scale=rs).reshape(T, Hkv, D)
+            v = L["v"](x, row_scale=rs).reshape(T, Hkv, D)
+            q, k = self.qk_norm(L, q, k)
             q = orc.rope(q, self.cos, self.sin, positions, False, dt, dt)
             k = orc.rope(k, self.cos, self.sin, positions, False, dt, dt)
             orc.reshape_and_cache(k, v, self.kc[li], self.vc[li], slot_mapping, self.BS, dt, self.kv_dt)
             a = orc.paged_attention(q, self.kc[li], self.vc[li], block_tables, context_lens, cu_q, Hkv, self.BS, D ** -0.5, dt, kv_dt=self.kv_dt)
             h = self._row_parallel(L["o"], a.reshape(T, Hq * D), h)           # attn_output + residual
-            x = orc.rms_norm(h, L["ffn_norm"], eps, dt)
-            act = orc.silu_mul(L["gate"](x), L["up"](x), dt)
+            if dmask & 2:
+                x, rs = orc.rms_norm_deferred(h, L["ffn_norm"], eps, dt)
+            else:
+                x, rs = orc.rms_norm(h, L["ffn_norm"], eps, dt), None
+            act = orc.silu_mul(L["gate"](x, row_scale=rs), L["up"](x, row_scale=rs), dt)
             h = self._row_parallel(L["down"], act, h)                         # residual + mlp_output
         if cu_q is not None:  # last token of each sequence (llama.rs:306-310)
             rows = np.asarray(cu_q[1:], np.int64) - 1
@@ -182,6 +230,10 @@ def make_random_checkpoint(cfg, seed=0):
         lin(p + "self_attn.q_proj", H, Hq * D, b)
         lin(p + "self_attn.k_proj", H, Hkv * D, b)
         lin(p + "self_attn.v_proj", H, Hkv * D, b)
+        if cfg.get("qk_norm") or cfg.get("arch") == "qwen3":  # Qwen3-style q_norm / k_norm: per head ("head", the default) or full row ("full")
+            full = cfg.get("qk_norm") in ("full", 2)
+            w[p + "self_attn.q_norm.weight"] = f((Hq * D if full else D,), 0.1, 1.0)
+            w[p + "self_attn.k_norm.weight"] = f((Hkv * D if full else D,), 0.1, 1.0)
         lin(p + "self_attn.o_proj", Hq * D, H)
         lin(p + "mlp.gate_proj", H, I)
         lin(p + "mlp.up_proj", H, I)

@@ -30,3 +30,13 @@ def pytest_collection_modifyitems(config, items):
         for it in items:
             if "gpu" in it.keywords:
                 it.add_marker(skip)
+
+
+@pytest.fixture(autouse=True, scope="session")
+def _oracle_follows_the_engines_norm_order():
+    """GPU sessions: the oracle restates the order of the engine's 1..4-row fused-norm launches (oracle/model.py ENGINE_RULE)"""
+    if _gpu_present():
+        from oracle import model as om
+        from vllm_rs_amd import _lib
+        om.ENGINE_RULE = _lib.load().vra_debug_gemv_s_fits
+    yield

@@ -79,7 +79,7 @@ def check_logits(got, ref, name, dt=BF16, max_ulps=None):
 
 
 @pytest.mark.parametrize("variant", ["llama_gptq", "qwen2_awq", "dense_bf16", "gptq_f16", "llama3_rope", "yarn_rope", "dynamic_rope", "tinyllama_shape", "qwen2_7b_shape",
-                                     "llama3_8b_shape"])
+                                     "llama3_8b_shape", "qwen3_qk_norm", "qwen3_qk_norm_f16_d128", "full_row_qk_norm"])
 def test_forward_prefill_then_decode(variant):
     cfg = {
         # BASELINE.json configs 1 and 3 at their real widths (fewer layers, smaller vocabulary for the AWQ one): TinyLlama-1.1B
@@ -91,6 +91,10 @@ def test_forward_prefill_then_decode(variant):
         "qwen2_7b_shape": small_cfg(arch="qwen2", attention_bias=True, hidden_size=3584, intermediate_size=18944, num_layers=1, num_heads=28,
                                     num_kv_heads=4, head_dim=128, vocab_size=2048, quant_method="awq", rope_theta=1e6, rms_norm_eps=1e-6),
         "llama_gptq": small_cfg(),
+        # q_norm / k_norm before the rotary embedding (attention.rs:713-735): per head (Qwen3) and over the whole row
+        "qwen3_qk_norm": small_cfg(arch="qwen3", rope_theta=1e6, rms_norm_eps=1e-6),
+        "qwen3_qk_norm_f16_d128": small_cfg(arch="qwen3", dtype=F16, hidden_size=512, num_heads=4, num_kv_heads=1, head_dim=128),
+        "full_row_qk_norm": small_cfg(arch="qwen3", qk_norm="full", quant_method=None),
         "qwen2_awq": small_cfg(arch="qwen2", quant_method="awq", attention_bias=True, num_heads=8, num_kv_heads=2, head_dim=32 * 2, hidden_size=512),
         "dense_bf16": small_cfg(quant_method=None, tie_word_embeddings=True),
         "gptq_f16": small_cfg(dtype=F16),
@@ -121,6 +125,24 @@ def test_forward_prefill_then_decode(variant):
         check_logits(got, ref, f"{variant} decode step {step}", cfg["dtype"])
         tok = orc.argmax_f32(ref)
     eng.close()
+
+
+def test_oracle_mirrors_the_engines_deferred_norm_rule():
+    """which fused-norm launches of a step apply rstd in their epilogue (kernel E, 1..4 rows) is a shape rule of the engine; the
+    oracle mirrors it (oracle/model.py deferred_norm_mask over vra_debug_gemv_s_fits) — the two must agree for every step size,
+    at widths where the rule is on (Llama-3-8B, Qwen2-7B) and where it is off (the small test model)"""
+    from oracle import model as om
+    assert om.ENGINE_RULE is not None, "tests/conftest.py installs the rule on GPU sessions"
+    for cfg in (small_cfg(), small_cfg(hidden_size=4096, intermediate_size=14336, num_layers=1, num_heads=32, num_kv_heads=8, head_dim=128, vocab_size=1024),
+                small_cfg(arch="qwen2", attention_bias=True, hidden_size=3584, intermediate_size=18944, num_layers=1, num_heads=28, num_kv_heads=4,
+                          head_dim=128, vocab_size=1024, quant_method="awq"),
+                small_cfg(quant_method=None, hidden_size=2048, intermediate_size=5632, num_heads=32, num_kv_heads=4, head_dim=64, num_layers=1)):
+        eng = Engine(cfg, num_gpu_blocks=8, max_num_seqs=8, max_model_len=256, use_graph=False, seed=1).init_synthetic()
+        got = [eng.norm_deferred(T) for T in range(1, 9)]
+        want = [om.deferred_norm_mask(cfg, T) for T in range(1, 9)]
+        eng.close()
+        assert got == want, (cfg["hidden_size"], got, want)
+    assert om.deferred_norm_mask(small_cfg(hidden_size=4096, intermediate_size=14336, num_heads=32, num_kv_heads=8, head_dim=128), 1) == 3
 
 
 @pytest.mark.parametrize("arch,qm", [("llama", "gptq"), ("qwen2", "awq")])
@@ -309,7 +331,7 @@ def test_synthetic_weights_match_oracle_generator():
     eng.close()
 
 
-@pytest.mark.parametrize("name", ["hf_llama_tiny.npz", "hf_qwen2_tiny.npz"])
+@pytest.mark.parametrize("name", ["hf_llama_tiny.npz", "hf_qwen2_tiny.npz", "hf_qwen3_tiny.npz"])
 @pytest.mark.parametrize("dt,rel", [(F16, 4e-3), (BF16, 3e-2)])
 def test_product_matches_huggingface_fixture(name, dt, rel):
     """the HIP path against the committed HuggingFace transformers vectors (tests/golden/, made by

@@ -109,8 +109,8 @@ def test_gemv_s_gate_up_pair(M, K, N, awq):
 @pytest.mark.parametrize("dt", [BF16, F16])
 @pytest.mark.parametrize("K,N", [(4096, 6144), (8192, 1280)])
 def test_gemv_s_fused_rms_norm(M, dt, K, N):
-    """RMSNorm fused into the prologue (every wave normalises its own x slices; the only cross-wave step is the 16 x 4 table
-    of partial sums of squares) against the oracle's norm -> GEMM, and against the two separate device calls.  8192 x 1280: the
+    """RMSNorm fused into kernel E (round 5: the factor rstd applied in the epilogue, no cross-wave step before the stream) against
+    the oracle's deferred order, and against the two separate device calls (reference order).  8192 x 1280: the
     q/k/v launch of a Llama-3-70B TP=8 rank — 80 units, fewer than half the CUs (kernel E since round 3)"""
     r = rng(M + dt + N)
     q = make_quant(r, K, N, 128, dt, False)
@@ -119,17 +119,21 @@ def test_gemv_s_fused_rms_norm(M, dt, K, N):
     t = _tiled(q)
     out = ops.rms_norm_wna16_gemm(ops.dev(x), ops.dev(nw), 1e-5, t, ops.dev(q["scales"]), None, M, K, N, 128, bias=ops.dev(bias), dtype=dt)
     got = out.numpy(np.uint16, (M, N))
-    xn = orc.rms_norm(x, nw, 1e-5, dt)
-    ref = orc.wna16_gemm(xn, q["idx"], None, q["scales"], 128, dt, bias)
-    g0 = np.abs(orc.from_dt(orc.wna16_gemm(xn, q["idx"], None, q["scales"], 128, dt), dt))
-    # a 1-ulp flip of one normalised activation (f32 vs f64 sum of squares) moves an output by far less than an output ulp;
+    # round 5: kernel E applies the normalisation factor in its EPILOGUE (x staged as round(x * g), rstd on the f32 dot products:
+    # gemv_q4s.cuh) — the oracle's stated second order, orc.rms_norm_deferred + row_scale
+    xg, rs = orc.rms_norm_deferred(x, nw, 1e-5, dt)
+    ref = orc.wna16_gemm(xg, q["idx"], None, q["scales"], 128, dt, bias, row_scale=rs)
+    g0 = np.abs(orc.from_dt(orc.wna16_gemm(xg, q["idx"], None, q["scales"], 128, dt, row_scale=rs), dt))
     # GEMM and + bias are two roundings: a few double flips in 25k outputs
     # (abs_floor: a flipped activation moves an output by ~|w| * ulp(x) whatever the output's own magnitude)
     assert_close_dt(got, ref, dt, max_ulp=2.0, max_mismatch_frac=0.03, name="fused norm gemv", mag=g0, abs_floor=2e-3 if dt == BF16 else 3e-4)
+    # against the reference order (norm, then GEMM, as separate launches: others.rs:11-29): another rounding pattern of the same size —
+    # outputs differ by single roundings of the intermediate
     sep = ops.wna16_gemm(ops.rms_norm(ops.dev(x), ops.dev(nw), M, K, 1e-5, dt), t, ops.dev(q["scales"]), None, M, K, N, 128, bias=ops.dev(bias), dtype=dt)
-    frac = float((got != sep.numpy(np.uint16, (M, N))).mean())
-    print(f"[fused norm] M={M} dt={dt}: {100 * frac:.3f}% of outputs differ from rms_norm + gemm as separate launches")
-    assert frac < 0.01
+    sepv = sep.numpy(np.uint16, (M, N))
+    frac = float((got != sepv).mean())
+    print(f"[fused norm] M={M} dt={dt}: {100 * frac:.3f}% of outputs differ from rms_norm + gemm as separate launches (reference order)")
+    assert_close_dt(got, sepv, dt, max_ulp=2.0, max_mismatch_frac=0.6, name="deferred vs reference order", mag=g0, abs_floor=4e-3 if dt == BF16 else 6e-4)
 
 
 @pytest.mark.parametrize("M", [1, 4])
@@ -140,9 +144,9 @@ def test_gemv_s_fused_rms_norm_gate_up(M):
     x, nw = rand_dt(r, (M, K), BF16, 2.0), orc.to_dt((1.0 + 0.1 * r.standard_normal(K)).astype(np.float32), BF16)
     out = ops.rms_norm_wna16_gate_up_silu(ops.dev(x), ops.dev(nw), 1e-5, _tiled(qg), ops.dev(qg["scales"]), None, _tiled(qu), ops.dev(qu["scales"]), None,
                                           M, K, N, 128)
-    xn = orc.rms_norm(x, nw, 1e-5, BF16)
-    g = orc.wna16_gemm(xn, qg["idx"], None, qg["scales"], 128, BF16)
-    u = orc.wna16_gemm(xn, qu["idx"], None, qu["scales"], 128, BF16)
+    xg, rs = orc.rms_norm_deferred(x, nw, 1e-5, BF16)  # kernel E: rstd in the epilogue (see test_gemv_s_fused_rms_norm)
+    g = orc.wna16_gemm(xg, qg["idx"], None, qg["scales"], 128, BF16, row_scale=rs)
+    u = orc.wna16_gemm(xg, qu["idx"], None, qu["scales"], 128, BF16, row_scale=rs)
     assert_close_dt(out.numpy(np.uint16, (M, N)), orc.silu_mul(g, u, BF16), BF16, max_ulp=3.0, max_mismatch_frac=0.05, name="fused norm gate/up", abs_floor=4e-3)
 
 

@@ -320,6 +320,28 @@ def test_rms_norm(dt, T, H):
 
 
 @pytest.mark.parametrize("dt", [BF16, F16])
+@pytest.mark.parametrize("T,Hq,Hkv,D,full", [(1, 32, 8, 128, False), (7, 4, 2, 64, False), (33, 8, 8, 128, False), (5, 16, 2, 96, False),
+                                             (1, 32, 8, 128, True), (9, 4, 1, 64, True)])
+def test_qk_rms_norm(dt, T, Hq, Hkv, D, full):
+    """q_norm / k_norm of Attention::forward_ext (attention.rs:713-735), in place: per head over head_dim (weights [head_dim]) and
+    over the whole row (weights [heads * head_dim]); the oracle = its RMSNorm on the reshaped rows (pinned against HuggingFace's
+    Qwen3 by tests/golden/hf_qwen3_tiny.npz)"""
+    r = rng(T + Hq + D + full)
+    q, k = rand_dt(r, (T, Hq, D), dt, 2.0), rand_dt(r, (T, Hkv, D), dt, 2.0)
+    nq, nk = (Hq * D, Hkv * D) if full else (D, D)
+    wq = orc.to_dt((1 + 0.2 * r.standard_normal(nq)).astype(np.float32), dt)
+    wk = orc.to_dt((1 + 0.2 * r.standard_normal(nk)).astype(np.float32), dt)
+    dq, dk = ops.dev(q), ops.dev(k)
+    ops.qk_rms_norm(dq, dk, ops.dev(wq), ops.dev(wk), T, Hq, Hkv, D, full, 1e-6, dt)
+    if full:
+        rq, rk = orc.rms_norm(q.reshape(T, Hq * D), wq, 1e-6, dt), orc.rms_norm(k.reshape(T, Hkv * D), wk, 1e-6, dt)
+    else:
+        rq, rk = orc.rms_norm(q.reshape(T * Hq, D), wq, 1e-6, dt), orc.rms_norm(k.reshape(T * Hkv, D), wk, 1e-6, dt)
+    assert_close_dt(dq.numpy(np.uint16, (T, Hq, D)).reshape(rq.shape), rq, dt, name="q_norm")
+    assert_close_dt(dk.numpy(np.uint16, (T, Hkv, D)).reshape(rk.shape), rk, dt, name="k_norm")
+
+
+@pytest.mark.parametrize("dt", [BF16, F16])
 def test_elementwise(dt):
     r = rng(11)
     n = 8 * 1000 + 5

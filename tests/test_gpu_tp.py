@@ -187,37 +187,54 @@ def test_tp8_llama3_70b_widths_one_gpu(monkeypatch):
     cfg = small_cfg(hidden_size=8192, intermediate_size=28672, num_layers=1, num_heads=64, num_kv_heads=8, head_dim=128, vocab_size=1024,
                     rope_theta=500000.0, quant_method="gptq")
     world = 8
-    # eight runner processes + this one on ONE GPU are more than the hardware scheduler keeps resident: a rank can be
-    # descheduled for seconds while its peers spin in the all-reduce (seen: the 4 s bound expiring on the first forward)
-    monkeypatch.setenv("VRA_COMM_TIMEOUT_S", "60")
+    # Eight runner processes + this one on ONE GPU are more than the device keeps running at once: a rank whose kernels are not
+    # scheduled while its peers SPIN in the one-shot exchange arrives late, and the peers' bounded wait expires — a LOUD failure
+    # ("one-shot all-reduce timed out ... [slice j, waiting for rank r: expected epoch e, its flag read e-1]"; tools/tp8_stress.py,
+    # profiles/r05_tp8_stress_*.txt: ranks r..7 then finish normally, every flag and partial of the timed-out ranks is in place).
+    # That starvation is a property of the single-GPU stand-in, not of tensor parallelism with one rank per GPU; it is the ONLY
+    # thing this test gives a fresh attempt for.  A numerical deviation is never retried: it fails with the rank and stage that
+    # first leave the per-stage oracle.
+    monkeypatch.setenv("VRA_COMM_TIMEOUT_S", "30")
     w = om.make_random_checkpoint(cfg, 21)
-    oracle_tp = om.OracleModel(cfg, w, num_blocks=16, tp_world=world)
-    oracle_st = om.OracleModel(cfg, w, num_blocks=16, tp_world=world)  # its own KV cache: the per-stage oracle of a failing step
-    oracle_1 = om.OracleModel(cfg, w, num_blocks=16)
     r = np.random.default_rng(21)
     prompts = [r.integers(1, cfg["vocab_size"] - 1, size=n).tolist() for n in (19, 6)]
     bt = simple_tables([len(p) + 4 for p in prompts])
-    steps = []  # (args of the forward, every rank's logits, every rank's stage snapshots)
-    with TPEngine(cfg, world, devices=[0] * world, transport="ipc", tensors=w, num_gpu_blocks=16, max_num_seqs=8,
-                  max_model_len=cfg["max_position_embeddings"], use_graph=False, timeout=900, snapshots=True) as tp:
-        ids, pos, slots, ctx, cu = prefill_inputs(prompts, bt)
-        args = (ids, pos, slots, bt, ctx, cu)
-        steps.append((args, tp.forward_raw(*args), tp.snapshots()))
-        ref_tp = [oracle_tp.forward(*args)]
-        ref_1 = [oracle_1.forward(*args)]
-        seqs = [list(p) for p in prompts]
-        for step in range(2):
-            nxt = orc.argmax_f32(ref_tp[-1])
-            for s, t in zip(seqs, nxt):
-                s.append(int(t))
-            ids = np.array([s[-1] for s in seqs], np.uint32)
-            pos = np.array([len(s) - 1 for s in seqs], np.int64)
-            slots = np.array([int(bt[b, (len(s) - 1) // 64]) * 64 + (len(s) - 1) % 64 for b, s in enumerate(seqs)], np.int64)
-            ctx = np.array([len(s) for s in seqs], np.uint32)
-            args = (ids, pos, slots, bt, ctx, None)
-            ref_tp.append(oracle_tp.forward(*args))
-            ref_1.append(oracle_1.forward(*args))
-            steps.append((args, tp.forward_raw(*args[:5]), tp.snapshots()))
+
+    def run_once():
+        oracle_tp = om.OracleModel(cfg, w, num_blocks=16, tp_world=world)
+        oracle_1 = om.OracleModel(cfg, w, num_blocks=16)
+        steps = []  # (args of the forward, every rank's logits, every rank's stage snapshots)
+        with TPEngine(cfg, world, devices=[0] * world, transport="ipc", tensors=w, num_gpu_blocks=16, max_num_seqs=8,
+                      max_model_len=cfg["max_position_embeddings"], use_graph=False, timeout=900, snapshots=True) as tp:
+            ids, pos, slots, ctx, cu = prefill_inputs(prompts, bt)
+            args = (ids, pos, slots, bt, ctx, cu)
+            steps.append((args, tp.forward_raw(*args), tp.snapshots()))
+            ref_tp = [oracle_tp.forward(*args)]
+            ref_1 = [oracle_1.forward(*args)]
+            seqs = [list(p) for p in prompts]
+            for step in range(2):
+                nxt = orc.argmax_f32(ref_tp[-1])
+                for s, t in zip(seqs, nxt):
+                    s.append(int(t))
+                ids = np.array([s[-1] for s in seqs], np.uint32)
+                pos = np.array([len(s) - 1 for s in seqs], np.int64)
+                slots = np.array([int(bt[b, (len(s) - 1) // 64]) * 64 + (len(s) - 1) % 64 for b, s in enumerate(seqs)], np.int64)
+                ctx = np.array([len(s) for s in seqs], np.uint32)
+                args = (ids, pos, slots, bt, ctx, None)
+                ref_tp.append(oracle_tp.forward(*args))
+                ref_1.append(oracle_1.forward(*args))
+                steps.append((args, tp.forward_raw(*args[:5]), tp.snapshots()))
+        return steps, ref_tp, ref_1
+
+    for attempt in range(4):
+        try:
+            steps, ref_tp, ref_1 = run_once()
+            break
+        except RuntimeError as e:
+            if "timed out waiting for a peer" not in str(e) or attempt == 3:
+                raise
+            print(f"\nWARNING: attempt {attempt}: a rank was starved behind its spinning peers (single-GPU stand-in), fresh runner processes:\n{str(e)[-900:]}", flush=True)
+    oracle_st = om.OracleModel(cfg, w, num_blocks=16, tp_world=world)  # its own KV cache: the per-stage oracle
     # No retry: a deviation is reported WITH the first stage and rank whose value leaves the per-stage TP oracle —
     # one rank's GEMM partial, the exchange (h_after_* wrong behind correct partials) or an input of the layer (tests/tp_stages.py).
     from tests.tp_stages import first_deviation, oracle_stages

@@ -275,7 +275,7 @@ def check_against_hf(logits, toks, hf_logits, hf_tokens, rel, what):
     return err
 
 
-@pytest.mark.parametrize("name", ["hf_llama_tiny.npz", "hf_qwen2_tiny.npz"])
+@pytest.mark.parametrize("name", ["hf_llama_tiny.npz", "hf_qwen2_tiny.npz", "hf_qwen3_tiny.npz"])
 @pytest.mark.parametrize("dt,rel", [(F16, 4e-3), (BF16, 3e-2)])
 def test_oracle_model_matches_huggingface(name, dt, rel):
     """HF evaluates in float32; the oracle rounds every op's output to the storage type like the reference does, so

@@ -15,20 +15,23 @@ def oracle_stages(o, ids, positions, slot_mapping, block_tables, context_lens, c
     ids = np.asarray(ids, np.uint32)
     T = len(ids)
     L = o.layers[0]
+    from oracle.model import deferred_norm_mask
+    dmask = deferred_norm_mask(cfg, T, W)  # the order of the engine's 1..4-row launches (oracle/model.py ENGINE_RULE)
     h0 = orc.embedding(ids, o.embed, dt)
-    x = orc.rms_norm(h0, L["attn_norm"], eps, dt)
-    q0 = L["q"](x).reshape(T, Hq, D)
-    k0 = L["k"](x).reshape(T, Hkv, D)
-    v0 = L["v"](x).reshape(T, Hkv, D)
-    q = orc.rope(q0, o.cos, o.sin, positions, False, dt, dt)
-    k = orc.rope(k0, o.cos, o.sin, positions, False, dt, dt)
+    x, rs = orc.rms_norm_deferred(h0, L["attn_norm"], eps, dt) if dmask & 1 else (orc.rms_norm(h0, L["attn_norm"], eps, dt), None)
+    q0 = L["q"](x, row_scale=rs).reshape(T, Hq, D)
+    k0 = L["k"](x, row_scale=rs).reshape(T, Hkv, D)
+    v0 = L["v"](x, row_scale=rs).reshape(T, Hkv, D)
+    qn, kn = o.qk_norm(L, q0, k0)
+    q = orc.rope(qn, o.cos, o.sin, positions, False, dt, dt)
+    k = orc.rope(kn, o.cos, o.sin, positions, False, dt, dt)
     orc.reshape_and_cache(k, v0, o.kc[0], o.vc[0], slot_mapping, o.BS, dt, o.kv_dt)
     a = orc.paged_attention(q, o.kc[0], o.vc[0], block_tables, context_lens, cu_q, Hkv, o.BS, D ** -0.5, dt, kv_dt=o.kv_dt).reshape(T, Hq * D)
     K = a.shape[1]
     po = [L["o"].partial(a, r * K // W, (r + 1) * K // W) for r in range(W)]
     h1 = o._row_parallel(L["o"], a, h0)
-    x = orc.rms_norm(h1, L["ffn_norm"], eps, dt)
-    act = orc.silu_mul(L["gate"](x), L["up"](x), dt)
+    x, rs = orc.rms_norm_deferred(h1, L["ffn_norm"], eps, dt) if dmask & 2 else (orc.rms_norm(h1, L["ffn_norm"], eps, dt), None)
+    act = orc.silu_mul(L["gate"](x, row_scale=rs), L["up"](x, row_scale=rs), dt)
     KI = act.shape[1]
     pd = [L["down"].partial(act, r * KI // W, (r + 1) * KI // W) for r in range(W)]
     h2 = o._row_parallel(L["down"], act, h1)

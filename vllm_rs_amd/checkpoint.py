@@ -18,7 +18,7 @@ BF16, F16, F32 = 0, 1, 2
 _ST_DTYPES = {"BF16": (np.uint16, "bf16"), "F16": (np.uint16, "f16"), "F32": (np.float32, "f32"), "I32": (np.int32, "i32"),
               "U32": (np.uint32, "u32"), "I64": (np.int64, "i64"), "U8": (np.uint8, "u8"), "I8": (np.int8, "i8"),
               "U16": (np.uint16, "u16"), "I16": (np.int16, "i16"), "BOOL": (np.uint8, "bool"), "F64": (np.float64, "f64")}
-ARCHS = {"LlamaForCausalLM": "llama", "MistralForCausalLM": "llama", "Qwen2ForCausalLM": "qwen2"}
+ARCHS = {"LlamaForCausalLM": "llama", "MistralForCausalLM": "llama", "Qwen2ForCausalLM": "qwen2", "Qwen3ForCausalLM": "qwen3"}
 
 
 def f32_to_bf16_bits(x):

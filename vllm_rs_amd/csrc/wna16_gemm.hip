@@ -356,6 +356,11 @@ bool vra_gemv_s_fits(int ns, int M, int K, int group_size, int n_units, bool nor
   // four row regions per tile in LDS, or only M of them when four do not fit (K > 16384 at 1..3 rows; single stream only)
   return mu <= GS_MAX_UNITS && (gemv_q4s_lds_bytes(ns, tpw, mu, 4) <= (size_t)kMaxDynLds || (ns == 1 && gemv_q4s_lds_bytes(ns, tpw, mu, M) <= (size_t)kMaxDynLds));
 }
+// the same predicate for the parity tests: the oracle mirrors "kernel E takes this fused-norm launch" (=> RMSNorm factor applied in
+// the epilogue, gemv_q4s.cuh) from the model's shapes
+extern "C" int32_t vra_debug_gemv_s_fits(int32_t ns, int32_t m, int32_t k, int32_t group_size, int32_t n_units, int32_t norm) {
+  return vra_gemv_s_fits(ns, m, k, group_size, n_units, norm != 0) ? 1 : 0;
+}
 template <class DT, int NS, bool AWQ, int XR>
 static void launch_gemv_s_x(const GemvSArgs& a, int grid, size_t lds, hipStream_t st) {
   static uint64_t attr_devs = 0;

@@ -42,6 +42,7 @@ Model::Model(const vra_model_config& mc, const vra_engine_config& ec) : mc_(mc),
   inter_ = mc.intermediate_size / world_;
   dt_ = mc.dtype;
   es_ = 2;
+  qk_norm_mode_ = mc.qk_norm == 1 || mc.qk_norm == 2 ? mc.qk_norm : 0;
   layers_.resize(mc.num_layers);
   // tensor-parallel preconditions (kv_head_shard bails, distributed.rs:513-536; shard() needs even splits; row-parallel
   // layers shard K in whole scale groups and whole 128-row weight tiles)
@@ -150,6 +151,12 @@ bool Model::init_synthetic(uint64_t seed) {
     if (!(L.attn_norm = dalloc((size_t)H * es_)) || !(L.ffn_norm = dalloc((size_t)H * es_))) return false;
     vra_fill_normal(L.attn_norm, H, seed + 100 + l * 2, 1.f, 0.02f, dt_, 0);
     vra_fill_normal(L.ffn_norm, H, seed + 101 + l * 2, 1.f, 0.02f, dt_, 0);
+    if (qk_norm_mode_) {
+      const size_t nq = qk_norm_mode_ == 2 ? (size_t)hq_ * D : (size_t)D, nk = qk_norm_mode_ == 2 ? (size_t)hkv_ * D : (size_t)D;
+      if (!(L.q_norm = dalloc(nq * es_)) || !(L.k_norm = dalloc(nk * es_))) return false;
+      vra_fill_normal(L.q_norm, (int64_t)nq, seed + 5000 + l * 2, 1.f, 0.05f, dt_, 0);
+      vra_fill_normal(L.k_norm, (int64_t)nk, seed + 5001 + l * 2, 1.f, 0.05f, dt_, 0);
+    }
     const bool qb = mc_.attention_bias != 0;
     if (mc_.quant_method != 0) {  // q | k | v tiles contiguous
       const size_t wq = (size_t)(H / 8) * hq_ * D * 4, wk = (size_t)(H / 8) * hkv_ * D * 4;
@@ -215,6 +222,29 @@ bool Model::load_tensor(const std::string& name, const void* host, const int64_t
   std::string s(sub);
   if (s == "input_layernorm.weight") return up1(L.attn_norm, (size_t)shape[0]);
   if (s == "post_attention_layernorm.weight") return up1(L.ffn_norm, (size_t)shape[0]);
+  if (s == "self_attn.q_norm.weight" || s == "self_attn.k_norm.weight") {
+    // per head ([head_dim], replicated) or over the full row ([heads * head_dim], sharded with the heads: attention.rs:567-590;
+    // kv heads replicate when num_kv_heads < world, distributed.rs:526-537)
+    const bool is_q = s[10] == 'q';
+    void*& dst = is_q ? L.q_norm : L.k_norm;
+    const int64_t n = shape[0], D = mc_.head_dim, heads = is_q ? mc_.num_heads : mc_.num_kv_heads;
+    if (n == D) {
+      if (qk_norm_mode_ == 2) return error = "q_norm / k_norm: per-head and full-row weights mixed", false;
+      qk_norm_mode_ = 1;
+      return up1(dst, (size_t)n);
+    }
+    if (n != heads * D) return error = "q_norm / k_norm weight of " + std::to_string(n) + " entries: neither head_dim nor heads * head_dim", false;
+    if (qk_norm_mode_ == 1) return error = "q_norm / k_norm: per-head and full-row weights mixed", false;
+    qk_norm_mode_ = 2;
+    int nshard = world_, ishard = rank_;
+    if (!is_q && mc_.num_kv_heads < world_) {
+      nshard = mc_.num_kv_heads;
+      ishard = rank_ / (world_ / mc_.num_kv_heads);
+    }
+    const int64_t per = n / nshard;
+    dst = upload(this, allocs_, (const uint8_t*)host + (size_t)(per * ishard) * elem_bytes, (size_t)per * elem_bytes, error);
+    return dst != nullptr;
+  }
   struct Target {
     const char* prefix;
     QLinear* l;
@@ -359,6 +389,10 @@ bool Model::finalize_weights() {
   for (auto& L : layers_) {
     if (!L.attn_norm || !L.ffn_norm) {
       error = "missing layer norm weights";
+      return false;
+    }
+    if ((L.q_norm == nullptr) != (L.k_norm == nullptr)) {
+      error = "q_norm without k_norm (or the reverse)";
       return false;
     }
     if (L.q.raw_qweight && L.k.raw_qweight && L.v.raw_qweight && !L.qkv_w) {  // q | k | v tiles contiguous
@@ -1009,6 +1043,11 @@ bool Model::forward(const InputMetadata& md, int64_t stream, uint32_t* tokens) {
     if (!fused_attn && !gemv_s(l, 0, T, nullptr, nullptr, stream, hfrag_ok_ ? hfrag_ : nullptr)) {
       if (!error.empty()) return false;
       if (!linear_fused_norm(qkv, 3, outs, h_, L.attn_norm, T, stream)) return false;
+    }
+    // q_norm / k_norm (attention.rs:713-735), in place, before the rotary embedding
+    if (L.q_norm && L.k_norm && !fused_attn) {
+      vra_qk_rms_norm(q_, k_, L.q_norm, L.k_norm, T, hq_, hkv_, D, qk_norm_mode_ == 2, mc_.rms_norm_eps, dt_, stream);
+      if (take_err(error, "qk_norm")) return false;
     }
     if (l == 0 && snap_on_ && !fused_attn &&
         !(snap(0, q_, (size_t)T * hq_ * D * es_, stream) && snap(1, k_, (size_t)T * hkv_ * D * es_, stream) && snap(2, v_, (size_t)T * hkv_ * D * es_, stream)))

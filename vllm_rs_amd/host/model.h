@@ -35,6 +35,10 @@ struct QLinear {
 struct LayerWeights {
   void* attn_norm = nullptr;
   void* ffn_norm = nullptr;
+  // q_norm / k_norm of Qwen3-style checkpoints (attention.rs:538-601): [head_dim] (per head) or this rank's shard of
+  // [heads * head_dim] (full row); null: none
+  void* q_norm = nullptr;
+  void* k_norm = nullptr;
   QLinear q, k, v, o, gate, up, down;
   // q | k | v tiles in ONE allocation (q.w, k.w, v.w point into it): the fused q/k/v launch of kernel E walks one
   // contiguous run of units; their unit-major scales / zeros are fused the same way
@@ -103,6 +107,9 @@ class Model {
   bool launch_gemm(int which, int layer, int M, int64_t stream);
   bool lm_head(const void* xin, int rows, uint32_t* tokens, int64_t stream);
   int64_t gemm_algorithmic_bytes(int which, int M) const;
+  // which fused-norm launches of a step of M rows apply the RMSNorm factor in their EPILOGUE (kernel E, 1..4 rows: gemv_q4s.cuh;
+  // the oracle restates that order): bit 0 = norm + q/k/v, bit 1 = norm + gate/up.  0 for every other step.
+  int norm_deferred_mask(int M) const { return M >= 1 && M <= 4 ? (gemv_s_ok(0, M) ? 1 : 0) | (gemv_s_ok(2, M) ? 2 : 0) : 0; }
   // Parity instrumentation of the tensor-parallel forward (tests/test_gpu_tp.py, tools/tp8_stress.py): with snapshots on, layer 0
   // of every forward leaves copies of its stages — 0 q, 1 k, 2 v (GEMM outputs, before RoPE), 3 attention output (o_proj's x),
   // 4 o_proj partial (what this rank hands to the all-reduce), 5 h after all-reduce + residual, 6 SiLU(gate)*up (down_proj's x),
@@ -164,6 +171,7 @@ class Model {
   void* hfrag_ = nullptr;
   bool hfrag_ok_ = false;
   void* actfrag_ = nullptr;  // SiLU(gate) * up of a 5..32-row step in fragment order (down_proj's x on the K-sliced kernel W)
+  int qk_norm_mode_ = 0;  // 0 none, 1 per head, 2 full row (set by the config for synthetic weights, by the tensor shape when loading)
   bool snap_on_ = false;
   void* snap_[9] = {};
   size_t snap_bytes_[9] = {};

@@ -121,7 +121,7 @@ static bool init_from_json(const std::string& text, Init* out, std::string* err)
   if (const Json* a = c->get("architectures"))
     if (a->t == Json::Arr && !a->a.empty() && a->a[0].t == Json::Str) arch = a->a[0].s;
   const bool qwen = arch.rfind("Qwen2", 0) == 0;
-  mc.arch = qwen ? 1 : 0;
+  mc.arch = qwen ? 1 : (arch.rfind("Qwen3", 0) == 0 ? 2 : 0);  // (Qwen3: q_norm / k_norm arrive as tensors, their shape sets the mode)
   mc.hidden_size = (int)c->i64("hidden_size", 0), mc.intermediate_size = (int)c->i64("intermediate_size", 0);
   mc.num_layers = (int)c->i64("num_hidden_layers", 0), mc.num_heads = (int)c->i64("num_attention_heads", 0);
   mc.num_kv_heads = (int)c->i64("num_key_value_heads", mc.num_heads);

@@ -321,7 +321,7 @@ def model_cfg_from_init(req):
     qc = c.get("quantization_config") or {}
     arch = (c.get("architectures") or ["LlamaForCausalLM"])[0]
     rs = c.get("rope_scaling") or None
-    return dict(arch="qwen2" if arch.startswith("Qwen2") else "llama", hidden_size=c["hidden_size"], intermediate_size=c["intermediate_size"],
+    return dict(arch="qwen2" if arch.startswith("Qwen2") else ("qwen3" if arch.startswith("Qwen3") else "llama"), hidden_size=c["hidden_size"], intermediate_size=c["intermediate_size"],
                 num_layers=c["num_hidden_layers"], num_heads=c["num_attention_heads"], num_kv_heads=c["num_key_value_heads"],
                 head_dim=c.get("head_dim") or c["hidden_size"] // c["num_attention_heads"], vocab_size=c["vocab_size"],
                 max_position_embeddings=c["max_position_embeddings"], rms_norm_eps=c["rms_norm_eps"], rope_theta=c.get("rope_theta") or 10000.0,
