@@ -1,0 +1,9 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+( time timeout 1200 python -m pytest tests/ -x -q -m gpu ) > gpurun_out/r05_c6_pytest_gpu.txt 2>&1
+echo "== rc $?" >> gpurun_out/r05_c6_pytest_gpu.txt
+( time timeout 400 python bench.py ) > gpurun_out/r05_c6_bench.json 2> gpurun_out/r05_c6_bench.err
+echo "== rc $?" >> gpurun_out/r05_c6_bench.err
+true

@@ -62,7 +62,13 @@ struct GemvSArgs {
   int res_ld;
   GemvSSeg seg[GS_MAX_SEG];
   int nseg;
-  int M, K, KT, TPW, gsh;  // KT = K/128, TPW = ceil(KT/16), k >> gsh = scale group
+  int M, K, KT, TPW, gsh;  // KT = K/128, TPW = k-tiles per wave and unit at most (LDS stride of a wave's slices), k >> gsh = scale group
+  // skew (round 5): 0 = wave w owns the k-tiles w, w + 16, ... of every unit (equal shares); d > 0 = CONTIGUOUS shares, the four
+  // waves that start first own d tiles more and the four that start last d fewer than the middle eight.  A 16-wave workgroup's
+  // waves are launched ~0.1 us apart and the four waves of a SIMD are served oldest first: with equal shares the last group
+  // finishes 1.6 us (q/k/v) .. 3.8 us (gate/up) after the first (profiles/r02_timeline_kernel_e.txt), and the final barrier
+  // waits for it with most of the CU's loads no longer in flight
+  int skew;
   int n_units, units_q, units_r;  // workgroup b owns units_q (+1 if b < units_r) units starting at b*units_q + min(b, units_r)
   int dbg;  // VRA_EXP=1: prologue only (timeline tool)
   unsigned long long* ts;
@@ -119,7 +125,13 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
   const int wg = (int)blockIdx.x;
   const int u0 = wg * a.units_q + min(wg, a.units_r);
   const int nu = a.units_q + (wg < a.units_r ? 1 : 0);
-  const int S = (a.dbg & 1) ? 0 : nu * TPW;  // tile-steps of this wave
+  // this wave's share of a unit's k-tiles: CW tiles, the i-th of them k-tile  skew ? O0 + i : wave + 16*i
+  const int kbase = KT >> 4, krem = KT & 15, sk = a.skew;
+  const int wgrp = wave < 4 ? 1 : (wave >= 12 ? -1 : 0);
+  const int CW = kbase + (wave < krem ? 1 : 0) + sk * wgrp;
+  //   (first tile of a contiguous share: the shares of the waves in front of this one)
+  const int O0 = wave * kbase + min(wave, krem) + sk * (wave < 4 ? wave : (wave >= 12 ? 4 - (wave - 12) : 4));
+  const int S = (a.dbg & 1) ? 0 : nu * CW;  // tile-steps of this wave
   GEMV_STAMP(0);
 
   // ---- LDS carve-up
@@ -171,7 +183,7 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
   }
   auto issue = [&](int ui, int ti, u32x4 (&w)[NS], uint32_t (&sc)[NS], uint32_t (&zp)[AWQ ? NS : 1]) {
     const int unit = u0 + ui;
-    const int kt = min(wave + 16 * ti, KT - 1);
+    const int kt = min(sk ? O0 + ti : wave + 16 * ti, KT - 1);
     const int grp = (kt * 128) >> gsh;
     const int ucol = a.marlin ? ((unit >> 2) << 6) + ((unit & 3) << 1) : unit * a.s_unit_stride;  // (even)
     const uint32_t so_w = (uint32_t)(unit * KT + kt) * 1024u;
@@ -186,8 +198,8 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
   };
   int iu = 0, it = 0;  // issue cursor, clamped to the last step
   auto advance_issue = [&]() {
-    const bool last = iu == nu - 1 && it == TPW - 1;
-    const bool wrap = it == TPW - 1;
+    const bool last = iu == nu - 1 && it >= CW - 1;
+    const bool wrap = it >= CW - 1;
     it = last ? it : (wrap ? 0 : it + 1);
     iu = last ? iu : (wrap ? iu + 1 : iu);
   };
@@ -211,15 +223,16 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
       u32x4 xv[4];
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        const int kt = min(wave + 16 * min(t0 + i, TPW - 1), KT - 1);
+        const int ti = min(t0 + i, TPW - 1);
+        const int kt = min(sk ? O0 + ti : wave + 16 * ti, KT - 1);
         xv[i] = *reinterpret_cast<const u32x4*>(xrow + (size_t)kt * 128);
       }
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         const int ti = t0 + i;
         if (ti < TPW) {
-          const bool valid = wave + 16 * ti < KT;
-          if (!valid) xv[i] = u32x4{0u, 0u, 0u, 0u};  // a wave without this k-tile: zero slice (its partial sums are exactly 0)
+          const bool valid = ti < CW;
+          if (!valid) xv[i] = u32x4{0u, 0u, 0u, 0u};  // a tile beyond this wave's share: zero slice (never multiplied: S = nu * CW steps)
           unsigned char* tp = xw + (size_t)ti * TLS;
           *reinterpret_cast<u32x4*>(tp + srg + nn * 16) = xv[i];
           const float s8 = row16_sum(octet_sum<DT>(xv[i]));
@@ -245,7 +258,8 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
     const uint16_t* nwp = static_cast<const uint16_t*>(a.norm_w) + nn * 8;
 #pragma unroll
     for (int i = 0; i < GS_NORM_TPW; i++) {  // (norm => TPW <= GS_NORM_TPW)
-      const int kt = min(wave + 16 * min(i, TPW - 1), KT - 1);
+      const int ti = min(i, TPW - 1);
+      const int kt = min(sk ? O0 + ti : wave + 16 * ti, KT - 1);
       xv[i] = *reinterpret_cast<const u32x4*>(xrow + (size_t)kt * 128);
       nr[i] = *reinterpret_cast<const u32x4*>(nwp + (size_t)kt * 128);
     }
@@ -257,7 +271,7 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
         float f[8], g[8];
         unpack8<DT>(xv[ti], f);
         unpack8<DT>(nr[ti], g);
-        const bool valid = wave + 16 * ti < KT;  // a wave without this k-tile: zero slice (its partial sums are exactly 0)
+        const bool valid = ti < CW;  // a tile beyond this wave's share: zero slice, and nothing of it in the sum of squares
 #pragma unroll
         for (int e = 0; e < 8; e++) {
           ss += valid ? f[e] * f[e] : 0.f;
@@ -321,7 +335,7 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
           for (int e = 0; e < 4; e++) acc[b][e] = fmaf(s, fmaf(-zc, sx[e], ag[b][e]), acc[b][e]);
         }
         GEMV_STAMP(3 + 2 * (s0 + r < 5 ? s0 + r : 5));
-        if (++ct == TPW) {  // end of a unit: park the partial tile (rows 0..3 live in lanes 0..15)
+        if (++ct == CW) {  // end of a unit: park the partial tile (rows 0..3 live in lanes 0..15)
           ct = 0;
           if (oct == 0) {
 #pragma unroll
@@ -334,6 +348,12 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
       }
       issue(iu, it, wb[r], sb[r], zb[r]);  // refill this ring slot with the step D ahead (unconditionally)
       advance_issue();
+    }
+  }
+  if (CW == 0 && oct == 0) {  // a wave without any k-tile (K < 2048): its partial tiles are zeros
+    for (int u = 0; u < nu; u++) {
+#pragma unroll
+      for (int b = 0; b < NS; b++) red[((u * NS + b) * GS_WAVES + wave) * 16 + nn] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
   GEMV_STAMP(15);

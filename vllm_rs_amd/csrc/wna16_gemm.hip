@@ -338,14 +338,25 @@ void vra_gemv_s_plan(int n_units, int* grid, int* q, int* r) {
   *q = n_units / g;
   *r = n_units % g;
 }
+// skew of the k-tile shares of kernel E's waves (gemv_q4s.cuh GemvSArgs::skew): one tile more for the four waves that start first, one
+// fewer for the four that start last — where the middle waves hold at least two tiles, a wave has at least four tile-steps in all
+// (o_proj, one unit of two tiles per workgroup, measured 0.1 us SLOWER with it) and the longest share still fits.  Measured on one
+// box (profiles/r05_ab_kernel_e_skew.txt): bs 1 1.709 -> 1.689 ms per step; a skew of two tiles for down_proj (7 tiles per wave): slower.
+static int gemv_s_skew(int K, bool norm, int max_units) {
+  static const char* e = getenv("VRA_GS_SKEW");  // tuning aid: 0 = equal shares
+  const int KT = K / 128, tpw = (KT + 15) / 16;
+  if ((e && atoi(e) == 0) || KT / 16 < 2 || max_units * (KT / 16) < 4) return 0;
+  return tpw + 1 <= (norm ? GS_NORM_TPW : GS_MAX_TPW) ? 1 : 0;
+}
 bool vra_gemv_s_fits(int ns, int M, int K, int group_size, int n_units, bool norm) {
   static const char* off = getenv("VRA_NO_GEMV_S");
   if (off && off[0] == '1') return false;
   if (M < 1 || M > 4 || K % 128 || K > 128 * 16 * GS_MAX_TPW) return false;
   const int g = group_size > 0 && group_size < K ? group_size : K;
   if (g < K && (g < 128 || (g & (g - 1)))) return false;  // power-of-two groups of >= one k-tile, or channel-wise
-  const int KT = K / 128, tpw = (KT + 15) / 16;
-  if (norm && tpw > GS_NORM_TPW) return false;
+  const int KT = K / 128, tpw0 = (KT + 15) / 16;
+  if (norm && tpw0 > GS_NORM_TPW) return false;
+
   static const char* mu_env = getenv("VRA_GS_MIN_UNITS");  // tuning aid
   // too few n-blocks to spread over the chip without slicing K: kernel A / B.  (A quarter of the CUs, not half, since round 3:
   // the q/k/v launch of a Llama-3-70B TP=8 rank — K = 8192, 80 units — takes 8.7 us here against 12.3 in kernel A.)
@@ -353,6 +364,7 @@ bool vra_gemv_s_fits(int ns, int M, int K, int group_size, int n_units, bool nor
   int grid, q, r;
   vra_gemv_s_plan(n_units, &grid, &q, &r);
   const int mu = q + (r ? 1 : 0);
+  const int tpw = tpw0 + gemv_s_skew(K, norm, mu);  // (the longest share of a wave)
   // four row regions per tile in LDS, or only M of them when four do not fit (K > 16384 at 1..3 rows; single stream only)
   return mu <= GS_MAX_UNITS && (gemv_q4s_lds_bytes(ns, tpw, mu, 4) <= (size_t)kMaxDynLds || (ns == 1 && gemv_q4s_lds_bytes(ns, tpw, mu, M) <= (size_t)kMaxDynLds));
 }
@@ -377,10 +389,11 @@ template <class DT, int NS, bool AWQ>
 static void launch_gemv_s_v(GemvSArgs a, hipStream_t st) {
   const int g = a.K / 128;
   a.KT = g;
-  a.TPW = (a.KT + 15) / 16;
   int grid;
   vra_gemv_s_plan(a.n_units, &grid, &a.units_q, &a.units_r);
   const int mu = a.units_q + (a.units_r ? 1 : 0);
+  a.skew = gemv_s_skew(a.K, a.norm_w != nullptr, mu);
+  a.TPW = (a.KT + 15) / 16 + a.skew;
   const int xrows = gemv_q4s_lds_bytes(NS, a.TPW, mu, 4) <= (size_t)kMaxDynLds ? 4 : a.M;  // (vra_gemv_s_fits: one of the two fits)
   const size_t lds = gemv_q4s_lds_bytes(NS, a.TPW, mu, xrows);
   static const char* exp_env = getenv("VRA_EXP");
