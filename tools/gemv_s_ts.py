@@ -12,7 +12,7 @@ from vllm_rs_amd import engine as E
 cfg = dict(E.LLAMA3_8B)
 cfg["num_layers"] = int(os.environ.get("TS_LAYERS", "8"))
 eng = E.Engine(cfg, max_num_seqs=8, max_model_len=2048, num_gpu_blocks=64, use_graph=False).init_synthetic()
-names = {0: "start", 16: "x in LDS", 1: "ring issued", 18: "norm barrier", 2: "staged", 3: "step0 done", 5: "step1 done", 7: "step2 done", 9: "step3 done",
+names = {0: "start", 16: "x staged", 1: "ring issued", 18: "norm barrier", 2: "staged", 3: "step0 done", 5: "step1 done", 7: "step2 done", 9: "step3 done",
          11: "step4 done", 13: "step5+ done", 15: "loop end", 17: "final barrier", 14: "end"}
 for which in [int(a) for a in sys.argv[1:]] or [1, 2]:
     ms = eng.bench_gemm(which, 1, 50)

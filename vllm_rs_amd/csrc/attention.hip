@@ -392,6 +392,11 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
   FD_STAMP(0);
   const int G = a.Hq / a.Hkv;
   const int b = blockIdx.z, hk = blockIdx.y, split = blockIdx.x;
+  // The sequence's block ids as ONE wave-wide load at kernel entry (lane l: block l), in parallel with ctx / pos / slot; a tile's
+  // block id is then a v_readlane.  (Rounds 1-4 fetched the id of a tile with a load of its own "one tile ahead" — and hipcc sank
+  // that load to its use: every tile started with a dependent round trip, `global_load_dword; s_waitcnt vmcnt(0)` in front of its
+  // K/V loads — profiles/r05_timeline_attn_decode.txt: 1.24 us between the prologue barrier and the first K/V load.)
+  uint32_t blkvec = a.block_tables[(size_t)b * a.max_blocks + min(lane, a.max_blocks - 1)];
   const int ctx = (int)a.context_lens[b];
   const int64_t pos = a.positions[b];
   const int64_t slot = a.slots[b];
@@ -416,7 +421,13 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
     const int T0 = tile << 5;
     return (size_t)b * a.max_blocks + (a.bs_shift >= 0 ? T0 >> a.bs_shift : T0 / a.BS);
   };
-  auto tile_blk = [&](int tile) -> uint32_t { return a.block_tables[tile_blk_index(tile)]; };
+  int vec_base = 0;  // the block index lane 0 of `blkvec` holds
+  auto tile_blk = [&](int tile) -> uint32_t {
+    const int T0 = tile << 5;
+    const int bi = __builtin_amdgcn_readfirstlane(a.bs_shift >= 0 ? T0 >> a.bs_shift : T0 / a.BS);
+    if (bi >= vec_base && bi < vec_base + 64) return (uint32_t)__builtin_amdgcn_readlane((int)blkvec, bi - vec_base);
+    return a.block_tables[tile_blk_index(tile)];  // (not reached: the vector is re-based on the wave's first block below)
+  };
   const kv_t* kcache = static_cast<const kv_t*>(a.kc);
   const kv_t* vcache = static_cast<const kv_t*>(a.vc);
   // the raw loads of one tile (nothing is converted or consumed here: all of them go out back to back)
@@ -435,6 +446,16 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
 #pragma unroll
     for (int t = 0; t < DT16; t++) vr[t] = *reinterpret_cast<const vraw_t*>(vcache + vbase + (size_t)(t * 16 + rq) * a.BS + oct * 8);
   };
+  {
+    // a wave whose tiles reach beyond block 63 (contexts above 4096 tokens at 64-token blocks) re-bases the vector on its own
+    // first block: one dependent load, once per wave (a wave's share never spans more than 64 blocks: <= 16 tiles per wave)
+    const int t_hi = min(kv_w1, ntiles - 1) << 5;
+    if ((a.bs_shift >= 0 ? t_hi >> a.bs_shift : t_hi / a.BS) >= 64) {
+      const int t_lo = min(kv_w0, max(ntiles - 1, 0)) << 5;
+      vec_base = __builtin_amdgcn_readfirstlane(a.bs_shift >= 0 ? t_lo >> a.bs_shift : t_lo / a.BS);
+      blkvec = a.block_tables[(size_t)b * a.max_blocks + min(vec_base + lane, a.max_blocks - 1)];
+    }
+  }
   uint32_t blk_cur = tile_blk(min(kv_w0, max(ntiles - 1, 0)));
   u32x4 ka0[KR], ka1[KR];
   vraw_t va[DT16];
@@ -489,49 +510,49 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
   // DJ 16-byte loads per lane either way); the FP8 cache uses oct*(D/4) + j*8 + e — lane-contiguous, so that a lane's share of a
   // K row (D/4 bytes) is D/64 16-byte loads instead of DJ 8-byte ones (the FP8 cache read half the bytes in the same number
   // of load instructions).  q is laid out to match; the contraction order inside an MFMA changes, nothing else.
-  if constexpr (KV8) {
-    const uint16_t* qp = static_cast<const uint16_t*>(a.q) + ((size_t)b * a.Hq + qhead) * D;
-    const bool first = oct < 2;  // channels oct*(D/4) .. : the first half of the head for oct 0, 1
+  // (round 5) in three steps: the loads of q / cos / sin; the request of this wave's FIRST K/V tile — behind the prologue's own
+  // loads (L2 hits: not queued behind HBM misses), in front of the rotation of q and of the barrier; then the rotation.  The
+  // timeline of the round-4 kernel showed 1.2 us between the barrier and the first K/V load, all of it waiting for and rotating q
+  // (profiles/r05_timeline_attn_decode.txt); the tile's HBM round trip now runs under it.
+  const uint16_t* qp = static_cast<const uint16_t*>(a.q) + ((size_t)b * a.Hq + qhead) * D;
+  constexpr int QJ = KV8 ? DJ : DJ / 2;
+  u32x4 q_a[QJ], q_b[QJ], q_c[QJ], q_s[QJ];
+  const bool first = oct < 2;  // (FP8 map) channels oct*(D/4) .. : the first half of the head for oct 0, 1
 #pragma unroll
-    for (int j = 0; j < DJ; j++) {
-      const int c = oct * (D / 4) + j * 8, cl = c & (HALF - 1);
-      u32x4 va = {0u, 0u, 0u, 0u}, vb = {0u, 0u, 0u, 0u};
-      if (row_valid) {
-        va = *reinterpret_cast<const u32x4*>(qp + c);
-        vb = *reinterpret_cast<const u32x4*>(qp + (first ? c + HALF : c - HALF));
-      }
-      float x1[8], x2[8], cs[8], sn[8], y[8];
-      unpack8<DT>(va, x1);
-      unpack8<DT>(vb, x2);
-      unpack8<DT>(*reinterpret_cast<const u32x4*>(cosp + cl), cs);
-      unpack8<DT>(*reinterpret_cast<const u32x4*>(sinp + cl), sn);
+  for (int j = 0; j < QJ; j++) {
+    const int c = KV8 ? oct * (D / 4) + j * 8 : j * 32 + oct * 8, cl = KV8 ? c & (HALF - 1) : c;
+    q_a[j] = q_b[j] = u32x4{0u, 0u, 0u, 0u};
+    if (row_valid) {
+      q_a[j] = *reinterpret_cast<const u32x4*>(qp + c);
+      q_b[j] = *reinterpret_cast<const u32x4*>(qp + (KV8 ? (first ? c + HALF : c - HALF) : HALF + c));
+    }
+    q_c[j] = *reinterpret_cast<const u32x4*>(cosp + cl);
+    q_s[j] = *reinterpret_cast<const u32x4*>(sinp + cl);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  load_tile(min(kv_w0, max(ntiles - 1, 0)), blk_cur, ka0, ka1, va);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < QJ; j++) {
+    float x1[8], x2[8], cs[8], sn[8];
+    unpack8<DT>(q_a[j], x1);
+    unpack8<DT>(q_b[j], x2);
+    unpack8<DT>(q_c[j], cs);
+    unpack8<DT>(q_s[j], sn);
+    if constexpr (KV8) {
+      float y[8];
 #pragma unroll
       for (int e = 0; e < 8; e++) y[e] = first ? x1[e] * cs[e] - x2[e] * sn[e] : x1[e] * cs[e] + x2[e] * sn[e];
       qf[j] = __builtin_bit_cast(s16x8, pack8<DT>(y));
-    }
-  } else {
-    const uint16_t* qp = static_cast<const uint16_t*>(a.q) + ((size_t)b * a.Hq + qhead) * D;
-#pragma unroll
-    for (int j = 0; j < DJ / 2; j++) {
-      u32x4 va = {0u, 0u, 0u, 0u}, vb = {0u, 0u, 0u, 0u};
-      const int c0 = j * 32 + oct * 8;
-      if (row_valid) {
-        va = *reinterpret_cast<const u32x4*>(qp + c0);
-        vb = *reinterpret_cast<const u32x4*>(qp + HALF + c0);
-      }
-      float x1[8], x2[8], cs[8], sn[8], y1[8], y2[8];
-      unpack8<DT>(va, x1);
-      unpack8<DT>(vb, x2);
-      unpack8<DT>(*reinterpret_cast<const u32x4*>(cosp + c0), cs);
-      unpack8<DT>(*reinterpret_cast<const u32x4*>(sinp + c0), sn);
+    } else {
+      float y1[8], y2[8];
 #pragma unroll
       for (int e = 0; e < 8; e++) {
         y1[e] = x1[e] * cs[e] - x2[e] * sn[e];
         y2[e] = x2[e] * cs[e] + x1[e] * sn[e];
       }
-      const u32x4 r1 = pack8<DT>(y1), r2 = pack8<DT>(y2);
-      qf[j] = __builtin_bit_cast(s16x8, r1);
-      qf[j + DJ / 2] = __builtin_bit_cast(s16x8, r2);
+      qf[j] = __builtin_bit_cast(s16x8, pack8<DT>(y1));
+      qf[j + DJ / 2] = __builtin_bit_cast(s16x8, pack8<DT>(y2));
     }
   }
   FD_STAMP(3);
@@ -650,10 +671,9 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
       DT::mfma(o[t], pfrag, __builtin_bit_cast(s16x8, vv));
     }
   };
-  for (int tile = kv_w0; tile < kv_w1; tile++) {
-    const uint32_t blk = blk_cur;
-    blk_cur = tile_blk(min(tile + 1, ntiles - 1));  // next tile's block id, in flight during this tile
-    load_tile(tile, blk, ka0, ka1, va);
+  if (kv_w0 < kv_w1) compute_tile(kv_w0, ka0, ka1, va);  // (its loads went out in front of the barrier)
+  for (int tile = kv_w0 + 1; tile < kv_w1; tile++) {
+    load_tile(tile, tile_blk(tile), ka0, ka1, va);
     compute_tile(tile, ka0, ka1, va);
   }
   FD_STAMP(8);
