@@ -263,6 +263,10 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
       xv[i] = *reinterpret_cast<const u32x4*>(xrow + (size_t)kt * 128);
       nr[i] = *reinterpret_cast<const u32x4*>(nwp + (size_t)kt * 128);
     }
+    // the ring goes out the moment x and g have landed, BEFORE the staging arithmetic (0.3 us of VALU per wave): -0.4 % of the bs-1
+    // step against issuing it behind the staging (profiles/r05_ab_kernel_e_prologue.txt); issuing it before x is requested loses
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    fill_ring();
     float ss = 0.f;
 #pragma unroll
     for (int ti = 0; ti < GS_NORM_TPW; ti++) {
@@ -286,7 +290,6 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
     const float rsum = row16_sum(ss);  // Σx² of this wave's slices of row min(oct, M-1): met in the epilogue, fixed order
     if (nn == 0) part[wave * 4 + oct] = rsum;
     GEMV_STAMP(16);
-    fill_ring();
     GEMV_STAMP(1);
   }
   GEMV_STAMP(2);
