@@ -84,6 +84,11 @@ def test_parse_config_and_rejections():
         ck.parse_config(hf_config(quantization_config=dict(quant_method="gptq", bits=8)))
     with pytest.raises(ValueError, match="architecture"):
         ck.parse_config(hf_config(architectures=["MixtralForCausalLM"]))
+    with pytest.raises(ValueError, match="sliding_window"):  # Mistral-7B-v0.1: a window the native forward would ignore
+        ck.parse_config(hf_config(architectures=["MistralForCausalLM"], sliding_window=4096, max_position_embeddings=32768))
+    assert ck.parse_config(hf_config(architectures=["MistralForCausalLM"], sliding_window=None))["arch"] == "llama"
+    assert ck.parse_config(hf_config(architectures=["Qwen2ForCausalLM"], sliding_window=131072, use_sliding_window=False))["arch"] == "qwen2"
+    assert ck.parse_config(hf_config(architectures=["Qwen3ForCausalLM"], head_dim=128))["arch"] == "qwen3"
     from vllm_rs_amd.engine import model_config
     mc = model_config(l3)
     assert mc.rope_scaling_type == 2 and mc.rope_factor == 8.0 and mc.num_kv_heads == 1

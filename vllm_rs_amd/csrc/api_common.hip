@@ -159,6 +159,14 @@ int vra_scratch_take_error() {
   if (!s) return 0;
   uint32_t v = 0;
   if (hipMemcpy(&v, s->counters + kCounters, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return 0;
-  if (v) (void)hipMemset(s->counters + kCounters, 0, sizeof(v));
+  // a wait that gave up leaves the exchange state of that launch undefined: the owner cleared a flag it never saw raised and the
+  // late slice may still raise it afterwards — the next launch would then consume stale slabs without waiting.  The
+  // device is idle here (the copy above synchronised): every flag goes back to zero together with the error word.
+  if (v) (void)hipMemset(s->counters, 0, (kCounters + 1) * sizeof(uint32_t));
   return v != 0;
+}
+// the same for callers that read the error word with their own copy (host/engine.cpp): queue the reset of flags + error word
+void vra_scratch_reset_after_error(hipStream_t st) {
+  ScratchSet* s = scratch_for_current_device(false);
+  if (s) (void)hipMemsetAsync(s->counters, 0, (kCounters + 1) * sizeof(uint32_t), st);
 }

@@ -439,6 +439,7 @@ class Engine {
       InputMetadata md = prepare_prefill(ids, &nb);
       if (md.n_tokens < 0) return fail("prefill step exceeds max_step_tokens / max_num_seqs");
       if (!upload_meta(md)) return fail("metadata upload failed");
+      last_graph_ = nullptr;  // (vra_engine_bench_replay replays the decode graph of the MOST RECENT step only: ADVICE r4)
       if (!model_.forward(md, (int64_t)stream_, d_tokens_)) return fail(model_.error);
     } else {
       const int bucket = std::min(batch_bucket(B), max_seqs_);
@@ -456,6 +457,7 @@ class Engine {
         }
       }
       if (!launched) {
+        last_graph_ = nullptr;
         if (!model_.forward(md, (int64_t)stream_, d_tokens_)) return fail(model_.error);
       }
     }
@@ -486,7 +488,7 @@ class Engine {
     }
     if (h_err_[0]) {
       h_err_[0] = 0;
-      (void)hipMemsetAsync(dev_err, 0, 4, stream_);
+      vra_scratch_reset_after_error(stream_);  // flags too: a timed-out exchange leaves them undefined
       return fail("split-K exchange timed out on the device (results of this step are invalid)");
     }
     tokens->assign(h_tokens_, h_tokens_ + B);
@@ -1110,7 +1112,7 @@ extern "C" int32_t vra_engine_forward_raw(void* e, const uint32_t* h_ids, const 
   }
   if (dev_err && en->h_err_[0]) {
     en->h_err_[0] = 0;
-    (void)hipMemsetAsync(dev_err, 0, 4, en->stream_);
+    vra_scratch_reset_after_error(en->stream_);  // flags too: a timed-out exchange leaves them undefined
     en->error = "split-K exchange timed out on the device (results of this forward are invalid)";
     return -1;
   }

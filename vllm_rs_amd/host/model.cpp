@@ -432,8 +432,11 @@ bool Model::finalize_weights() {
   // the lm_head also in tile-major form for the decode GEMV kernels (one contiguous KiB per wave load instead of 16 half lines:
   // gemv.cuh GemvArgs::dense_tiled); the row-major tensor stays for the embedding gather of tied models and the prefill GEMM
   static const char* lt_env = getenv("VRA_LM_HEAD_TILED");
-  if (!(lt_env && lt_env[0] == '0') && !lm_head_.quant && lm_head_.N % 16 == 0 && lm_head_.K % 128 == 0 && !lm_head_tiled_) {
-    if (!(lm_head_tiled_ = dalloc((size_t)lm_head_.N * lm_head_.K * es_))) return false;
+  if (!(lt_env && lt_env[0] == '0') && !lm_head_.quant && lm_head_.N % 16 == 0 && lm_head_.K % 128 == 0) {
+    if (!lm_head_tiled_) {  // (+1 copy of the lm_head in HBM: counted)
+      if (!(lm_head_tiled_ = dalloc((size_t)lm_head_.N * lm_head_.K * es_))) return false;
+      weight_bytes_ += (size_t)lm_head_.N * lm_head_.K * es_;
+    }
     vra_dense_tile_weights(lm_head_.w, lm_head_tiled_, lm_head_.N, lm_head_.K, 0);
     if (const char* e = vra_last_error(); e && e[0]) {
       error = std::string("lm_head tiling: ") + e;
