@@ -16,25 +16,24 @@ from . import oracle as orc
 
 BF16, F16, F32 = 0, 1, 2
 
-# The engine's decode launches of 1..4 rows apply the RMSNorm factor in the GEMV's epilogue (vllm_rs_amd/csrc/gemv_q4s.cuh: rstd
-# commutes with the product; orc.rms_norm_deferred + the row_scale of orc.wna16_gemm restate that order).  WHICH launches of a step
-# take that kernel is a shape rule of the engine; GPU parity runs install it here (tests/conftest.py, tests/full_depth.py:
-# `vra_debug_gemv_s_fits`, checked against the engine's own report by tests/test_gpu_engine.py) so that the oracle restates the
-# order the engine runs.  None (CPU runs, no engine to compare with): the reference order everywhere (others.rs:11-29).
-ENGINE_RULE = None  # callable(ns, rows, K, group_size, n_units, norm) -> bool
+# The engine's fused RMSNorm + int4 GEMV launches apply the RMSNorm factor in the GEMV's EPILOGUE where that saves a pass over x:
+# the 1..4-row decode kernel always (vllm_rs_amd/csrc/gemv_q4s.cuh), and at 5..32 rows the launches whose producer left them
+# ready-made operands (gemv_q4w.cuh, GemvSArgs::pre_*) — rstd commutes with the product; orc.rms_norm_deferred + the row_scale of
+# orc.wna16_gemm restate that order.  WHICH launches of a step do so is a shape rule of the engine; GPU parity runs install the
+# library here (tests/conftest.py, tests/full_depth.py: `vra_debug_norm_deferred_mask`, checked against the engine's own report by
+# tests/test_gpu_engine.py) so that the oracle restates the order the engine runs.  None (CPU runs, no engine to compare with): the
+# reference order everywhere (others.rs:11-29).
+ENGINE_RULE = None  # the loaded library (ctypes)
 
 
-def deferred_norm_mask(cfg, T, tp_world=1):
-    """bit 0: norm + q/k/v of a T-row step in the deferred order, bit 1: norm + gate/up (mirror of Model::norm_deferred_mask)"""
-    if ENGINE_RULE is None or T < 1 or T > 4 or cfg.get("quant_method") not in ("gptq", "awq"):
+def deferred_norm_mask(cfg, T, tp_world=1, layer=1):
+    """bit 0: norm + q/k/v of a T-row step of layer `layer` in the deferred order, bit 1: norm + gate/up (Model::norm_deferred_mask)"""
+    if ENGINE_RULE is None or T < 1 or cfg.get("quant_method") not in ("gptq", "awq"):
         return 0
-    H, D, gs = cfg["hidden_size"], cfg["head_dim"], cfg.get("group_size", 128)
     hq = cfg["num_heads"] // tp_world
     hkv = max(1, cfg["num_kv_heads"] // tp_world)
-    inter = cfg["intermediate_size"] // tp_world
-    if (hq * D) % 16 or (hkv * D) % 16 or inter % 16 or H % 16:
-        return 0
-    return (1 if ENGINE_RULE(1, T, H, gs, (hq + 2 * hkv) * D // 16, 1) else 0) | (2 if ENGINE_RULE(2, T, H, gs, inter // 16, 1) else 0)
+    return int(ENGINE_RULE.vra_debug_norm_deferred_mask(cfg["hidden_size"], cfg["intermediate_size"] // tp_world, hq, hkv, cfg["head_dim"],
+                                                        cfg.get("group_size", 128), 1, int(bool(cfg.get("attention_bias"))), tp_world, T, layer))
 
 
 class Linear:
@@ -158,8 +157,8 @@ class OracleModel:
         ids = np.asarray(ids, np.uint32)
         T = len(ids)
         h = orc.embedding(ids, self.embed, dt)
-        dmask = deferred_norm_mask(cfg, T, self.tp)
         for li, L in enumerate(self.layers):
+            dmask = deferred_norm_mask(cfg, T, self.tp, li)
             if dmask & 1:  # the engine's 1..4-row launch: x staged as round(x * g), rstd on the f32 dot products (gemv_q4s.cuh)
                 x, rs = orc.rms_norm_deferred(h, L["attn_norm"], eps, dt)
             else:

@@ -38,5 +38,5 @@ def _oracle_follows_the_engines_norm_order():
     if _gpu_present():
         from oracle import model as om
         from vllm_rs_amd import _lib
-        om.ENGINE_RULE = _lib.load().vra_debug_gemv_s_fits
+        om.ENGINE_RULE = _lib.load()
     yield

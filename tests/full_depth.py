@@ -82,7 +82,7 @@ def run(cfg, *, n_prompt=32, n_gen=16, seed=1234, use_graph=True, blocks=64, eng
     t_eng = time.perf_counter() - t0
     w = synthetic_checkpoint(cfg, seed)
     t_w = time.perf_counter() - t0 - t_eng
-    om.ENGINE_RULE = eng.L.vra_debug_gemv_s_fits  # the oracle restates the order of the engine's 1..4-row fused-norm launches (oracle/model.py)
+    om.ENGINE_RULE = eng.L  # the oracle restates the order of the engine's 1..4-row fused-norm launches (oracle/model.py)
     oracle = om.OracleModel(dict(cfg, max_position_embeddings=min(cfg["max_position_embeddings"], 2048)), w, num_blocks=blocks)
     del w
     BS = 64

@@ -128,21 +128,24 @@ def test_forward_prefill_then_decode(variant):
 
 
 def test_oracle_mirrors_the_engines_deferred_norm_rule():
-    """which fused-norm launches of a step apply rstd in their epilogue (kernel E, 1..4 rows) is a shape rule of the engine; the
-    oracle mirrors it (oracle/model.py deferred_norm_mask over vra_debug_gemv_s_fits) — the two must agree for every step size,
-    at widths where the rule is on (Llama-3-8B, Qwen2-7B) and where it is off (the small test model)"""
+    """which fused-norm launches of a step apply rstd in their epilogue is a shape rule of the engine (kernel E at 1..4 rows; at 5..32
+    rows the kernel-W launches fed ready-made operands by their producer, per layer); the oracle mirrors it (oracle/model.py
+    deferred_norm_mask over vra_debug_norm_deferred_mask) — the two must agree for every step size and layer, at widths where the
+    rule is on (Llama-3-8B, Qwen2-7B) and where it is off (the small test model, a dense model)"""
     from oracle import model as om
     assert om.ENGINE_RULE is not None, "tests/conftest.py installs the rule on GPU sessions"
-    for cfg in (small_cfg(), small_cfg(hidden_size=4096, intermediate_size=14336, num_layers=1, num_heads=32, num_kv_heads=8, head_dim=128, vocab_size=1024),
-                small_cfg(arch="qwen2", attention_bias=True, hidden_size=3584, intermediate_size=18944, num_layers=1, num_heads=28, num_kv_heads=4,
+    L8 = dict(hidden_size=4096, intermediate_size=14336, num_layers=2, num_heads=32, num_kv_heads=8, head_dim=128, vocab_size=1024)
+    for cfg in (small_cfg(), small_cfg(**L8),
+                small_cfg(arch="qwen2", attention_bias=True, hidden_size=3584, intermediate_size=18944, num_layers=2, num_heads=28, num_kv_heads=4,
                           head_dim=128, vocab_size=1024, quant_method="awq"),
                 small_cfg(quant_method=None, hidden_size=2048, intermediate_size=5632, num_heads=32, num_kv_heads=4, head_dim=64, num_layers=1)):
-        eng = Engine(cfg, num_gpu_blocks=8, max_num_seqs=8, max_model_len=256, use_graph=False, seed=1).init_synthetic()
-        got = [eng.norm_deferred(T) for T in range(1, 9)]
-        want = [om.deferred_norm_mask(cfg, T) for T in range(1, 9)]
+        eng = Engine(cfg, num_gpu_blocks=8, max_num_seqs=32, max_model_len=256, use_graph=False, seed=1).init_synthetic()
+        steps = list(range(1, 9)) + [16, 17, 32, 33, 64, 128, 200, 256, 257, 512]
+        got = [(eng.norm_deferred(T, 0), eng.norm_deferred(T, 1)) for T in steps]
+        want = [(om.deferred_norm_mask(cfg, T, 1, 0), om.deferred_norm_mask(cfg, T, 1, 1)) for T in steps]
         eng.close()
         assert got == want, (cfg["hidden_size"], got, want)
-    assert om.deferred_norm_mask(small_cfg(hidden_size=4096, intermediate_size=14336, num_heads=32, num_kv_heads=8, head_dim=128), 1) == 3
+    assert om.deferred_norm_mask(small_cfg(**L8), 1) == 3 and om.deferred_norm_mask(small_cfg(**L8), 32, 1, 0) == 2 and om.deferred_norm_mask(small_cfg(**L8), 32, 1, 1) == 3
 
 
 @pytest.mark.parametrize("arch,qm", [("llama", "gptq"), ("qwen2", "awq")])

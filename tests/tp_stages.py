@@ -16,7 +16,7 @@ def oracle_stages(o, ids, positions, slot_mapping, block_tables, context_lens, c
     T = len(ids)
     L = o.layers[0]
     from oracle.model import deferred_norm_mask
-    dmask = deferred_norm_mask(cfg, T, W)  # the order of the engine's 1..4-row launches (oracle/model.py ENGINE_RULE)
+    dmask = deferred_norm_mask(cfg, T, W, 0)  # (layer 0) the order of the engine's 1..4-row launches (oracle/model.py ENGINE_RULE)
     h0 = orc.embedding(ids, o.embed, dt)
     x, rs = orc.rms_norm_deferred(h0, L["attn_norm"], eps, dt) if dmask & 1 else (orc.rms_norm(h0, L["attn_norm"], eps, dt), None)
     q0 = L["q"](x, row_scale=rs).reshape(T, Hq, D)

@@ -1,0 +1,6 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+( time timeout 150 python tools/pre_dbg.py 31 ) > gpurun_out/r05_c17_pre_dbg.txt 2>&1
+true

@@ -92,7 +92,20 @@ struct GemvSArgs {
   float* slabs;
   uint32_t* counters;
   uint32_t* err;
+  // kernel W, steps of 5..32 rows (round 5): READY-MADE OPERANDS for the next fused-norm launch.  Every workgroup of a norm + q/k/v
+  // or norm + gate/up launch used to normalise the whole [32, K] x for itself — X.X^T MFMAs, a barrier, ~900 VALU instructions per
+  // wave, two waves per SIMD: 3.5 of the 12 us of the q/k/v launch (profiles/r05_timeline_kernel_w.txt; with that work skipped a
+  // bs-32 step drops from 2.69 to 2.30 ms, profiles/r05_probe_kernel_w_without_norm.txt).  rstd commutes with the GEMM, so the
+  // PRODUCER of the hidden state (o_proj / down_proj epilogue: it holds the rows in LDS anyway) writes them a second time as
+  // x̃ = round(h * g_next) in fragment order plus its workgroup's partial sums of squares per row, and the consumer loads finished
+  // MFMA operands, adds the partial sums in a fixed order and multiplies its f32 dot products by rstd in the epilogue — the
+  // order kernel E uses (gemv_q4s.cuh header), restated by the oracle's deferred variant.
+  const void* pre_norm_w;  // producer: the NEXT launch's RMSNorm weights, [columns of this launch]; null: nothing of this
+  void* pre_frag;          //   x̃ in fragment order (the layout of out_frag)
+  float* pre_sq;           //   [GW_PRE_PARTS][32 rows] partial sums of squares, slot = this workgroup (slots never written stay 0)
+  const float* x_sq;       // consumer (NORM launch whose x_frag holds x̃): the producers' partial sums, [GW_PRE_PARTS][32]
 };
+#define GW_PRE_PARTS 256  // slots of the partial-sum table: one per producing workgroup (grid <= CUs), unused ones zero
 
 static inline size_t gemv_q4s_lds_bytes(int ns, int tpw, int max_units, int xrows = 4) {
   return (size_t)GS_WAVES * tpw * (xrows * 272 + 16) + 256 + (size_t)max_units * ns * GS_WAVES * 256;

@@ -230,7 +230,27 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
   // D layout the fix-up reads (lane (oct, ·): rows oct*4 .. +3).  The round-1 VALU form (convert + fma per element, convert +
   // add + two ds_bpermute per tile) was ~1250 VALU instructions per wave at 32 rows — x 2 waves per SIMD x 4 cycles: the
   // launch was VALU-bound BEFORE its first weight MFMA (tools/gemv_w_ts.py: 10 of 18.6 µs of the q/k/v launch).
-  if (norm) {
+  const bool pre = NORM && a.x_sq != nullptr;  // the fragments already hold x̃ = round(h * g): no normalisation here
+  if (norm && pre) {
+    // the producers' partial sums of squares -> `part` (what the epilogue reads), fixed order: wave w adds the slots
+    // [32w, 32w + 32) — lane (r4 = lane & 7, pl = lane >> 3) rows 4*r4 .. +3 of the slots 32w + pl + 8j, j ascending — then the
+    // eight pl of a wave by xor-shuffles (8, 16, 32)
+    const int r4 = lane & 7, pl = lane >> 3;
+    f32x4 sq[GW_PRE_PARTS / 64];
+#pragma unroll
+    for (int j = 0; j < GW_PRE_PARTS / 64; j++)
+      sq[j] = *reinterpret_cast<const f32x4*>(a.x_sq + (size_t)(wave * (GW_PRE_PARTS / 8) + pl + 8 * j) * 32 + r4 * 4);
+    f32x4 t = sq[0];
+#pragma unroll
+    for (int j = 1; j < GW_PRE_PARTS / 64; j++) t += sq[j];
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) t[e] += __shfl_xor(t[e], o, 64);
+    }
+    if (pl == 0) *reinterpret_cast<f32x4*>(part + wave * 32 + r4 * 4) = t;
+  }
+  if (norm && !pre) {
     f32x4 g2[GW_TPW][MT];
 #pragma unroll
     for (int ti = 0; ti < GW_TPW; ti++)  // (a chain per tile: a tile this wave does not have is masked on the VALU side)
@@ -373,6 +393,14 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
       if constexpr (KZ) {  // the slice's partial tile waits in LDS; exchange and epilogue run after the stream
         outf[ui * OPU + tid] = v;
       } else {
+        if (NORM && pre) {  // the deferred normalisation factor of this row, on the f32 dot products
+          float tot = 0.f;
+#pragma unroll
+          for (int w = 0; w < GW_WAVES; w++) tot += part[w * 32 + row];
+          const float rstd = 1.0f / sqrtf(tot / (float)a.K + a.eps);
+          v *= rstd;
+          if (NS == 2) v2 *= rstd;
+        }
         const float bias = DT::to_f32(biass[(ui * NS + 0) * 16 + col]);
         v = rnd_dt<DT>(v);
         if (any_bias) v = rnd_dt<DT>(v + bias);  // (a segment without a bias was staged as +0: adding it changes nothing but the sign of -0)
@@ -476,6 +504,37 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
       const int n = (PSEQ ? (u0 + ui) >> 1 : u0 + ui) * 16 + col;  // (single-segment launch: the launch-wide column is the output column)
       static_cast<u32x4*>(a.out_frag)[(size_t)((((n >> 7) * 2 + (row >> 4)) * 4 + ((n >> 5) & 3)) * 64) + ((n >> 3) & 3) * 16 + (row & 15)] =
           *reinterpret_cast<const u32x4*>(outs + idx);
+    }
+  }
+  if (a.pre_norm_w && gridDim.y == 1 && !PSEQ) {
+    // ---- ready-made operands for the next fused-norm launch (GemvSArgs::pre_*): x̃ = round(out * g_next) in fragment order ...
+    for (int i8 = tid; i8 < nu * OPU / 8; i8 += GW_THREADS) {
+      const int idx = i8 * 8, ui = idx / OPU, rem = idx - ui * OPU, row = rem >> 4, col = rem & 15;
+      if (row >= M) continue;
+      const int n = (u0 + ui) * 16 + col;
+      float f[8], g[8];
+      unpack8<DT>(*reinterpret_cast<const u32x4*>(outs + idx), f);
+      unpack8<DT>(*reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.pre_norm_w) + n), g);
+#pragma unroll
+      for (int e = 0; e < 8; e++) f[e] *= g[e];
+      static_cast<u32x4*>(a.pre_frag)[(size_t)((((n >> 7) * 2 + (row >> 4)) * 4 + ((n >> 5) & 3)) * 64) + ((n >> 3) & 3) * 16 + (row & 15)] = pack8<DT>(f);
+    }
+    // ... and this workgroup's share of the rows' sums of squares (of the ROUNDED outputs, what the reference's norm would read):
+    // thread r adds the columns of row r in order; rows beyond M: 0
+    if (tid < 32) {
+      float s2 = 0.f;
+      if (tid < M) {
+        for (int ui = 0; ui < nu; ui++) {
+#pragma unroll
+          for (int c8 = 0; c8 < 2; c8++) {
+            float f[8];
+            unpack8<DT>(*reinterpret_cast<const u32x4*>(outs + ui * OPU + tid * 16 + c8 * 8), f);
+#pragma unroll
+            for (int e = 0; e < 8; e++) s2 = fmaf(f[e], f[e], s2);
+          }
+        }
+      }
+      a.pre_sq[(size_t)wg * 32 + tid] = s2;
     }
   }
   GEMV_STAMP(15);

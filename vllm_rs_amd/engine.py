@@ -233,9 +233,9 @@ class Engine:
 
     TP_STAGES = ("q", "k", "v", "attn", "o_partial", "h_after_o", "act", "down_partial", "h_after_down")
 
-    def norm_deferred(self, rows):
-        """bit 0 / bit 1: the norm + q/k/v / norm + gate/up launch of a step of `rows` rows applies rstd in its epilogue"""
-        return int(self.L.vra_engine_norm_deferred(self.h, int(rows)))
+    def norm_deferred(self, rows, layer=1):
+        """bit 0 / bit 1: the norm + q/k/v / norm + gate/up launch of a step of `rows` rows of layer `layer` applies rstd in its epilogue"""
+        return int(self.L.vra_engine_norm_deferred(self.h, int(rows), int(layer)))
 
     def tp_snapshots(self, on=True):
         """parity instrumentation: keep copies of layer 0's stages of every forward (vra_engine_debug_tp_snapshots)"""

@@ -799,9 +799,9 @@ extern "C" int32_t vra_engine_copy_logits(void* e, float* h_out, int32_t n_seqs)
 }
 // which fused-norm launches of a step of `rows` rows use the deferred order (model.h norm_deferred_mask): what the parity tests ask
 // the engine so that the oracle restates the order the engine actually runs
-extern "C" int32_t vra_engine_norm_deferred(void* e, int32_t rows) {
+extern "C" int32_t vra_engine_norm_deferred(void* e, int32_t rows, int32_t layer) {
   auto* en = static_cast<Engine*>(e);
-  return en->dry() ? 0 : en->model_.norm_deferred_mask(rows);
+  return en->dry() ? 0 : en->model_.norm_deferred_mask(rows, layer);
 }
 // parity instrumentation of the tensor-parallel forward (model.h `set_tp_snapshots`): stage copies of layer 0, read back per stage
 extern "C" void vra_engine_debug_tp_snapshots(void* e, int32_t on) { static_cast<Engine*>(e)->model_.set_tp_snapshots(on != 0); }

@@ -492,6 +492,10 @@ bool Model::init_buffers(int max_tokens, int max_seqs) {
   if (H % 128 == 0) {
     const size_t fb = (size_t)(H / 128) * 2 * 4096;
     if (!(hfrag_ = dalloc(fb)) || hipMemset(hfrag_, 0, fb) != hipSuccess) return false;
+    const size_t sqb = (size_t)GW_PRE_PARTS * 32 * sizeof(float);
+    if (!(pre_o_ = dalloc(fb)) || hipMemset(pre_o_, 0, fb) != hipSuccess || !(pre_d_ = dalloc(fb)) || hipMemset(pre_d_, 0, fb) != hipSuccess) return false;
+    if (!(sq_o_ = (float*)dalloc(sqb)) || hipMemset(sq_o_, 0, sqb) != hipSuccess || !(sq_d_ = (float*)dalloc(sqb)) || hipMemset(sq_d_, 0, sqb) != hipSuccess)
+      return false;
   }
   if (inter_ % 128 == 0) {
     const size_t fb = (size_t)(inter_ / 128) * 2 * 4096;
@@ -772,16 +776,50 @@ static void gemv_s_shape(const LayerWeights& L, int which, int* K, int* units, i
     default: *K = L.down.K, *units = L.down.N / 16, *ns = 1, *norm = false; break;
   }
 }
+// "the decode GEMV family (kernels E / W) takes launch `which` of an M-row step", from shapes: shared by the model and by the parity
+// tests' mirror of the norm order (vra_debug_norm_deferred_mask); `bias`: the launch's projection(s) carry a bias
+static bool family_takes(int which, int M, int H, int inter, int hq, int hkv, int D, int group_size, bool bias) {
+  const int nq = hq * D, nkv = hkv * D;
+  if ((nq | nkv | H | inter) % 16) return false;
+  int K, units, ns;
+  bool norm;
+  switch (which) {
+    case 0: K = H, units = (nq + 2 * nkv) / 16, ns = 1, norm = true; break;
+    case 1: K = nq, units = H / 16, ns = 1, norm = false; break;
+    case 2: K = H, units = inter / 16, ns = 2, norm = true; break;
+    default: K = inter, units = H / 16, ns = 1, norm = false; break;
+  }
+  return vra_gemv_s_fits(ns, M, K, group_size, units, norm) || vra_gemv_w_fits(ns, M, K, group_size, units, which == 1 || which == 3, bias, norm || which == 0);
+}
 bool Model::gemv_s_ok(int which, int M) const {
   const LayerWeights& L = layers_[0];
   if (!L.q.quant || !L.qkv_s_um || !L.o.s_um || !L.gate.s_um || !L.up.s_um || !L.down.s_um) return false;
-  if ((L.q.N | L.k.N | L.v.N | L.o.N | L.gate.N | L.down.N) % 16) return false;
-  int K, units, ns;
-  bool norm;
-  gemv_s_shape(L, which, &K, &units, &ns, &norm);
-  return vra_gemv_s_fits(ns, M, K, mc_.group_size, units, norm) || vra_gemv_w_fits(ns, M, K, mc_.group_size, units, which == 1 || which == 3,
-                         which == 0 ? (L.q.bias || L.k.bias || L.v.bias) : (which == 2 ? (L.gate.bias || L.up.bias) : (which == 1 ? L.o.bias != nullptr : L.down.bias != nullptr)),
-                         norm || which == 0);
+  const bool bias = which == 0 ? (L.q.bias || L.k.bias || L.v.bias) : (which == 2 ? (L.gate.bias || L.up.bias) : (which == 1 ? L.o.bias != nullptr : L.down.bias != nullptr));
+  return family_takes(which, M, mc_.hidden_size, inter_, hq_, hkv_, mc_.head_dim, mc_.group_size, bias);
+}
+// which fused-norm launches of an M-row step of layer `layer` apply the RMSNorm factor in their epilogue (model.h); takes(which) =
+// "the family takes launch `which` of this step"
+template <class F>
+static int norm_deferred_rule(int M, int layer, int H, int world, bool x_frag_on, F takes) {
+  if (M < 1) return 0;
+  if (M <= 4) return (takes(0) ? 1 : 0) | (takes(2) ? 2 : 0);  // kernel E
+  // kernel W, 5..32 rows: the launches whose producer (a kernel-W o_proj / down_proj of the same step) left ready-made operands
+  if (!x_frag_on || M > 32 || world != 1 || H % 128) return 0;
+  int m = 0;
+  if (takes(1) && takes(2)) m |= 2;
+  if (layer >= 1 && takes(3) && takes(0)) m |= 1;
+  return m;
+}
+int Model::norm_deferred_mask(int M, int layer) const {
+  return norm_deferred_rule(M, layer, mc_.hidden_size, world_, g_x_frag && hfrag_ && pre_o_ && pre_d_, [&](int which) { return gemv_s_ok(which, M); });
+}
+// the same from shapes alone (Llama / Qwen2 / Qwen3 checkpoints: q/k/v biases only), for the oracle (oracle/model.py deferred_norm_mask)
+extern "C" int32_t vra_debug_norm_deferred_mask(int32_t hidden, int32_t inter_local, int32_t heads_local, int32_t kv_heads_local, int32_t head_dim,
+                                                int32_t group_size, int32_t quant, int32_t qkv_bias, int32_t world, int32_t rows, int32_t layer) {
+  if (!quant) return 0;
+  return norm_deferred_rule(rows, layer, hidden, world, g_x_frag != 0, [&](int which) {
+    return family_takes(which, rows, hidden, inter_local, heads_local, kv_heads_local, head_dim, group_size, which == 0 && qkv_bias != 0);
+  });
 }
 // the argument block of decode GEMV `which` of layer l (shared by the single launch and the two-phase launch)
 void Model::gemv_s_args(int l, int which, int M, void* out, const void* residual, GemvSArgs* ap, int* nsp) {
@@ -852,13 +890,17 @@ bool Model::qkv_attn(int l, const InputMetadata& md, int64_t stream) {
   return !take_err(error, "qkv_attn");
 }
 #endif
-bool Model::gemv_s(int l, int which, int M, void* out, const void* residual, int64_t stream, const void* x_frag, void* out_frag) {
+bool Model::gemv_s(int l, int which, int M, void* out, const void* residual, int64_t stream, const void* x_frag, void* out_frag, const PreOps* pre) {
   if (!gemv_s_ok(which, M)) return false;
   const LayerWeights& L = layers_[l];
   GemvSArgs a;
   int ns;
   gemv_s_args(l, which, M, out, residual, &a, &ns);
   if (M > 4 && M <= 32) a.x_frag = x_frag, a.out_frag = out_frag;  // kernel W only (1..4 rows: kernel E reads and writes row-major)
+  if (pre && M > 4 && M <= 32) {
+    if (pre->consume) a.x_frag = pre->frag, a.x_sq = pre->sq;  // the fragments hold x̃ = round(h * g): rstd in the epilogue
+    else a.pre_norm_w = pre->next_norm_w, a.pre_frag = pre->frag, a.pre_sq = pre->sq;
+  }
   if (M > 4) vra_launch_gemv_w(a, ns, mc_.group_size, L.q.awq, dt_, stream);  // kernel W: 5..32 rows, K <= 4096
   else vra_launch_gemv_s(a, ns, mc_.group_size, L.q.awq, dt_, stream);
   return !take_err(error, "gemv_s");
@@ -1024,6 +1066,7 @@ bool Model::forward(const InputMetadata& md, int64_t stream, uint32_t* tokens) {
   const bool use_frag = g_x_frag && hfrag_ && T > 4 && T <= 32 && world_ == 1;
   vra_embedding_bump(md.input_ids, embed_, h_, T, H, mc_.vocab_size, dt_, epoch_, use_frag ? hfrag_ : nullptr, stream);
   hfrag_ok_ = use_frag;
+  pre_o_ok_ = pre_d_ok_ = false;
 #ifdef VRA_EXPERIMENTS
   // decode of 1..2 sequences at short contexts: all layers in ONE persistent launch (experiments/csrc/decode_step.hip)
   const bool one_launch = !md.is_prefill && B == T && decode_step_ok(T, md.max_context_len);
@@ -1043,7 +1086,9 @@ bool Model::forward(const InputMetadata& md, int64_t stream, uint32_t* tokens) {
     const bool fused_attn = false;
 #endif
     if (!fused_attn && !error.empty()) return false;
-    if (!fused_attn && !gemv_s(l, 0, T, nullptr, nullptr, stream, hfrag_ok_ ? hfrag_ : nullptr)) {
+    PreOps take_d;  // x̃ of this layer's attention norm, left by the previous layer's down_proj (5..32 rows, kernel W)
+    take_d.consume = true, take_d.frag = pre_d_, take_d.sq = sq_d_;
+    if (!fused_attn && !gemv_s(l, 0, T, nullptr, nullptr, stream, hfrag_ok_ ? hfrag_ : nullptr, nullptr, pre_d_ok_ ? &take_d : nullptr)) {
       if (!error.empty()) return false;
       if (!linear_fused_norm(qkv, 3, outs, h_, L.attn_norm, T, stream)) return false;
     }
@@ -1082,13 +1127,19 @@ bool Model::forward(const InputMetadata& md, int64_t stream, uint32_t* tokens) {
     } else {
       // o_proj writes h: on kernel W (5..32 rows) also its fragment-order copy; any other kernel leaves the copy stale
       if (!error.empty()) return false;
-      const bool w_o = gemv_s(l, 1, T, h_, h_, stream, attn_frag ? afrag_ : nullptr, use_frag ? hfrag_ : nullptr);
+      PreOps make_o;  // ... which also leaves x̃ = round(h * ffn_norm) + the partial sums of squares for the gate/up launch
+      make_o.next_norm_w = L.ffn_norm, make_o.frag = pre_o_, make_o.sq = sq_o_;
+      const bool w_o = gemv_s(l, 1, T, h_, h_, stream, attn_frag ? afrag_ : nullptr, use_frag ? hfrag_ : nullptr, use_frag && pre_o_ ? &make_o : nullptr);
       if (!error.empty()) return false;
       hfrag_ok_ = use_frag && w_o;
+      pre_o_ok_ = use_frag && w_o && pre_o_ != nullptr;
       if (!w_o && !linear(L.o, attn_, h_, T, h_, stream)) return false;
     }
     // ---- MLP block (llama.rs:127-130)
-    const bool w_gu = gemv_s(l, 2, T, nullptr, nullptr, stream, hfrag_ok_ ? hfrag_ : nullptr, use_frag ? actfrag_ : nullptr);
+    PreOps take_o;
+    take_o.consume = true, take_o.frag = pre_o_, take_o.sq = sq_o_;
+    const bool w_gu = gemv_s(l, 2, T, nullptr, nullptr, stream, hfrag_ok_ ? hfrag_ : nullptr, use_frag ? actfrag_ : nullptr, pre_o_ok_ ? &take_o : nullptr);
+    pre_o_ok_ = false;
     if (!w_gu && (!error.empty() || !gate_up(L, h_, L.ffn_norm, act_, T, stream))) return false;
     if (l == 0 && !snap(6, act_, (size_t)T * inter_ * es_, stream)) return false;
     if (world_ > 1) {
@@ -1100,9 +1151,14 @@ bool Model::forward(const InputMetadata& md, int64_t stream, uint32_t* tokens) {
     } else {
       // down_proj writes h: kernel E at 1..4 rows (no copy), kernel C with the fragment-order copy at 5..32, anything else: stale
       if (!error.empty()) return false;
-      const bool e_d = gemv_s(l, 3, T, h_, h_, stream, use_frag && w_gu && actfrag_ ? actfrag_ : nullptr, use_frag ? hfrag_ : nullptr);
+      PreOps make_d;  // x̃ for the NEXT layer's q/k/v (the last layer's consumer is the final norm of the lm_head launch: nothing)
+      const bool has_next = l + 1 < mc_.num_layers;
+      if (has_next) make_d.next_norm_w = layers_[l + 1].attn_norm, make_d.frag = pre_d_, make_d.sq = sq_d_;
+      const bool e_d = gemv_s(l, 3, T, h_, h_, stream, use_frag && w_gu && actfrag_ ? actfrag_ : nullptr, use_frag ? hfrag_ : nullptr,
+                              use_frag && has_next && pre_d_ ? &make_d : nullptr);
       if (!error.empty()) return false;
       bool wrote = e_d && T > 4;  // (kernel W, K-sliced: writes the fragment copy; kernel E at 1..4 rows does not)
+      pre_d_ok_ = use_frag && has_next && e_d && T > 4 && pre_d_ != nullptr;
       if (!e_d && !linear(L.down, act_, h_, T, h_, stream, true, use_frag ? hfrag_ : nullptr, &wrote)) return false;
       hfrag_ok_ = use_frag && wrote;
     }

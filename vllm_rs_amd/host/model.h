@@ -107,9 +107,11 @@ class Model {
   bool launch_gemm(int which, int layer, int M, int64_t stream);
   bool lm_head(const void* xin, int rows, uint32_t* tokens, int64_t stream);
   int64_t gemm_algorithmic_bytes(int which, int M) const;
-  // which fused-norm launches of a step of M rows apply the RMSNorm factor in their EPILOGUE (kernel E, 1..4 rows: gemv_q4s.cuh;
+  // which fused-norm launches of a step of M rows apply the RMSNorm factor in their EPILOGUE (kernel E at 1..4 rows, gemv_q4s.cuh;
   // the oracle restates that order): bit 0 = norm + q/k/v, bit 1 = norm + gate/up.  0 for every other step.
-  int norm_deferred_mask(int M) const { return M >= 1 && M <= 4 ? (gemv_s_ok(0, M) ? 1 : 0) | (gemv_s_ok(2, M) ? 2 : 0) : 0; }
+  // (steps of 5..32 rows, round 5: the launches that take ready-made operands from their producer — gate/up behind a kernel-W
+  // o_proj, the q/k/v of layers >= 1 behind a kernel-W down_proj: per LAYER)
+  int norm_deferred_mask(int M, int layer = 1) const;
   // Parity instrumentation of the tensor-parallel forward (tests/test_gpu_tp.py, tools/tp8_stress.py): with snapshots on, layer 0
   // of every forward leaves copies of its stages — 0 q, 1 k, 2 v (GEMM outputs, before RoPE), 3 attention output (o_proj's x),
   // 4 o_proj partial (what this rank hands to the all-reduce), 5 h after all-reduce + residual, 6 SiLU(gate)*up (down_proj's x),
@@ -129,7 +131,16 @@ class Model {
   bool build_decode_step();  // descriptor table of the persistent decode step (needs weights, buffers and the KV cache)
   // kernel E launch of one decode GEMV of layer `l` (which: 0 norm+q/k/v, 1 o_proj, 2 norm+gate/up+SiLU*mul, 3 down);
   // false = shape not covered (the caller takes the general path).  `out`/`residual` as for linear().
-  bool gemv_s(int l, int which, int M, void* out, const void* residual, int64_t stream, const void* x_frag = nullptr, void* out_frag = nullptr);
+  // pre (kernel W, 5..32 rows; csrc/gemv_q4s.cuh GemvSArgs::pre_*): a producer launch also leaves the NEXT fused-norm launch's
+  // operands (x̃ = round(out * next_norm_w) in fragment order + partial sums of squares); a consumer launch takes them
+  struct PreOps {
+    const void* next_norm_w = nullptr;  // producer
+    void* frag = nullptr;               // producer: where x̃ goes / consumer: where it comes from
+    float* sq = nullptr;                // the partial-sum table
+    bool consume = false;
+  };
+  bool gemv_s(int l, int which, int M, void* out, const void* residual, int64_t stream, const void* x_frag = nullptr, void* out_frag = nullptr,
+              const PreOps* pre = nullptr);
   bool gemv_s_ok(int which, int M) const;
   void gemv_s_args(int l, int which, int M, void* out, const void* residual, ::GemvSArgs* a, int* ns);
   vra_model_config mc_;
@@ -177,6 +188,12 @@ class Model {
   size_t snap_bytes_[9] = {};
   size_t snap_cap_[9] = {};
   bool snap(int idx, const void* src, size_t bytes, int64_t stream);
+  // ready-made operands of the fused-norm launches of a 5..32-row step (PreOps): x̃ for gate/up (written by o_proj) and for the
+  // next layer's q/k/v (written by down_proj), each with its table of partial sums of squares; *_ok_: written by this step's
+  // producer launch and not overtaken by another writer of h
+  void *pre_o_ = nullptr, *pre_d_ = nullptr;
+  float *sq_o_ = nullptr, *sq_d_ = nullptr;
+  bool pre_o_ok_ = false, pre_d_ok_ = false;
   void* afrag_ = nullptr;  // the decode attention's output of a 5..32-sequence step in fragment order (o_proj's x on kernel W)
   bool qkv_attn(int l, const InputMetadata& md, int64_t stream);  // false = not covered (error empty) or failed (error set)
   // persistent decode step
