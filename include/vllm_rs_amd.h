@@ -480,19 +480,19 @@ int32_t vra_engine_finalize_weights(void* eng); /* repack + scale layout + KV ca
  * until buffers exist), then vra_engine_finalize_weights for activations, KV cache and graphs. */
 /* parity instrumentation: the f32 logits [n_seqs, vocab] the last step (hipGraph replay or eager) left on the device */
 int32_t vra_engine_copy_logits(void* eng, float* h_out, int32_t n_seqs);
-/* parity instrumentation of the tensor-parallel forward: with snapshots on, layer 0 of every forward keeps copies of its stages
+/* parity instrumentation of the tensor-parallel forward: with snapshots on (`on` = 1 + the layer; 0 = off), that layer of every forward keeps copies of its stages
  * (0 q, 1 k, 2 v before RoPE, 3 attention output, 4 o_proj partial of this rank, 5 h after the first all-reduce + residual,
  * 6 SiLU(gate)*up, 7 down_proj partial, 8 h after the second all-reduce); read returns the bytes copied or -1. */
 /* parity instrumentation: which fused RMSNorm launches of a step of `rows` rows of decoder layer `layer` apply the normalisation factor in
  * their epilogue (rstd commutes with the product: the 1..4-row decode kernel always; at 5..32 rows the launches whose producer — a
- * kernel-W o_proj / down_proj of the same step — left them ready-made operands x~ = round(h * g)); bit 0 = norm + q/k/v, bit 1 = norm +
+ * kernel-W o_proj / down_proj of the same step, the embedding launch for layer 0's q/k/v — left them ready-made operands x~ = round(h * g)); bit 0 = norm + q/k/v, bit 1 = norm +
  * gate/up.  vra_debug_norm_deferred_mask is the same rule from shapes alone (per-rank sizes; q/k/v biases only) and
  * vra_debug_gemv_s_fits the 1..4-row predicate behind it — the oracle restates the order the engine runs (oracle/model.py ENGINE_RULE). */
 int32_t vra_engine_norm_deferred(void* eng, int32_t rows, int32_t layer);
 int32_t vra_debug_norm_deferred_mask(int32_t hidden, int32_t inter_local, int32_t heads_local, int32_t kv_heads_local, int32_t head_dim,
                                      int32_t group_size, int32_t quant, int32_t qkv_bias, int32_t world, int32_t rows, int32_t layer);
 int32_t vra_debug_gemv_s_fits(int32_t ns, int32_t m, int32_t k, int32_t group_size, int32_t n_units, int32_t norm);
-void vra_engine_debug_tp_snapshots(void* eng, int32_t on);
+void vra_engine_debug_tp_snapshots(void* eng, int32_t on); /* on = 1 + the layer whose stages are kept; 0 = off */
 int64_t vra_engine_debug_read_tp_snapshot(void* eng, int32_t idx, void* h_out, int64_t max_bytes);
 int32_t vra_engine_finalize_model(void* eng);
 int32_t vra_engine_update_config(void* eng, const vra_engine_config* cfg);

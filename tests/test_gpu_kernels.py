@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as orc
-from tests.util import BF16, F16, F32, assert_close_dt, make_quant, rand_dt, rng
+from tests.util import BF16, F16, F32, assert_close_dt, make_quant, rand_dt, rng, ulp_of
 from vllm_rs_amd import ops
 
 pytestmark = pytest.mark.gpu
@@ -171,7 +171,18 @@ def test_gate_up_silu_143_to_221_rows_at_the_llama3_8b_widths(M):
     g = orc.wna16_gemm(x, qg["idx"], None, qg["scales"], 128, BF16)
     u = orc.wna16_gemm(x, qu["idx"], None, qu["scales"], 128, BF16)
     ref = orc.silu_mul(g, u, BF16)
-    assert_close_dt(out.numpy(np.uint16, (M, N)), ref, BF16, max_ulp=3.0, max_mismatch_frac=0.04, name=f"gate_up_silu {M} rows", abs_floor=4e-3)
+    # 2..3 million outputs per case: the tail of "a 1-ulp accumulation-order flip of gate, amplified by silu" shows up (3..7 elements
+    # beyond 3 ulp of the PRODUCT at gate < -4, where d ln silu / d ln g = 1 + g (1 - sigmoid(g)) reaches -4..-7), so the bound is the
+    # propagated one: one ulp of gate through silu' (+ half an ulp of the re-rounded silu), one ulp of up, 1.5 ulp of the result
+    gf, uf = orc.from_dt(g, BF16).astype(np.float64), orc.from_dt(u, BF16).astype(np.float64)
+    sg = 1.0 / (1.0 + np.exp(-gf))
+    tol = (ulp_of(gf, BF16) * np.abs(sg * (1.0 + gf * (1.0 - sg))) + 0.5 * ulp_of(gf * sg, BF16)) * np.abs(uf) + ulp_of(uf, BF16) * np.abs(gf * sg) + 1.5 * ulp_of(orc.from_dt(ref, BF16), BF16)
+    got = out.numpy(np.uint16, (M, N))
+    diff = np.abs(orc.from_dt(got, BF16).astype(np.float64) - orc.from_dt(ref, BF16))
+    bad = diff > np.maximum(tol * 1.0001, 4e-3)
+    assert not bad.any(), f"gate_up_silu {M} rows: {int(bad.sum())} elements beyond the propagated one-ulp bound; worst excess {float((diff / np.maximum(tol, 4e-3)).max()):.2f}x"
+    assert float(((diff > 3.0001 * ulp_of(orc.from_dt(ref, BF16), BF16)) & (diff > 4e-3)).mean()) < 2e-5  # (the plain 3-ulp bound: all but a handful)
+    assert float((got != ref).mean()) <= 0.04
 
 
 @pytest.mark.parametrize("gs,with_g_idx", [(128, True), (64, True), (64, False), (32, False), (128, False)])

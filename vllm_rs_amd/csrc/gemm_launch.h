@@ -39,8 +39,9 @@ void vra_rms_norm_xsum(const void* x, const void* weight, void* out, float* xsum
 
 // ---- internal helpers of ops.hip / wna16_gemm.hip used by the native runtime
 // vra_embedding + one increment of *bump (null: none; the forward's epoch word of the experiments build) in the same launch
-// (+ rows 0..31 in kernel W's fragment order into `frag`, GemvSArgs::x_frag, when frag != null)
+// (+ rows 0..31 in kernel W's fragment order into `frag`, GemvSArgs::x_frag, when frag != null; + with pre_norm_w and <= 32 rows: the
+// ready-made operands of layer 0's attention norm, x̃ = round(row * g) into pre_frag and the rows' sums of squares into pre_sq[0..31])
 void vra_embedding_bump(const uint32_t* ids, const void* table, void* out, int32_t tokens, int32_t hidden, int32_t vocab, int32_t dtype,
-                        uint32_t* bump, void* frag, int64_t stream);
+                        uint32_t* bump, void* frag, const void* pre_norm_w, void* pre_frag, float* pre_sq, int64_t stream);
 // dense [n, k] 16-bit row-major -> the tile-major copy the dense GEMV kernels stream one contiguous KiB per wave load from
 void vra_dense_tile_weights(const void* w_rowmajor, void* out_tiled, int32_t n, int32_t k, int64_t stream);

@@ -213,6 +213,45 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const uint32_t* __rest
     if (frag && r < 32) frag[(((i >> 4) * 2 + (size_t)(r >> 4)) * 4 + ((i >> 2) & 3)) * 64 + (i & 3) * 16 + (r & 15)] = v;
   }
 }
+// the embedding launch of a 5..32-row step as a PRODUCER of ready-made operands (gemv_q4s.cuh GemvSArgs::pre_*): next to the rows
+// and their fragment-order copy, x̃ = round(row * g) for layer 0's attention norm in fragment order and the rows' sums of squares
+// (slot 0 of the partial-sum table; the other slots of that table are never written and stay zero) — layer 0's q/k/v launch then
+// normalises in the same (deferred) order as every later layer's and as kernel E's
+template <class DT>
+__global__ __launch_bounds__(256) void embed_rows_pre_kernel(const uint32_t* __restrict__ idx, const uint16_t* __restrict__ table,
+                                                              uint16_t* __restrict__ out, int hidden, uint32_t n_table_rows,
+                                                              uint32_t* __restrict__ bump, u32x4* __restrict__ frag,
+                                                              const uint16_t* __restrict__ norm_w, u32x4* __restrict__ pre_frag,
+                                                              float* __restrict__ pre_sq) {
+  __shared__ float red[4];
+  const int r = blockIdx.x;  // < 32
+  if (bump && r == 0 && threadIdx.x == 0) *bump += 1u;
+  uint32_t src = idx[r];
+  if (src >= n_table_rows) src = n_table_rows - 1;
+  const u32x4* s = reinterpret_cast<const u32x4*>(table + (size_t)src * hidden);
+  u32x4* d = reinterpret_cast<u32x4*>(out + (size_t)r * hidden);
+  float ss = 0.f;
+  for (int i = threadIdx.x; i < hidden / 8; i += 256) {
+    const u32x4 v = s[i];
+    d[i] = v;
+    const size_t fi = (((size_t)(i >> 4) * 2 + (size_t)(r >> 4)) * 4 + ((i >> 2) & 3)) * 64 + (i & 3) * 16 + (r & 15);
+    frag[fi] = v;
+    float f[8], g[8];
+    unpack8<DT>(v, f);
+    unpack8<DT>(reinterpret_cast<const u32x4*>(norm_w)[i], g);
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      ss = fmaf(f[e], f[e], ss);
+      f[e] *= g[e];
+    }
+    pre_frag[fi] = pack8<DT>(f);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  if (threadIdx.x == 0) pre_sq[r] = (red[0] + red[1]) + (red[2] + red[3]);
+}
 extern "C" void vra_embedding(const uint32_t* ids, const void* table, void* out, int32_t tokens, int32_t hidden,
                               int32_t vocab, int32_t dtype, int64_t stream) {
   size_t es = dtype == VRA_F32 ? 4 : 2;
@@ -240,11 +279,20 @@ void vra_dense_tile_weights(const void* w_rowmajor, void* out_tiled, int32_t n, 
   dense_tile_kernel<<<grid, 256, 0, as_stream(stream)>>>((const u32x4*)w_rowmajor, (u32x4*)out_tiled, n, k);
 }
 void vra_embedding_bump(const uint32_t* ids, const void* table, void* out, int32_t tokens, int32_t hidden, int32_t vocab, int32_t dtype,
-                        uint32_t* bump, void* frag, int64_t stream) {
+                        uint32_t* bump, void* frag, const void* pre_norm_w, void* pre_frag, float* pre_sq, int64_t stream) {
   size_t es = dtype == VRA_F32 ? 4 : 2;
   VRA_CHECK_ARG((hidden * es) % 16 == 0, "vra_embedding: row bytes must be a multiple of 16");
   if (tokens <= 0) return;
   if (es != 2 || hidden % 128) frag = nullptr;
+  if (frag && pre_norm_w && pre_frag && pre_sq && tokens <= 32) {
+    if (dtype == VRA_BF16)
+      embed_rows_pre_kernel<BF16><<<tokens, 256, 0, as_stream(stream)>>>(ids, (const uint16_t*)table, (uint16_t*)out, hidden, (uint32_t)vocab, bump, (u32x4*)frag,
+                                                                         (const uint16_t*)pre_norm_w, (u32x4*)pre_frag, pre_sq);
+    else
+      embed_rows_pre_kernel<F16><<<tokens, 256, 0, as_stream(stream)>>>(ids, (const uint16_t*)table, (uint16_t*)out, hidden, (uint32_t)vocab, bump, (u32x4*)frag,
+                                                                        (const uint16_t*)pre_norm_w, (u32x4*)pre_frag, pre_sq);
+    return;
+  }
   gather_rows_kernel<<<tokens, 256, 0, as_stream(stream)>>>(ids, (const unsigned char*)table, (unsigned char*)out, tokens, hidden * es, (uint32_t)vocab, bump,
                                                             (u32x4*)frag);
 }

@@ -237,9 +237,9 @@ class Engine:
         """bit 0 / bit 1: the norm + q/k/v / norm + gate/up launch of a step of `rows` rows of layer `layer` applies rstd in its epilogue"""
         return int(self.L.vra_engine_norm_deferred(self.h, int(rows), int(layer)))
 
-    def tp_snapshots(self, on=True):
-        """parity instrumentation: keep copies of layer 0's stages of every forward (vra_engine_debug_tp_snapshots)"""
-        self.L.vra_engine_debug_tp_snapshots(self.h, int(on))
+    def tp_snapshots(self, on=True, layer=0):
+        """parity instrumentation: keep copies of one layer's stages of every forward (vra_engine_debug_tp_snapshots)"""
+        self.L.vra_engine_debug_tp_snapshots(self.h, 1 + int(layer) if on else 0)
         return self
 
     def read_tp_snapshots(self):

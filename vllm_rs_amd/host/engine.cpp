@@ -803,8 +803,8 @@ extern "C" int32_t vra_engine_norm_deferred(void* e, int32_t rows, int32_t layer
   auto* en = static_cast<Engine*>(e);
   return en->dry() ? 0 : en->model_.norm_deferred_mask(rows, layer);
 }
-// parity instrumentation of the tensor-parallel forward (model.h `set_tp_snapshots`): stage copies of layer 0, read back per stage
-extern "C" void vra_engine_debug_tp_snapshots(void* e, int32_t on) { static_cast<Engine*>(e)->model_.set_tp_snapshots(on != 0); }
+// parity instrumentation of the tensor-parallel forward (model.h `set_tp_snapshots`): stage copies of one layer (`on` = 1 + the layer, 0 = off), read back per stage
+extern "C" void vra_engine_debug_tp_snapshots(void* e, int32_t on) { static_cast<Engine*>(e)->model_.set_tp_snapshots(on); }
 extern "C" int64_t vra_engine_debug_read_tp_snapshot(void* e, int32_t idx, void* h_out, int64_t max_bytes) {
   auto* en = static_cast<Engine*>(e);
   if (en->dry()) return -1;

@@ -496,6 +496,7 @@ bool Model::init_buffers(int max_tokens, int max_seqs) {
     if (!(pre_o_ = dalloc(fb)) || hipMemset(pre_o_, 0, fb) != hipSuccess || !(pre_d_ = dalloc(fb)) || hipMemset(pre_d_, 0, fb) != hipSuccess) return false;
     if (!(sq_o_ = (float*)dalloc(sqb)) || hipMemset(sq_o_, 0, sqb) != hipSuccess || !(sq_d_ = (float*)dalloc(sqb)) || hipMemset(sq_d_, 0, sqb) != hipSuccess)
       return false;
+    if (!(pre_e_ = dalloc(fb)) || hipMemset(pre_e_, 0, fb) != hipSuccess || !(sq_e_ = (float*)dalloc(sqb)) || hipMemset(sq_e_, 0, sqb) != hipSuccess) return false;
   }
   if (inter_ % 128 == 0) {
     const size_t fb = (size_t)(inter_ / 128) * 2 * 4096;
@@ -803,15 +804,15 @@ template <class F>
 static int norm_deferred_rule(int M, int layer, int H, int world, bool x_frag_on, F takes) {
   if (M < 1) return 0;
   if (M <= 4) return (takes(0) ? 1 : 0) | (takes(2) ? 2 : 0);  // kernel E
-  // kernel W, 5..32 rows: the launches whose producer (a kernel-W o_proj / down_proj of the same step) left ready-made operands
+  // kernel W, 5..32 rows: the launches whose producer (a kernel-W o_proj / down_proj of the same step; the embedding launch for layer 0) left ready-made operands
   if (!x_frag_on || M > 32 || world != 1 || H % 128) return 0;
   int m = 0;
   if (takes(1) && takes(2)) m |= 2;
-  if (layer >= 1 && takes(3) && takes(0)) m |= 1;
+  if ((layer == 0 || takes(3)) && takes(0)) m |= 1;  // (layer 0's producer is the embedding launch)
   return m;
 }
 int Model::norm_deferred_mask(int M, int layer) const {
-  return norm_deferred_rule(M, layer, mc_.hidden_size, world_, g_x_frag && hfrag_ && pre_o_ && pre_d_, [&](int which) { return gemv_s_ok(which, M); });
+  return norm_deferred_rule(M, layer, mc_.hidden_size, world_, g_x_frag && hfrag_ && pre_o_ && pre_d_ && pre_e_, [&](int which) { return gemv_s_ok(which, M); });
 }
 // the same from shapes alone (Llama / Qwen2 / Qwen3 checkpoints: q/k/v biases only), for the oracle (oracle/model.py deferred_norm_mask)
 extern "C" int32_t vra_debug_norm_deferred_mask(int32_t hidden, int32_t inter_local, int32_t heads_local, int32_t kv_heads_local, int32_t head_dim,
@@ -1064,7 +1065,11 @@ bool Model::forward(const InputMetadata& md, int64_t stream, uint32_t* tokens) {
   // embed_forward (llama.rs:260-267)
   // (+ the forward's epoch word: qkv_attn.h; + steps of 5..32 rows: h also in kernel W's fragment order, GemvSArgs::x_frag)
   const bool use_frag = g_x_frag && hfrag_ && T > 4 && T <= 32 && world_ == 1;
-  vra_embedding_bump(md.input_ids, embed_, h_, T, H, mc_.vocab_size, dt_, epoch_, use_frag ? hfrag_ : nullptr, stream);
+  // (+ steps of 5..32 rows whose q/k/v launch of layer 0 runs on kernel W: its ready-made operands, like the ones every later
+  // layer's gets from the down_proj in front of it — one norm order for all layers of a step shape)
+  const bool make_e = use_frag && pre_e_ && sq_e_ && mc_.num_layers > 0 && gemv_s_ok(0, T);
+  vra_embedding_bump(md.input_ids, embed_, h_, T, H, mc_.vocab_size, dt_, epoch_, use_frag ? hfrag_ : nullptr, make_e ? layers_[0].attn_norm : nullptr,
+                     pre_e_, sq_e_, stream);
   hfrag_ok_ = use_frag;
   pre_o_ok_ = pre_d_ok_ = false;
 #ifdef VRA_EXPERIMENTS
@@ -1087,8 +1092,8 @@ bool Model::forward(const InputMetadata& md, int64_t stream, uint32_t* tokens) {
 #endif
     if (!fused_attn && !error.empty()) return false;
     PreOps take_d;  // x̃ of this layer's attention norm, left by the previous layer's down_proj (5..32 rows, kernel W)
-    take_d.consume = true, take_d.frag = pre_d_, take_d.sq = sq_d_;
-    if (!fused_attn && !gemv_s(l, 0, T, nullptr, nullptr, stream, hfrag_ok_ ? hfrag_ : nullptr, nullptr, pre_d_ok_ ? &take_d : nullptr)) {
+    take_d.consume = true, take_d.frag = l == 0 ? pre_e_ : pre_d_, take_d.sq = l == 0 ? sq_e_ : sq_d_;  // (layer 0: left by the embedding launch)
+    if (!fused_attn && !gemv_s(l, 0, T, nullptr, nullptr, stream, hfrag_ok_ ? hfrag_ : nullptr, nullptr, (l == 0 ? make_e : pre_d_ok_) ? &take_d : nullptr)) {
       if (!error.empty()) return false;
       if (!linear_fused_norm(qkv, 3, outs, h_, L.attn_norm, T, stream)) return false;
     }
@@ -1097,7 +1102,7 @@ bool Model::forward(const InputMetadata& md, int64_t stream, uint32_t* tokens) {
       vra_qk_rms_norm(q_, k_, L.q_norm, L.k_norm, T, hq_, hkv_, D, qk_norm_mode_ == 2, mc_.rms_norm_eps, dt_, stream);
       if (take_err(error, "qk_norm")) return false;
     }
-    if (l == 0 && snap_on_ && !fused_attn &&
+    if (l == snap_layer_ && snap_on_ && !fused_attn &&
         !(snap(0, q_, (size_t)T * hq_ * D * es_, stream) && snap(1, k_, (size_t)T * hkv_ * D * es_, stream) && snap(2, v_, (size_t)T * hkv_ * D * es_, stream)))
       return false;
     if (fused_attn) {
@@ -1115,15 +1120,15 @@ bool Model::forward(const InputMetadata& md, int64_t stream, uint32_t* tokens) {
                                            attn_ws_, dt_, kv_dt, attn_frag ? afrag_ : nullptr, stream);
     }
     if (take_err(error, "attention")) return false;
-    if (l == 0 && !snap(3, attn_, (size_t)T * hq_ * D * es_, stream)) return false;
+    if (l == snap_layer_ && !snap(3, attn_, (size_t)T * hq_ * D * es_, stream)) return false;
     if (world_ > 1) {
       // TensorParallelRowLinear::forward (distributed.rs:438-455): partial GEMM -> all_reduce -> + bias; then the layer's
       // residual add (llama.rs:126) — the last two fused behind the reduction
       if (!gemv_s(l, 1, T, tmp_, nullptr, stream) && (!error.empty() || !linear(L.o, attn_, tmp_, T, nullptr, stream, false))) return false;
-      if (l == 0 && !snap(4, tmp_, (size_t)T * H * es_, stream)) return false;
+      if (l == snap_layer_ && !snap(4, tmp_, (size_t)T * H * es_, stream)) return false;
       vra_all_reduce_fused(comm_, tmp_, h_, L.o.bias, h_, T, H, dt_, stream);
       if (take_err(error, "all_reduce(o_proj)")) return false;
-      if (l == 0 && !snap(5, h_, (size_t)T * H * es_, stream)) return false;
+      if (l == snap_layer_ && !snap(5, h_, (size_t)T * H * es_, stream)) return false;
     } else {
       // o_proj writes h: on kernel W (5..32 rows) also its fragment-order copy; any other kernel leaves the copy stale
       if (!error.empty()) return false;
@@ -1141,13 +1146,13 @@ bool Model::forward(const InputMetadata& md, int64_t stream, uint32_t* tokens) {
     const bool w_gu = gemv_s(l, 2, T, nullptr, nullptr, stream, hfrag_ok_ ? hfrag_ : nullptr, use_frag ? actfrag_ : nullptr, pre_o_ok_ ? &take_o : nullptr);
     pre_o_ok_ = false;
     if (!w_gu && (!error.empty() || !gate_up(L, h_, L.ffn_norm, act_, T, stream))) return false;
-    if (l == 0 && !snap(6, act_, (size_t)T * inter_ * es_, stream)) return false;
+    if (l == snap_layer_ && !snap(6, act_, (size_t)T * inter_ * es_, stream)) return false;
     if (world_ > 1) {
       if (!gemv_s(l, 3, T, tmp_, nullptr, stream) && (!error.empty() || !linear(L.down, act_, tmp_, T, nullptr, stream, false))) return false;
-      if (l == 0 && !snap(7, tmp_, (size_t)T * H * es_, stream)) return false;
+      if (l == snap_layer_ && !snap(7, tmp_, (size_t)T * H * es_, stream)) return false;
       vra_all_reduce_fused(comm_, tmp_, h_, L.down.bias, h_, T, H, dt_, stream);
       if (take_err(error, "all_reduce(down_proj)")) return false;
-      if (l == 0 && !snap(8, h_, (size_t)T * H * es_, stream)) return false;
+      if (l == snap_layer_ && !snap(8, h_, (size_t)T * H * es_, stream)) return false;
     } else {
       // down_proj writes h: kernel E at 1..4 rows (no copy), kernel C with the fragment-order copy at 5..32, anything else: stale
       if (!error.empty()) return false;

@@ -117,7 +117,7 @@ class Model {
   // 4 o_proj partial (what this rank hands to the all-reduce), 5 h after all-reduce + residual, 6 SiLU(gate)*up (down_proj's x),
   // 7 down_proj partial, 8 h after the second all-reduce — so that a deviating logit can be traced to the first stage and rank
   // that deviates from the oracle.  Off (the default): no buffers, no copies.
-  void set_tp_snapshots(bool on) { snap_on_ = on; }
+  void set_tp_snapshots(int on) { snap_on_ = on != 0; snap_layer_ = on > 0 ? on - 1 : 0; }  // on = 1 + the layer to copy
   int64_t read_tp_snapshot(int idx, void* host, int64_t max_bytes, int64_t stream);  // bytes copied, -1 on error
 
  private:
@@ -184,6 +184,7 @@ class Model {
   void* actfrag_ = nullptr;  // SiLU(gate) * up of a 5..32-row step in fragment order (down_proj's x on the K-sliced kernel W)
   int qk_norm_mode_ = 0;  // 0 none, 1 per head, 2 full row (set by the config for synthetic weights, by the tensor shape when loading)
   bool snap_on_ = false;
+  int snap_layer_ = 0;
   void* snap_[9] = {};
   size_t snap_bytes_[9] = {};
   size_t snap_cap_[9] = {};
@@ -191,8 +192,8 @@ class Model {
   // ready-made operands of the fused-norm launches of a 5..32-row step (PreOps): x̃ for gate/up (written by o_proj) and for the
   // next layer's q/k/v (written by down_proj), each with its table of partial sums of squares; *_ok_: written by this step's
   // producer launch and not overtaken by another writer of h
-  void *pre_o_ = nullptr, *pre_d_ = nullptr;
-  float *sq_o_ = nullptr, *sq_d_ = nullptr;
+  void *pre_o_ = nullptr, *pre_d_ = nullptr, *pre_e_ = nullptr;  // producers: o_proj, down_proj, the embedding launch (layer 0)
+  float *sq_o_ = nullptr, *sq_d_ = nullptr, *sq_e_ = nullptr;
   bool pre_o_ok_ = false, pre_d_ok_ = false;
   void* afrag_ = nullptr;  // the decode attention's output of a 5..32-sequence step in fragment order (o_proj's x on kernel W)
   bool qkv_attn(int l, const InputMetadata& md, int64_t stream);  // false = not covered (error empty) or failed (error set)
