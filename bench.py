@@ -129,10 +129,10 @@ def pmc_traffic(kernel):
 
 
 def load_pmc():
-    """the committed counter / trace pass of this round (profiles/r04_pmc.json, tools/summarise_profiles.py) — only if it was taken
+    """the committed counter / trace pass of this round (profiles/r05_pmc.json, tools/summarise_profiles.py) — only if it was taken
     with a library built from these very sources"""
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc.json")))
     except Exception:
         return None
     if pmc.get("src_sha16") != src_sha16() and pmc.get("lib_sha16") != lib_sha16():
@@ -142,14 +142,14 @@ def load_pmc():
 
 def in_situ_family():
     """the dequant-GEMV family INSIDE the decode step: average launch durations of the two kernel-E instantiations in
-    the rocprofv3 kernel trace of the eager bs-1 step (profiles/r04_decode_bs1_kernel_trace.txt) — 3 launches of <BF16,1,false> and
+    the rocprofv3 kernel trace of the eager bs-1 step (profiles/r05_decode_bs1_kernel_trace.txt) — 3 launches of <BF16,1,false> and
     one of <BF16,2,false> per layer — next to the isolated-launch figure bench.py times itself"""
     pmc = load_pmc()
     try:
         t = pmc["in_situ_decode_bs1_kernel_trace"]
         us = 3 * t["gemv_q4s_kernel<BF16,1,false>"]["avg_us"] + t["gemv_q4s_kernel<BF16,2,false>"]["avg_us"]
         return {"us_per_layer": us, "GBps": 113475584 / us / 1e3, "frac": 113475584 / us / 1e3 / HBM_PEAK_GBS,
-                "source": "profiles/r04_decode_bs1_kernel_trace.txt (rocprofv3 --kernel-trace of the eager step, same sources)"}
+                "source": "profiles/r05_decode_bs1_kernel_trace.txt (rocprofv3 --kernel-trace of the eager step, same sources)"}
     except Exception:
         return None
 

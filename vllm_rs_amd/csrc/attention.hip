@@ -26,12 +26,6 @@
 // split the tiles of their (sequence, kv head).  8 waves measured worse than 4 except at 8k context (bs 32: 3.84 vs 3.69
 // ms/step): the wider merge and the larger workgroup cost more than the shorter tile chains save.
 #define FD_WAVES 4
-#ifndef FD_EARLY_TILE
-#define FD_EARLY_TILE 1
-#endif
-#ifndef FD_BLKVEC
-#define FD_BLKVEC 1
-#endif
 #define FD_THREADS (FD_WAVES * 64)
 
 struct PagedAttnArgs {
@@ -431,9 +425,7 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
   auto tile_blk = [&](int tile) -> uint32_t {
     const int T0 = tile << 5;
     const int bi = __builtin_amdgcn_readfirstlane(a.bs_shift >= 0 ? T0 >> a.bs_shift : T0 / a.BS);
-#if FD_BLKVEC
     if (bi >= vec_base && bi < vec_base + 64) return (uint32_t)__builtin_amdgcn_readlane((int)blkvec, bi - vec_base);
-#endif
     return a.block_tables[tile_blk_index(tile)];  // (not reached: the vector is re-based on the wave's first block below)
   };
   const kv_t* kcache = static_cast<const kv_t*>(a.kc);
@@ -538,9 +530,7 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
     q_s[j] = *reinterpret_cast<const u32x4*>(sinp + cl);
   }
   __builtin_amdgcn_sched_barrier(0);
-#if FD_EARLY_TILE
   load_tile(min(kv_w0, max(ntiles - 1, 0)), blk_cur, ka0, ka1, va);
-#endif
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int j = 0; j < QJ; j++) {
@@ -681,9 +671,6 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
       DT::mfma(o[t], pfrag, __builtin_bit_cast(s16x8, vv));
     }
   };
-#if !FD_EARLY_TILE
-  if (kv_w0 < kv_w1) load_tile(kv_w0, blk_cur, ka0, ka1, va);
-#endif
   if (kv_w0 < kv_w1) compute_tile(kv_w0, ka0, ka1, va);  // (its loads went out in front of the barrier)
   for (int tile = kv_w0 + 1; tile < kv_w1; tile++) {
     load_tile(tile, tile_blk(tile), ka0, ka1, va);
@@ -791,7 +778,10 @@ static int decode_nsplit(int batch, int kv_heads, int max_context_len) {
     // workgroups because their merge kernel walked the splits one dependent round trip at a time; measured on one box
     // (profiles/r05_ab_attention_splits.txt): keep 4 beats 2, 8 and 16 at ctx 150..400, 1024 and 8000.
     const int keep = forced ? forced : 4;
-    while (wg * s * 2 <= cus && tiles / (s * 2) >= keep && s < 64) s *= 2;
+    // (more than one workgroup per CU loses: ctx 8000 2.04 -> 2.17 ms per step at 2 and at 4, profiles/r05_ab_attention_wg_per_cu.txt)
+    static const char* pc = getenv("VRA_ATTN_WG_PER_CU");  // tuning aid: workgroups per CU the split count may reach
+    const int cap = cus * (pc && atoi(pc) > 0 ? atoi(pc) : 1);
+    while (wg * s * 2 <= cap && tiles / (s * 2) >= keep && s < 64) s *= 2;
     return s;
   }
   // enough workgroups to cover the chip (256 CUs); each split keeps >= 8 tiles (256 tokens): at bs 32 shorter splits do not pay

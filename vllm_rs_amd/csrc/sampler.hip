@@ -46,7 +46,7 @@ struct SampleArgs {
 __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const SampleArgs a) {
   __shared__ float red[SMP_THREADS / 64];
   __shared__ uint32_t hist[256];
-  __shared__ uint32_t s_prefix, s_remaining, s_count, s_ties;
+  __shared__ uint32_t s_prefix, s_remaining, s_count;
   __shared__ uint32_t c_key[SMP_MAXK], c_idx[SMP_MAXK];
   __shared__ float c_prob[SMP_MAXK];
   __shared__ float chunk_sum[SMP_THREADS];
@@ -123,10 +123,7 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const SampleArgs a)
   const uint32_t kth = s_prefix;       // key of the k-th largest element
   const uint32_t need_ties = s_remaining;  // how many elements equal to it belong to the top k (lowest token ids first)
   // ---- gather: everything above the k-th key, and the first `need_ties` elements equal to it in token order
-  if (tid == 0) {
-    s_count = 0u;
-    s_ties = 0u;
-  }
+  if (tid == 0) s_count = 0u;
   __syncthreads();
   {
     // ties must be taken in token order: one thread walks them per chunk in order — chunks are processed by increasing
