@@ -537,7 +537,7 @@ def main():
                 per32[name] = {"ms": ms, "bytes": b, "GBps": b / ms / 1e6}
                 b32 += b
                 ms32 += ms
-            line["roofline_bs32"] = {"bound": "hbm", "kernel": "dequant-GEMM family at 32 rows (gemv_q4w_kernel: norm+qkv, o_proj, norm+gate/up in its sequential pair form, down_proj in K slices; x in fragment order)",
+            line["roofline_bs32"] = {"bound": "hbm", "kernel": "dequant-GEMM family at 32 rows (gemv_q4w_kernel: norm+qkv, o_proj, norm+gate/up in its sequential pair form, down_proj in K slices; x in fragment order; launched as the step launches them: o_proj / down_proj also write the next norm's ready-made operands, the two fused-norm launches consume them)",
                                      "achieved": b32 / ms32 / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b32 / ms32 / 1e6 / HBM_PEAK_GBS,
                                      "family": per32, "family_ms_per_step": ms32 * cfg["num_layers"], "step_ms": dt32 * 1e3 / 64}
         # ---------------- the KV term ("also ctx in {1k, 8k}"): decode at long contexts

@@ -8,13 +8,22 @@
 //   * wave w owns the k-tiles w, w+8, w+16, w+24: its x fragments (32 rows x 512 columns) live in REGISTERS for the whole
 //     launch (loaded once, with W's half-line swizzle), optionally RMS-normalised in place — Σx² per row from the matrix cores
 //     (the diagonal of X·Xᵀ), one barrier;
-//   * the weight stream is a 2-slot ring of tile-steps (4 KiB per wave and slot, 64 KiB per CU in flight), branch-free,
+//   * the weight stream is a 2-slot (two m-tiles) or 4-slot (one m-tile) ring of tile-steps (4 KiB per wave and slot), branch-free,
 //     no store inside the loop; a unit's 8 partial tiles meet in a double-buffered LDS slab behind one barrier per unit and
 //     the finished outputs are parked in LDS until the stream has ended.
 // Roofline: HBM (every weight byte once).  Arithmetic contract: exact 16-bit products, f32 accumulation, one rounding.
 #pragma once
 #include "gemv_q4w.cuh"
 
+// slots of the weight ring: 2 or 4 (a divisor of the four tile-steps of a unit, so that the slot of a step is a compile-time index).
+// One m-tile (4..16 rows): 4 slots, 172 -> 165..166 us for the Llama-3 lm_head; two m-tiles (17..32 rows): the x fragments take 128
+// VGPRs, 4 slots spill 28 registers and lose (186 -> 208 us), 2 stay (profiles/r05_ab_dense_w_ring.txt)
+#ifndef GDW_RING_MT1
+#define GDW_RING_MT1 4
+#endif
+#ifndef GDW_RING_MT2
+#define GDW_RING_MT2 2
+#endif
 #define GDW_MAX_UNITS 40  // units per workgroup at most (parked outputs: 40 x 32 rows x 16 columns x 4 B = 80 KiB)
 
 struct GemvDWArgs {
@@ -57,9 +66,11 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_dw_kernel(const GemvDWArgs a)
   float* outs = reinterpret_cast<float*>(smem + off);  // [unit][MT*16 rows][16 columns] f32
   constexpr int OPU = MT * 256;
 
-  // ---- the weight stream: global step g = unit * 4 + tile index; slot g & 1.  Lane (oct, nn) holds the B fragment of column
+  // ---- the weight stream: global step g = unit * 4 + tile index; slot g % GDW_RING.  Lane (oct, nn) holds the B fragment of column
   // unit*16 + nn: W[n][kt*128 + j*32 + oct*8 .. +8]
-  u32x4 wb[2][4];
+  constexpr int GDW_RING = MT == 1 ? GDW_RING_MT1 : GDW_RING_MT2;
+  static_assert(GDW_RING == 2 || GDW_RING == 4, "GDW_RING");
+  u32x4 wb[GDW_RING][4];
   auto issue = [&](int g, u32x4 (&w)[4]) {
     const int ui = min(g >> 2, nu - 1), ti = g & 3;  // steps past the end re-read the last unit (never consumed)
     const int kt = min(wave + GW_WAVES * ti, KT - 1);
@@ -69,8 +80,8 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_dw_kernel(const GemvDWArgs a)
 #pragma unroll
     for (int j = 0; j < 4; j++) w[j] = __builtin_nontemporal_load(p + j * jstep);
   };
-  issue(0, wb[0]);
-  issue(1, wb[1]);
+#pragma unroll
+  for (int sl = 0; sl < GDW_RING; sl++) issue(sl, wb[sl]);
   __builtin_amdgcn_sched_barrier(0);
 
   // ---- x fragments (see gemv_q4w.cuh for the odd-row swizzle)
@@ -160,7 +171,7 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_dw_kernel(const GemvDWArgs a)
       const uint32_t vmask = wave + GW_WAVES * ti < KT ? 0xffffffffu : 0u;  // a tile this wave does not have contributes zeros
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        u32x4 wv = wb[ti & 1][j];
+        u32x4 wv = wb[ti % GDW_RING][j];
 #pragma unroll
         for (int c = 0; c < 4; c++) wv[c] &= vmask;
         const s16x8 bf = __builtin_bit_cast(s16x8, wv);
@@ -170,7 +181,7 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_dw_kernel(const GemvDWArgs a)
           else DT::mfma(acc[mt], __builtin_bit_cast(s16x8, xf[ti][j][mt]), bf);
         }
       }
-      issue(ui * 4 + ti + 2, wb[ti & 1]);
+      issue(ui * 4 + ti + GDW_RING, wb[ti % GDW_RING]);
     }
     VRA_MFMA_DRAIN();
     // ---- the unit's partial tiles meet in LDS (double-buffered by unit parity: one barrier per unit)

@@ -1231,7 +1231,19 @@ bool Model::launch_gemm(int which, int layer, int M, int64_t stream) {
   // (5..32 rows: x in fragment order where the forward pass reads it that way — the timing does not depend on the values)
   const bool xf = g_x_frag && M > 4 && M <= 32 && world_ == 1;
   const void* x_frag = !xf ? nullptr : (which == 1 ? afrag_ : (which == 3 ? actfrag_ : hfrag_));
-  if (gemv_s(layer, which, M, which == 1 || which == 3 ? tmp_ : nullptr, which == 1 || which == 3 ? h_ : nullptr, stream, x_frag)) return true;
+  // ... and the launch in the form the forward pass runs it: fragment-order copies of the outputs, o_proj / down_proj as PRODUCERS of the
+  // next fused-norm launch's ready-made operands, norm + q/k/v / norm + gate/up as their CONSUMERS where the step's rule says so
+  void* out_frag = !xf ? nullptr : (which == 2 ? actfrag_ : (which == 1 || which == 3 ? hfrag_ : nullptr));
+  PreOps pre;
+  const PreOps* pp = nullptr;
+  if (xf && pre_o_ && pre_d_ && pre_e_) {
+    const int dm = norm_deferred_mask(M, layer);
+    if (which == 0 && (dm & 1)) pre.consume = true, pre.frag = layer == 0 ? pre_e_ : pre_d_, pre.sq = layer == 0 ? sq_e_ : sq_d_, pp = &pre;
+    else if (which == 2 && (dm & 2)) pre.consume = true, pre.frag = pre_o_, pre.sq = sq_o_, pp = &pre;
+    else if (which == 1) pre.next_norm_w = L.ffn_norm, pre.frag = pre_o_, pre.sq = sq_o_, pp = &pre;
+    else if (which == 3 && layer + 1 < mc_.num_layers) pre.next_norm_w = layers_[layer + 1].attn_norm, pre.frag = pre_d_, pre.sq = sq_d_, pp = &pre;
+  }
+  if (gemv_s(layer, which, M, which == 1 || which == 3 ? tmp_ : nullptr, which == 1 || which == 3 ? h_ : nullptr, stream, x_frag, out_frag, pp)) return true;
   if (!error.empty()) return false;
   switch (which) {
     case 0: {
