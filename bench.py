@@ -610,10 +610,18 @@ def main():
                 keys = ("workload", "tokens_equal", "first_divergence", "n_steps", "max_abs", "mean_abs", "min_frac_within_1e3_abs",
                         "min_frac_within_1e3_of_scale", "max_ulp_of_row_scale", "logit_scale", "per_step_max_abs", "seconds")
                 line["parity_full_depth"] = {k: rep[k] for k in keys}
+                # ... and against the REFERENCE's arithmetic: its norm order everywhere (others.rs:11-29) with the exact int4 product, and
+                # the same with Marlin's 16-bit weight rounding (gptq.rs:116-178) — not only against the order the engine chose
+                vkeys = ("arithmetic", "tokens_equal", "first_divergence", "n_steps", "max_abs", "mean_abs", "min_frac_within_1e3_of_scale",
+                         "max_ulp_of_row_scale", "mean_ulp_of_row_scale", "per_step_max_abs", "seconds")
+                line["parity_full_depth_reference_order"] = {k: rep["reference_order"][k] for k in vkeys}
+                line["parity_full_depth_marlin_rounded"] = {k: rep["marlin_rounded"][k] for k in vkeys}
                 if not a.no_extras:
                     # config 3 (Qwen2-7B AWQ, L = 28, V = 152064) the same way; zero points drawn as in real AWQ checkpoints
                     rep = full_depth.run(dict(E.QWEN2_7B), log=lambda *_: None)
                     line["parity_full_depth_qwen2"] = {k: rep[k] for k in keys}
+                    line["parity_full_depth_qwen2_reference_order"] = {k: rep["reference_order"][k] for k in vkeys}
+                    line["parity_full_depth_qwen2_marlin_rounded"] = {k: rep["marlin_rounded"][k] for k in vkeys}
     if eng is not None:
         eng.close()
     if dist is not None:

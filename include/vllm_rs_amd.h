@@ -112,8 +112,12 @@ void vra_wna16_gate_up_silu(const void* in, const void* qw_gate, const void* sc_
 /* NormX::forward + QLinear::forward in one call (others.rs:11-29 in front of wna16.rs:263-306):
  * out = rmsnorm(in, norm_weight, eps)·W (+ bias).  Decode batches of 1..4 rows run fused (the
  * normalised activations never reach HBM); other shapes write rmsnorm(in) to `xn_workspace`
- * [m, k] (may be NULL only for the fused shapes) and run the general GEMM.  Rounding points are
- * those of the two separate calls. */
+ * [m, k] (may be NULL only for the fused shapes) and run the general GEMM.
+ * Rounding: at 5+ rows the rounding points are those of the two separate calls.  At 1..4 rows (since round 5) the fused
+ * launch applies the normalisation factor in its EPILOGUE: it stages round(in * norm_weight), forms the f32 dot products and
+ * multiplies them by rstd before the single output rounding — the reference rounds round(in * rstd) * norm_weight ahead of the
+ * GEMM (others.rs:11-29).  Same error size, another rounding pattern: per call <= 4 ulps of the output row's scale apart
+ * (tests/test_gpu_gemv_s.py), full depth in bench.py's parity_full_depth_reference_order. */
 void vra_rms_norm_wna16_gemm(const void* in, const void* norm_weight, float eps,
                              const void* qweight_tiled, const void* scales, const void* qzeros,
                              const void* bias, void* out, void* xn_workspace, int32_t m, int32_t k,
@@ -490,7 +494,8 @@ int32_t vra_engine_copy_logits(void* eng, float* h_out, int32_t n_seqs);
  * vra_debug_gemv_s_fits the 1..4-row predicate behind it — the oracle restates the order the engine runs (oracle/model.py ENGINE_RULE). */
 int32_t vra_engine_norm_deferred(void* eng, int32_t rows, int32_t layer);
 int32_t vra_debug_norm_deferred_mask(int32_t hidden, int32_t inter_local, int32_t heads_local, int32_t kv_heads_local, int32_t head_dim,
-                                     int32_t group_size, int32_t quant, int32_t qkv_bias, int32_t world, int32_t rows, int32_t layer);
+                                     int32_t group_size, int32_t quant, int32_t qkv_bias, int32_t world, int32_t rows, int32_t layer,
+                                     int32_t dtype); /* f16 models defer at 1..4 rows only (no ready-made operands: their range is bf16's) */
 int32_t vra_debug_gemv_s_fits(int32_t ns, int32_t m, int32_t k, int32_t group_size, int32_t n_units, int32_t norm);
 void vra_engine_debug_tp_snapshots(void* eng, int32_t on); /* on = 1 + the layer whose stages are kept; 0 = off */
 int64_t vra_engine_debug_read_tp_snapshot(void* eng, int32_t idx, void* h_out, int64_t max_bytes);

@@ -25,6 +25,12 @@ BF16, F16, F32 = 0, 1, 2
 # reference order everywhere (others.rs:11-29).
 ENGINE_RULE = None  # the loaded library (ctypes)
 
+# How the int4 product treats the dequantised weight.  "exact" (default): out = rnd(Σ x·s·(q − z)), one rounding at the output — what
+# the HIP kernels compute.  "marlin": every weight rounded to the model dtype first, w = rnd((q − z)·s), then the
+# product — what the reference's CUDA build computes (Marlin, src/utils/gptq.rs:116-178).  tests/full_depth.py reports the engine
+# against BOTH, each with the reference's norm order (ENGINE_RULE None, others.rs:11-29), beside the mirrored order.
+WEIGHT_ROUNDING = "exact"
+
 
 def deferred_norm_mask(cfg, T, tp_world=1, layer=1):
     """bit 0: norm + q/k/v of a T-row step of layer `layer` in the deferred order, bit 1: norm + gate/up (Model::norm_deferred_mask)"""
@@ -33,7 +39,7 @@ def deferred_norm_mask(cfg, T, tp_world=1, layer=1):
     hq = cfg["num_heads"] // tp_world
     hkv = max(1, cfg["num_kv_heads"] // tp_world)
     return int(ENGINE_RULE.vra_debug_norm_deferred_mask(cfg["hidden_size"], cfg["intermediate_size"] // tp_world, hq, hkv, cfg["head_dim"],
-                                                        cfg.get("group_size", 128), 1, int(bool(cfg.get("attention_bias"))), tp_world, T, layer))
+                                                        cfg.get("group_size", 128), 1, int(bool(cfg.get("attention_bias"))), tp_world, T, layer, cfg["dtype"]))
 
 
 class Linear:
@@ -66,12 +72,13 @@ class Linear:
             assert k0 % g == 0 and k1 % g == 0
             z = None if self.zeros is None else np.ascontiguousarray(self.zeros[k0 // g:k1 // g])
             return orc.wna16_gemm(x, np.ascontiguousarray(self.idx[k0:k1]), z, np.ascontiguousarray(self.scales[k0 // g:k1 // g]),
-                                  self.gs, self.dt, None, None)
+                                  self.gs, self.dt, None, None, marlin_rounded=WEIGHT_ROUNDING == "marlin")
         return orc.dense_gemm(x, np.ascontiguousarray(self.w[:, k0:k1]), None, self.dt, self.dt)
 
     def __call__(self, x, residual=None, row_scale=None):
         if self.quant:
-            return orc.wna16_gemm(x, self.idx, self.zeros, self.scales, self.gs, self.dt, self.bias, residual, row_scale)
+            return orc.wna16_gemm(x, self.idx, self.zeros, self.scales, self.gs, self.dt, self.bias, residual, row_scale,
+                                  marlin_rounded=WEIGHT_ROUNDING == "marlin")
         assert row_scale is None, "the deferred norm order exists for the int4 decode kernel only"
         out = orc.dense_gemm(x, self.w, self.bias, self.dt, self.dt)
         return orc.add(out, residual, self.dt) if residual is not None else out
@@ -82,6 +89,11 @@ class OracleModel:
     produce exact slices of the unsharded result (nothing to simulate); the row-parallel o_proj / down_proj produce
     per-rank partial sums rounded to the model dtype, which the all-reduce adds (here: in rank order, f32, one
     rounding — NCCL's order is unspecified), then bias, then the residual (distributed.rs:438-455, llama.rs:126,130)."""
+
+    def reset_cache(self):
+        """empty KV cache: the same weights can replay a request under another arithmetic variant (tests/full_depth.py)"""
+        for c in self.kc + self.vc:
+            c[...] = 0
 
     def __init__(self, cfg, weights, num_blocks, block_size=64, tp_world=1, fp8_kvcache=False):
         self.cfg, self.w, self.BS = cfg, weights, block_size

@@ -212,13 +212,18 @@ def gemm_wdense(x, w, bias, residual, dt):
     return out
 
 
-def wna16_gemm(x, idx, zeros, scales, group_size, dt, bias=None, residual=None, row_scale=None):
-    """row_scale [M] f32: the deferred RMSNorm factor, applied to the f32 sums before the output rounding (rms_norm_deferred)"""
+def wna16_gemm(x, idx, zeros, scales, group_size, dt, bias=None, residual=None, row_scale=None, marlin_rounded=False):
+    """row_scale [M] f32: the deferred RMSNorm factor, applied to the f32 sums before the output rounding (rms_norm_deferred).
+    marlin_rounded: every dequantised weight rounded to dt before the product (what the reference's Marlin kernels compute,
+    gptq.rs:116-178) — bit-identical to dequant() + gemm_wdense()."""
     x, idx, zeros, scales, bias, residual = _c(x), _c(idx, np.uint8), _c(zeros, np.uint8), _c(scales), _c(bias), _c(residual)
     M, K = x.shape
     N = idx.shape[1]
     out = np.empty((M, N), np_dt(dt))
-    if row_scale is None:
+    if marlin_rounded:
+        assert row_scale is None, "the reference applies the norm before the GEMM"
+        lib().orc_wna16_gemm_marlin(_p(x), _p(idx), _p(zeros), _p(scales), _p(bias), _p(residual), M, K, N, group_size, dt, _p(out))
+    elif row_scale is None:
         lib().orc_wna16_gemm(_p(x), _p(idx), _p(zeros), _p(scales), _p(bias), _p(residual), M, K, N, group_size, dt, _p(out))
     else:
         rs = _c(row_scale, np.float32)

@@ -342,12 +342,16 @@ void orc_gemm_wdense(const void* x, const void* w, const void* bias, const void*
  * GPTQ/AWQ weights W = s·(q − z) and ONE rounding at the output,
  *     out = rnd( Σ_k x_k · s_g(k) · (q_k − z_g(k)) )   [+ bias, + residual, each rounded as the reference's ops].
  * (The Marlin kernels behind src/utils/gptq.rs:116-178 additionally round every dequantised weight
- * to 16 bits before the MMA — orc_dequant/orc_gemm_wdense above restate that variant; the two differ
- * by < 1 output ulp and the reference's kernel sources are not in the tree to arbitrate.)
+ * to 16 bits before the MMA — orc_dequant/orc_gemm_wdense above, and `wround` here, restate that
+ * variant.  MEASURED distance between the two at the Llama-3-8B shapes: 4-8 ulps of the output row's
+ * scale per GEMM (tests/test_gpu_tolerance.py reports both against float64), NOT "< 1 ulp" as this
+ * comment claimed until round 5; the reference's kernel sources are not in the tree to arbitrate, so
+ * the full-depth reports carry both (tests/full_depth.py: `reference_order`, `marlin_rounded`).)
+ * wround != 0: every dequantised weight rounded to dt first, w = rnd((q - z) * s)  (Marlin's arithmetic).
  * x [M,K] dt; idx [K,N]; scales [G,N]; zeros [G,N] or NULL. */
 static void wna16_gemm_rs(const void* x, const uint8_t* idx, const uint8_t* zeros, const void* scales,
                           const void* bias, const void* residual, const float* row_scale, int M, int K, int N, int group_size,
-                          int dt, void* out) {
+                          int dt, void* out, int wround) {
   /* Blocked for the caches (32 columns x 64 rows of accumulators per thread, k outermost inside a block, weights
    * dequantised once per (k, column) and row block); every output is still the SEQUENTIAL sum over k = 0..K-1 in double,
    * i.e. bit-identical to the plain triple loop. */
@@ -372,7 +376,9 @@ static void wna16_gemm_rs(const void* x, const uint8_t* idx, const uint8_t* zero
           for (int c = 0; c < nc; c++) {
             int n = n0 + c;
             int z = zeros ? zeros[(int64_t)grp * N + n] : 8;
-            wv[c] = (double)((int)idx[(int64_t)k * N + n] - z) * (double)ld(scales, (int64_t)grp * N + n, dt);
+            int qz = (int)idx[(int64_t)k * N + n] - z;
+            float sc = ld(scales, (int64_t)grp * N + n, dt);
+            wv[c] = wround ? (double)rnd((float)qz * sc, dt) : (double)qz * (double)sc;  /* (q - z) * s is exact in f32: 5 x 11 bits */
           }
           for (int m = 0; m < mc; m++) {
             double xv = (double)xf[(int64_t)(m0 + m) * K + k];
@@ -396,7 +402,14 @@ static void wna16_gemm_rs(const void* x, const uint8_t* idx, const uint8_t* zero
 void orc_wna16_gemm(const void* x, const uint8_t* idx, const uint8_t* zeros, const void* scales,
                     const void* bias, const void* residual, int M, int K, int N, int group_size,
                     int dt, void* out) {
-  wna16_gemm_rs(x, idx, zeros, scales, bias, residual, NULL, M, K, N, group_size, dt, out);
+  wna16_gemm_rs(x, idx, zeros, scales, bias, residual, NULL, M, K, N, group_size, dt, out, 0);
+}
+/* Marlin's arithmetic (weights rounded to 16 bits before the product) without materialising the dense tensor:
+ * bit-identical to orc_dequant + orc_gemm_wdense (tests/test_oracle.py). */
+void orc_wna16_gemm_marlin(const void* x, const uint8_t* idx, const uint8_t* zeros, const void* scales,
+                           const void* bias, const void* residual, int M, int K, int N, int group_size,
+                           int dt, void* out) {
+  wna16_gemm_rs(x, idx, zeros, scales, bias, residual, NULL, M, K, N, group_size, dt, out, 1);
 }
 /* The same product with a per-row f32 factor applied to the f32 sum BEFORE the output rounding:
  *     out = rnd( row_scale[m] · Σ_k x_k · s_g(k) · (q_k − z_g(k)) )   [+ bias, + residual as above]
@@ -404,7 +417,7 @@ void orc_wna16_gemm(const void* x, const uint8_t* idx, const uint8_t* zeros, con
 void orc_wna16_gemm_row_scale(const void* x, const uint8_t* idx, const uint8_t* zeros, const void* scales,
                               const void* bias, const void* residual, const float* row_scale, int M, int K, int N,
                               int group_size, int dt, void* out) {
-  wna16_gemm_rs(x, idx, zeros, scales, bias, residual, row_scale, M, K, N, group_size, dt, out);
+  wna16_gemm_rs(x, idx, zeros, scales, bias, residual, row_scale, M, K, N, group_size, dt, out, 0);
 }
 /* Fast path of the same arithmetic straight from GPTQ-packed words (timed CPU baseline, bs small):
  * qw [K/8,N] u32 (gptq layout), symmetric zero 8, scales [G,N] dt. f32 accumulation. */

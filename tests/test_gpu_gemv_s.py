@@ -139,6 +139,37 @@ def test_gemv_s_fused_rms_norm(M, dt, K, N):
     assert frac < 0.6 and float((np.abs(gv - sv) / row_ulp).max()) <= 4.0
 
 
+@pytest.mark.parametrize("M", [1, 3])
+@pytest.mark.parametrize("case", ["tiny", "outlier"])
+def test_gemv_s_fused_rms_norm_f16_range(M, case):
+    """the deferred order stages round(x * g) WITHOUT rstd.  In f16 that leaves the range the reference's
+    round(round(x * rstd) * g) lives in: 'tiny' = layer-0 magnitudes (|x| ~ 1e-2 times norm weights ~ 1e-2: x * g ~ 1e-4 sits in f16's
+    subnormals, 2^-14 = 6.1e-5), 'outlier' = a massive-activation channel with g > 1 (x * g = 9e4 > 65504: inf without a rescale).
+    Kernel E stages each wave's slices times a power of two of its own (gemv_q4s.cuh) — checked here against the REFERENCE-order
+    oracle (others.rs:11-29: norm, then GEMM), not the mirrored one: finite, and within 4 ulps of the row scale like the
+    well-scaled case of test_gemv_s_fused_rms_norm."""
+    K, N, dt = 4096, 6144, F16
+    r = rng(M + len(case))
+    q = make_quant(r, K, N, 128, dt, False)
+    if case == "tiny":
+        x = orc.to_dt((0.01 * r.standard_normal((M, K))).astype(np.float32), dt)
+        nw = orc.to_dt((0.01 * (1.0 + 0.2 * r.standard_normal(K))).astype(np.float32), dt)
+    else:
+        xf = r.standard_normal((M, K)).astype(np.float32)
+        gf = (1.0 + 0.1 * r.standard_normal(K)).astype(np.float32)
+        xf[:, 1234] = 300.0
+        gf[1234] = 300.0
+        x, nw = orc.to_dt(xf, dt), orc.to_dt(gf, dt)
+    out = ops.rms_norm_wna16_gemm(ops.dev(x), ops.dev(nw), 1e-5, _tiled(q), ops.dev(q["scales"]), None, M, K, N, 128, dtype=dt)
+    got = orc.from_dt(out.numpy(np.uint16, (M, N)), dt)
+    assert np.isfinite(got).all(), "the staged operand left f16's range"
+    ref = orc.from_dt(orc.wna16_gemm(orc.rms_norm(x, nw, 1e-5, dt), q["idx"], None, q["scales"], 128, dt), dt)
+    row_ulp = 2.0 ** (np.floor(np.log2(np.abs(ref).max(axis=-1, keepdims=True))) - 10)
+    dev = float((np.abs(got - ref) / row_ulp).max())
+    print(f"[f16 range] {case} M={M}: max {dev:.2f} ulps of the row scale against the reference order")
+    assert dev <= 4.0, dev
+
+
 @pytest.mark.parametrize("M", [1, 4])
 def test_gemv_s_fused_rms_norm_gate_up(M):
     K, N = 4096, 14336

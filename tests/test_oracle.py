@@ -153,6 +153,47 @@ def test_dequant_is_marlin_style_single_rounding():
 
 
 @pytest.mark.parametrize("dt", [BF16, F16])
+@pytest.mark.parametrize("awq", [False, True])
+def test_marlin_rounded_gemm_is_dequant_then_dense_gemm(dt, awq):
+    """orc.wna16_gemm(marlin_rounded=True) — the arithmetic of the reference's Marlin kernels (gptq.rs:116-178: every weight
+    rounded to 16 bits before the MMA) — is bit for bit orc.dequant + orc.gemm_wdense, with bias and residual; and it is NOT the
+    exact product (the two contracts are distinguishable at these sizes)."""
+    r = np.random.default_rng(21 + dt + 2 * awq)
+    M, K, N, g = 3, 512, 48, 128
+    idx = r.integers(0, 16, size=(K, N), dtype=np.uint8)
+    zeros = r.integers(0, 16, size=(K // g, N), dtype=np.uint8) if awq else None
+    scales = orc.to_dt((0.002 + 0.018 * r.random((K // g, N))).astype(np.float32), dt)
+    x = orc.to_dt(r.standard_normal((M, K)).astype(np.float32), dt)
+    bias = orc.to_dt(r.standard_normal(N).astype(np.float32) * 0.1, dt)
+    res = orc.to_dt(r.standard_normal((M, N)).astype(np.float32), dt)
+    got = orc.wna16_gemm(x, idx, zeros, scales, g, dt, bias, res, marlin_rounded=True)
+    w = orc.dequant(idx, zeros if awq else np.full((K // g, N), 8, np.uint8), scales, g, dt)
+    assert (got == orc.gemm_wdense(x, w, bias, res, dt)).all()
+    exact = orc.wna16_gemm(x, idx, zeros, scales, g, dt, bias, res)
+    assert (got != exact).any(), "exact and Marlin-rounded products coincide: the test no longer separates the contracts"
+
+
+def test_model_weight_rounding_switch():
+    """oracle/model.py WEIGHT_ROUNDING: 'marlin' routes every int4 linear through the Marlin-rounded product"""
+    from oracle import model as om
+    cfg = dict(arch="llama", hidden_size=128, intermediate_size=256, num_layers=1, num_heads=2, num_kv_heads=1, head_dim=64, vocab_size=64,
+               max_position_embeddings=64, rms_norm_eps=1e-5, rope_theta=10000.0, quant_method="gptq", group_size=128, dtype=BF16)
+    w = om.make_random_checkpoint(cfg, 3)
+    m = om.OracleModel(cfg, w, num_blocks=2)
+    ids, pos, bt = np.arange(5, dtype=np.uint32), np.arange(5, dtype=np.int64), np.array([[0]], np.uint32)
+    a = m.forward(ids, pos, pos.copy(), bt, [5], [0, 5])
+    try:
+        om.WEIGHT_ROUNDING = "marlin"
+        m.reset_cache()
+        b = m.forward(ids, pos, pos.copy(), bt, [5], [0, 5])
+    finally:
+        om.WEIGHT_ROUNDING = "exact"
+    m.reset_cache()
+    assert (m.forward(ids, pos, pos.copy(), bt, [5], [0, 5]) == a).all()
+    assert (a != b).any() and np.abs(a - b).max() < 0.25 * np.abs(a).max()
+
+
+@pytest.mark.parametrize("dt", [BF16, F16])
 def test_rms_norm_silu_add_vs_float64(dt):
     r = np.random.default_rng(9)
     x = orc.to_dt(r.standard_normal((5, 96)).astype(np.float32) * 3, dt)

@@ -201,7 +201,7 @@ def load():
     _sig(lib, "vra_engine_copy_logits", c_i32, P, P, c_i32)
     _sig(lib, "vra_engine_debug_tp_snapshots", None, P, c_i32)
     _sig(lib, "vra_engine_norm_deferred", c_i32, P, c_i32, c_i32)
-    _sig(lib, "vra_debug_norm_deferred_mask", c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32)
+    _sig(lib, "vra_debug_norm_deferred_mask", c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32)
     _sig(lib, "vra_debug_gemv_s_fits", c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32)
     _sig(lib, "vra_engine_debug_read_tp_snapshot", c_i64, P, c_i32, P, c_i64)
     _sig(lib, "vra_engine_finalize_model", c_i32, P)

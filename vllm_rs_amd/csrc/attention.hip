@@ -333,14 +333,23 @@ static unsigned long long* attn_ts_buf() {
   return g_attn_ts;
 }
 extern "C" void vra_debug_attn_ts(unsigned long long* host, int n) { (void)hipMemcpy(host, attn_ts_buf(), (size_t)n * 8, hipMemcpyDeviceToHost); }
-#define FD_STAMP(i)                                                                                                              \
-  do {                                                                                                                           \
-    __builtin_amdgcn_sched_barrier(0);                                                                                           \
-    if (a.ts && tid == 0) a.ts[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + (i)] = wall_clock64(); \
-    __builtin_amdgcn_sched_barrier(0);                                                                                           \
+// (round 6) stamps are parked in LDS and written out once at the end: a global store per stamp counts in vmcnt like the loads, hipcc
+// then waits vmcnt(0) where it would have counted, and the timeline showed the instrument (gemv.cuh GEMV_STAMP)
+#define FD_STAMP(i)                                                  \
+  do {                                                               \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    if (a.ts && tid == 0) fd_ts_[(i)] = wall_clock64();              \
+    __builtin_amdgcn_sched_barrier(0);                               \
+  } while (0)
+#define FD_STAMP_DECL __shared__ unsigned long long fd_ts_[16];
+#define FD_STAMP_FLUSH()                                                                                                                     \
+  do {                                                                                                                                       \
+    if (a.ts && tid < 16) a.ts[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + tid] = fd_ts_[tid];            \
   } while (0)
 #else
 #define FD_STAMP(i) do {} while (0)
+#define FD_STAMP_DECL
+#define FD_STAMP_FLUSH() do {} while (0)
 #endif
 struct FusedDecodeArgs {
   void* out;          // [B, Hq, D]
@@ -375,7 +384,11 @@ __device__ __forceinline__ size_t vra_frag_index16(int m, int c) {
 // 1.744 against 1.722, ctx 8000 2.063 against 2.054, bs 32 2.682 against 2.673; profiles/r05_ab_attention_lat.txt): the vector-memory
 // path of a CU returns in order, so the early HBM loads stand in front of the prologue's L2 hits and the chain is no shorter.
 // Removed; what stayed of it: raw loads first / conversion at use, the split rule and the merge kernel below.)
-template <class DT, int D, bool KV8>
+// (Round 6) PRE2: a wave requests its first TWO tiles in the prologue.  With 5..8 tiles per workgroup (contexts of 129..256 tokens
+// unsplit, the two-way split up to 512, ...) one or two waves own two tiles, and the second one's load -> wait -> compute round trip
+// stood between "lds_o written" and the merge barrier of everybody else: 1.35 us of the 6.15 at ctx 150
+// (profiles/r05_timeline_attn_decode.txt).  ~64 more VGPRs: chosen by the launcher only while the grid is within one workgroup per CU.
+template <class DT, int D, bool KV8, bool PRE2 = false>
 __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const FusedDecodeArgs a) {
   typedef typename KVT<KV8>::elem kv_t;
   constexpr int DJ = D / 32, DT16 = D / 16, HALF = D / 2;
@@ -385,6 +398,7 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
   __shared__ float lds_ml[FD_WAVES][16][2];
   __shared__ __attribute__((aligned(16))) kv_t knew[D];       // the new token's K row in CACHE format (read like a cache row)
   __shared__ __attribute__((aligned(16))) uint16_t vnew[D];   // its V column as the model-dtype values a cache read returns
+  FD_STAMP_DECL
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rq = lane & 15, oct = lane >> 4;
@@ -417,16 +431,13 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
   const int n_s = s1t - s0t;
   const int kv_w0 = s0t + ((n_s * wave) >> 2), kv_w1 = s0t + ((n_s * (wave + 1)) >> 2);
   static_assert(FD_WAVES == 4, "tile split assumes 4 waves");
-  auto tile_blk_index = [&](int tile) {
-    const int T0 = tile << 5;
-    return (size_t)b * a.max_blocks + (a.bs_shift >= 0 ? T0 >> a.bs_shift : T0 / a.BS);
-  };
   int vec_base = 0;  // the block index lane 0 of `blkvec` holds
   auto tile_blk = [&](int tile) -> uint32_t {
     const int T0 = tile << 5;
     const int bi = __builtin_amdgcn_readfirstlane(a.bs_shift >= 0 ? T0 >> a.bs_shift : T0 / a.BS);
-    if (bi >= vec_base && bi < vec_base + 64) return (uint32_t)__builtin_amdgcn_readlane((int)blkvec, bi - vec_base);
-    return a.block_tables[tile_blk_index(tile)];  // (not reached: the vector is re-based on the wave's first block below)
+    // (the vector is re-based on the wave's first block below, so bi - vec_base is in 0..63 for every tile of the wave; clamped rather
+    // than backed by a load: a load on a never-taken path still put `s_waitcnt vmcnt` between the tile requests of the prologue)
+    return (uint32_t)__builtin_amdgcn_readlane((int)blkvec, min(max(bi - vec_base, 0), 63));
   };
   const kv_t* kcache = static_cast<const kv_t*>(a.kc);
   const kv_t* vcache = static_cast<const kv_t*>(a.vc);
@@ -456,53 +467,28 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
       blkvec = a.block_tables[(size_t)b * a.max_blocks + min(vec_base + lane, a.max_blocks - 1)];
     }
   }
-  uint32_t blk_cur = tile_blk(min(kv_w0, max(ntiles - 1, 0)));
+  // first tile(s) of this wave, clamped to the sequence's last tile: the requests below are UNCONDITIONAL (straight-line code lets hipcc
+  // count them in its s_waitcnt; inside branches it assumed none were issued and made the new token's staging wait for all of them).
+  // A wave without tiles re-reads a tile its neighbours read; a padded lane (ctx 0: its table row is not validated by the engine,
+  // ADVICE r5) reads block 0.
+  const int t_first = min(kv_w0, max(ntiles - 1, 0)), t_second = min(kv_w0 + 1, max(ntiles - 1, 0));
+  uint32_t blk_cur = ntiles > 0 ? tile_blk(t_first) : 0u;
   u32x4 ka0[KR], ka1[KR];
   vraw_t va[DT16];
-  // ---- new token: rotate k (threads 0 .. D/16-1), copy v (threads 64 .. 64+D/8-1); stage both in LDS
-  if (tid < HALF / 8) {
-    const uint16_t* kp = static_cast<const uint16_t*>(a.k) + ((size_t)b * a.Hkv + hk) * D;
-    const u32x4 xa = *reinterpret_cast<const u32x4*>(kp + tid * 8), xb = *reinterpret_cast<const u32x4*>(kp + HALF + tid * 8);
-    float x1[8], x2[8], cs[8], sn[8], y1[8], y2[8];
-    unpack8<DT>(xa, x1);
-    unpack8<DT>(xb, x2);
-    unpack8<DT>(*reinterpret_cast<const u32x4*>(cosp + tid * 8), cs);
-    unpack8<DT>(*reinterpret_cast<const u32x4*>(sinp + tid * 8), sn);
-#pragma unroll
-    for (int e = 0; e < 8; e++) {
-      y1[e] = x1[e] * cs[e] - x2[e] * sn[e];
-      y2[e] = x2[e] * cs[e] + x1[e] * sn[e];
-    }
-    const u32x4 r1 = pack8<DT>(y1), r2 = pack8<DT>(y2);
-    kv_store8<DT, KV8>(knew + tid * 8, r1);
-    kv_store8<DT, KV8>(knew + HALF + tid * 8, r2);
-    if (split == 0 && slot >= 0) {
-      kv_t* kcp = static_cast<kv_t*>(a.kc) + ((((size_t)slot_blk) * a.Hkv + hk) * a.BS + slot_off) * D;
-      kv_store8<DT, KV8>(kcp + tid * 8, r1);
-      kv_store8<DT, KV8>(kcp + HALF + tid * 8, r2);
-    }
-  } else if (tid >= 64 && tid < 64 + D / 8) {
-    const int c = tid - 64;
-    const u32x4 vv = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.v) + ((size_t)b * a.Hkv + hk) * D + c * 8);
-    *reinterpret_cast<u32x4*>(vnew + c * 8) = kv_roundtrip8<DT, KV8>(vv);
-    if (split == 0 && slot >= 0) {
-      kv_t* vcp = static_cast<kv_t*>(a.vc) + (((size_t)slot_blk) * a.Hkv + hk) * D * a.BS + slot_off;
-      if constexpr (KV8) {
-        const u32x2 q8 = vra_pack_e4m3x8<DT>(vv);
-#pragma unroll
-        for (int e = 0; e < 8; e++) vcp[(size_t)(c * 8 + e) * a.BS] = (uint8_t)(q8[e >> 2] >> (8 * (e & 3)));
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          vcp[(size_t)(c * 8 + 2 * e) * a.BS] = (uint16_t)(vv[e] & 0xffffu);
-          vcp[(size_t)(c * 8 + 2 * e + 1) * a.BS] = (uint16_t)(vv[e] >> 16);
-        }
-      }
-    }
-  }
-
-  FD_STAMP(2);
-  // ---- Q fragments, rotated in registers: lane (row rq = q head of the group, octet oct)
+  u32x4 kb0[PRE2 ? KR : 1], kb1[PRE2 ? KR : 1];
+  vraw_t vb[PRE2 ? DT16 : 1];
+  // ---- (round 6) EVERY load of the prologue goes out before the first wait: the new token's k / v rows and their cos / sin, q and
+  // its cos / sin, then this wave's first K/V tile(s) — L2 hits in front, the cache (HBM / Infinity Cache) behind them, so the
+  // in-order return path of the CU delays nothing.  Rounds 1-5 staged the new k / v first (its own round trip, 0.46 -> 1.19 us on the
+  // timeline) and only then requested q (a second one, -> 1.94 us).
+  // new token: threads 0 .. D/16-1 rotate k, threads 64 .. 64+D/8-1 copy v (every thread loads — clamped, the same few lines)
+  const bool kthr = tid < HALF / 8, vthr = tid >= 64 && tid < 64 + D / 8;
+  const int kt8 = (tid & (HALF / 8 - 1)) * 8, vc8 = (tid & (D / 8 - 1)) * 8;
+  const uint16_t* kp = static_cast<const uint16_t*>(a.k) + ((size_t)b * a.Hkv + hk) * D;
+  const u32x4 nk_a = *reinterpret_cast<const u32x4*>(kp + kt8), nk_b = *reinterpret_cast<const u32x4*>(kp + HALF + kt8);
+  const u32x4 nk_c = *reinterpret_cast<const u32x4*>(cosp + kt8), nk_s = *reinterpret_cast<const u32x4*>(sinp + kt8);
+  const u32x4 nv_v = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.v) + ((size_t)b * a.Hkv + hk) * D + vc8);
+  // Q fragments, rotated in registers: lane (row rq = q head of the group, octet oct)
   const bool row_valid = rq < G;
   const int qhead = hk * G + rq;
   s16x8 qf[DJ];
@@ -510,10 +496,6 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
   // DJ 16-byte loads per lane either way); the FP8 cache uses oct*(D/4) + j*8 + e — lane-contiguous, so that a lane's share of a
   // K row (D/4 bytes) is D/64 16-byte loads instead of DJ 8-byte ones (the FP8 cache read half the bytes in the same number
   // of load instructions).  q is laid out to match; the contraction order inside an MFMA changes, nothing else.
-  // (round 5) in three steps: the loads of q / cos / sin; the request of this wave's FIRST K/V tile — behind the prologue's own
-  // loads (L2 hits: not queued behind HBM misses), in front of the rotation of q and of the barrier; then the rotation.  The
-  // timeline of the round-4 kernel showed 1.2 us between the barrier and the first K/V load, all of it waiting for and rotating q
-  // (profiles/r05_timeline_attn_decode.txt); the tile's HBM round trip now runs under it.
   const uint16_t* qp = static_cast<const uint16_t*>(a.q) + ((size_t)b * a.Hq + qhead) * D;
   constexpr int QJ = KV8 ? DJ : DJ / 2;
   u32x4 q_a[QJ], q_b[QJ], q_c[QJ], q_s[QJ];
@@ -530,8 +512,57 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
     q_s[j] = *reinterpret_cast<const u32x4*>(sinp + cl);
   }
   __builtin_amdgcn_sched_barrier(0);
-  load_tile(min(kv_w0, max(ntiles - 1, 0)), blk_cur, ka0, ka1, va);
+  load_tile(t_first, blk_cur, ka0, ka1, va);
+  if constexpr (PRE2) load_tile(t_second, ntiles > 0 ? tile_blk(t_second) : 0u, kb0, kb1, vb);
   __builtin_amdgcn_sched_barrier(0);
+  // ---- new token: rotate k, copy v; stage both in LDS (and in the cache: split 0 only)
+  u32x4 nk_r1 = {0u, 0u, 0u, 0u}, nk_r2 = {0u, 0u, 0u, 0u};
+  if (kthr) {
+    float x1[8], x2[8], cs[8], sn[8], y1[8], y2[8];
+    unpack8<DT>(nk_a, x1);
+    unpack8<DT>(nk_b, x2);
+    unpack8<DT>(nk_c, cs);
+    unpack8<DT>(nk_s, sn);
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      y1[e] = x1[e] * cs[e] - x2[e] * sn[e];
+      y2[e] = x2[e] * cs[e] + x1[e] * sn[e];
+    }
+    nk_r1 = pack8<DT>(y1), nk_r2 = pack8<DT>(y2);
+    kv_store8<DT, KV8>(knew + tid * 8, nk_r1);
+    kv_store8<DT, KV8>(knew + HALF + tid * 8, nk_r2);
+  } else if (vthr) {
+    *reinterpret_cast<u32x4*>(vnew + (tid - 64) * 8) = kv_roundtrip8<DT, KV8>(nv_v);
+  }
+  // (the CACHE writes of the new token come after the q rotation: stores count in vmcnt like the loads, and with them queued here hipcc
+  // made the rotation wait for every tile load — the barrier then stood behind the cache round trip instead of under it)
+  auto store_new_token = [&]() {
+  if (kthr) {
+    if (split == 0 && slot >= 0) {
+      kv_t* kcp = static_cast<kv_t*>(a.kc) + ((((size_t)slot_blk) * a.Hkv + hk) * a.BS + slot_off) * D;
+      kv_store8<DT, KV8>(kcp + tid * 8, nk_r1);
+      kv_store8<DT, KV8>(kcp + HALF + tid * 8, nk_r2);
+    }
+  } else if (vthr) {
+    const int c = tid - 64;
+    const u32x4 vv = nv_v;
+    if (split == 0 && slot >= 0) {
+      kv_t* vcp = static_cast<kv_t*>(a.vc) + (((size_t)slot_blk) * a.Hkv + hk) * D * a.BS + slot_off;
+      if constexpr (KV8) {
+        const u32x2 q8 = vra_pack_e4m3x8<DT>(vv);
+#pragma unroll
+        for (int e = 0; e < 8; e++) vcp[(size_t)(c * 8 + e) * a.BS] = (uint8_t)(q8[e >> 2] >> (8 * (e & 3)));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          vcp[(size_t)(c * 8 + 2 * e) * a.BS] = (uint16_t)(vv[e] & 0xffffu);
+          vcp[(size_t)(c * 8 + 2 * e + 1) * a.BS] = (uint16_t)(vv[e] >> 16);
+        }
+      }
+    }
+  }
+  };
+  FD_STAMP(2);
 #pragma unroll
   for (int j = 0; j < QJ; j++) {
     float x1[8], x2[8], cs[8], sn[8];
@@ -558,6 +589,7 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
   FD_STAMP(3);
   __syncthreads();  // knew / vnew staged
   FD_STAMP(4);
+  store_new_token();
 
   const int last = ctx - 1;
 
@@ -566,7 +598,10 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
   for (int t = 0; t < DT16; t++) o[t] = vra_zero_acc();
   float m_run = -INFINITY, l_run = 0.f;
   // one tile: QK^T, online softmax, PV on the RAW registers of that tile (converted here: FP8 caches widen to 16 bits)
-  auto compute_tile = [&](int tile, const u32x4 (&kr0)[KR], const u32x4 (&kr1)[KR], const vraw_t (&vr)[DT16]) {
+  // FIRST (compile time): the wave's first tile — o is still zero and alpha = exp2(-inf) = 0: the rescale of o (32 multiplies behind four
+  // cross-lane reads of alpha) is skipped; 0 * 0 = 0, the same bits
+  auto compute_tile = [&](int tile, const u32x4 (&kr0)[KR], const u32x4 (&kr1)[KR], const vraw_t (&vr)[DT16], auto first_c) {
+    constexpr bool FIRST = decltype(first_c)::value;
     const int T0 = tile << 5;
     const bool has_new = last >= T0 && last < T0 + 32;  // wave-uniform: the tile that holds the new token
     u32x4 k0[DJ], k1[DJ];
@@ -618,8 +653,8 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
       sv[e] = x;
       tmax = fmaxf(tmax, x);
     }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    tmax = vra_xor16_max(tmax);  // (v_permlane16/32_swap: VALU, not the LDS round trip of __shfl_xor; the same maxima)
+    tmax = vra_xor32_max(tmax);
     const float m_new = fmaxf(m_run, tmax);
     const float m_safe = m_new == -INFINITY ? 0.f : m_new;
     const float alpha = exp2f(m_run - m_safe);
@@ -631,9 +666,19 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
     }
     l_run = l_run * alpha + psum;
     m_run = m_new;
-    float ar[4];
+    float ar[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (!FIRST) {
+      // alpha of q row oct*4 + r.  Groups of <= 4 q heads per kv head (Llama-3: 4, Qwen2-7B: 7 takes the general path): only rows 0..3
+      // are real and lanes 0..3 hold their alphas — v_readlane into SGPRs instead of four ds_bpermute round trips; the lanes of
+      // oct > 0 scale rows that are never stored
+      if (G <= 4) {
 #pragma unroll
-    for (int r = 0; r < 4; r++) ar[r] = __shfl(alpha, oct * 4 + r, 64);
+        for (int r = 0; r < 4; r++) ar[r] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(alpha), r));
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++) ar[r] = __shfl(alpha, oct * 4 + r, 64);
+      }
+    }
     u32x4 pa;
     pa[0] = DT::pack2(p[0], p[1]);
     pa[1] = DT::pack2(p[2], p[3]);
@@ -666,20 +711,25 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
 #pragma unroll
         for (int i = 0; i < 4; i++) vv[i] &= vm[i];
       }
+      if constexpr (!FIRST) {
 #pragma unroll
-      for (int r = 0; r < 4; r++) o[t][r] *= ar[r];
+        for (int r = 0; r < 4; r++) o[t][r] *= ar[r];
+      }
       DT::mfma(o[t], pfrag, __builtin_bit_cast(s16x8, vv));
     }
   };
-  if (kv_w0 < kv_w1) compute_tile(kv_w0, ka0, ka1, va);  // (its loads went out in front of the barrier)
-  for (int tile = kv_w0 + 1; tile < kv_w1; tile++) {
+  if (kv_w0 < kv_w1) compute_tile(kv_w0, ka0, ka1, va, std::true_type{});  // (its loads went out in front of the barrier)
+  if constexpr (PRE2) {
+    if (kv_w0 + 1 < kv_w1) compute_tile(kv_w0 + 1, kb0, kb1, vb, std::false_type{});  // (so did these)
+  }
+  for (int tile = kv_w0 + (PRE2 ? 2 : 1); tile < kv_w1; tile++) {
     load_tile(tile, tile_blk(tile), ka0, ka1, va);
-    compute_tile(tile, ka0, ka1, va);
+    compute_tile(tile, ka0, ka1, va, std::false_type{});
   }
   FD_STAMP(8);
   VRA_MFMA_DRAIN();
-  l_run += __shfl_xor(l_run, 16, 64);
-  l_run += __shfl_xor(l_run, 32, 64);
+  l_run = vra_xor16_sum(l_run);  // (a + b in either order: the same bits as the __shfl_xor form)
+  l_run = vra_xor32_sum(l_run);
 #pragma unroll
   for (int t = 0; t < DT16; t++)
 #pragma unroll
@@ -718,6 +768,7 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
     }
   }
   FD_STAMP(11);
+  FD_STAMP_FLUSH();
 }
 
 // second pass for split-KV decode: merge nsplit partials per (b, head).  The (max, sum) pairs of the splits go through LDS once
@@ -1038,10 +1089,20 @@ void vra_rope_cache_attention_decode_frag(void* out, const void* q, const void* 
   dim3 grid(a.nsplit, kv_heads, batch);
   hipStream_t st = as_stream(stream);
   const bool kv8 = kv_dtype == VRA_FP8_E4M3;
-#define VRA_FD(DT, DD)                                                                   \
-  do {                                                                                   \
-    if (kv8) decode_attn_fused_kernel<DT, DD, true><<<grid, FD_THREADS, 0, st>>>(a);     \
-    else decode_attn_fused_kernel<DT, DD, false><<<grid, FD_THREADS, 0, st>>>(a);        \
+  // PRE2 (two tiles requested in the prologue): when some wave owns a second tile (more than 4 tiles per split) and the grid is within
+  // one workgroup per CU (its ~64 extra VGPRs cost occupancy that larger grids need: bs 32 at long contexts)
+  const int tiles_per_split = ((max_context_len + 31) / 32 + a.nsplit - 1) / a.nsplit;
+  static const char* pre2_env = getenv("VRA_ATTN_PRE2");  // tuning aid: 0 = never, 1 = whenever a wave owns two tiles
+  const bool pre2 = tiles_per_split > 4 && (pre2_env ? atoi(pre2_env) != 0 : (long)a.nsplit * kv_heads * batch <= num_cus_attn());
+#define VRA_FD(DT, DD)                                                                                  \
+  do {                                                                                                  \
+    if (kv8) {                                                                                          \
+      if (pre2) decode_attn_fused_kernel<DT, DD, true, true><<<grid, FD_THREADS, 0, st>>>(a);           \
+      else decode_attn_fused_kernel<DT, DD, true, false><<<grid, FD_THREADS, 0, st>>>(a);               \
+    } else {                                                                                            \
+      if (pre2) decode_attn_fused_kernel<DT, DD, false, true><<<grid, FD_THREADS, 0, st>>>(a);          \
+      else decode_attn_fused_kernel<DT, DD, false, false><<<grid, FD_THREADS, 0, st>>>(a);              \
+    }                                                                                                   \
   } while (0)
   if (dtype == VRA_BF16) {
     if (head_dim == 128) VRA_FD(BF16, 128);

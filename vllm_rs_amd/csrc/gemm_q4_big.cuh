@@ -23,6 +23,17 @@
 // x chunks (16*MB rows x 128 k) are staged through LDS, triple buffered, one workgroup barrier per k-tile
 // (16*MB MFMAs per wave between barriers).  Scale groups of >= 128 (or per channel) only; row-major scales.
 // DUAL: a wave owns 2 gate + 2 up n-blocks of the same columns and the epilogue is silu(gate)·up (mlp.rs:451-469).
+//
+// Round 6 — the zero-point term leaves the k loop (ZH: GPTQ symmetric + bf16, the headline configuration).  With z = 8 for every
+// group the fix-up  acc += s_g·(acc_g − (C + 8)·Σx_g)  splits into  acc += s_g·acc_g  in the loop and ONE correction at the end,
+//     acc −= (C + 8) · Σ_g s_g[n] · Σx_g[m],
+// which is itself a small GEMM over the k-tiles — S [16 columns x k-tiles] times Σx [k-tiles x 16 rows] — and runs on the matrix
+// core: the scales are 16-bit floats already, the f32 row sums go in as three bf16 pieces (hi + mid + lo = 24 bits), 3 MFMAs per
+// 32 k-tiles and (n-block, m-tile) against the 128 of the main loop.  Per k-tile and wave that removes half of the fix-up (32 of 64
+// v_pk_fma_f32 at MB = 4) and the MB row-sum loads.  The kernel is bound by the SUM of its VALU and MFMA cycles (tools/mfma_valu_probe.hip),
+// so the removed VALU work is time.  Same exact arithmetic contract, another f32 summation order (<= 1 output ulp against the oracle as before).
+// AWQ (per-group zero points: the correction's A operand (C + z_g)·s_g is not a 16-bit float) and f16 (row sums beyond its range)
+// keep the in-loop form.
 #pragma once
 #include "gemv.cuh"  // GemvSeg
 #include "wna16.cuh"
@@ -37,6 +48,9 @@
 #endif
 #ifndef GD_XDEPTH
 #define GD_XDEPTH 2
+#endif
+#ifndef GD_ZHOIST
+#define GD_ZHOIST 1
 #endif
 
 struct GemmDArgs {
@@ -102,6 +116,7 @@ template <class DT, bool DUAL, bool AWQ, int MB>
 __global__ __launch_bounds__(GD_THREADS, 2) void gemm_q4_big_kernel(const GemmDArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NB = GD_NB;
+  constexpr bool ZH = GD_ZHOIST && !AWQ && std::is_same<DT, BF16>::value;  // zero-point term hoisted out of the k loop (header)
   constexpr int ROWS = 16 * GD_WM * MB;  // rows of x per workgroup
   constexpr int RPP = GD_THREADS / 16;   // rows one pass of the workgroup's threads stages
   constexpr int RS = (16 + 1) * 4;    // LDS row stride in u32: 16 octets + one of padding (see gemm_skinny.cuh)
@@ -194,6 +209,7 @@ __global__ __launch_bounds__(GD_THREADS, 2) void gemm_q4_big_kernel(const GemmDA
     }
   };
   auto sum_load = [&](int kt, float (&sx)[MB]) {
+    if constexpr (ZH) return;  // (the row sums are read once, behind the loop)
 #pragma unroll
     for (int mt = 0; mt < MB; mt++)
       sx[mt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsum, vo_sum[mt], (uint32_t)(kt * 4), 0));
@@ -211,7 +227,7 @@ __global__ __launch_bounds__(GD_THREADS, 2) void gemm_q4_big_kernel(const GemmDA
   u32x4 wq[NB];
   u32x2 scw[NB];
   uint32_t zw[NB];
-  float sxn[MB];
+  float sxn[MB] = {};
   {
     u32x4 x0[XPT], x1[XPT];
     x_load(kt0, x0);
@@ -273,12 +289,21 @@ __global__ __launch_bounds__(GD_THREADS, 2) void gemm_q4_big_kernel(const GemmDA
       if (j == 3) {
         VRA_MFMA_DRAIN();
 #if GD_PK_FIXUP
+        if constexpr (ZH) {
+#pragma unroll
+          for (int b = 0; b < NB; b++) {
+            const f32x2 g0 = {ag[b][0], ag[b][1]}, g1 = {ag[b][2], ag[b][3]};
+            acc[b][mt][0] = __builtin_elementwise_fma(sc2[b][0], g0, acc[b][mt][0]);
+            acc[b][mt][1] = __builtin_elementwise_fma(sc2[b][1], g1, acc[b][mt][1]);
+          }
+        } else {
         const f32x2 sx2 = {sxc[mt], sxc[mt]};
 #pragma unroll
         for (int b = 0; b < NB; b++) {
           const f32x2 g0 = {ag[b][0], ag[b][1]}, g1 = {ag[b][2], ag[b][3]};
           acc[b][mt][0] = __builtin_elementwise_fma(sc2[b][0], __builtin_elementwise_fma(nzc2[b][0], sx2, g0), acc[b][mt][0]);
           acc[b][mt][1] = __builtin_elementwise_fma(sc2[b][1], __builtin_elementwise_fma(nzc2[b][1], sx2, g1), acc[b][mt][1]);
+        }
         }
 #else
         // scalar v_fma_f32 (2 cycles each), not v_pk_fma_f32: packed f32 VALU beside MFMAs costs more than its two halves
@@ -308,6 +333,68 @@ __global__ __launch_bounds__(GD_THREADS, 2) void gemm_q4_big_kernel(const GemmDA
     t[0] = (unsigned long long)sB, t[1] = (unsigned long long)sC, t[2] = (unsigned long long)sD, t[3] = (unsigned long long)sE;
   }
 #endif
+
+  // ---- ZH: the zero-point term of this workgroup's k-tiles [kt0, kt1), 32 k-tiles per MFMA step (header).
+  //   A (scales): lane (column nn, octet oct) holds s[grp(t)][column] for the 8 tiles t = t0 + oct*8 .. +7 (tiles >= kt1: zero);
+  //   B (row sums): lane (row nn of the m-tile, octet oct) holds the 8 sums of those tiles as hi / mid / lo bf16 pieces.
+  if constexpr (ZH) {
+    const uint32_t vo_sn = (uint32_t)nn * 2u;  // the lane's column within the n-block (16-bit scales)
+    for (int t0 = kt0; t0 < kt1; t0 += 32) {
+      const int tb0 = t0 + oct * 8;  // this lane's first tile
+      s16x8 sa[NB];
+#pragma unroll
+      for (int b = 0; b < NB; b++) {
+        uint32_t sv[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const int t = min(tb0 + e, kt1 - 1);
+          const int grp = grouped ? (t * 128) >> gsh : 0;
+          sv[e] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rsc[tb(b)], vo_sn, (uint32_t)((grp * Nt + nbc[b] * 16) * 2), 0);
+        }
+        u32x4 w;
+#pragma unroll
+        for (int i = 0; i < 4; i++) w[i] = (tb0 + 2 * i < kt1 ? sv[2 * i] : 0u) | ((tb0 + 2 * i + 1 < kt1 ? sv[2 * i + 1] : 0u) << 16);
+        sa[b] = __builtin_bit_cast(s16x8, w);
+      }
+#pragma unroll
+      for (int mt = 0; mt < MB; mt++) {
+        // the 8 sums of this lane's tiles (index clamped to the slice: tiles >= kt1 meet zero scales in the A operand)
+        float sxv[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+          sxv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsum, vo_sum[mt], (uint32_t)(min(tb0 + e, kt1 - 1) * 4), 0));
+        u32x4 ph, pm, pl;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          uint32_t hw[2], mw[2], lw[2];
+#pragma unroll
+          for (int c = 0; c < 2; c++) {
+            const float v = sxv[2 * i + c];
+            const uint32_t hb = __float_as_uint(v) & 0xffff0000u;  // top 8 significant bits (truncated: v - hi is exact)
+            const float r1 = v - __uint_as_float(hb);
+            const uint32_t mb_ = __float_as_uint(r1) & 0xffff0000u;
+            const float r2 = r1 - __uint_as_float(mb_);
+            hw[c] = hb >> 16, mw[c] = mb_ >> 16, lw[c] = (uint32_t)BF16::from_f32(r2);
+          }
+          ph[i] = hw[0] | (hw[1] << 16), pm[i] = mw[0] | (mw[1] << 16), pl[i] = lw[0] | (lw[1] << 16);
+        }
+        f32x4 zt[NB];
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+          BF16::mfma0(zt[b], sa[b], __builtin_bit_cast(s16x8, pl));  // smallest pieces first
+          BF16::mfma(zt[b], sa[b], __builtin_bit_cast(s16x8, pm));
+          BF16::mfma(zt[b], sa[b], __builtin_bit_cast(s16x8, ph));
+        }
+        VRA_MFMA_DRAIN();
+        constexpr float NZC = -(Magic<BF16>::bias + 8.0f);
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+          acc[b][mt][0] = __builtin_elementwise_fma(f32x2{NZC, NZC}, f32x2{zt[b][0], zt[b][1]}, acc[b][mt][0]);
+          acc[b][mt][1] = __builtin_elementwise_fma(f32x2{NZC, NZC}, f32x2{zt[b][2], zt[b][3]}, acc[b][mt][1]);
+        }
+      }
+    }
+  }
 
   // ---- split-K: the slices of a tile meet through memory (see gemm_skinny.cuh): write-through 16-byte stores, one flag
   // line per slice, the last slice ("owner") polls, adds the slabs to its own partial in slice order and resets the flags

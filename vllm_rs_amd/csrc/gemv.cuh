@@ -87,16 +87,30 @@ struct GemvArgs {
   int dense_tiled;
 };
 #ifdef VRA_GEMV_TS
+// (round 6) stamps are parked in LDS and leave in ONE store per thread at the end of the kernel (GEMV_STAMP_FLUSH).  Rounds 2-5 stored
+// every stamp to global memory on the spot: on gfx9 stores count in vmcnt like the loads, hipcc then waits vmcnt(0) where it would
+// have counted, and the stamped wave (wave 0) ran behind its peers — the "wave 0 ends 1.2 us late" of profiles/r05_timeline_kernel_e.txt
+// was the instrument, not the kernel.
+__device__ __forceinline__ unsigned long long* vra_ts_lds() {
+  __shared__ unsigned long long t[32];
+  return t;
+}
 #define GEMV_STAMP(i)                                                     \
   do {                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                    \
-    if (a.ts && tid == 0) a.ts[(size_t)blockIdx.x * 32 + (i)] = wall_clock64(); \
+    if (a.ts && tid == 0) vra_ts_lds()[(i)] = wall_clock64();             \
     __builtin_amdgcn_sched_barrier(0);                                    \
+  } while (0)
+#define GEMV_STAMP_FLUSH()                                                                        \
+  do {                                                                                            \
+    if (a.ts && tid < 32) a.ts[(size_t)blockIdx.x * 32 + tid] = vra_ts_lds()[tid]; /* (same wave as the writer: in order) */ \
   } while (0)
 #elif defined(VRA_GEMV_SB)
 #define GEMV_STAMP(i) __builtin_amdgcn_sched_barrier(0)
+#define GEMV_STAMP_FLUSH() do {} while (0)
 #else
 #define GEMV_STAMP(i) do {} while (0)
+#define GEMV_STAMP_FLUSH() do {} while (0)
 #endif
 
 // Stage x[M,K] into LDS (image xs[(oct*M + m)*4 .. +4] = x[m][oct*8 .. +8]), optionally RMS-normalised,
@@ -436,6 +450,7 @@ __global__ __launch_bounds__(GEMV_THREADS, 4) void gemv_kernel(const GemvArgs a)
     }
   }
   GEMV_STAMP(15);
+  GEMV_STAMP_FLUSH();
 }
 
 static inline size_t gemv_lds_bytes(bool int4, int nbw, int M, int K, int group_size) {

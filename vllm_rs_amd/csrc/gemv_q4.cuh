@@ -499,4 +499,5 @@ __global__ __launch_bounds__(1024) void gemv_q4_kernel(const GemvArgs a) {
     }
   }
   GEMV_STAMP(15);
+  GEMV_STAMP_FLUSH();
 }

@@ -112,6 +112,9 @@ static inline size_t gemv_q4s_lds_bytes(int ns, int tpw, int max_units, int xrow
 }
 
 #define GS_MIN_WAVES_PER_SIMD 4
+#ifndef GS_XRING
+#define GS_XRING 1
+#endif
 #ifndef GS_RING_PAIR
 #define GS_RING_PAIR 2
 #endif
@@ -222,6 +225,7 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
   // missing regions rewrite the last one with the same bytes).
   const int srg = (XR == 4 ? oct : min(oct, XR - 1)) * 272;
   const bool norm = a.norm_w != nullptr;
+  float unstage[4] = {1.f, 1.f, 1.f, 1.f};  // F16 + fused norm: 2^-k of rows 0..3 of this wave's slices (wave-uniform), see below
   const uint16_t* xrow = static_cast<const uint16_t*>(a.x) + (size_t)min(oct, M - 1) * a.x_ld + nn * 8;
   auto fill_ring = [&]() {
 #pragma unroll
@@ -231,7 +235,48 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
     }
     __builtin_amdgcn_sched_barrier(0);
   };
+  // (round 6) single-stream launches put the ring right behind the x requests; the gate/up pair (4 KiB per wave in its ring) still waits
+  // for x first — same-box A/B, profiles/r06_ab_kernel_e_ring.txt: norm + q/k/v 7.5 -> 7.3 us, o_proj 5.7 -> 5.3, gate/up 13.9 -> 14.3
+  constexpr bool XRING = GS_XRING && NS == 1;
   if (!norm) {
+   if constexpr (XRING) {
+    // (round 6) ALL of the wave's x slices are requested first, the ring right behind them with no wait in between, and the staging
+    // arithmetic runs while both are in flight: tools/prologue_probe.hip, first tile of the median wave 1.45 -> 1.25 us after launch
+    // (the slices of a wave with more than 4 k-tiles take a second batch of registers: K = 14336 has 7..8 per wave)
+    u32x4 xa[4], xb[GS_MAX_TPW - 4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int kt = min(sk ? O0 + min(i, TPW - 1) : wave + 16 * min(i, TPW - 1), KT - 1);
+      xa[i] = *reinterpret_cast<const u32x4*>(xrow + (size_t)kt * 128);
+    }
+    const bool more = TPW > 4;  // (wave-uniform)
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < GS_MAX_TPW - 4; i++) {
+        const int kt = min(sk ? O0 + min(4 + i, TPW - 1) : wave + 16 * min(4 + i, TPW - 1), KT - 1);
+        xb[i] = *reinterpret_cast<const u32x4*>(xrow + (size_t)kt * 128);
+      }
+    }
+    fill_ring();
+    auto stage = [&](int ti, u32x4 v) {
+      const bool valid = ti < CW;
+      if (!valid) v = u32x4{0u, 0u, 0u, 0u};  // a tile beyond this wave's share: zero slice (never multiplied: S = nu * CW steps)
+      unsigned char* tp = xw + (size_t)ti * TLS;
+      *reinterpret_cast<u32x4*>(tp + srg + nn * 16) = v;
+      const float s8 = row16_sum(octet_sum<DT>(v));
+      if (nn == 0) reinterpret_cast<float*>(tp + XR * 272)[oct] = s8;
+    };
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      if (i < TPW) stage(i, xa[i]);
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < GS_MAX_TPW - 4; i++)
+        if (4 + i < TPW) stage(4 + i, xb[i]);
+    }
+    GEMV_STAMP(16);
+    GEMV_STAMP(1);
+   } else {
     for (int t0 = 0; t0 < TPW; t0 += 4) {
       u32x4 xv[4];
 #pragma unroll
@@ -257,6 +302,7 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
     // the ring is filled right behind the x loads (in order per wave: x first); the staging above overlaps nothing of it
     fill_ring();
     GEMV_STAMP(1);
+   }
   } else {
     // Fused RMSNorm (round 5): the normalisation factor is applied in the EPILOGUE.  rstd = 1 / sqrt(mean(x²) + eps) is one scalar
     // per row and commutes with the GEMV:  Σ_k (x_k · rstd · g_k) · w_kn  =  rstd · Σ_k (x_k · g_k) · w_kn.  Rounds 1-4 normalised x
@@ -278,8 +324,38 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
     }
     // the ring goes out the moment x and g have landed, BEFORE the staging arithmetic (0.3 us of VALU per wave): -0.4 % of the bs-1
     // step against issuing it behind the staging (profiles/r05_ab_kernel_e_prologue.txt); issuing it before x is requested loses
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (!XRING) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     fill_ring();
+    // F16: x·g without rstd leaves the range the reference's round(x·rstd·g) lives in — |x|, g ~ 1e-2 fall into f16
+    // subnormals, an outlier channel with g > 1 passes 65504.  x never crosses waves, so every wave stages ITS slices of a row times
+    // a power of two of its own, 2^k with the largest |x·g| of the slices in [2^10, 2^11), and takes 2^-k back out of its partial tiles
+    // when they are parked (both exact in f32): the same bits as round(x·g) wherever that is a normal f16, full precision where it is
+    // not.  bf16 has the exponent range of f32: nothing to do.
+    float stage_sc = 1.f;
+    if constexpr (std::is_same<DT, F16>::value) {
+      float mx = 0.f;
+#pragma unroll
+      for (int ti = 0; ti < GS_NORM_TPW; ti++) {
+        if (ti < TPW && ti < CW) {
+          float f[8], g[8];
+          unpack8<DT>(xv[ti], f);
+          unpack8<DT>(nr[ti], g);
+#pragma unroll
+          for (int e = 0; e < 8; e++) mx = fmaxf(mx, fabsf(f[e] * g[e]));
+        }
+      }
+      mx = fmaxf(mx, vra_dpp_f<0xB1>(mx));
+      mx = fmaxf(mx, vra_dpp_f<0x4E>(mx));
+      mx = fmaxf(mx, vra_dpp_f<0x141>(mx));
+      mx = fmaxf(mx, vra_dpp_f<0x140>(mx));  // the row group's (16 lanes = one row's slices) maximum
+      const int ex = (int)((__float_as_uint(mx) >> 23) & 0xFFu) - 127;  // floor(log2(mx)); -127 for 0 / f32 subnormals
+      const int k = mx > 0.f ? min(max(10 - ex, -60), 60) : 0;
+      stage_sc = __uint_as_float((uint32_t)(127 + k) << 23);
+      unstage[0] = __uint_as_float((uint32_t)(127 - __builtin_amdgcn_readlane(k, 0)) << 23);
+      unstage[1] = __uint_as_float((uint32_t)(127 - __builtin_amdgcn_readlane(k, 16)) << 23);
+      unstage[2] = __uint_as_float((uint32_t)(127 - __builtin_amdgcn_readlane(k, 32)) << 23);
+      unstage[3] = __uint_as_float((uint32_t)(127 - __builtin_amdgcn_readlane(k, 48)) << 23);
+    }
     float ss = 0.f;
 #pragma unroll
     for (int ti = 0; ti < GS_NORM_TPW; ti++) {
@@ -292,7 +368,7 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
 #pragma unroll
         for (int e = 0; e < 8; e++) {
           ss += valid ? f[e] * f[e] : 0.f;
-          f[e] = valid ? f[e] * g[e] : 0.f;
+          f[e] = valid ? (std::is_same<DT, F16>::value ? (f[e] * g[e]) * stage_sc : f[e] * g[e]) : 0.f;
         }
         const u32x4 v = pack8<DT>(f);
         *reinterpret_cast<u32x4*>(tp + srg + nn * 16) = v;
@@ -355,7 +431,13 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
           ct = 0;
           if (oct == 0) {
 #pragma unroll
-            for (int b = 0; b < NS; b++) red[((cu * NS + b) * GS_WAVES + wave) * 16 + nn] = acc[b];
+            for (int b = 0; b < NS; b++) {
+              if constexpr (std::is_same<DT, F16>::value) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc[b][e] *= unstage[e];  // (1.0 without a fused norm)
+              }
+              red[((cu * NS + b) * GS_WAVES + wave) * 16 + nn] = acc[b];
+            }
           }
 #pragma unroll
           for (int b = 0; b < NS; b++) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -427,6 +509,7 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
     }
   }
   GEMV_STAMP(14);
+  GEMV_STAMP_FLUSH();
 }
 
 template <class DT, int NS, bool AWQ>

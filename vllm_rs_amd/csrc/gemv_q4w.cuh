@@ -538,4 +538,5 @@ __global__ __launch_bounds__(GW_THREADS) void gemv_q4w_kernel(const GemvSArgs a)
     }
   }
   GEMV_STAMP(15);
+  GEMV_STAMP_FLUSH();
 }

@@ -323,8 +323,12 @@ void vra_launch_gemv(const GemvArgs& a, bool int4, int dtype, int64_t stream) {
 // distribution of `n_units` units over the workgroups of one launch: grid <= #CUs, the first `r` workgroups own q+1 units.
 // A grid that divides the units evenly is preferred when it keeps at least 3/4 of the CUs busy (Llama-3-8B: 384 q/k/v
 // units -> 192 x 2, 896 gate/up pairs -> 224 x 4): equal streams end together, which a ragged last unit does not.
+//  The grid of kernels E / W never exceeds GW_PRE_PARTS workgroups: the producers of ready-made operands write one slot of
+// the [GW_PRE_PARTS][32] partial-sum tables per workgroup (gemv_q4w.cuh) and the consumers add exactly that many.  MI355X has 256 CUs;
+// a part with more (MI300X: 304) would otherwise write past the tables.
+static int gemv_sw_cus() { return std::min(num_cus(), GW_PRE_PARTS); }
 void vra_gemv_s_plan(int n_units, int* grid, int* q, int* r) {
-  const int cus = num_cus();
+  const int cus = gemv_sw_cus();
   int g = n_units < cus ? n_units : cus;
   static const char* mode = getenv("VRA_GS_GRID");  // tuning aid: "all" = always every CU, ragged
   if (!(mode && mode[0] == 'a')) {
@@ -448,7 +452,7 @@ static void gemv_w_plan(int ns, int M, int n_units, bool plain, int* grid, int* 
     return;
   }
   *rb = (M + rows - 1) / rows;
-  int cg = num_cus() / *rb;
+  int cg = gemv_sw_cus() / *rb;
   if (cg < 1) cg = 1;
   const int need = (n_units + max_units - 1) / max_units;
   if (cg < need) cg = need;
@@ -471,7 +475,7 @@ static bool gemv_w_kz_plan(int K, int n_units, int rb, int* kz, int* ktz, int* g
   const int KT = K / 128, per = GW_WAVES * GW_TPW;
   const int z = (KT + per - 1) / per;
   if (z < 2 || z > 8 || rb < 1) return false;
-  const int g = num_cus() / (z * rb);
+  const int g = gemv_sw_cus() / (z * rb);
   if (g < 1 || n_units < g) return false;
   const int t = (KT + z - 1) / z;
   if ((z - 1) * t >= KT) return false;  // every slice holds at least one tile
@@ -541,6 +545,10 @@ static void launch_gemv_w_n(GemvSArgs a, hipStream_t st) {
 #else
   a.ts = nullptr;
 #endif
+  if (a.pre_norm_w && grid > GW_PRE_PARTS) {
+    vra_set_error("gemv_w: %d workgroups exceed the %d slots of the partial-sum table", grid, GW_PRE_PARTS);
+    return;
+  }
   kern<<<dim3(grid, rb), GW_THREADS, lds, st>>>(a);
 }
 template <class DT, int MT, bool AWQ, bool XF>
@@ -571,6 +579,10 @@ static void launch_gemv_w_kz(GemvSArgs a, hipStream_t st) {
 #else
   a.ts = nullptr;
 #endif
+  if (a.pre_norm_w && a.kz * a.kz_groups > GW_PRE_PARTS) {
+    vra_set_error("gemv_w: %d workgroups exceed the %d slots of the partial-sum table", a.kz * a.kz_groups, GW_PRE_PARTS);
+    return;
+  }
   kern<<<dim3(a.kz * a.kz_groups, rb), GW_THREADS, lds, st>>>(a);
 }
 template <class DT, int NS, int MT, bool AWQ>

@@ -493,10 +493,14 @@ bool Model::init_buffers(int max_tokens, int max_seqs) {
     const size_t fb = (size_t)(H / 128) * 2 * 4096;
     if (!(hfrag_ = dalloc(fb)) || hipMemset(hfrag_, 0, fb) != hipSuccess) return false;
     const size_t sqb = (size_t)GW_PRE_PARTS * 32 * sizeof(float);
-    if (!(pre_o_ = dalloc(fb)) || hipMemset(pre_o_, 0, fb) != hipSuccess || !(pre_d_ = dalloc(fb)) || hipMemset(pre_d_, 0, fb) != hipSuccess) return false;
-    if (!(sq_o_ = (float*)dalloc(sqb)) || hipMemset(sq_o_, 0, sqb) != hipSuccess || !(sq_d_ = (float*)dalloc(sqb)) || hipMemset(sq_d_, 0, sqb) != hipSuccess)
-      return false;
-    if (!(pre_e_ = dalloc(fb)) || hipMemset(pre_e_, 0, fb) != hipSuccess || !(sq_e_ = (float*)dalloc(sqb)) || hipMemset(sq_e_, 0, sqb) != hipSuccess) return false;
+    // ready-made operands x̃ = round(h·γ) travel through memory in the model dtype WITHOUT rstd: bf16 only (f16 would leave its
+    // exponent range where round(h·rstd·γ) does not) — an f16 model keeps the in-kernel norm of kernel W at 5..32 rows
+    if (dt_ == VRA_BF16) {
+      if (!(pre_o_ = dalloc(fb)) || hipMemset(pre_o_, 0, fb) != hipSuccess || !(pre_d_ = dalloc(fb)) || hipMemset(pre_d_, 0, fb) != hipSuccess) return false;
+      if (!(sq_o_ = (float*)dalloc(sqb)) || hipMemset(sq_o_, 0, sqb) != hipSuccess || !(sq_d_ = (float*)dalloc(sqb)) || hipMemset(sq_d_, 0, sqb) != hipSuccess)
+        return false;
+      if (!(pre_e_ = dalloc(fb)) || hipMemset(pre_e_, 0, fb) != hipSuccess || !(sq_e_ = (float*)dalloc(sqb)) || hipMemset(sq_e_, 0, sqb) != hipSuccess) return false;
+    }
   }
   if (inter_ % 128 == 0) {
     const size_t fb = (size_t)(inter_ / 128) * 2 * 4096;
@@ -816,9 +820,11 @@ int Model::norm_deferred_mask(int M, int layer) const {
 }
 // the same from shapes alone (Llama / Qwen2 / Qwen3 checkpoints: q/k/v biases only), for the oracle (oracle/model.py deferred_norm_mask)
 extern "C" int32_t vra_debug_norm_deferred_mask(int32_t hidden, int32_t inter_local, int32_t heads_local, int32_t kv_heads_local, int32_t head_dim,
-                                                int32_t group_size, int32_t quant, int32_t qkv_bias, int32_t world, int32_t rows, int32_t layer) {
+                                                int32_t group_size, int32_t quant, int32_t qkv_bias, int32_t world, int32_t rows, int32_t layer,
+                                                int32_t dtype) {
   if (!quant) return 0;
-  return norm_deferred_rule(rows, layer, hidden, world, g_x_frag != 0, [&](int which) {
+  // (f16 models have no ready-made operands: 5..32-row steps keep the reference's order, Model::init_buffers)
+  return norm_deferred_rule(rows, layer, hidden, world, g_x_frag != 0 && dtype == VRA_BF16, [&](int which) {
     return family_takes(which, rows, hidden, inter_local, heads_local, kv_heads_local, head_dim, group_size, which == 0 && qkv_bias != 0);
   });
 }
