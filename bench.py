@@ -224,6 +224,219 @@ def ffi_path(L, cfg, iters=6):
                     "launch), eager launches on the null stream; attention excluded"}
 
 
+def ffi_step(L, cfg, ctx=150, replays=24):
+    """A WHOLE decode step (bs 1, context `ctx`) issued call by call the way the reference's Rust layers issue it (VERDICT r5 #7a):
+    embedding; per layer NormX, marlin_4bit_bf16 x (q, k, v) (gptq.rs:116-178), the rotary embedding (rotary_emb.rs:88-103),
+    reshape_and_cache + paged attention (attention.rs:745-820), marlin (o), + residual, NormX, marlin x (gate, up), silu * mul,
+    marlin (down), + residual; final norm, lm_head, argmax (llama.rs:269-321) — 17 launches per layer, nothing fused across calls,
+    Marlin-permuted scales, 32 layers with their own weights.  Timed twice: eager from this (ctypes) host, and captured ONCE into a
+    hipGraph by the host and replayed, as the reference replays its decode graphs (runner.rs graph capture).  HIP events on the stream."""
+    import ctypes as C
+    import numpy as np
+    from vllm_rs_amd import ops
+    H, I, D, Hq, Hkv, g, V, NL = (cfg[k] for k in ("hidden_size", "intermediate_size", "head_dim", "num_heads", "num_kv_heads", "group_size", "vocab_size", "num_layers"))
+    BS, nblk = 64, (ctx + 63) // 64
+    shapes = dict(q=(H, Hq * D), k=(H, Hkv * D), v=(H, Hkv * D), o=(Hq * D, H), gate=(H, I), up=(H, I), down=(I, H))
+    allocs = []
+
+    def dalloc(nbytes):
+        ptr = L.vra_malloc(nbytes)
+        allocs.append(ptr)
+        return ptr
+    layers = []
+    for l in range(NL):
+        lw = {}
+        for i, (name, (K, N)) in enumerate(shapes.items()):
+            w, sc = dalloc(K * N // 2), dalloc(K // g * N * 2)
+            L.vra_fill_hash_u32(w, K * N // 8, 5000 + l * 16 + i, 0)
+            L.vra_fill_uniform(sc, K // g * N, 6000 + l * 16 + i, 0.002, 0.02, 0, 0)
+            lw[name] = (w, sc, K, N)
+        lw["n1"], lw["n2"] = dalloc(H * 2), dalloc(H * 2)
+        L.vra_fill_normal(lw["n1"], H, 7 + l, 1.0, 0.02, 0, 0)
+        L.vra_fill_normal(lw["n2"], H, 90 + l, 1.0, 0.02, 0, 0)
+        cache = nblk * Hkv * BS * D
+        lw["kc"], lw["vc"] = dalloc(cache * 2), dalloc(cache * 2)
+        L.vra_fill_normal(lw["kc"], cache, 11 + l, 0.0, 1.0, 0, 0)
+        L.vra_fill_normal(lw["vc"], cache, 12 + l, 0.0, 1.0, 0, 0)
+        layers.append(lw)
+    embed, lm_head, fnorm = dalloc(V * H * 2), dalloc(V * H * 2), dalloc(H * 2)
+    L.vra_fill_normal(embed, V * H, 1, 0.0, 0.02, 0, 0)
+    L.vra_fill_normal(lm_head, V * H, 2, 0.0, 0.02, 0, 0)
+    L.vra_fill_normal(fnorm, H, 3, 1.0, 0.02, 0, 0)
+    h, xn, q, k, v, att, t1, gt, up, act = (dalloc(n * 2) for n in (H, H, Hq * D, Hkv * D, Hkv * D, Hq * D, H, I, I, I))
+    logits, tok = dalloc(V * 4), dalloc(64)
+    ws = dalloc(I * 4)
+    L.vra_memset(ws, 0, I * 4, 0)
+    am_ws = dalloc(L.vra_dense_gemm_argmax_workspace_bytes())
+    L.vra_memset(am_ws, 0, L.vra_dense_gemm_argmax_workspace_bytes(), 0)
+    cos, sin = dalloc(8192 * (D // 2) * 2), dalloc(8192 * (D // 2) * 2)
+    L.vra_fill_uniform(cos, 8192 * (D // 2), 21, -1.0, 1.0, 0, 0)
+    L.vra_fill_uniform(sin, 8192 * (D // 2), 22, -1.0, 1.0, 0, 0)
+    ids = ops.dev(np.array([1234], np.uint32))
+    pos = ops.dev(np.array([ctx - 1], np.int64))
+    slot = ops.dev(np.array([((ctx - 1) // BS) * BS + (ctx - 1) % BS], np.int64))
+    bt = ops.dev(np.arange(nblk, dtype=np.uint32)[None])
+    cl = ops.dev(np.array([ctx], np.uint32))
+    attn_ws = dalloc(L.vra_paged_attention_decode_workspace_bytes(1, Hq, D, ctx))
+    scale = 1.0 / float(np.sqrt(D))
+
+    def step(st):
+        L.vra_embedding(ids.ptr, embed, h, 1, H, V, 0, st)
+        for lw in layers:
+            L.vra_rms_norm(h, lw["n1"], xn, 1, H, 1e-5, 0, st)
+            for name, out in (("q", q), ("k", k), ("v", v)):
+                w, sc, K, N = lw[name]
+                L.marlin_4bit_bf16(xn, w, sc, None, None, out, 1, K, N, ws, g, st)
+            L.vra_fused_rope(q, k, cos, sin, pos.ptr, 1, Hq, Hkv, D, D, 0, 0, 0, st)
+            L.vra_reshape_and_cache(k, v, lw["kc"], lw["vc"], slot.ptr, 1, Hkv, D, BS, 0, 0, st)
+            L.vra_paged_attention_decode(att, q, lw["kc"], lw["vc"], bt.ptr, cl.ptr, 1, Hq, Hkv, D, BS, nblk, ctx, scale, 0.0, attn_ws, 0, 0, st)
+            w, sc, K, N = lw["o"]
+            L.marlin_4bit_bf16(att, w, sc, None, None, t1, 1, K, N, ws, g, st)
+            L.vra_add(t1, h, h, H, 0, st)
+            L.vra_rms_norm(h, lw["n2"], xn, 1, H, 1e-5, 0, st)
+            for name, out in (("gate", gt), ("up", up)):
+                w, sc, K, N = lw[name]
+                L.marlin_4bit_bf16(xn, w, sc, None, None, out, 1, K, N, ws, g, st)
+            L.vra_silu_mul(gt, up, act, I, 0, st)
+            w, sc, K, N = lw["down"]
+            L.marlin_4bit_bf16(act, w, sc, None, None, t1, 1, K, N, ws, g, st)
+            L.vra_add(t1, h, h, H, 0, st)
+        L.vra_rms_norm(h, fnorm, xn, 1, H, 1e-5, 0, st)
+        L.vra_dense_gemm_argmax(xn, lm_head, None, logits, tok, am_ws, 1, H, V, 0, st)
+
+    out = {"launches_per_step": 17 * NL + 3, "context": ctx}
+    try:
+        st = L.vra_stream_create()
+        e0, e1 = L.vra_event_create(), L.vra_event_create()
+        for _ in range(2):
+            step(st)
+        L.vra_device_sync()
+        L.vra_event_record(e0, st)
+        for _ in range(4):
+            step(st)
+        L.vra_event_record(e1, st)
+        out["eager_ms_per_step"] = L.vra_event_elapsed_ms(e0, e1) / 4
+        # the host's own graph capture (plain HIP runtime calls, as a Rust host would make them through hip-sys)
+        hip = C.CDLL("libamdhip64.so")
+        graph, gexec = C.c_void_p(), C.c_void_p()
+        sp = C.c_void_p(st)
+        assert hip.hipStreamBeginCapture(sp, 0) == 0
+        step(st)
+        assert hip.hipStreamEndCapture(sp, C.byref(graph)) == 0
+        assert hip.hipGraphInstantiate(C.byref(gexec), graph, None, None, C.c_size_t(0)) == 0
+        for _ in range(3):
+            assert hip.hipGraphLaunch(gexec, sp) == 0
+        L.vra_device_sync()
+        L.vra_event_record(e0, st)
+        for _ in range(replays):
+            hip.hipGraphLaunch(gexec, sp)
+        L.vra_event_record(e1, st)
+        out["graph_ms_per_step"] = L.vra_event_elapsed_ms(e0, e1) / replays
+        hip.hipGraphExecDestroy(gexec), hip.hipGraphDestroy(graph)
+        L.vra_event_destroy(e0), L.vra_event_destroy(e1)
+        err = L.vra_last_error().decode()
+        if err:
+            out["error"] = err
+    finally:
+        L.vra_device_sync()
+        for ptr in allocs:
+            L.vra_free(ptr)
+    out["note"] = ("one decode token through the seven FFI symbols + the section-B ops, attention included, nothing fused across calls; "
+                   "graph = the same sequence captured once by the host and replayed; compare ms_per_step of the native engine")
+    return out
+
+
+def runner_ipc_step(cfg, steps=96, warmup=8, prompt_len=128):
+    """A decode step through the literal drop-in path (VERDICT r5 #7b): this process plays the reference's ENGINE (src/core/engine.rs:
+    300-378 handshake, :844-892 RunPrefill / RunDecode) over the reference's framing (src/runner/mod.rs:246-295: abstract-namespace
+    Unix socket, `ready`, JSON Init, bincode frames, 1-byte acks) against the native `vra_runner` process with synthetic weights of the
+    named shape.  One bincode round trip per step, as engine.rs:849-885 does; wall-clock per step on the engine side."""
+    import socket
+    import subprocess
+    from vllm_rs_amd import wire
+    runner = os.path.join(ROOT, "vllm_rs_amd", "vra_runner")
+    if not os.path.exists(runner):
+        return {"error": "vra_runner not built"}
+    uuid = f"bench{os.getpid()}"
+    name = f"vra-bench-{os.getpid()}"
+    srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    srv.bind("\0" + name)
+    srv.listen(1)
+    srv.settimeout(600)
+    hb_srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    hb_srv.bind("\0command_" + uuid + "@vllm-rs-runner-heartbeat.sock")
+    hb_srv.listen(1)
+    hb_srv.settimeout(60)
+    hf = dict(architectures=["LlamaForCausalLM"], hidden_size=cfg["hidden_size"], intermediate_size=cfg["intermediate_size"],
+              num_hidden_layers=cfg["num_layers"], num_attention_heads=cfg["num_heads"], num_key_value_heads=cfg["num_kv_heads"],
+              head_dim=cfg["head_dim"], vocab_size=cfg["vocab_size"], max_position_embeddings=cfg["max_position_embeddings"],
+              rms_norm_eps=cfg["rms_norm_eps"], rope_theta=cfg["rope_theta"], torch_dtype="bfloat16", tie_word_embeddings=False,
+              quantization_config=dict(quant_method="gptq", bits=4, group_size=cfg["group_size"], desc_act=False, sym=True))
+    proc = subprocess.Popen([runner, "--sock", name, "--uuid", uuid], cwd=ROOT)
+    conn = hb = None
+    try:
+        conn, _ = srv.accept()
+        conn.settimeout(600)
+        assert wire._recv_exact(conn, 6) == b"ready\n"
+        hb, _ = hb_srv.accept()
+        hb.settimeout(60)
+        assert wire._recv_exact(hb, 6) == b"ready\n"
+        init = dict(rank=0, dev_id=0, num_shards=1, model_type="LLaMa", dtype="BF16", is_gguf=False, is_rope_i=False, config=hf,
+                    econfig=dict(block_size=64, max_num_seqs=8, num_blocks=128, max_model_len=2048, seed=5),
+                    model_pathes=dict(config_filename="/nonexistent/config.json", filenames=[]))  # no checkpoint: synthetic weights (bench mode)
+        wire.send_frame(conn, wire.encode_init_json(init))
+        assert wire.decode(wire.recv_frame(conn)) == ("InitAck", True)
+        nblocks = 64
+        ecfg = dict(model_id=None, weight_path="/nonexistent", weight_file=None, enforce_parser=None, hf_token=None, hf_token_path=None, num_blocks=nblocks,
+                    kv_fraction=0.5, mamba_fraction=None, cpu_mem_fold=0.0, kvcache_memory_bytes=0, mamba_memory_bytes=0, mamba_slot_bytes=0,
+                    mamba_cache_capacity=None, block_size=64, max_num_seqs=8, max_num_batched_tokens=2048, config_model_len=2048, max_model_len=2048,
+                    max_tokens=None, isq=None, num_shards=1, device_ids=[0], generation_cfg=None, seed=5, prefix_cache=False, prefix_cache_max_tokens=None,
+                    fp8_kvcache=False, server_mode=False, pd_config=None, mcp_command=None, mcp_config=None, mcp_args=None, tool_prompt_template=None,
+                    pd_server_prefix_cache_ratio=None, pd_client_prefix_cache_ratio=None, yarn_scaling_factor=None, disable_reasoning=False)
+        wire.send_frame(conn, wire.encode_usable_memory_left_json(ecfg))
+        assert wire.decode(wire.recv_frame(conn)) == ("InitAck", True)
+        greedy = dict(temperature=0.0)
+        toks = [int(t) for t in make_prompts(1, prompt_len, cfg["vocab_size"], seed=3)[0]]
+        table = list(range((prompt_len + 63) // 64))
+        seq = dict(id=1, token_ids=toks, block_table=table, num_cached_tokens=0, sampling_params=greedy, status="Running")
+        wire.send_frame(conn, wire.encode(("RunPrefill", ([seq], True))))
+        _, out = wire.decode(wire.recv_frame(conn))
+        if not out:
+            return {"error": "the runner answered the prefill with an empty RunResponse"}
+        toks.append(int(out[0]))
+        t0 = 0.0
+        for i in range(warmup + steps):
+            if i == warmup:
+                t0 = time.perf_counter()
+            if (len(toks) + 63) // 64 > len(table):
+                table.append(len(table))
+            d = dict(id=1, last_token=toks[-1], len=len(toks), last_block_tokens=len(toks) - (len(table) - 1) * 64, block_table_last=table[-1],
+                     block_tables=table, sampling_params=greedy)
+            wire.send_frame(conn, wire.encode(("RunDecode", ([d], False))))
+            _, out = wire.decode(wire.recv_frame(conn))
+            if not out:
+                return {"error": f"empty RunResponse at decode step {i}"}
+            toks.append(int(out[0]))
+        dt = time.perf_counter() - t0
+        wire.send_frame(conn, wire.encode(("Shutdown", None)))
+        return {"ms_per_step": dt * 1e3 / steps, "steps": steps, "tokens_per_s": steps / dt,
+                "note": "bs 1 greedy decode, one RunDecode/RunResponse bincode round trip per step over the abstract Unix socket, engine side in "
+                        "Python; the runner replays its captured hipGraph and returns token ids (vra_engine_forward_tokens)"}
+    except Exception as ex:
+        return {"error": repr(ex)}
+    finally:
+        for c in (conn, hb, srv, hb_srv):
+            try:
+                if c is not None:
+                    c.close()
+            except OSError:
+                pass
+        try:
+            proc.wait(timeout=20)
+        except Exception:
+            proc.kill()
+
+
 def oracle_decode_tokens_per_s(cfg, layers_sample, n_tokens, prompt_len, label):
     """CPU baseline: a REAL greedy decode through oracle/model.py (all ops: norm, GEMMs, rope, paged attention, lm_head,
     argmax) on a model of the named shape with `layers_sample` of its layers; the per-layer time comes from the difference to
@@ -590,6 +803,13 @@ def main():
             # ---------------- the reference's binding path
             line["ffi_path"] = ffi_path(L, cfg)
             line["ffi_path"]["native_family_ms_per_token"] = line["roofline"]["family_ms_per_token"]
+            try:
+                line["ffi_step"] = ffi_step(L, cfg)
+                line["ffi_step_ms"] = line["ffi_step"].get("graph_ms_per_step")
+            except Exception as ex:  # a leg of the extras never takes the line down
+                line["ffi_step"] = {"error": repr(ex)}
+            line["runner_ipc_step"] = runner_ipc_step(cfg)
+            line["runner_ipc_step_ms"] = line["runner_ipc_step"].get("ms_per_step")
             # ---------------- config 3: Qwen2-7B AWQ
             eq = E.Engine(E.QWEN2_7B, max_num_seqs=32, max_model_len=8192, num_gpu_blocks=2048, use_graph=not a.no_graph, device=local_rank,
                           seed=99, cpu_mem_fold=0.0).init_synthetic()

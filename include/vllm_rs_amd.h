@@ -69,8 +69,11 @@ void marlin_awq_4bit_f16(const void* in, const int32_t* qweight, const void* sca
                          int32_t n, const void* workspace, int32_t group_size, int64_t stream);
 /* replaces ffi::gemm_half_q_half_alt — src/utils/gptq.rs:182-195 (NOTE n before k). Plain GPTQ:
  * qweight [k/8, n] u32 (checkpoint layout), qzeros [k/g, n/8] u32 (stored z-1), scales [k/g, n] f16
- * row-major, g_idx [k] i32 (may be NULL = k/g), f16 activations only.  bits = 4, or 8 (wna16.rs:154-176 sends every
- * non-Marlin checkpoint here): qweight [k/4, n], qzeros [k/g, n/4], four values per word, zero = stored + 1 as well. */
+ * row-major, g_idx [k] i32, f16 activations only.  bits = 4, or 8 (wna16.rs:154-176 sends every
+ * non-Marlin checkpoint here): qweight [k/4, n], qzeros [k/g, n/4], four values per word, zero = stored + 1 as well.
+ * The reference's signature carries no group size.  With g_idx the group of row k is g_idx[k].  g_idx == NULL: the group size is read
+ * off the extent of the `scales` allocation, so `scales` must then be the BASE of its own [k/g, n] device allocation — a view into a
+ * larger buffer (candle's layout.start_offset(), gptq.rs:67) is rejected through vra_last_error() instead of being mis-sized. */
 void gemm_half_q_half_alt(const void* in, const uint32_t* qweight, const uint32_t* qzeros,
                           const void* scales, const int32_t* g_idx, void* out, int32_t m, int32_t n,
                           int32_t k, int32_t bits, int64_t stream);
@@ -369,6 +372,11 @@ float vra_event_elapsed_ms(void* start, void* stop); /* syncs on `stop` */
 
 /* Model/engine configuration — the fields of `Config` (src/utils/config.rs:218-255),
  * `QuantConfig` (:735-757) and `EngineConfig` (:285-328) the hot path consumes. */
+/* NOT wired into the native forward: sliding-window attention.  LLaMaForCausalLM passes config.sliding_window into attention and
+ * mask (llama.rs:46,284; Mistral-type checkpoints).  The ops exist (vra_paged_attention_decode_sw / _prefill_sw, vra_causal_mask, with
+ * oracle and parity tests) but Model::forward runs full causal attention only, so every loader REFUSES a config whose sliding_window is
+ * shorter than max_position_embeddings (runner_main.cpp init_from_json, checkpoint.py parse_config, wire.py model_cfg_from_init)
+ * rather than run it silently with another mask.  None of the five BASELINE configs uses one. */
 typedef struct vra_model_config {
   int32_t arch;              /* 0 = LlamaForCausalLM/Mistral (llama.rs), 1 = Qwen2ForCausalLM, 2 = Qwen3ForCausalLM (both qwen3.rs) */
   int32_t hidden_size, intermediate_size, num_layers;
@@ -570,6 +578,17 @@ int32_t vra_engine_forward_raw(void* eng, const uint32_t* h_ids, const int64_t* 
                                const uint32_t* h_block_tables, int32_t max_blocks,
                                const uint32_t* h_context_lens, const uint32_t* h_cu_seqlens_q,
                                int32_t n_seqs, float* h_logits_out);
+/* The same forward, answered with the SAMPLED TOKEN IDS instead of the logits — what the reference's runner process sends back
+ * (RunResponse, runner.rs:246-292).  Decode steps replay the hipGraph of their batch / context bucket when the engine was built with
+ * use_graph (the reference replays its captured decode graphs the same way, graph.rs:370-377); greedy tokens are the first maximal
+ * index (logits_processor.rs:67-70), `stochastic` != 0 runs LogitsProcessor::sample_with_strategy on the device logits
+ * (logits_processor.rs:199-271: top_k <= 256, 0 = off; top_p < 0 = off) with `seed`.  Nothing of vocabulary size crosses PCIe. */
+int32_t vra_engine_forward_tokens(void* eng, const uint32_t* h_ids, const int64_t* h_positions,
+                                  const int64_t* h_slot_mapping, int32_t n_tokens, int32_t is_prefill,
+                                  const uint32_t* h_block_tables, int32_t max_blocks,
+                                  const uint32_t* h_context_lens, const uint32_t* h_cu_seqlens_q,
+                                  int32_t n_seqs, int32_t stochastic, int32_t top_k, float top_p,
+                                  float temperature, uint64_t seed, uint32_t* h_tokens_out);
 /* decode-step microbenchmark hook used by bench.py: runs `steps` decode steps of the current
  * running batch back to back (graph replay when enabled) and returns elapsed ms measured with HIP
  * events on the engine stream; tokens are sampled and appended exactly as in vra_engine_step. */

@@ -204,6 +204,25 @@ def test_gemm_half_q_half_alt(gs, with_g_idx):
     assert_close_dt(got, ref, F16, name="gptq alt", abs_floor=2e-3)
 
 
+def test_gemm_half_q_half_alt_refuses_a_scales_view_without_g_idx():
+    """without g_idx the group size comes from the extent of the scales allocation; a pointer INTO a larger allocation
+    (a candle tensor with a start offset, gptq.rs:67) used to be mis-sized silently — now it is an error, and g_idx still works"""
+    M, K, N, gs = 2, 256, 128, 64
+    r = rng(77)
+    q = make_quant(r, K, N, gs, F16, False)
+    qz = np.full((q["G"], N // 8), 0x77777777, np.uint32)
+    x = rand_dt(r, (M, K), F16)
+    big = ops.DevBuf(q["scales"].nbytes + 4096)
+    ops.lib().vra_memcpy_h2d(big.ptr + 1024, q["scales"].ctypes.data, q["scales"].nbytes, 0)
+    view = big.ptr + 1024
+    with pytest.raises(RuntimeError, match="base of"):
+        ops.gptq_matmul(ops.dev(x), ops.dev(q["qweight"]), view, ops.dev(qz), None, None, 4, gs, False, M, K, N, F16)
+    g_idx = ops.dev((np.arange(K) // gs).astype(np.int32))
+    out = ops.gptq_matmul(ops.dev(x), ops.dev(q["qweight"]), view, ops.dev(qz), g_idx, None, 4, gs, False, M, K, N, F16)
+    ref = orc.wna16_gemm(x, q["idx"], orc.gptq_unpack_zeros(qz, q["G"], N), q["scales"], gs, F16)
+    assert_close_dt(out.numpy(np.uint16, (M, N)), ref, F16, name="gptq alt (view + g_idx)", abs_floor=2e-3)
+
+
 @pytest.mark.parametrize("gs,with_g_idx", [(128, True), (64, False)])
 def test_gemm_half_q_half_alt_8bit(gs, with_g_idx):
     """8-bit plain GPTQ through the same symbol (utils/mod.rs:1313, wna16.rs:154-176): four values per word, zero = stored + 1"""

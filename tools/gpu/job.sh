@@ -34,6 +34,11 @@ case "$job" in
       ( timeout 200 python tools/gemv_s_ts.py 0 1 2 3 ) > $O/${RN}_timeline_kernel_e.txt 2>&1
       ( for c in "1 150" "1 384" "1 1024" "1 8000" "32 150"; do echo "== $c"; timeout 100 python tools/attn_ts.py $c; done ) > $O/${RN}_timeline_attn_decode.txt 2>&1
       ( timeout 200 python tools/gemv_w_ts.py 32 0 1 2 3 ) > $O/${RN}_timeline_kernel_w.txt 2>&1 ) ;;
+  trace)      # trace <tag> [bench flags]: rocprofv3 kernel trace of the eager decode bench (VRA_LIB / env vars pass through) -> per-kernel summary
+    tag=$1; shift
+    ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_$tag -- python $R/bench.py --steps 32 --warmup 4 --no-graph --no-extras "$@" > $O/prof_$tag.log 2>&1 )
+    db=$(find $O/prof_$tag -name "*.db" | head -1); [ -n "$db" ] && python tools/rocpd_stats.py $db 14 > $O/${RN}_trace_$tag.txt 2>&1
+    rm -rf $O/prof_$tag ;;
   profiles)   # rocprofv3 traces + counter passes (tools/collect_profiles.sh)
     ROUND=$RN bash tools/collect_profiles.sh > $O/${RN}_collect.log 2>&1 ;;
   final)      # the round's closing evidence: bench line as the driver runs it, full GPU suite, smoke

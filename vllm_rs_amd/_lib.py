@@ -222,6 +222,7 @@ def load():
     _sig(lib, "vra_engine_request_times", c_i32, P, c_i64, P)
     _sig(lib, "vra_engine_release_request", None, P, c_i64)
     _sig(lib, "vra_engine_forward_raw", c_i32, P, P, P, P, c_i32, c_i32, P, c_i32, P, P, c_i32, P)
+    _sig(lib, "vra_engine_forward_tokens", c_i32, P, P, P, P, c_i32, c_i32, P, c_i32, P, P, c_i32, c_i32, c_i32, c_f32, c_f32, c_u64, P)
     _sig(lib, "vra_engine_timed_decode", C.c_double, P, c_i32)
     _sig(lib, "vra_engine_bench_replay", C.c_double, P, c_i32)
     _sig(lib, "vra_engine_set_comm", c_i32, P, P)

@@ -384,11 +384,12 @@ __device__ __forceinline__ size_t vra_frag_index16(int m, int c) {
 // 1.744 against 1.722, ctx 8000 2.063 against 2.054, bs 32 2.682 against 2.673; profiles/r05_ab_attention_lat.txt): the vector-memory
 // path of a CU returns in order, so the early HBM loads stand in front of the prologue's L2 hits and the chain is no shorter.
 // Removed; what stayed of it: raw loads first / conversion at use, the split rule and the merge kernel below.)
-// (Round 6) PRE2: a wave requests its first TWO tiles in the prologue.  With 5..8 tiles per workgroup (contexts of 129..256 tokens
-// unsplit, the two-way split up to 512, ...) one or two waves own two tiles, and the second one's load -> wait -> compute round trip
-// stood between "lds_o written" and the merge barrier of everybody else: 1.35 us of the 6.15 at ctx 150
-// (profiles/r05_timeline_attn_decode.txt).  ~64 more VGPRs: chosen by the launcher only while the grid is within one workgroup per CU.
-template <class DT, int D, bool KV8, bool PRE2 = false>
+// (Round 6 built a form that requests a wave's first TWO tiles in the prologue — the second tile's load -> wait -> compute round trip of
+// the one or two waves that own two tiles stands between "lds_o written" and the merge barrier, 1.35 us at ctx 150.  In the step's
+// trace it LOST: 8.69 against 7.47 us per launch (profiles/r06_trace_attention.txt) — with 8..16 workgroups on the chip the K/V tiles
+// arrive at the L1 fill rate of 8..16 CUs, and twice the requests (the clamped second tile of waves that own one included) is twice
+// the time.  Removed.)
+template <class DT, int D, bool KV8>
 __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const FusedDecodeArgs a) {
   typedef typename KVT<KV8>::elem kv_t;
   constexpr int DJ = D / 32, DT16 = D / 16, HALF = D / 2;
@@ -467,16 +468,14 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
       blkvec = a.block_tables[(size_t)b * a.max_blocks + min(vec_base + lane, a.max_blocks - 1)];
     }
   }
-  // first tile(s) of this wave, clamped to the sequence's last tile: the requests below are UNCONDITIONAL (straight-line code lets hipcc
+  // first tile of this wave, clamped to the sequence's last tile: the requests below are UNCONDITIONAL (straight-line code lets hipcc
   // count them in its s_waitcnt; inside branches it assumed none were issued and made the new token's staging wait for all of them).
   // A wave without tiles re-reads a tile its neighbours read; a padded lane (ctx 0: its table row is not validated by the engine,
   // ADVICE r5) reads block 0.
-  const int t_first = min(kv_w0, max(ntiles - 1, 0)), t_second = min(kv_w0 + 1, max(ntiles - 1, 0));
+  const int t_first = min(kv_w0, max(ntiles - 1, 0));
   uint32_t blk_cur = ntiles > 0 ? tile_blk(t_first) : 0u;
-  u32x4 ka0[KR], ka1[KR];
-  vraw_t va[DT16];
-  u32x4 kb0[PRE2 ? KR : 1], kb1[PRE2 ? KR : 1];
-  vraw_t vb[PRE2 ? DT16 : 1];
+  u32x4 ka0[KR], ka1[KR], kb0[KR], kb1[KR];
+  vraw_t va[DT16], vb[DT16];
   // ---- (round 6) EVERY load of the prologue goes out before the first wait: the new token's k / v rows and their cos / sin, q and
   // its cos / sin, then this wave's first K/V tile(s) — L2 hits in front, the cache (HBM / Infinity Cache) behind them, so the
   // in-order return path of the CU delays nothing.  Rounds 1-5 staged the new k / v first (its own round trip, 0.46 -> 1.19 us on the
@@ -513,7 +512,13 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
   }
   __builtin_amdgcn_sched_barrier(0);
   load_tile(t_first, blk_cur, ka0, ka1, va);
-  if constexpr (PRE2) load_tile(t_second, ntiles > 0 ? tile_blk(t_second) : 0u, kb0, kb1, vb);
+  // a wave that owns a SECOND tile (5..8 tiles per workgroup: contexts of 129..256 tokens unsplit, the two-way split up to 512, ...)
+  // requests it now as well — its load -> wait -> compute round trip used to stand between "lds_o written" and the merge barrier of
+  // everybody else, 1.6 us of the 6.4 at ctx 150 (profiles/r06_timeline_attn_decode.txt).  Only that wave: requesting a clamped
+  // second tile from every wave doubled the L1 fills of the 8..16 CUs that run a short context and lost 1.2 us per launch
+  // (profiles/r06_trace_attention.txt).  (hipcc cannot count loads behind a branch: this wave's first tile waits for both.)
+  const bool two = kv_w0 + 1 < kv_w1;  // (wave-uniform)
+  if (two) load_tile(kv_w0 + 1, tile_blk(kv_w0 + 1), kb0, kb1, vb);
   __builtin_amdgcn_sched_barrier(0);
   // ---- new token: rotate k, copy v; stage both in LDS (and in the cache: split 0 only)
   u32x4 nk_r1 = {0u, 0u, 0u, 0u}, nk_r2 = {0u, 0u, 0u, 0u};
@@ -719,10 +724,8 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
     }
   };
   if (kv_w0 < kv_w1) compute_tile(kv_w0, ka0, ka1, va, std::true_type{});  // (its loads went out in front of the barrier)
-  if constexpr (PRE2) {
-    if (kv_w0 + 1 < kv_w1) compute_tile(kv_w0 + 1, kb0, kb1, vb, std::false_type{});  // (so did these)
-  }
-  for (int tile = kv_w0 + (PRE2 ? 2 : 1); tile < kv_w1; tile++) {
+  if (two) compute_tile(kv_w0 + 1, kb0, kb1, vb, std::false_type{});  // (requested in the prologue)
+  for (int tile = kv_w0 + 2; tile < kv_w1; tile++) {
     load_tile(tile, tile_blk(tile), ka0, ka1, va);
     compute_tile(tile, ka0, ka1, va, std::false_type{});
   }
@@ -771,6 +774,10 @@ __global__ __launch_bounds__(FD_THREADS) void decode_attn_fused_kernel(const Fus
   FD_STAMP_FLUSH();
 }
 
+// (Round 6 built the merge INTO the attention launch — write-through partial rows, an arrival ticket per (sequence, kv head), the last
+// workgroup to arrive combines them — to save this launch (4.6 us per layer in the step's trace).  Same-box A/B, profiles/r06_ab_attention_merge.txt:
+// -0.6 % of the bs-1 step at two splits, but +1.8 % at ctx 1024 (8 splits) and +4 % at ctx 8000 (32): the last arriver walks agent-scope
+// loads of every split on ONE workgroup per kv head where this kernel has one per q head behind a kernel boundary.  Removed.)
 // second pass for split-KV decode: merge nsplit partials per (b, head).  The (max, sum) pairs of the splits go through LDS once
 // (thread s fetches split s: one round trip instead of a dependent pair per split), the partial rows are fetched eight splits at
 // a time (independent loads, clamped index with weight 0) and added in split order — the same sums in the same order as the
@@ -1089,20 +1096,10 @@ void vra_rope_cache_attention_decode_frag(void* out, const void* q, const void* 
   dim3 grid(a.nsplit, kv_heads, batch);
   hipStream_t st = as_stream(stream);
   const bool kv8 = kv_dtype == VRA_FP8_E4M3;
-  // PRE2 (two tiles requested in the prologue): when some wave owns a second tile (more than 4 tiles per split) and the grid is within
-  // one workgroup per CU (its ~64 extra VGPRs cost occupancy that larger grids need: bs 32 at long contexts)
-  const int tiles_per_split = ((max_context_len + 31) / 32 + a.nsplit - 1) / a.nsplit;
-  static const char* pre2_env = getenv("VRA_ATTN_PRE2");  // tuning aid: 0 = never, 1 = whenever a wave owns two tiles
-  const bool pre2 = tiles_per_split > 4 && (pre2_env ? atoi(pre2_env) != 0 : (long)a.nsplit * kv_heads * batch <= num_cus_attn());
-#define VRA_FD(DT, DD)                                                                                  \
-  do {                                                                                                  \
-    if (kv8) {                                                                                          \
-      if (pre2) decode_attn_fused_kernel<DT, DD, true, true><<<grid, FD_THREADS, 0, st>>>(a);           \
-      else decode_attn_fused_kernel<DT, DD, true, false><<<grid, FD_THREADS, 0, st>>>(a);               \
-    } else {                                                                                            \
-      if (pre2) decode_attn_fused_kernel<DT, DD, false, true><<<grid, FD_THREADS, 0, st>>>(a);          \
-      else decode_attn_fused_kernel<DT, DD, false, false><<<grid, FD_THREADS, 0, st>>>(a);              \
-    }                                                                                                   \
+#define VRA_FD(DT, DD)                                                                   \
+  do {                                                                                   \
+    if (kv8) decode_attn_fused_kernel<DT, DD, true><<<grid, FD_THREADS, 0, st>>>(a);     \
+    else decode_attn_fused_kernel<DT, DD, false><<<grid, FD_THREADS, 0, st>>>(a);        \
   } while (0)
   if (dtype == VRA_BF16) {
     if (head_dim == 128) VRA_FD(BF16, 128);

@@ -72,11 +72,6 @@ struct GemvSArgs {
   int n_units, units_q, units_r;  // workgroup b owns units_q (+1 if b < units_r) units starting at b*units_q + min(b, units_r)
   int dbg;  // VRA_EXP=1: prologue only (timeline tool)
   unsigned long long* ts;
-  // granule epilogue (GRAN = true: the fused q/k/v + attention launch, qkv_attn.hip): outputs leave as 8-byte {two 16-bit values,
-  // tag} granules, ONE write-through (sc1) store each, into [M][gran_ld] granules indexed by the launch-wide column
-  // (unit * 16 + column) / 2 — the consumer workgroup of the SAME launch polls the tags instead of waiting for a flag
-  void* gran;
-  int gran_ld;
   // kernel W, launches of up to 32 rows: x in FRAGMENT order (u32x4 word ((kt*2 + mt)*4 + j)*64 + lane = row mt*16 + nn, columns
   // kt*128 + j*32 + oct*8 .. +7 — what the producing launch left beside the row-major tensor): one contiguous KiB per wave load;
   // and the same for the outputs of a single-segment launch (the next consumer's x).  tools/xload_probe.hip: 256 KB per CU in 1.0
@@ -127,8 +122,8 @@ static inline size_t gemv_q4s_lds_bytes(int ns, int tpw, int max_units, int xrow
 
 // XR = row regions per tile in LDS (compile time: the addressing of the hot loop stays constant-folded): 4, or M = 1..3 for
 // K > 16384 where four do not fit
-template <class DT, int NS, bool AWQ, int XR = 4, bool GRAN = false>
-__device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char* smem, uint32_t gran_tag = 0u) {
+template <class DT, int NS, bool AWQ, int XR = 4>
+__device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char* smem) {
   constexpr int D = NS == 2 ? GS_RING_PAIR : GS_RING_KIB;  // ring depth in tile-steps (1 KiB per stream and step)
   // every kernel argument the way to the first load needs, requested in ONE batch of scalar loads
   asm volatile("" ::"s"(a.x), "s"(a.x_ld), "s"(a.norm_w), "s"(a.K), "s"(a.M), "s"(a.KT), "s"(a.TPW), "s"(a.gsh), "s"(a.units_q), "s"(a.units_r),
@@ -462,7 +457,6 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
   // ---- all partial tiles of the workgroup meet once; units*64 threads finish the outputs
   __syncthreads();
   GEMV_STAMP(17);
-  uint32_t e_vbits = 0u;
   if (e_act) {
     const float* rf = reinterpret_cast<const float*>(red);
     float v = 0.f, v2 = 0.f;
@@ -491,22 +485,8 @@ __device__ __forceinline__ void gemv_q4s_body(const GemvSArgs& a, unsigned char*
       v = sl * v2;
     }
     if (a.residual) v = rnd_dt<DT>(v) + e_res;
-    if constexpr (GRAN) {
-      e_vbits = DT::from_f32(v);
-    } else {
-      uint16_t* const op = static_cast<uint16_t*>(e_out) + (size_t)e_m * e_ld + e_col;
-      *op = DT::from_f32(v);
-    }
-  }
-  if constexpr (GRAN) {
-    // even columns take their right neighbour's value (DPP row_shl:1 — a row of 16 lanes is one (unit, row): all active or none)
-    // and store ONE granule {pair, tag}, write-through
-    const uint32_t nbv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)e_vbits, 0x101, 0xF, 0xF, true);
-    if (e_act && !(e_nl & 1)) {
-      const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(a.gran, 0, 0x7FFFFFF0, 0x00020000);
-      const uint32_t gi = (uint32_t)e_m * (uint32_t)a.gran_ld + (((uint32_t)e_unit * 16u + (uint32_t)e_nl) >> 1);
-      __builtin_amdgcn_raw_buffer_store_b64(u32x2{e_vbits | (nbv << 16), gran_tag}, grs, gi * 8u, 0, 16);  // sc1
-    }
+    uint16_t* const op = static_cast<uint16_t*>(e_out) + (size_t)e_m * e_ld + e_col;
+    *op = DT::from_f32(v);
   }
   GEMV_STAMP(14);
   GEMV_STAMP_FLUSH();

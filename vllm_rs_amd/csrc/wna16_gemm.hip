@@ -1379,18 +1379,22 @@ extern "C" void gemm_half_q_half_alt(const void* in, const uint32_t* qweight, co
   VRA_CHECK_ARG(k % 8 == 0 && n % 8 == 0, "gemm_half_q_half_alt: k,n must be multiples of 8");
   // The reference's signature carries no group size: with g_idx (every GPTQ checkpoint has one, and wna16.rs:127-148 always
   // passes it on this path) the group of a row is g_idx[k].  Without it the group size is read off the EXTENT of the scales
-  // allocation ([k/g, n] f16: g = k * n * 2 / bytes) when `scales` is the start of its own allocation; 128 otherwise.
+  // allocation ([k/g, n] f16: g = k * n * 2 / bytes), which is only meaningful when `scales` IS its own allocation.  A view into
+  // a larger one (candle's layout.start_offset(), gptq.rs:67) would give another group size silently: refused.
   int group = 128;
   if (!g_idx) {
     void* base = nullptr;
     size_t bytes = 0;
-    if (hipMemGetAddressRange((hipDeviceptr_t*)&base, &bytes, (hipDeviceptr_t)scales) == hipSuccess && base == scales && bytes >= (size_t)n * 2 &&
-        bytes % ((size_t)n * 2) == 0) {
-      const size_t groups = bytes / ((size_t)n * 2);
-      if (groups <= (size_t)k && (size_t)k % groups == 0) group = (int)((size_t)k / groups);
-    } else {
-      (void)hipGetLastError();
+    const bool known = hipMemGetAddressRange((hipDeviceptr_t*)&base, &bytes, (hipDeviceptr_t)scales) == hipSuccess;
+    if (!known) (void)hipGetLastError();
+    size_t groups = 0;
+    if (known && base == scales && bytes >= (size_t)n * 2 && bytes % ((size_t)n * 2) == 0) groups = bytes / ((size_t)n * 2);
+    if (!groups || groups > (size_t)k || (size_t)k % groups != 0) {
+      vra_set_error("gemm_half_q_half_alt: without g_idx the group size comes from the extent of the scales allocation — `scales` must be the base of "
+                    "its own [k/g, n] allocation (it is %s); pass g_idx", !known ? "not a device allocation this process knows" : (base != scales ? "a view into a larger one" : "of another size"));
+      return;
     }
+    group = (int)((size_t)k / groups);
   }
   dim3 grid((n + 63) / 64, m);
   if (bits == 8) gptq_alt_kernel<8><<<grid, 256, 0, as_stream(stream)>>>((const uint16_t*)in, qweight, qzeros, (const uint16_t*)scales, g_idx, (uint16_t*)out, m, n, k, group);

@@ -13,9 +13,6 @@
 #include <thread>
 #include <memory>
 
-#ifdef VRA_EXPERIMENTS
-#include "decode_step.h"
-#endif
 #include "../csrc/scratch.h"
 #include "core.h"
 #include "model.h"
@@ -468,19 +465,7 @@ class Engine {
     if (dev_err && hipMemcpyAsync(h_err_, dev_err, 4, hipMemcpyDeviceToHost, stream_) != hipSuccess) return fail("error-word download failed");
     uint32_t* comm_err = comm_ ? vra_comm_error_word(comm_) : nullptr;
     if (comm_err && hipMemcpyAsync(h_err_ + 1, comm_err, 4, hipMemcpyDeviceToHost, stream_) != hipSuccess) return fail("error-word download failed");
-#ifdef VRA_EXPERIMENTS
-    uint32_t* step_err = vra_decode_step_error_word();
-    if (step_err && hipMemcpyAsync(h_err_ + 2, step_err, 4, hipMemcpyDeviceToHost, stream_) != hipSuccess) return fail("error-word download failed");
-#endif
     if (hipStreamSynchronize(stream_) != hipSuccess) return fail(std::string("stream error: ") + hipGetErrorString(hipGetLastError()));
-#ifdef VRA_EXPERIMENTS
-    if (h_err_[2]) {
-      const uint32_t code = h_err_[2];
-      h_err_[2] = 0;
-      vra_decode_step_reset();
-      return fail("persistent decode step: a wait timed out on the device (code " + std::to_string(code) + "; results of this step are invalid)");
-    }
-#endif
     if (h_err_[1]) {
       h_err_[1] = 0;
       (void)hipMemsetAsync(comm_err, 0, 4, stream_);
@@ -1004,11 +989,20 @@ extern "C" int32_t vra_engine_request_times(const void* e, int64_t req, double h
 extern "C" void vra_engine_release_request(void* e, int64_t req) { static_cast<Engine*>(e)->results_.erase(req); }
 extern "C" int64_t vra_engine_stream(const void* e) { return (int64_t) static_cast<const Engine*>(e)->stream_; }
 
-extern "C" int32_t vra_engine_forward_raw(void* e, const uint32_t* h_ids, const int64_t* h_positions, const int64_t* h_slot_mapping,
-                                          int32_t n_tokens, int32_t is_prefill, const uint32_t* h_block_tables, int32_t max_blocks,
-                                          const uint32_t* h_context_lens, const uint32_t* h_cu_seqlens_q, int32_t n_seqs,
-                                          float* h_logits_out) {
-  auto* en = static_cast<Engine*>(e);
+// One forward with caller-built metadata (the runner process' path).  h_logits_out: the f32 logits [n_seqs, vocab] come back to the host
+// (vra_engine_forward_raw).  h_tokens_out: only the sampled token ids do (vra_engine_forward_tokens): the decode step replays the
+// captured hipGraph of its batch / context bucket when the engine has graphs, greedy tokens come out of the lm_head launch itself and
+// a stochastic strategy runs on the device logits (vra_sample) — nothing of vocabulary size crosses PCIe.
+struct RawSampling {
+  int kind = 0;  // 0 greedy (first maximal index), 1 temperature / top-k / top-p
+  int k = 0;
+  float p = -1.f, t = 1.f;
+  uint64_t seed = 0;
+};
+static int32_t forward_raw_impl(Engine* en, const uint32_t* h_ids, const int64_t* h_positions, const int64_t* h_slot_mapping,
+                                int32_t n_tokens, int32_t is_prefill, const uint32_t* h_block_tables, int32_t max_blocks,
+                                const uint32_t* h_context_lens, const uint32_t* h_cu_seqlens_q, int32_t n_seqs,
+                                float* h_logits_out, uint32_t* h_tokens_out, const RawSampling* smp) {
   if (!en->sched_) {
     en->error = "engine not finalised";
     return -1;
@@ -1024,7 +1018,7 @@ extern "C" int32_t vra_engine_forward_raw(void* e, const uint32_t* h_ids, const 
   // The metadata comes from a peer (the runner process hands over what the engine process sent): nothing reaches the device
   // that could index outside the cache, the block tables, the embedding or the logits rows.
   if (n_tokens <= 0 || n_seqs <= 0 || max_blocks <= 0 || !h_ids || !h_positions || !h_slot_mapping || !h_block_tables || !h_context_lens ||
-      !h_logits_out || (is_prefill && !h_cu_seqlens_q)) {
+      (!h_logits_out && !h_tokens_out) || (is_prefill && !h_cu_seqlens_q)) {
     en->error = "forward_raw: empty batch or null argument";
     return -1;
   }
@@ -1054,17 +1048,32 @@ extern "C" int32_t vra_engine_forward_raw(void* e, const uint32_t* h_ids, const 
       }
     }
   }
+  // decode with graphs (tokens wanted): the static layout of Engine::prepare_decode — block-table rows max_blocks_per_seq_ apart, the
+  // batch padded to its bucket with lanes that write nothing and attend to nothing — so that the captured graph can be replayed
+  const bool graph_decode = !is_prefill && h_tokens_out && en->ec_.use_graph;
+  const int bucket = graph_decode ? std::max(std::min(Engine::batch_bucket(n_seqs), en->max_seqs_), (int)n_seqs) : n_tokens;
+  const int bt_stride = graph_decode ? en->max_blocks_per_seq_ : max_blocks;
   memcpy(en->h_meta_ + (is_prefill ? en->off_ids_ : en->off_dids_), h_ids, (size_t)n_tokens * 4);
   memcpy(en->h_meta_ + (is_prefill ? en->off_pos_ : en->off_dpos_), h_positions, (size_t)n_tokens * 8);
   memcpy(en->h_meta_ + (is_prefill ? en->off_slots_ : en->off_dslots_), h_slot_mapping, (size_t)n_tokens * 8);
-  memcpy(en->h_meta_ + en->off_bt_, h_block_tables, (size_t)n_seqs * max_blocks * 4);
+  if (bt_stride == max_blocks) {
+    memcpy(en->h_meta_ + en->off_bt_, h_block_tables, (size_t)n_seqs * max_blocks * 4);
+  } else {
+    for (int b = 0; b < n_seqs; b++) memcpy(en->h_meta_ + en->off_bt_ + (size_t)b * bt_stride * 4, h_block_tables + (size_t)b * max_blocks, (size_t)max_blocks * 4);
+  }
   memcpy(en->h_meta_ + en->off_ctx_, h_context_lens, (size_t)n_seqs * 4);
+  for (int b = n_seqs; b < bucket && graph_decode; b++) {
+    ((uint32_t*)(en->h_meta_ + en->off_dids_))[b] = 0;
+    ((int64_t*)(en->h_meta_ + en->off_dpos_))[b] = 0;
+    ((int64_t*)(en->h_meta_ + en->off_dslots_))[b] = -1;
+    ((uint32_t*)(en->h_meta_ + en->off_ctx_))[b] = 0;
+  }
   uint32_t* h_last = (uint32_t*)(en->h_meta_ + en->off_last_);
   vra::InputMetadata md;
   md.is_prefill = is_prefill != 0;
-  md.n_tokens = n_tokens;
-  md.n_seqs = n_seqs;
-  md.max_blocks = max_blocks;
+  md.n_tokens = graph_decode ? bucket : n_tokens;
+  md.n_seqs = graph_decode ? bucket : n_seqs;
+  md.max_blocks = bt_stride;
   md.max_seqlen_q = 1;
   md.max_context_len = 0;
   for (int b = 0; b < n_seqs; b++) md.max_context_len = std::max(md.max_context_len, (int)h_context_lens[b]);
@@ -1077,33 +1086,41 @@ extern "C" int32_t vra_engine_forward_raw(void* e, const uint32_t* h_ids, const 
   }
   en->bind(md);
   if (!en->upload_meta(md)) return -1;
-  if (!en->model_.forward(md, (int64_t)en->stream_)) {
+  bool launched = false;
+  if (graph_decode) {
+    hipGraphExec_t ge = en->graph_for(md.n_tokens, Engine::ctx_bucket(md.max_context_len));  // captured at init; a miss captures now
+    if (!ge && !en->error.empty()) return -1;
+    if (ge) {
+      if (hipGraphLaunch(ge, en->stream_) != hipSuccess) return en->error = "hipGraphLaunch failed", -1;
+      launched = true;
+    }
+  }
+  if (!launched && !en->model_.forward(md, (int64_t)en->stream_, h_tokens_out ? en->d_tokens_ : nullptr)) {
     en->error = en->model_.error;
     return -1;
   }
-  if (hipMemcpyAsync(h_logits_out, en->model_.logits(), (size_t)n_seqs * en->mc_.vocab_size * 4, hipMemcpyDeviceToHost, en->stream_) != hipSuccess) return -1;
+  en->last_graph_ = nullptr;
+  if (h_logits_out &&
+      hipMemcpyAsync(h_logits_out, en->model_.logits(), (size_t)n_seqs * en->mc_.vocab_size * 4, hipMemcpyDeviceToHost, en->stream_) != hipSuccess)
+    return -1;
+  if (h_tokens_out) {
+    if (smp && smp->kind == 1) {  // LogitsProcessor::sample_with_strategy on the device logits (logits_processor.rs:199-271)
+      if (smp->k > 256) return en->error = "top_k > 256 is not supported by the device sampler", -1;
+      vra_sample(en->model_.logits(), en->d_tokens_, n_seqs, en->mc_.vocab_size, smp->k, smp->p, smp->t, smp->seed, nullptr, nullptr, (int64_t)en->stream_);
+      const char* se = vra_last_error();
+      if (se && se[0]) return en->error = std::string("sampler: ") + se, -1;
+    }
+    if (hipMemcpyAsync(en->h_tokens_, en->d_tokens_, (size_t)n_seqs * 4, hipMemcpyDeviceToHost, en->stream_) != hipSuccess) return en->error = "token download failed", -1;
+  }
   // the device error words (a split-K slice or a tensor-parallel peer that never arrived) ride along, as in step()
   uint32_t* dev_err = vra_scratch_error_word();
   uint32_t* comm_err = en->comm_ ? vra_comm_error_word(en->comm_) : nullptr;
   if (dev_err) (void)hipMemcpyAsync(en->h_err_, dev_err, 4, hipMemcpyDeviceToHost, en->stream_);
   if (comm_err) (void)hipMemcpyAsync(en->h_err_ + 1, comm_err, 4, hipMemcpyDeviceToHost, en->stream_);
-#ifdef VRA_EXPERIMENTS
-  uint32_t* step_err = vra_decode_step_error_word();
-  if (step_err) (void)hipMemcpyAsync(en->h_err_ + 2, step_err, 4, hipMemcpyDeviceToHost, en->stream_);
-#endif
   if (hipStreamSynchronize(en->stream_) != hipSuccess) {
     en->error = "stream error in forward_raw";
     return -1;
   }
-#ifdef VRA_EXPERIMENTS
-  if (step_err && en->h_err_[2]) {
-    const uint32_t code = en->h_err_[2];
-    en->h_err_[2] = 0;
-    vra_decode_step_reset();
-    en->error = "persistent decode step: a wait timed out on the device (code " + std::to_string(code) + "; results of this forward are invalid)";
-    return -1;
-  }
-#endif
   if (comm_err && en->h_err_[1]) {
     en->h_err_[1] = 0;
     (void)hipMemsetAsync(comm_err, 0, 4, en->stream_);
@@ -1116,7 +1133,27 @@ extern "C" int32_t vra_engine_forward_raw(void* e, const uint32_t* h_ids, const 
     en->error = "split-K exchange timed out on the device (results of this forward are invalid)";
     return -1;
   }
+  if (h_tokens_out) memcpy(h_tokens_out, en->h_tokens_, (size_t)n_seqs * 4);
   return 0;
+}
+extern "C" int32_t vra_engine_forward_raw(void* e, const uint32_t* h_ids, const int64_t* h_positions, const int64_t* h_slot_mapping,
+                                          int32_t n_tokens, int32_t is_prefill, const uint32_t* h_block_tables, int32_t max_blocks,
+                                          const uint32_t* h_context_lens, const uint32_t* h_cu_seqlens_q, int32_t n_seqs,
+                                          float* h_logits_out) {
+  if (!h_logits_out) return static_cast<Engine*>(e)->error = "forward_raw: empty batch or null argument", -1;
+  return forward_raw_impl(static_cast<Engine*>(e), h_ids, h_positions, h_slot_mapping, n_tokens, is_prefill, h_block_tables, max_blocks, h_context_lens,
+                          h_cu_seqlens_q, n_seqs, h_logits_out, nullptr, nullptr);
+}
+extern "C" int32_t vra_engine_forward_tokens(void* e, const uint32_t* h_ids, const int64_t* h_positions, const int64_t* h_slot_mapping,
+                                             int32_t n_tokens, int32_t is_prefill, const uint32_t* h_block_tables, int32_t max_blocks,
+                                             const uint32_t* h_context_lens, const uint32_t* h_cu_seqlens_q, int32_t n_seqs,
+                                             int32_t stochastic, int32_t top_k, float top_p, float temperature, uint64_t seed,
+                                             uint32_t* h_tokens_out) {
+  if (!h_tokens_out) return static_cast<Engine*>(e)->error = "forward_tokens: null token buffer", -1;
+  RawSampling smp;
+  smp.kind = stochastic ? 1 : 0, smp.k = top_k, smp.p = top_p, smp.t = temperature, smp.seed = seed;
+  return forward_raw_impl(static_cast<Engine*>(e), h_ids, h_positions, h_slot_mapping, n_tokens, is_prefill, h_block_tables, max_blocks, h_context_lens,
+                          h_cu_seqlens_q, n_seqs, nullptr, h_tokens_out, &smp);
 }
 
 extern "C" double vra_engine_timed_decode(void* e, int32_t steps) {

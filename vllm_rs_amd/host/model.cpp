@@ -10,22 +10,7 @@
 #include "../csrc/gemm_launch.h"
 #include "../csrc/scratch.h"
 #include "host_utils.h"
-#ifdef VRA_EXPERIMENTS  // `make EXPERIMENTS=1` (libvra_experiments.so): the kernels that lost their A/B, /experiments/csrc
-#include "decode_step.h"
-#include "qkv_attn.h"
-#endif
 
-#ifdef VRA_EXPERIMENTS
-// The fused decode launch of csrc/qkv_attn.hip (norm + q/k/v + RoPE + KV write + attention) is OPT-IN: measured at parity with the
-// two launches (kernel E, then decode_attn_fused_kernel [+ merge]) — bs 1 1.737 / 1.743 against 1.743 / 1.743 ms per step on
-// one box — and a spin wait inside a kernel is not taken for nothing.  VRA_FUSED_QKV_ATTN=1 or
-// vra_debug_set_fused_qkv_attn(1) turn it on (the parity tests do).
-static int g_fused_qkv_attn = [] {
-  const char* e = getenv("VRA_FUSED_QKV_ATTN");
-  return e ? atoi(e) : 0;
-}();
-extern "C" void vra_debug_set_fused_qkv_attn(int on) { g_fused_qkv_attn = on; }
-#endif
 // VRA_X_FRAG=0 / vra_debug_set_x_frag(0): steps of 5..32 rows read h row-major in kernel W (no fragment-order copy)
 static int g_x_frag = [] {
   const char* e = getenv("VRA_X_FRAG");
@@ -460,11 +445,7 @@ bool Model::init_kv_cache(int num_blocks) {
     (void)hipMemset(vc_[l], 0, per);
   }
   if (hipDeviceSynchronize() != hipSuccess) return false;
-#ifdef VRA_EXPERIMENTS
-  return build_decode_step();
-#else
   return true;
-#endif
 }
 
 bool Model::init_buffers(int max_tokens, int max_seqs) {
@@ -484,11 +465,6 @@ bool Model::init_buffers(int max_tokens, int max_seqs) {
   }
   const size_t ws = vra_paged_attention_decode_workspace_bytes(max_seqs, hq_, mc_.head_dim, vra_rope_table_rows(&mc_));
   if (!(attn_ws_ = dalloc(ws))) return false;
-#ifdef VRA_EXPERIMENTS
-  const size_t gb = vra_qkv_attn_granule_bytes(4, hq_, hkv_, mc_.head_dim);
-  if (!(qkv_gran_ = dalloc(gb)) || hipMemset(qkv_gran_, 0, gb) != hipSuccess) return false;
-  if (!(epoch_ = (uint32_t*)dalloc(64)) || hipMemset(epoch_, 0, 64) != hipSuccess) return false;
-#endif
   if (H % 128 == 0) {
     const size_t fb = (size_t)(H / 128) * 2 * 4096;
     if (!(hfrag_ = dalloc(fb)) || hipMemset(hfrag_, 0, fb) != hipSuccess) return false;
@@ -513,11 +489,7 @@ bool Model::init_buffers(int max_tokens, int max_seqs) {
   // (hipMemset of device memory may return before the fill has run: nothing of this may still be pending when the engine's
   // non-blocking stream starts its first forward)
   if (hipDeviceSynchronize() != hipSuccess) return false;
-#ifdef VRA_EXPERIMENTS
-  return build_decode_step();
-#else
   return true;
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -875,28 +847,6 @@ void Model::gemv_s_args(int l, int which, int M, void* out, const void* residual
       break;
   }
 }
-#ifdef VRA_EXPERIMENTS
-// decode steps of 1..4 sequences: norm + q/k/v + RoPE + KV write + attention in ONE launch (experiments/csrc/qkv_attn.hip)
-bool Model::qkv_attn(int l, const InputMetadata& md, int64_t stream) {
-  const int M = md.n_tokens;
-  if (md.is_prefill || md.n_seqs != M || M > 4 || !gemv_s_ok(0, M) || l >= 255 || !qkv_gran_) return false;
-  const LayerWeights& L = layers_[l];
-  const int kv_dt = ec_.fp8_kvcache ? VRA_FP8_E4M3 : dt_;
-  if (!vra_qkv_attn_fits(M, L.q.K, mc_.group_size, (L.q.N + L.k.N + L.v.N) / 16, hq_, hkv_, mc_.head_dim, ec_.block_size, kv_dt, dt_, md.max_context_len))
-    return false;
-  GemvSArgs a;
-  int ns;
-  gemv_s_args(l, 0, M, nullptr, nullptr, &a, &ns);
-  QkvAttnTail t = {};
-  t.epoch = epoch_, t.layer_tag = l + 1;
-  t.out = attn_, t.kc = kc_[l], t.vc = vc_[l], t.cosv = cos_, t.sinv = sin_;
-  t.positions = md.positions, t.slots = md.slot_mapping, t.block_tables = md.block_tables, t.context_lens = md.context_lens;
-  t.B = M, t.Hq = hq_, t.Hkv = hkv_, t.BS = ec_.block_size, t.max_blocks = md.max_blocks;
-  t.scale_log2e = (1.0f / sqrtf((float)mc_.head_dim)) * 1.44269504088896f;
-  vra_launch_qkv_attn(a, t, qkv_gran_, mc_.group_size, L.q.awq, dt_, mc_.head_dim, stream);
-  return !take_err(error, "qkv_attn");
-}
-#endif
 bool Model::gemv_s(int l, int which, int M, void* out, const void* residual, int64_t stream, const void* x_frag, void* out_frag, const PreOps* pre) {
   if (!gemv_s_ok(which, M)) return false;
   const LayerWeights& L = layers_[l];
@@ -913,125 +863,6 @@ bool Model::gemv_s(int l, int which, int M, void* out, const void* residual, int
   return !take_err(error, "gemv_s");
 }
 
-#ifdef VRA_EXPERIMENTS
-// ---------------------------------------------------------------------------------------------
-// persistent decode step (experiments/csrc/decode_step.hip)
-// ---------------------------------------------------------------------------------------------
-bool Model::build_decode_step() {
-  if (dp_layers_ || !finalized_ || !h_ || kc_.empty() || world_ > 1 || mc_.quant_method == 0) return true;  // (not an error: the step keeps its launches)
-  const LayerWeights& L0 = layers_[0];
-  if (!L0.qkv_s_um || !L0.o.s_um || !L0.gate.s_um || !L0.up.s_um || !L0.down.s_um) return true;
-  if ((L0.q.N | L0.k.N | L0.v.N | L0.o.N | L0.gate.N | L0.down.N) % 16) return true;
-  if ((L0.q.K | L0.o.K | L0.gate.K | L0.down.K) % 128) return true;
-  if (mc_.head_dim != 64 && mc_.head_dim != 128) return true;
-  if (ec_.block_size % 32 || hq_ % hkv_ || hq_ / hkv_ > 16) return true;
-  if (!vra_decode_step_init()) return true;
-  const int grid = vra_decode_step_grid();
-  if (grid < 8) return true;
-  int max_kt = 0, max_red = 0;
-  std::vector<DPLayer> tab(mc_.num_layers);
-  for (int l = 0; l < mc_.num_layers; l++) {
-    const LayerWeights& L = layers_[l];
-    DPLayer& T = tab[l];
-    memset(&T, 0, sizeof(T));
-    int rot = 0;  // the workgroups that own one unit more rotate from GEMV to GEMV, so that no CU's stream is the longest in all
-    for (int which = 0; which < 4; which++) {
-      DPGemv& g = T.g[which];
-      int K, units, ns;
-      bool norm;
-      gemv_s_shape(L, which, &K, &units, &ns, &norm);
-      const int gs = mc_.group_size > 0 && mc_.group_size < K ? mc_.group_size : K;
-      if (gs < K && (gs < 128 || (gs & (gs - 1)))) return true;
-      const int G = K / gs;
-      g.K = K, g.KT = K / 128, g.TPW = (g.KT + 15) / 16, g.G = G, g.NS = ns;
-      g.gsh = gs < K ? 31 - __builtin_clz((unsigned)gs) : 31;
-      if (norm && g.TPW > 4) return true;
-      g.n_units = units, g.units_q = units / grid, g.units_r = units % grid, g.rot = rot;
-      rot = (rot + g.units_r) % grid;
-      g.sc_bytes = units * G * 32, g.zr_bytes = units * G * 8;
-      if (g.sc_bytes < 512 || (L.q.awq && g.zr_bytes < 128)) return true;
-      g.nseg = 1;
-      switch (which) {
-        case 0:
-          g.w[0] = L.qkv_w, g.sc[0] = L.qkv_s_um, g.zr[0] = L.qkv_z_um;
-          g.x = h_, g.x_ld = mc_.hidden_size, g.norm_w = L.attn_norm;
-          g.nseg = 3;
-          g.out[0] = q_, g.out[1] = k_, g.out[2] = v_;
-          g.bias[0] = L.q.bias, g.bias[1] = L.k.bias, g.bias[2] = L.v.bias;
-          g.out_ld[0] = L.q.N, g.out_ld[1] = L.k.N, g.out_ld[2] = L.v.N;
-          g.unit_start[1] = L.q.N / 16, g.unit_start[2] = (L.q.N + L.k.N) / 16;
-          break;
-        case 1:
-          g.w[0] = L.o.w, g.sc[0] = L.o.s_um, g.zr[0] = L.o.z_um;
-          g.x = attn_, g.x_ld = L.o.K;
-          g.out[0] = h_, g.out_ld[0] = L.o.N, g.bias[0] = L.o.bias;
-          g.residual = h_, g.res_ld = L.o.N;
-          break;
-        case 2:
-          g.w[0] = L.gate.w, g.sc[0] = L.gate.s_um, g.zr[0] = L.gate.z_um;
-          g.w[1] = L.up.w, g.sc[1] = L.up.s_um, g.zr[1] = L.up.z_um;
-          g.x = h_, g.x_ld = mc_.hidden_size, g.norm_w = L.ffn_norm;
-          g.out[0] = act_, g.out_ld[0] = L.gate.N, g.bias[0] = L.gate.bias, g.bias[1] = L.up.bias;
-          break;
-        default:
-          g.w[0] = L.down.w, g.sc[0] = L.down.s_um, g.zr[0] = L.down.z_um;
-          g.x = act_, g.x_ld = L.down.K;
-          g.out[0] = h_, g.out_ld[0] = L.down.N, g.bias[0] = L.down.bias;
-          g.residual = h_, g.res_ld = L.down.N;
-          break;
-      }
-      max_kt = std::max(max_kt, g.KT);
-      max_red = std::max(max_red, (g.units_q + (g.units_r ? 1 : 0)) * ns);
-    }
-    T.kc = kc_[l], T.vc = vc_[l];
-  }
-  bool any = false;
-  for (int M = 1; M <= DP_MAX_ROWS; M++) {
-    DPPlan p;
-    if (!vra_decode_step_plan(M, max_kt, max_red, hq_ / hkv_, mc_.head_dim, &p)) continue;
-    if (M * hkv_ > grid) continue;
-    dp_plan_[M][0] = p.nslot, dp_plan_[M][1] = p.ring_off, dp_plan_[M][2] = p.x_off, dp_plan_[M][3] = p.red_off, dp_plan_[M][4] = p.xt,
-    dp_plan_[M][5] = p.lds_bytes, dp_plan_[M][6] = p.zero_off;
-    any = true;
-  }
-  if (!any) return true;
-  if (!(dp_layers_ = dalloc(tab.size() * sizeof(DPLayer)))) return false;
-  if (hipMemcpy(dp_layers_, tab.data(), tab.size() * sizeof(DPLayer), hipMemcpyHostToDevice) != hipSuccess) {
-    error = "decode step table upload failed";
-    return false;
-  }
-  // one (sequence, kv head) per workgroup and 4 waves over its 32-token tiles: past this context the split-KV launches win
-  const char* e = getenv("VRA_DP_MAX_CTX");
-  dp_max_ctx_ = e && atoi(e) > 0 ? atoi(e) : 1024;
-  return true;
-}
-bool Model::decode_step_ok(int M, int max_context_len) const {
-  return dp_layers_ && vra_decode_step_enabled() && M >= 1 && M <= DP_MAX_ROWS && dp_plan_[M][0] > 0 && max_context_len <= dp_max_ctx_;
-}
-bool Model::launch_decode_phases(const InputMetadata& md, int ph0, int ph1, int64_t stream) {
-  const int M = md.n_tokens;
-  if (md.is_prefill || !decode_step_ok(M, md.max_context_len) || md.n_seqs != M) {
-    error = "decode step: not applicable to this batch";
-    return false;
-  }
-  DPStepArgs a = {};
-  a.layers = static_cast<const DPLayer*>(dp_layers_);
-  a.n_layers = mc_.num_layers;
-  a.M = M;
-  a.ph0 = ph0, a.ph1 = ph1;
-  a.eps = mc_.rms_norm_eps;
-  a.q = q_, a.k = k_, a.v = v_, a.attn = attn_;
-  a.cosv = cos_, a.sinv = sin_;
-  a.positions = md.positions, a.slots = md.slot_mapping, a.block_tables = md.block_tables, a.context_lens = md.context_lens;
-  a.Hq = hq_, a.Hkv = hkv_, a.BS = ec_.block_size, a.max_blocks = md.max_blocks;
-  a.bs_shift = (ec_.block_size & (ec_.block_size - 1)) == 0 ? 31 - __builtin_clz((unsigned)ec_.block_size) : -1;
-  a.scale_log2e = (1.0f / sqrtf((float)mc_.head_dim)) * 1.44269504088896f;
-  a.nslot = dp_plan_[M][0], a.ring_off = dp_plan_[M][1], a.x_off = dp_plan_[M][2], a.red_off = dp_plan_[M][3], a.xt = dp_plan_[M][4];
-  a.zero_off = dp_plan_[M][6];
-  vra_launch_decode_step(a, dt_, layers_[0].q.awq, ec_.fp8_kvcache != 0, mc_.head_dim, stream);
-  return !take_err(error, "decode step");
-}
-#endif
 
 // ---------------------------------------------------------------------------------------------
 // stage snapshots of layer 0 (parity instrumentation, model.h)
@@ -1069,50 +900,36 @@ bool Model::forward(const InputMetadata& md, int64_t stream, uint32_t* tokens) {
   const int kv_dt = ec_.fp8_kvcache ? VRA_FP8_E4M3 : dt_;
   error.clear();
   // embed_forward (llama.rs:260-267)
-  // (+ the forward's epoch word: qkv_attn.h; + steps of 5..32 rows: h also in kernel W's fragment order, GemvSArgs::x_frag)
+  // (+ steps of 5..32 rows: h also in kernel W's fragment order, GemvSArgs::x_frag)
   const bool use_frag = g_x_frag && hfrag_ && T > 4 && T <= 32 && world_ == 1;
   // (+ steps of 5..32 rows whose q/k/v launch of layer 0 runs on kernel W: its ready-made operands, like the ones every later
   // layer's gets from the down_proj in front of it — one norm order for all layers of a step shape)
   const bool make_e = use_frag && pre_e_ && sq_e_ && mc_.num_layers > 0 && gemv_s_ok(0, T);
-  vra_embedding_bump(md.input_ids, embed_, h_, T, H, mc_.vocab_size, dt_, epoch_, use_frag ? hfrag_ : nullptr, make_e ? layers_[0].attn_norm : nullptr,
+  vra_embedding_bump(md.input_ids, embed_, h_, T, H, mc_.vocab_size, dt_, nullptr, use_frag ? hfrag_ : nullptr, make_e ? layers_[0].attn_norm : nullptr,
                      pre_e_, sq_e_, stream);
   hfrag_ok_ = use_frag;
   pre_o_ok_ = pre_d_ok_ = false;
-#ifdef VRA_EXPERIMENTS
-  // decode of 1..2 sequences at short contexts: all layers in ONE persistent launch (experiments/csrc/decode_step.hip)
-  const bool one_launch = !md.is_prefill && B == T && decode_step_ok(T, md.max_context_len);
-  if (one_launch && !launch_decode_phases(md, 0, mc_.num_layers * DP_PHASES_PER_LAYER, stream)) return false;
-#else
-  const bool one_launch = false;
-#endif
-  for (int l = one_launch ? mc_.num_layers : 0; l < mc_.num_layers; l++) {
+  for (int l = 0; l < mc_.num_layers; l++) {
     const LayerWeights& L = layers_[l];
     // ---- attention block (llama.rs:115-126): norm -> q,k,v -> rope -> cache + attention -> o_proj (+ residual)
     const QLinear qkv[3] = {L.q, L.k, L.v};
     void* outs[3] = {q_, k_, v_};
     bool attn_frag = false;  // the attention output of this layer also exists in fragment order (afrag_)
-#ifdef VRA_EXPERIMENTS
-    const bool fused_attn = g_fused_qkv_attn && qkv_attn(l, md, stream);
-#else
-    const bool fused_attn = false;
-#endif
-    if (!fused_attn && !error.empty()) return false;
     PreOps take_d;  // x̃ of this layer's attention norm, left by the previous layer's down_proj (5..32 rows, kernel W)
     take_d.consume = true, take_d.frag = l == 0 ? pre_e_ : pre_d_, take_d.sq = l == 0 ? sq_e_ : sq_d_;  // (layer 0: left by the embedding launch)
-    if (!fused_attn && !gemv_s(l, 0, T, nullptr, nullptr, stream, hfrag_ok_ ? hfrag_ : nullptr, nullptr, (l == 0 ? make_e : pre_d_ok_) ? &take_d : nullptr)) {
+    if (!gemv_s(l, 0, T, nullptr, nullptr, stream, hfrag_ok_ ? hfrag_ : nullptr, nullptr, (l == 0 ? make_e : pre_d_ok_) ? &take_d : nullptr)) {
       if (!error.empty()) return false;
       if (!linear_fused_norm(qkv, 3, outs, h_, L.attn_norm, T, stream)) return false;
     }
     // q_norm / k_norm (attention.rs:713-735), in place, before the rotary embedding
-    if (L.q_norm && L.k_norm && !fused_attn) {
+    if (L.q_norm && L.k_norm) {
       vra_qk_rms_norm(q_, k_, L.q_norm, L.k_norm, T, hq_, hkv_, D, qk_norm_mode_ == 2, mc_.rms_norm_eps, dt_, stream);
       if (take_err(error, "qk_norm")) return false;
     }
-    if (l == snap_layer_ && snap_on_ && !fused_attn &&
+    if (l == snap_layer_ && snap_on_ &&
         !(snap(0, q_, (size_t)T * hq_ * D * es_, stream) && snap(1, k_, (size_t)T * hkv_ * D * es_, stream) && snap(2, v_, (size_t)T * hkv_ * D * es_, stream)))
       return false;
-    if (fused_attn) {
-    } else if (md.is_prefill) {
+    if (md.is_prefill) {
       // RoPE + KV write in one launch (two in the reference: rotary_emb.rs:88-103, attention.rs:808-820)
       vra_rope_cache_prefill(q_, k_, v_, kc_[l], vc_[l], cos_, sin_, md.positions, md.slot_mapping, T, hq_, hkv_, D, ec_.block_size, dt_,
                              kv_dt, stream);

@@ -96,12 +96,6 @@ class Model {
   int local_heads() const { return hq_; }
   int local_kv_heads() const { return hkv_; }
   size_t weight_bytes() const { return weight_bytes_; }
-  // the persistent decode step (csrc/decode_step.hip): every layer of a decode step for 1..2 sequences in ONE launch.
-  // decode_step_ok: the model / batch / context fit it.  launch_decode_phases runs phases [ph0, ph1) of the step
-  // (5 per layer: q/k/v, attention, o_proj, gate/up, down) on the static activation buffers — the whole step, or a
-  // slice for the per-phase parity tests.
-  bool decode_step_ok(int M, int max_context_len) const;
-  bool launch_decode_phases(const InputMetadata& md, int ph0, int ph1, int64_t stream);
   // microbenchmark hooks (bench.py roofline leg): launch one decode-shaped GEMM of layer `layer`
   // which: 0 qkv(fused norm) 1 o_proj 2 gate_up 3 down 4 lm_head ; M rows
   bool launch_gemm(int which, int layer, int M, int64_t stream);
@@ -128,7 +122,6 @@ class Model {
   bool linear_fused_norm(const QLinear* ls, int nl, void* const* outs, const void* x, const void* norm_w, int M, int64_t stream);
   bool gate_up(const LayerWeights& L, const void* x, const void* norm_w, void* act, int M, int64_t stream);
   bool build_decode_streams();
-  bool build_decode_step();  // descriptor table of the persistent decode step (needs weights, buffers and the KV cache)
   // kernel E launch of one decode GEMV of layer `l` (which: 0 norm+q/k/v, 1 o_proj, 2 norm+gate/up+SiLU*mul, 3 down);
   // false = shape not covered (the caller takes the general path).  `out`/`residual` as for linear().
   // pre (kernel W, 5..32 rows; csrc/gemv_q4s.cuh GemvSArgs::pre_*): a producer launch also leaves the NEXT fused-norm launch's
@@ -173,9 +166,6 @@ class Model {
   float* logits_ = nullptr;
   uint32_t* bench_tokens_ = nullptr;
   unsigned long long* argmax_ws_ = nullptr;  // kernel A's candidate keys + arrival counter (gemv.cuh)
-  // fused q/k/v + attention decode launch (csrc/qkv_attn.hip): the q|k|v granules of a step and the forward's epoch word
-  void* qkv_gran_ = nullptr;
-  uint32_t* epoch_ = nullptr;
   // the hidden state of a step of up to 32 rows in kernel W's fragment order (csrc/gemv_q4s.cuh GemvSArgs::x_frag), written beside
   // h_ by the launches that produce it (embedding, o_proj on kernel W, down_proj on kernel C) and read by the norm + q/k/v and
   // norm + gate/up launches of kernel W; hfrag_ok_: the copy matches h_ (false after any other writer of h_)
@@ -196,11 +186,6 @@ class Model {
   float *sq_o_ = nullptr, *sq_d_ = nullptr, *sq_e_ = nullptr;
   bool pre_o_ok_ = false, pre_d_ok_ = false;
   void* afrag_ = nullptr;  // the decode attention's output of a 5..32-sequence step in fragment order (o_proj's x on kernel W)
-  bool qkv_attn(int l, const InputMetadata& md, int64_t stream);  // false = not covered (error empty) or failed (error set)
-  // persistent decode step
-  void* dp_layers_ = nullptr;     // device: DPLayer[num_layers]
-  int dp_plan_[3][7] = {};        // per row count M = 1..2: nslot, ring_off, x_off, red_off, xt, lds_bytes, zero_off (nslot 0: not usable)
-  int dp_max_ctx_ = 0;            // longest context the single-workgroup attention phase takes
 };
 
 }  // namespace vra

@@ -103,7 +103,11 @@ static void econfig_from_json(const Json& e, vra_engine_config* ecp) {
   vra_engine_config& ec = *ecp;
   ec.block_size = (int)e.i64("block_size", 64), ec.max_num_seqs = (int)e.i64("max_num_seqs", 32);
   ec.max_model_len = (int)e.i64("max_model_len", 0), ec.num_gpu_blocks = (int)e.i64("num_blocks", 0);
-  ec.kv_fraction = 0.f, ec.prefill_chunk = 8192, ec.enable_prefix_cache = 0, ec.prefix_cache_fraction = 0.65f, ec.use_graph = 0;
+  ec.kv_fraction = 0.f, ec.prefill_chunk = 8192, ec.enable_prefix_cache = 0, ec.prefix_cache_fraction = 0.65f;
+  // decode graphs as the reference's runner captures them (graph.rs:370-377: batches {1..15, 16, 32, ...}), replayed by
+  // vra_engine_forward_tokens; VRA_RUNNER_GRAPH=0 keeps eager launches (tensor-parallel ranks stay eager: main() clears it)
+  const char* ge = getenv("VRA_RUNNER_GRAPH");
+  ec.use_graph = ge && ge[0] == '0' ? 0 : 1;
   ec.seed = (uint64_t)e.i64("seed", 1234);
   ec.fp8_kvcache = e.boolean("fp8_kvcache", false);
   ec.cpu_mem_fold = (float)e.num("cpu_mem_fold", 0.2);  // kvcache_allocator.rs:317: unwrap_or(0.2) — the engine plans its CPU block ids with it
@@ -337,36 +341,23 @@ struct Runner {
   uint64_t seed = 1234, calls = 0;
   bool have_strategy = false;
   Strategy cached;  // of the first sequence of the last prefill (runner.rs:1411,1499-1511: Appendix A3)
-  std::vector<float> logits;
-  void *d_logits = nullptr, *d_tokens = nullptr;
-  size_t d_cap = 0;
 
-  std::vector<uint32_t> sample(int B, const Strategy& st) {
+  // forward + sampling in one engine call (round 6): only the token ids come back — the decode step replays the engine's captured
+  // hipGraph, greedy tokens are the first maximal index as candle's argmax (logits_processor.rs:67-70), a stochastic strategy runs on
+  // the device logits.  (Rounds 3-5 copied [B, vocab] f32 logits to the host, took the argmax there and sent the logits back to the
+  // device for the stochastic strategies.)
+  std::vector<uint32_t> forward_tokens(const std::vector<uint32_t>& ids, const std::vector<int64_t>& pos, const std::vector<int64_t>& slots, bool prefill,
+                                       const std::vector<uint32_t>& bt, size_t mb, const std::vector<uint32_t>& ctx, const std::vector<uint32_t>* cu, int B,
+                                       const Strategy& st, const char* what) {
     std::vector<uint32_t> out((size_t)B);
-    if (st.greedy) {  // first maximal index, as candle's argmax (logits_processor.rs:67-70)
-      for (int b = 0; b < B; b++) {
-        const float* r = logits.data() + (size_t)b * vocab;
-        int best = 0;
-        for (int i = 1; i < vocab; i++)
-          if (r[i] > r[best]) best = i;
-        out[(size_t)b] = (uint32_t)best;
-      }
-      return out;
-    }
-    const size_t bytes = (size_t)B * vocab * 4;
-    if (bytes > d_cap) {
-      if (d_logits) vra_free(d_logits), vra_free(d_tokens);
-      d_logits = vra_malloc(bytes), d_tokens = vra_malloc((size_t)B * 4 + 64);
-      d_cap = bytes;
-      if (!d_logits || !d_tokens) die("device allocation for sampling failed");
-    }
-    vra_memcpy_h2d(d_logits, logits.data(), bytes, 0);
     ++calls;
-    vra_sample((const float*)d_logits, (uint32_t*)d_tokens, B, vocab, st.k, st.p, st.t, (seed << 20) + calls, nullptr, nullptr, 0);
-    vra_memcpy_d2h(out.data(), d_tokens, (size_t)B * 4, 0);
-    vra_device_sync();
-    const char* e = vra_last_error();
-    if (e && e[0]) die(std::string("vra_sample: ") + e);
+    if (vra_engine_forward_tokens(eng, ids.data(), pos.data(), slots.data(), (int)ids.size(), prefill ? 1 : 0, bt.data(), (int)mb, ctx.data(),
+                                  cu ? cu->data() : nullptr, B, st.greedy ? 0 : 1, st.k, st.p, st.t, (seed << 20) + calls, out.data()) != 0) {
+      // a runner error is answered with an empty RunResponse, as the reference does (runner.rs:246-292): the engine fails the
+      // step, the other ranks and later steps live on
+      fprintf(stderr, "vra_runner: forward (%s) failed: %s\n", what, vra_engine_last_error(eng));
+      return {};
+    }
     return out;
   }
   // ModelRunner::prepare_prefill (runner.rs:978-1241) on wire Sequences
@@ -395,14 +386,8 @@ struct Runner {
       ctx.push_back((uint32_t)(cached + n));
       std::copy(s.block_table.begin(), s.block_table.end(), bt.begin() + (size_t)b * mb);
     }
-    logits.resize((size_t)B * vocab);
-    if (vra_engine_forward_raw(eng, ids.data(), pos.data(), slots.data(), (int)ids.size(), 1, bt.data(), (int)mb, ctx.data(), cu.data(), B,
-                               logits.data()) != 0) {
-      fprintf(stderr, "vra_runner: forward (prefill) failed: %s\n", vra_engine_last_error(eng));
-      return {};  // RunResponse([]): runner.rs:246-292
-    }
     cached = strategy_of(seqs[0].sampling_params), have_strategy = true;
-    return sample(B, cached);
+    return forward_tokens(ids, pos, slots, true, bt, mb, ctx, &cu, B, cached, "prefill");
   }
   // ModelRunner::prepare_decode (runner.rs:1243-1388): slot = block_table_last * BS + last_block_tokens - 1 (:1259-1262)
   std::vector<uint32_t> run_decode(const std::vector<DecodeSequence>& seqs) {
@@ -420,16 +405,9 @@ struct Runner {
       slots.push_back((int64_t)s.block_table_last * block_size + (int64_t)s.last_block_tokens - 1);
       ctx.push_back((uint32_t)s.len);
     }
-    logits.resize((size_t)B * vocab);
-    if (vra_engine_forward_raw(eng, ids.data(), pos.data(), slots.data(), B, 0, bt.data(), (int)mb, ctx.data(), nullptr, B, logits.data()) != 0) {
-      // a runner error is answered with an empty RunResponse, as the reference does (runner.rs:246-292): the engine fails the
-      // step, the other ranks and later steps live on
-      fprintf(stderr, "vra_runner: forward (decode) failed: %s\n", vra_engine_last_error(eng));
-      return {};
-    }
     Strategy st = cached;
     if (!have_strategy) st.greedy = false, st.k = 32, st.p = 0.95f, st.t = 0.7f;
-    return sample(B, st);
+    return forward_tokens(ids, pos, slots, false, bt, mb, ctx, nullptr, B, st, "decode");
   }
 };
 
@@ -567,6 +545,7 @@ int main(int argc, char** argv) {
     comm = vra_comm_create(in.nccl_id.data(), in.rank, in.world, in.dev);
     if (!comm) die(std::string("vra_comm_create: ") + vra_last_error());
   }
+  if (in.world > 1) in.ec.use_graph = 0;  // (the one-shot all-reduce's epoch words change per step: tensor-parallel ranks launch eagerly)
   void* eng = vra_engine_create(&in.mc, &in.ec);
   if (!eng) die("vra_engine_create failed");
   if (comm && vra_engine_set_comm(eng, comm) != 0) die(std::string("vra_engine_set_comm: ") + vra_engine_last_error(eng));
@@ -673,7 +652,6 @@ int main(int argc, char** argv) {
     }
     send_msg(fd, out);
   }
-  if (r.d_logits) vra_free(r.d_logits), vra_free(r.d_tokens);
   vra_engine_destroy(eng);
   if (comm) vra_comm_destroy(comm);
   close(fd);
