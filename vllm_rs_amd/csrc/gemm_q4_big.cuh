@@ -312,9 +312,11 @@ __global__ __launch_bounds__(GD_THREADS, 2) void gemm_q4_big_kernel(const GemmDA
         for (int b = 0; b < NB; b++) {
 #pragma unroll
           for (int r = 0; r < 4; r++) {
-            float t = __builtin_fmaf(nzc2[b][r >> 1][r & 1], sxc[mt], ag[b][r]);
+            float t = ZH ? ag[b][r] : __builtin_fmaf(nzc2[b][r >> 1][r & 1], sxc[mt], ag[b][r]);
             asm volatile("" : "+v"(t));
-            acc[b][mt][r >> 1][r & 1] = __builtin_fmaf(sc2[b][r >> 1][r & 1], t, acc[b][mt][r >> 1][r & 1]);
+            float u = __builtin_fmaf(sc2[b][r >> 1][r & 1], t, acc[b][mt][r >> 1][r & 1]);
+            asm volatile("" : "+v"(u));
+            acc[b][mt][r >> 1][r & 1] = u;
           }
         }
 #endif
