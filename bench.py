@@ -129,10 +129,10 @@ def pmc_traffic(kernel):
 
 
 def load_pmc():
-    """the committed counter / trace pass of this round (profiles/r05_pmc.json, tools/summarise_profiles.py) — only if it was taken
+    """the committed counter / trace pass of this round (profiles/r06_pmc.json, tools/summarise_profiles.py) — only if it was taken
     with a library built from these very sources"""
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r06_pmc.json")))
     except Exception:
         return None
     if pmc.get("src_sha16") != src_sha16() and pmc.get("lib_sha16") != lib_sha16():
@@ -142,14 +142,14 @@ def load_pmc():
 
 def in_situ_family():
     """the dequant-GEMV family INSIDE the decode step: average launch durations of the two kernel-E instantiations in
-    the rocprofv3 kernel trace of the eager bs-1 step (profiles/r05_decode_bs1_kernel_trace.txt) — 3 launches of <BF16,1,false> and
+    the rocprofv3 kernel trace of the eager bs-1 step (profiles/r06_decode_bs1_kernel_trace.txt) — 3 launches of <BF16,1,false> and
     one of <BF16,2,false> per layer — next to the isolated-launch figure bench.py times itself"""
     pmc = load_pmc()
     try:
         t = pmc["in_situ_decode_bs1_kernel_trace"]
         us = 3 * t["gemv_q4s_kernel<BF16,1,false>"]["avg_us"] + t["gemv_q4s_kernel<BF16,2,false>"]["avg_us"]
         return {"us_per_layer": us, "GBps": 113475584 / us / 1e3, "frac": 113475584 / us / 1e3 / HBM_PEAK_GBS,
-                "source": "profiles/r05_decode_bs1_kernel_trace.txt (rocprofv3 --kernel-trace of the eager step, same sources)"}
+                "source": "profiles/r06_decode_bs1_kernel_trace.txt (rocprofv3 --kernel-trace of the eager step, same sources)"}
     except Exception:
         return None
 
@@ -222,6 +222,55 @@ def ffi_path(L, cfg, iters=6):
     return {"ms_per_token_gemm_path": per_layer * cfg["num_layers"], "us_per_layer": per_layer * 1e3, "launches_per_layer": 12,
             "note": "7 marlin_4bit_bf16 + 2 vra_rms_norm + vra_silu_mul + 2 vra_add per layer, Marlin-permuted scales read in place (no conversion "
                     "launch), eager launches on the null stream; attention excluded"}
+
+
+def roofline_prefill(eng, L, cfg, rows=4096):
+    """the MFMA roofline of the prefill kernels — the int4 GEMM (kernel D: gemm_q4_big_kernel) at `rows` activation rows,
+    per launch of a layer, timed with HIP events (vra_engine_bench_gemm: rotating layers), and the paged prefill attention
+    (prefill_attn_kernel) on one sequence of `rows` tokens.  FLOPs: 2*M*K*N per GEMM; 4*D*Hq*(T*(T+1)/2) for the causal attention.
+    Peak: 2.5 PFLOP/s dense bf16 (MI355X_MICROARCH.md)."""
+    import numpy as np
+    from vllm_rs_amd import ops
+    H, I, D, Hq, Hkv = cfg["hidden_size"], cfg["intermediate_size"], cfg["head_dim"], cfg["num_heads"], cfg["num_kv_heads"]
+    PEAK = 2500.0
+    out = {"bound": "mfma", "peak": PEAK, "unit": "TFLOP/s", "rows": rows, "kernels": {}}
+    shapes = {"norm+qkv": (0, H, (Hq + 2 * Hkv) * D), "o_proj+res": (1, Hq * D, H), "gate_up+silu": (2, H, 2 * I), "down+res": (3, I, H)}
+    tot_fl = tot_ms = 0.0
+    for name, (w, K, N) in shapes.items():
+        ms = eng.bench_gemm(w, rows, 6)
+        fl = 2.0 * rows * K * N
+        tot_fl += fl
+        tot_ms += ms
+        out["kernels"][name] = {"ms": ms, "TFLOPs": fl / ms / 1e9, "frac": fl / ms / 1e9 / PEAK}
+    out["kernel"] = "gemm_q4_big_kernel<BF16,*,false,4> (the four int4 GEMMs of a layer; norm+qkv includes its rms_norm launch)"
+    out["achieved"] = tot_fl / tot_ms / 1e9
+    out["frac"] = out["achieved"] / PEAK
+    # prefill attention
+    BS = 64
+    T = rows
+    nb = (T + BS - 1) // BS
+    r = np.random.default_rng(0)
+    att = ops.PagedAttention(Hq, D, D ** -0.5, Hkv, BS, ops.BF16)
+    q = ops.dev((r.standard_normal((T, Hq, D)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16))
+    kc = ops.DevBuf(nb * Hkv * BS * D * 2).fill_bytes(0x3c)
+    vc = ops.DevBuf(nb * Hkv * BS * D * 2).fill_bytes(0x3c)
+    bt, cl, cu = ops.dev(r.permutation(nb).astype(np.uint32)), ops.dev(np.array([T], np.uint32)), ops.dev(np.array([0, T], np.uint32))
+    e0, e1 = L.vra_event_create(), L.vra_event_create()
+    for _ in range(2):
+        att.forward_prefill(q, T, T, cu, 1, k_cache=kc, v_cache=vc, block_tables=bt, context_lens=cl, max_blocks=nb)
+    L.vra_device_sync()
+    n = 10
+    L.vra_event_record(e0, 0)
+    for _ in range(n):
+        att.forward_prefill(q, T, T, cu, 1, k_cache=kc, v_cache=vc, block_tables=bt, context_lens=cl, max_blocks=nb)
+    L.vra_event_record(e1, 0)
+    ms = L.vra_event_elapsed_ms(e0, e1) / n
+    L.vra_event_destroy(e0), L.vra_event_destroy(e1)
+    fl = 4.0 * D * Hq * (T * (T + 1) / 2)
+    out["prefill_attn"] = {"kernel": "prefill_attn_kernel<BF16,128,false,2>", "tokens": T, "ms": ms, "TFLOPs": fl / ms / 1e9, "frac": fl / ms / 1e9 / PEAK}
+    out["note"] = ("why kernel D stops where it does: profiles/r06_kernel_d_probes.txt (the same tiling without the int4 -> bf16 conversion runs "
+                   "1.08 PFLOP/s; the conversion and the per-group scale fix-up are VALU work the wave has no free issue slots for)")
+    return out
 
 
 def ffi_step(L, cfg, ctx=150, replays=24):
@@ -764,6 +813,10 @@ def main():
                                "bs1_prompt2048": ttft_p50(eng, 2048, V, 1, reps=3),
                                # (round 5: the cost-model fix of vra_gemm_q4_big_fits — a 200-token prompt must not be slower than a 256-token one)
                                "bs1_prompt200": ttft_p50(eng, 200, V, 1, reps=3), "bs1_prompt256": ttft_p50(eng, 256, V, 1, reps=3)}
+        try:  # the MFMA roofline of the prefill kernels (half of the headline metric is TTFT)
+            line["roofline_prefill"] = roofline_prefill(eng, L, cfg)
+        except Exception as ex:
+            line["roofline_prefill"] = {"error": repr(ex)}
         line["step_bytes_roofline"] = {"algorithmic_bytes_per_step": 3625975808 + 1050673152 + 532480,
                                        "frac_of_8TBps": (3625975808 + 1050673152 + 532480) / (dt / a.steps) / 8e12 if a.batch == 1 else None}
         eng.close()

@@ -372,11 +372,6 @@ float vra_event_elapsed_ms(void* start, void* stop); /* syncs on `stop` */
 
 /* Model/engine configuration — the fields of `Config` (src/utils/config.rs:218-255),
  * `QuantConfig` (:735-757) and `EngineConfig` (:285-328) the hot path consumes. */
-/* NOT wired into the native forward: sliding-window attention.  LLaMaForCausalLM passes config.sliding_window into attention and
- * mask (llama.rs:46,284; Mistral-type checkpoints).  The ops exist (vra_paged_attention_decode_sw / _prefill_sw, vra_causal_mask, with
- * oracle and parity tests) but Model::forward runs full causal attention only, so every loader REFUSES a config whose sliding_window is
- * shorter than max_position_embeddings (runner_main.cpp init_from_json, checkpoint.py parse_config, wire.py model_cfg_from_init)
- * rather than run it silently with another mask.  None of the five BASELINE configs uses one. */
 typedef struct vra_model_config {
   int32_t arch;              /* 0 = LlamaForCausalLM/Mistral (llama.rs), 1 = Qwen2ForCausalLM, 2 = Qwen3ForCausalLM (both qwen3.rs) */
   int32_t hidden_size, intermediate_size, num_layers;
@@ -408,6 +403,11 @@ typedef struct vra_model_config {
    * (attention.rs:538-601): 0 none, 1 per head (weights [head_dim]: Qwen3), 2 over the full q / k row (weights [heads * head_dim]).
    * Loaded checkpoints set it from the shape of `self_attn.q_norm.weight`; synthetic weights follow this field. */
   int32_t qk_norm;
+  /* appended in round 6: sliding-window attention (llama.rs:46,284 passes config.sliding_window into attention and mask; Mistral-type
+   * LlamaForCausalLM checkpoints, utils/mod.rs:1842-1856).  > 0: a query at position p attends the keys p-W+1 .. p — the decode step
+   * runs RoPE + KV write + vra_paged_attention_decode_sw, prefill vra_paged_attention_prefill_sw (KV tiles in front of the window are
+   * not read).  0 = full causal attention.  Every cached token stays in its block (the block manager frees nothing early). */
+  int32_t sliding_window;
 } vra_model_config;
 
 typedef struct vra_engine_config {

@@ -182,7 +182,8 @@ class OracleModel:
             q = orc.rope(q, self.cos, self.sin, positions, False, dt, dt)
             k = orc.rope(k, self.cos, self.sin, positions, False, dt, dt)
             orc.reshape_and_cache(k, v, self.kc[li], self.vc[li], slot_mapping, self.BS, dt, self.kv_dt)
-            a = orc.paged_attention(q, self.kc[li], self.vc[li], block_tables, context_lens, cu_q, Hkv, self.BS, D ** -0.5, dt, kv_dt=self.kv_dt)
+            a = orc.paged_attention(q, self.kc[li], self.vc[li], block_tables, context_lens, cu_q, Hkv, self.BS, D ** -0.5, dt, kv_dt=self.kv_dt,
+                                    sliding_window=int(cfg.get("sliding_window") or 0))  # llama.rs:46,284
             h = self._row_parallel(L["o"], a.reshape(T, Hq * D), h)           # attn_output + residual
             if dmask & 2:
                 x, rs = orc.rms_norm_deferred(h, L["ffn_norm"], eps, dt)

@@ -84,10 +84,12 @@ def test_parse_config_and_rejections():
         ck.parse_config(hf_config(quantization_config=dict(quant_method="gptq", bits=8)))
     with pytest.raises(ValueError, match="architecture"):
         ck.parse_config(hf_config(architectures=["MixtralForCausalLM"]))
-    with pytest.raises(ValueError, match="sliding_window"):  # Mistral-7B-v0.1: a window the native forward would ignore
-        ck.parse_config(hf_config(architectures=["MistralForCausalLM"], sliding_window=4096, max_position_embeddings=32768))
-    assert ck.parse_config(hf_config(architectures=["MistralForCausalLM"], sliding_window=None))["arch"] == "llama"
-    assert ck.parse_config(hf_config(architectures=["Qwen2ForCausalLM"], sliding_window=131072, use_sliding_window=False))["arch"] == "qwen2"
+    # Mistral-7B-v0.1: the window goes into the forward since round 6 (vra_model_config.sliding_window; llama.rs:46,284)
+    mi = ck.parse_config(hf_config(architectures=["MistralForCausalLM"], sliding_window=4096, max_position_embeddings=32768))
+    assert mi["arch"] == "llama" and mi["sliding_window"] == 4096
+    assert "sliding_window" not in ck.parse_config(hf_config(architectures=["MistralForCausalLM"], sliding_window=None))
+    q2 = ck.parse_config(hf_config(architectures=["Qwen2ForCausalLM"], sliding_window=131072, use_sliding_window=False))
+    assert q2["arch"] == "qwen2" and "sliding_window" not in q2
     assert ck.parse_config(hf_config(architectures=["Qwen3ForCausalLM"], head_dim=128))["arch"] == "qwen3"
     from vllm_rs_amd.engine import model_config
     mc = model_config(l3)

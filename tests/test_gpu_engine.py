@@ -103,7 +103,8 @@ def check_logits_conditioned(got, ref, name, dt, max_ulps, alt_ref):
 
 
 @pytest.mark.parametrize("variant", ["llama_gptq", "qwen2_awq", "dense_bf16", "gptq_f16", "llama3_rope", "yarn_rope", "dynamic_rope", "tinyllama_shape", "qwen2_7b_shape",
-                                     "llama3_8b_shape", "qwen3_qk_norm", "qwen3_qk_norm_f16_d128", "full_row_qk_norm"])
+                                     "llama3_8b_shape", "qwen3_qk_norm", "qwen3_qk_norm_f16_d128", "full_row_qk_norm", "mistral_sliding_window",
+                                     "sliding_window_dense_f16"])
 def test_forward_prefill_then_decode(variant):
     cfg = {
         # BASELINE.json configs 1 and 3 at their real widths (fewer layers, smaller vocabulary for the AWQ one): TinyLlama-1.1B
@@ -115,6 +116,10 @@ def test_forward_prefill_then_decode(variant):
         "qwen2_7b_shape": small_cfg(arch="qwen2", attention_bias=True, hidden_size=3584, intermediate_size=18944, num_layers=1, num_heads=28,
                                     num_kv_heads=4, head_dim=128, vocab_size=2048, quant_method="awq", rope_theta=1e6, rms_norm_eps=1e-6),
         "llama_gptq": small_cfg(),
+        # Mistral-type LlamaForCausalLM with config.sliding_window (llama.rs:46,284): the 70-token prompt and every decode step of it
+        # see only the last 48 keys (round 6: wired into Model::forward)
+        "mistral_sliding_window": small_cfg(sliding_window=48),
+        "sliding_window_dense_f16": small_cfg(sliding_window=33, quant_method=None, dtype=F16),
         # q_norm / k_norm before the rotary embedding (attention.rs:713-735): per head (Qwen3) and over the whole row
         "qwen3_qk_norm": small_cfg(arch="qwen3", rope_theta=1e6, rms_norm_eps=1e-6),
         "qwen3_qk_norm_f16_d128": small_cfg(arch="qwen3", dtype=F16, hidden_size=512, num_heads=4, num_kv_heads=1, head_dim=128),
@@ -239,6 +244,27 @@ def compare_tokens(got, ref, gaps, name):
             return i  # legitimate near-tie: everything after is a different trajectory
     assert len(got) == len(ref), f"{name}: lengths differ {len(got)} vs {len(ref)}"
     return None
+
+
+def test_sliding_window_changes_the_result_and_replays_in_a_graph():
+    """the window is really applied (logits differ from the full-causal engine on a prompt longer than the window) and the decode path
+    with a window — rotary embedding, cache write, windowed paged attention as three launches — is captured and replayed like the fused one"""
+    cfg = small_cfg(sliding_window=40)
+    eng, oracle = build(cfg, seed=11, use_graph=True)
+    full, _ = build(small_cfg(), seed=11)
+    r = np.random.default_rng(5)
+    prompts = [r.integers(0, cfg["vocab_size"], size=n).tolist() for n in (90, 20)]
+    bt = simple_tables([len(p) + 8 for p in prompts])
+    ids, pos, slots, ctx, cu = prefill_inputs(prompts, bt)
+    a, b = eng.forward_raw(ids, pos, slots, bt, ctx, cu), full.forward_raw(ids, pos, slots, bt, ctx, cu)
+    assert np.abs(a[0] - b[0]).max() > 1e-2, "a 90-token prompt under a 40-token window gave the full-causal logits"
+    assert np.abs(a[1] - b[1]).max() < 1e-6, "a 20-token prompt fits the window: same keys, same logits"
+    full.close()
+    outs = eng.generate(prompts, max_tokens=8, ignore_eos=True)
+    for i, p in enumerate(prompts):
+        ref, gaps = oracle_greedy(oracle, p, 8, first_block=i * 4)
+        compare_tokens(outs[i], ref, gaps, f"sliding window seq {i} (graph)")
+    eng.close()
 
 
 @pytest.mark.parametrize("use_graph", [False, True])

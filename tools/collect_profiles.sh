@@ -3,7 +3,7 @@
 #   kernel traces of the decode bench at bs 1 and bs 32 (eager launches: kernel tracing and hipGraph replay do not mix on
 #   ROCm 7.2), and SEPARATE counter passes (never combined with a trace domain): FETCH_SIZE, WRITE_SIZE, MFMA / busy cycles.
 # plus (round 4) a kernel trace of a 128-token prefill (TTFT 1 x 128) and the bs 1 / bs 32 traces of BASELINE config 3 (Qwen2-7B AWQ).
-# Outputs land in gpurun_out/prof_*/ ; tools/summarise_profiles.py turns them into profiles/r05_*.txt + r05_pmc.json.
+# Outputs land in gpurun_out/prof_*/ ; tools/summarise_profiles.py turns them into profiles/r06_*.txt + r06_pmc.json.
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out
 mkdir -p $OUT

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""gpurun_out/prof_* (tools/collect_profiles.sh) -> profiles/r05_*.txt and profiles/r05_pmc.json.
+"""gpurun_out/prof_* (tools/collect_profiles.sh) -> profiles/r06_*.txt and profiles/r06_pmc.json.
 
-r05_pmc.json carries the .so hash the counters were taken with: bench.py reports `roofline.traffic` only when the library it
+r06_pmc.json carries the .so hash the counters were taken with: bench.py reports `roofline.traffic` only when the library it
 runs is that very library (a kernel change can never leave a stale number in the driver's line).
 HBM bytes per launch = FETCH_SIZE [KiB] * 1024 * 2 — the gfx950 correction of MI355X_MICROARCH.md (HBM section): FETCH_SIZE reports
 half of the bytes of a wide coalesced read.  WRITE_SIZE is reported as measured (uncalibrated on this part)."""
@@ -29,14 +29,14 @@ def parse_pmc(path):
 
 def main():
     os.makedirs(P, exist_ok=True)
-    copies = {"prof_trace_bs1.summary.txt": "r05_decode_bs1_kernel_trace.txt", "prof_trace_bs32.summary.txt": "r05_decode_bs32_kernel_trace.txt",
-              "prof_trace_prefill.summary.txt": "r05_prefill_4096_kernel_trace.txt", "prof_pmc_fetch_bs1.summary.txt": "r05_pmc_fetch_size_decode_bs1.txt",
-              "prof_pmc_write_bs1.summary.txt": "r05_pmc_write_size_decode_bs1.txt", "prof_pmc_mfma_bs1.summary.txt": "r05_pmc_mfma_decode_bs1.txt",
-              "prof_pmc_mfma_bs32.summary.txt": "r05_pmc_mfma_decode_bs32.txt", "prof_pmc_fetch_bs32.summary.txt": "r05_pmc_fetch_size_decode_bs32.txt",
-              "prof_pmc_mfma_prefill.summary.txt": "r05_pmc_mfma_prefill_4096.txt", "prof_counters_available.txt": "r05_counters_available.txt",
-              "prof_trace_prefill128.summary.txt": "r05_prefill_128_kernel_trace.txt", "prof_trace_qwen2_bs1.summary.txt": "r05_decode_bs1_qwen2_7b_awq_kernel_trace.txt",
-              "prof_trace_qwen2_bs32.summary.txt": "r05_decode_bs32_qwen2_7b_awq_kernel_trace.txt",
-              "prof_pmc_fetch_qwen2_bs1.summary.txt": "r05_pmc_fetch_size_decode_bs1_qwen2_7b_awq.txt"}
+    copies = {"prof_trace_bs1.summary.txt": "r06_decode_bs1_kernel_trace.txt", "prof_trace_bs32.summary.txt": "r06_decode_bs32_kernel_trace.txt",
+              "prof_trace_prefill.summary.txt": "r06_prefill_4096_kernel_trace.txt", "prof_pmc_fetch_bs1.summary.txt": "r06_pmc_fetch_size_decode_bs1.txt",
+              "prof_pmc_write_bs1.summary.txt": "r06_pmc_write_size_decode_bs1.txt", "prof_pmc_mfma_bs1.summary.txt": "r06_pmc_mfma_decode_bs1.txt",
+              "prof_pmc_mfma_bs32.summary.txt": "r06_pmc_mfma_decode_bs32.txt", "prof_pmc_fetch_bs32.summary.txt": "r06_pmc_fetch_size_decode_bs32.txt",
+              "prof_pmc_mfma_prefill.summary.txt": "r06_pmc_mfma_prefill_4096.txt", "prof_counters_available.txt": "r06_counters_available.txt",
+              "prof_trace_prefill128.summary.txt": "r06_prefill_128_kernel_trace.txt", "prof_trace_qwen2_bs1.summary.txt": "r06_decode_bs1_qwen2_7b_awq_kernel_trace.txt",
+              "prof_trace_qwen2_bs32.summary.txt": "r06_decode_bs32_qwen2_7b_awq_kernel_trace.txt",
+              "prof_pmc_fetch_qwen2_bs1.summary.txt": "r06_pmc_fetch_size_decode_bs1_qwen2_7b_awq.txt"}
     notes = {"trace": "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 32 --warmup 4 --batch {B} --no-graph --no-extras (eager launches; includes the "
                       "one-time weight-fill and prefill kernels), summarised by tools/rocpd_stats.py\n",
              "pmc": "# rocprofv3 --pmc <counters> -- python bench.py --steps 32 --warmup 4 --batch {B} --no-graph --no-extras (counter pass on its own: no trace "
@@ -82,10 +82,10 @@ def main():
                 in_situ[re.sub(r",\s+", ",", m.group(1).strip())] = {"calls": int(m.group(2)), "avg_us": float(m.group(4))}
     # kernel names as bench.py spells them (no spaces inside the template list)
     kernels = {re.sub(r",\s+", ",", k): v for k, v in kernels.items()}
-    json.dump({"source": "profiles/r05_pmc_*_decode_bs1.txt (rocprofv3 --pmc, one counter set per pass)", "lib_sha16": sha, "src_sha16": src_sha,
+    json.dump({"source": "profiles/r06_pmc_*_decode_bs1.txt (rocprofv3 --pmc, one counter set per pass)", "lib_sha16": sha, "src_sha16": src_sha,
                "correction": "hbm_bytes_per_launch = FETCH_SIZE[KiB] * 1024 * 2 (gfx950 reports half of a wide coalesced read: MI355X_MICROARCH.md HBM section)",
-               "kernels": kernels, "in_situ_decode_bs1_kernel_trace": in_situ}, open(os.path.join(P, "r05_pmc.json"), "w"), indent=1)
-    print("wrote r05_pmc.json with", len(kernels), "kernels; lib", sha)
+               "kernels": kernels, "in_situ_decode_bs1_kernel_trace": in_situ}, open(os.path.join(P, "r06_pmc.json"), "w"), indent=1)
+    print("wrote r06_pmc.json with", len(kernels), "kernels; lib", sha)
 
 
 if __name__ == "__main__":

@@ -27,7 +27,7 @@ class ModelConfig(C.Structure):
         ("dtype", c_i32), ("tie_word_embeddings", c_i32),
         ("rope_dynamic_alpha", c_i32), ("rope_yarn_beta_fast", C.c_double), ("rope_yarn_beta_slow", C.c_double),
         ("rope_yarn_attn_factor", C.c_double), ("rope_yarn_extrapolation_factor", C.c_double),
-        ("rope_original_max_position_f", C.c_double), ("rope_yarn_explicit", c_i32), ("qk_norm", c_i32),
+        ("rope_original_max_position_f", C.c_double), ("rope_yarn_explicit", c_i32), ("qk_norm", c_i32), ("sliding_window", c_i32),
     ]
 
 

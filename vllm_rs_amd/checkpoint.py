@@ -67,13 +67,11 @@ def parse_config(cfg_json, dtype=None):
                rope_theta=float(cfg_json.get("rope_theta", (cfg_json.get("rope_parameters") or {}).get("rope_theta", 10000.0))),
                rope_scaling=cfg_json.get("rope_scaling"), tie_word_embeddings=bool(cfg_json.get("tie_word_embeddings", False)),
                attention_bias=bool(cfg_json.get("attention_bias", ARCHS[archs[0]] == "qwen2")), dtype=dt, quant_method=None)
-    # Sliding-window attention (Mistral-7B-v0.1: 4096; llama.rs:46,284 passes config.sliding_window into attention and mask) exists
-    # at the op layer (vra_paged_attention_*_sw) but is NOT wired into the native engine's forward: a window shorter than the context
-    # the model may see would silently run as full causal attention — refuse it.
+    # Sliding-window attention (Mistral-7B-v0.1: 4096; llama.rs:46,284 passes config.sliding_window into attention and mask): wired into
+    # the engine's forward since round 6 (vra_model_config.sliding_window).  A window that covers every position is full causal attention.
     sw = cfg_json.get("sliding_window")
     if sw and cfg_json.get("use_sliding_window", True) and int(sw) < int(out["max_position_embeddings"]):
-        raise ValueError(f"sliding_window {sw} < max_position_embeddings {out['max_position_embeddings']}: sliding-window attention is not wired into "
-                         "the engine's forward (only the vra_paged_attention_*_sw ops); refusing to run it as full causal attention")
+        out["sliding_window"] = int(sw)
     q = cfg_json.get("quantization_config")
     if q:
         method = q.get("quant_method", "").lower()

@@ -7,8 +7,10 @@
 //     acc += s_g · (acc_g − (C + z_g) · Σ_{k∈g} x_k)
 // — 2 VALU ops per output instead of ~2.4 VALU ops per WEIGHT for a per-weight scale multiply.
 // (Marlin rounds every dequantised weight to 16 bits before the MMA; that variant is kept as
-// `dequant_word` for the explicit dequantisation entry point and differs from the exact product by
-// < 1 output ulp.)
+// `dequant_word` for the explicit dequantisation entry point.  Per GEMM the two differ by 4-8 ulps of
+// the output row's scale at the Llama-3-8B shapes (tests/test_gpu_tolerance.py reports both against
+// float64); at full depth the engine stays within 1 ulp of the logit scale of either, tokens equal
+// (bench.py parity_full_depth_marlin_rounded).)
 #pragma once
 #include "common.cuh"
 

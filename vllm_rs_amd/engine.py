@@ -37,7 +37,8 @@ def model_config(cfg):
         rope_yarn_explicit=sum(1 << i for i, k in enumerate(("beta_fast", "beta_slow", "attn_factor", "extrapolation_factor")) if k in rs),
         attention_bias=int(bool(cfg.get("attention_bias"))), quant_method=QUANT[cfg.get("quant_method")],
         bits=4, group_size=cfg.get("group_size", 128), dtype=cfg.get("dtype", BF16),
-        tie_word_embeddings=int(bool(cfg.get("tie_word_embeddings"))))
+        tie_word_embeddings=int(bool(cfg.get("tie_word_embeddings"))),
+        sliding_window=int(cfg.get("sliding_window") or 0))
 
 
 LLAMA3_8B = dict(arch="llama", hidden_size=4096, intermediate_size=14336, num_layers=32, num_heads=32, num_kv_heads=8,

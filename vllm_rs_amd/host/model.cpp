@@ -214,13 +214,13 @@ bool Model::load_tensor(const std::string& name, const void* host, const int64_t
     void*& dst = is_q ? L.q_norm : L.k_norm;
     const int64_t n = shape[0], D = mc_.head_dim, heads = is_q ? mc_.num_heads : mc_.num_kv_heads;
     if (n == D) {
-      if (qk_norm_mode_ == 2) return error = "q_norm / k_norm: per-head and full-row weights mixed", false;
-      qk_norm_mode_ = 1;
+      if (qk_norm_loaded_ && qk_norm_mode_ == 2) return error = "q_norm / k_norm: per-head and full-row weights mixed", false;
+      qk_norm_mode_ = 1, qk_norm_loaded_ = true;
       return up1(dst, (size_t)n);
     }
     if (n != heads * D) return error = "q_norm / k_norm weight of " + std::to_string(n) + " entries: neither head_dim nor heads * head_dim", false;
-    if (qk_norm_mode_ == 1) return error = "q_norm / k_norm: per-head and full-row weights mixed", false;
-    qk_norm_mode_ = 2;
+    if (qk_norm_loaded_ && qk_norm_mode_ == 1) return error = "q_norm / k_norm: per-head and full-row weights mixed", false;
+    qk_norm_mode_ = 2, qk_norm_loaded_ = true;
     int nshard = world_, ishard = rank_;
     if (!is_q && mc_.num_kv_heads < world_) {
       nshard = mc_.num_kv_heads;
@@ -929,12 +929,20 @@ bool Model::forward(const InputMetadata& md, int64_t stream, uint32_t* tokens) {
     if (l == snap_layer_ && snap_on_ &&
         !(snap(0, q_, (size_t)T * hq_ * D * es_, stream) && snap(1, k_, (size_t)T * hkv_ * D * es_, stream) && snap(2, v_, (size_t)T * hkv_ * D * es_, stream)))
       return false;
+    const int sw = mc_.sliding_window > 0 ? mc_.sliding_window : 0;  // llama.rs:46,284 (Mistral-type checkpoints)
     if (md.is_prefill) {
       // RoPE + KV write in one launch (two in the reference: rotary_emb.rs:88-103, attention.rs:808-820)
       vra_rope_cache_prefill(q_, k_, v_, kc_[l], vc_[l], cos_, sin_, md.positions, md.slot_mapping, T, hq_, hkv_, D, ec_.block_size, dt_,
                              kv_dt, stream);
-      vra_paged_attention_prefill(attn_, q_, nullptr, nullptr, kc_[l], vc_[l], md.block_tables, md.context_lens, md.cu_seqlens_q,
-                                  nullptr, B, T, md.max_seqlen_q, hq_, hkv_, D, ec_.block_size, md.max_blocks, scale, 0.f, dt_, kv_dt, stream);
+      vra_paged_attention_prefill_sw(attn_, q_, nullptr, nullptr, kc_[l], vc_[l], md.block_tables, md.context_lens, md.cu_seqlens_q,
+                                     nullptr, B, T, md.max_seqlen_q, hq_, hkv_, D, ec_.block_size, md.max_blocks, scale, 0.f, sw, dt_, kv_dt, stream);
+    } else if (sw > 0) {
+      // sliding window: the three calls of the reference (rotary embedding, reshape_and_cache, paged attention with the window;
+      // attention.rs:745-820) — the fused decode launch is the full-causal fast path
+      vra_fused_rope(q_, k_, cos_, sin_, md.positions, T, hq_, hkv_, D, D, 0, dt_, dt_, stream);
+      vra_reshape_and_cache(k_, v_, kc_[l], vc_[l], md.slot_mapping, T, hkv_, D, ec_.block_size, dt_, kv_dt, stream);
+      vra_paged_attention_decode_sw(attn_, q_, kc_[l], vc_[l], md.block_tables, md.context_lens, B, hq_, hkv_, D, ec_.block_size, md.max_blocks,
+                                    md.max_context_len, scale, 0.f, sw, attn_ws_, dt_, kv_dt, stream);
     } else {
       // decode: RoPE + KV write + paged attention in ONE launch (three in the reference, attention.rs:745-820)
       attn_frag = use_frag && afrag_ && B == T;

@@ -173,6 +173,8 @@ class Model {
   bool hfrag_ok_ = false;
   void* actfrag_ = nullptr;  // SiLU(gate) * up of a 5..32-row step in fragment order (down_proj's x on the K-sliced kernel W)
   int qk_norm_mode_ = 0;  // 0 none, 1 per head, 2 full row (set by the config for synthetic weights, by the tensor shape when loading)
+  bool qk_norm_loaded_ = false;  // a q_norm / k_norm tensor has set the mode: only then can a later tensor "mix" with it (the
+                                 // config's value is a default for synthetic weights, a checkpoint's own shapes decide)
   bool snap_on_ = false;
   int snap_layer_ = 0;
   void* snap_[9] = {};

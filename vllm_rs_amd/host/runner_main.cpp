@@ -131,11 +131,12 @@ static bool init_from_json(const std::string& text, Init* out, std::string* err)
   mc.num_kv_heads = (int)c->i64("num_key_value_heads", mc.num_heads);
   mc.head_dim = c->has("head_dim") ? (int)c->i64("head_dim", 0) : (mc.num_heads ? mc.hidden_size / mc.num_heads : 0);
   mc.vocab_size = (int)c->i64("vocab_size", 0), mc.max_position_embeddings = (int)c->i64("max_position_embeddings", 4096);
-  // sliding-window attention is not wired into the native forward (only the vra_paged_attention_*_sw ops): a window shorter than the
-  // model's positions would silently run as full causal attention — refuse it (llama.rs:46,284)
+  // sliding-window attention (llama.rs:46,284): a window shorter than the model's positions goes into the forward; one that covers them
+  // all is full causal attention
+  mc.sliding_window = 0;
   if (c->has("sliding_window") && c->i64("sliding_window", 0) > 0 && c->i64("sliding_window", 0) < mc.max_position_embeddings &&
       c->boolean("use_sliding_window", true))
-    return *err = "Init.config.sliding_window < max_position_embeddings: sliding-window attention is not wired into the engine's forward", false;
+    mc.sliding_window = (int)c->i64("sliding_window", 0);
   mc.rms_norm_eps = (float)c->num("rms_norm_eps", 1e-5), mc.rope_theta = c->has("rope_theta") ? c->num("rope_theta", 10000.0) : 10000.0;
   mc.rope_scaling_type = 0, mc.rope_factor = 1.0, mc.rope_low_freq_factor = 1.0, mc.rope_high_freq_factor = 4.0;
   mc.rope_original_max_position = mc.max_position_embeddings;

@@ -322,9 +322,8 @@ def model_cfg_from_init(req):
     arch = (c.get("architectures") or ["LlamaForCausalLM"])[0]
     rs = c.get("rope_scaling") or None
     sw = c.get("sliding_window")
-    if sw and c.get("use_sliding_window", True) and int(sw) < int(c["max_position_embeddings"]):
-        raise ValueError(f"sliding_window {sw} < max_position_embeddings: not wired into the engine's forward (vllm_rs_amd/checkpoint.py parse_config)")
-    return dict(arch="qwen2" if arch.startswith("Qwen2") else ("qwen3" if arch.startswith("Qwen3") else "llama"), hidden_size=c["hidden_size"], intermediate_size=c["intermediate_size"],
+    sw = int(sw) if sw and c.get("use_sliding_window", True) and int(sw) < int(c["max_position_embeddings"]) else 0
+    return dict(sliding_window=sw, arch="qwen2" if arch.startswith("Qwen2") else ("qwen3" if arch.startswith("Qwen3") else "llama"), hidden_size=c["hidden_size"], intermediate_size=c["intermediate_size"],
                 num_layers=c["num_hidden_layers"], num_heads=c["num_attention_heads"], num_kv_heads=c["num_key_value_heads"],
                 head_dim=c.get("head_dim") or c["hidden_size"] // c["num_attention_heads"], vocab_size=c["vocab_size"],
                 max_position_embeddings=c["max_position_embeddings"], rms_norm_eps=c["rms_norm_eps"], rope_theta=c.get("rope_theta") or 10000.0,
