@@ -338,6 +338,7 @@ extern "C" void vra_debug_attn_ts(unsigned long long* host, int n) { (void)hipMe
 #define FD_STAMP(i)                                                  \
   do {                                                               \
     __builtin_amdgcn_sched_barrier(0);                               \
+    if ((i) == 0 && a.ts && tid < 16) fd_ts_[tid] = 0ull;            \
     if (a.ts && tid == 0) fd_ts_[(i)] = wall_clock64();              \
     __builtin_amdgcn_sched_barrier(0);                               \
   } while (0)

@@ -98,6 +98,7 @@ __device__ __forceinline__ unsigned long long* vra_ts_lds() {
 #define GEMV_STAMP(i)                                                     \
   do {                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                    \
+    if ((i) == 0 && a.ts && tid < 32) vra_ts_lds()[tid] = 0ull; /* (stamps a launch never reaches read 0) */ \
     if (a.ts && tid == 0) vra_ts_lds()[(i)] = wall_clock64();             \
     __builtin_amdgcn_sched_barrier(0);                                    \
   } while (0)
