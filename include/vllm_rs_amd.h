@@ -141,6 +141,19 @@ void vra_wna16_dequant(const void* qweight_tiled, const void* scales, const void
                        int32_t k, int32_t n, int32_t group_size, int32_t is_awq,
                        int32_t scales_layout, int32_t dtype, int64_t stream);
 
+/* Prefill of long prompts (round 6): the Marlin GEMM of a prefill chunk (src/utils/gptq.rs:116-178) as TWO launches — a streaming
+ * pass that dequantises a tiled int4 tensor ONCE into 16-bit MFMA fragments, w = round_dt((q - z) * s) (the weight Marlin feeds
+ * its MMAs), and a 256-row dense GEMM over them.  `wd` holds 1 KiB fragments (16 columns x 32 k in MFMA lane order): fragment
+ * (n-frag f, k-chunk c) at byte ((f * k/32) + c) * 1024; the tensor's n-block b lands at n-frag vfrag0 + b * vstride (q/k/v
+ * concatenated: stride 1 from the segment's first fragment; gate / up interleaved: vfrag0 0 / 1, stride 2). */
+void vra_wna16_dequant_frag(const void* qweight_tiled, const void* scales, const void* qzeros, void* wd, int32_t k, int32_t n,
+                            int32_t group_size, int32_t is_awq, int32_t scales_layout, int32_t dtype, int32_t vfrag0,
+                            int32_t vstride, int64_t stream);
+/* out[m, n] = x[m, k] . wd (+ bias, + residual; roundings as vra_wna16_gemm).  nv = columns of wd; dual != 0: wd interleaves gate and up
+ * fragments, out[m, nv/2] = silu(x.Wg) * (x.Wu) (mlp.rs:451-469; no bias).  tile_n: 0 (chosen from the shape), 128 or 256. */
+void vra_dense_frag_gemm(const void* x, const void* wd, const void* bias, const void* residual, void* out, int32_t m, int32_t k,
+                         int32_t nv, int32_t dual, int32_t dtype, int32_t tile_n, int64_t stream);
+
 /* candle_nn::RmsNorm::forward as used by NormX (src/models/layers/others.rs:11-29):
  * out[t,:] = x[t,:] * rsqrt(mean(x²)+eps) * w, f32 math, one rounding. */
 void vra_rms_norm(const void* x, const void* weight, void* out, int32_t tokens, int32_t hidden,
@@ -505,6 +518,11 @@ int32_t vra_debug_norm_deferred_mask(int32_t hidden, int32_t inter_local, int32_
                                      int32_t group_size, int32_t quant, int32_t qkv_bias, int32_t world, int32_t rows, int32_t layer,
                                      int32_t dtype); /* f16 models defer at 1..4 rows only (no ready-made operands: their range is bf16's) */
 int32_t vra_debug_gemv_s_fits(int32_t ns, int32_t m, int32_t k, int32_t group_size, int32_t n_units, int32_t norm);
+/* parity instrumentation: rows from which the int4 GEMMs of a prefill step run as dequant pass + dense GEMM on Marlin-rounded weights
+ * (vra_wna16_dequant_frag / vra_dense_frag_gemm; default 1024, VRA_DENSE_PREFILL_MIN_ROWS; 0 = never).  The oracle restates the
+ * weight rounding the engine runs (oracle/model.py dense_prefill_rows); tests lower it to reach the path with small models. */
+int32_t vra_debug_dense_prefill_min_rows(void);
+void vra_debug_set_dense_prefill_min_rows(int32_t rows);
 void vra_engine_debug_tp_snapshots(void* eng, int32_t on); /* on = 1 + the layer whose stages are kept; 0 = off */
 int64_t vra_engine_debug_read_tp_snapshot(void* eng, int32_t idx, void* h_out, int64_t max_bytes);
 int32_t vra_engine_finalize_model(void* eng);

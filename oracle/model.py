@@ -42,6 +42,16 @@ def deferred_norm_mask(cfg, T, tp_world=1, layer=1):
                                                         cfg.get("group_size", 128), 1, int(bool(cfg.get("attention_bias"))), tp_world, T, layer, cfg["dtype"]))
 
 
+def dense_prefill_rows(cfg, T):
+    """True when the engine runs the int4 GEMMs of a T-row step as dequant pass + dense GEMM (vllm_rs_amd/csrc/gemm_dense.cuh): every
+    weight rounded to the model dtype first — Marlin's arithmetic (gptq.rs:116-178), WEIGHT_ROUNDING "marlin" for that step.  A shape
+    rule of the engine like the deferred norm order: asked of the installed library (`vra_debug_dense_prefill_min_rows`; 0 = never)."""
+    if ENGINE_RULE is None or cfg.get("quant_method") not in ("gptq", "awq"):
+        return False
+    mr = int(ENGINE_RULE.vra_debug_dense_prefill_min_rows())
+    return mr > 0 and T >= mr
+
+
 class Linear:
     def __init__(self, w, prefix, cfg):
         self.dt = cfg["dtype"]
@@ -63,6 +73,8 @@ class Linear:
             self.quant = False
             self.w = w[prefix + ".weight"]  # [N, K]
 
+    marlin_step = False  # set per forward by OracleModel.forward (dense_prefill_rows)
+
     def partial(self, x, k0, k1):
         """row-parallel shard (TensorParallelRowLinear, distributed.rs:438-455): x[:, k0:k1] against rows k0..k1 of the
         weight, no bias, rounded to the model dtype — what ONE rank hands to the all-reduce"""
@@ -72,13 +84,13 @@ class Linear:
             assert k0 % g == 0 and k1 % g == 0
             z = None if self.zeros is None else np.ascontiguousarray(self.zeros[k0 // g:k1 // g])
             return orc.wna16_gemm(x, np.ascontiguousarray(self.idx[k0:k1]), z, np.ascontiguousarray(self.scales[k0 // g:k1 // g]),
-                                  self.gs, self.dt, None, None, marlin_rounded=WEIGHT_ROUNDING == "marlin")
+                                  self.gs, self.dt, None, None, marlin_rounded=WEIGHT_ROUNDING == "marlin" or Linear.marlin_step)
         return orc.dense_gemm(x, np.ascontiguousarray(self.w[:, k0:k1]), None, self.dt, self.dt)
 
     def __call__(self, x, residual=None, row_scale=None):
         if self.quant:
             return orc.wna16_gemm(x, self.idx, self.zeros, self.scales, self.gs, self.dt, self.bias, residual, row_scale,
-                                  marlin_rounded=WEIGHT_ROUNDING == "marlin")
+                                  marlin_rounded=WEIGHT_ROUNDING == "marlin" or Linear.marlin_step)
         assert row_scale is None, "the deferred norm order exists for the int4 decode kernel only"
         out = orc.dense_gemm(x, self.w, self.bias, self.dt, self.dt)
         return orc.add(out, residual, self.dt) if residual is not None else out
@@ -168,6 +180,15 @@ class OracleModel:
         Hq, Hkv, D, eps = cfg["num_heads"], cfg["num_kv_heads"], cfg["head_dim"], cfg["rms_norm_eps"]
         ids = np.asarray(ids, np.uint32)
         T = len(ids)
+        Linear.marlin_step = dense_prefill_rows(cfg, T)
+        try:
+            return self._forward(ids, T, positions, slot_mapping, block_tables, context_lens, cu_q)
+        finally:
+            Linear.marlin_step = False
+
+    def _forward(self, ids, T, positions, slot_mapping, block_tables, context_lens, cu_q):
+        cfg, dt = self.cfg, self.dt
+        Hq, Hkv, D, eps = cfg["num_heads"], cfg["num_kv_heads"], cfg["head_dim"], cfg["rms_norm_eps"]
         h = orc.embedding(ids, self.embed, dt)
         for li, L in enumerate(self.layers):
             dmask = deferred_norm_mask(cfg, T, self.tp, li)

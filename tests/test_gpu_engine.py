@@ -156,6 +156,46 @@ def test_forward_prefill_then_decode(variant):
     eng.close()
 
 
+@pytest.mark.parametrize("variant", ["llama_gptq", "qwen2_awq_bias", "gptq_f16"])
+def test_long_prefill_runs_marlin_rounded_weights_on_the_dense_gemm(variant):
+    """From `vra_debug_dense_prefill_min_rows` rows on (default 1024; lowered here) a prefill step dequantises each GEMM's weights once —
+    w = rnd((q - z) * s), the weight the reference's Marlin kernels multiply with (gptq.rs:116-178) — and runs the 256-row dense GEMM
+    (csrc/gemm_dense.cuh): q/k/v as one launch over the concatenated columns, gate/up interleaved with the SiLU*mul epilogue, o / down
+    with the residual.  The oracle restates that rounding for such a step (oracle/model.py dense_prefill_rows); decode steps and short
+    prefills keep the exact product."""
+    cfg = {
+        "llama_gptq": small_cfg(),
+        "qwen2_awq_bias": small_cfg(arch="qwen2", quant_method="awq", attention_bias=True, num_heads=8, num_kv_heads=2, head_dim=64, hidden_size=512),
+        "gptq_f16": small_cfg(dtype=F16),
+    }[variant]
+    eng, oracle = build(cfg, seed=5)
+    L = eng.L
+    old = L.vra_debug_dense_prefill_min_rows()
+    try:
+        r = np.random.default_rng(2)
+        prompts = [r.integers(0, cfg["vocab_size"], size=n).tolist() for n in (300, 5, 70)]
+        bt = simple_tables([len(p) + 8 for p in prompts])
+        ids, pos, slots, ctx, cu = prefill_inputs(prompts, bt)
+        L.vra_debug_set_dense_prefill_min_rows(0)
+        exact = eng.forward_raw(ids, pos, slots, bt, ctx, cu)
+        L.vra_debug_set_dense_prefill_min_rows(256)
+        assert om.dense_prefill_rows(cfg, len(ids)) and not om.dense_prefill_rows(cfg, 255)
+        got = eng.forward_raw(ids, pos, slots, bt, ctx, cu)
+        ref = oracle.forward(ids, pos, slots, bt, ctx, cu)
+        check_logits(got, ref, f"{variant} long prefill (dense path)", cfg["dtype"])
+        assert (got != exact).mean() > 0.05, "the row threshold did not switch the arithmetic"
+        # a decode step behind it: 3 rows, the exact product again on both sides
+        seqs = [list(p) + [int(t)] for p, t in zip(prompts, orc.argmax_f32(ref))]
+        ids = np.array([s[-1] for s in seqs], np.uint32)
+        pos = np.array([len(s) - 1 for s in seqs], np.int64)
+        slots = np.array([int(bt[b, (len(s) - 1) // 64]) * 64 + (len(s) - 1) % 64 for b, s in enumerate(seqs)], np.int64)
+        ctx = np.array([len(s) for s in seqs], np.uint32)
+        check_logits(eng.forward_raw(ids, pos, slots, bt, ctx, None), oracle.forward(ids, pos, slots, bt, ctx, None), f"{variant} decode behind it", cfg["dtype"])
+    finally:
+        L.vra_debug_set_dense_prefill_min_rows(old)
+        eng.close()
+
+
 def test_oracle_mirrors_the_engines_deferred_norm_rule():
     """which fused-norm launches of a step apply rstd in their epilogue is a shape rule of the engine (kernel E at 1..4 rows; at 5..32
     rows the kernel-W launches fed ready-made operands by their producer — o_proj, down_proj, the embedding launch for layer 0);

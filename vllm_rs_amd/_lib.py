@@ -98,6 +98,8 @@ def load():
     _sig(lib, "vra_rms_norm_wna16_gate_up_silu", None, P, P, c_f32, P, P, P, P, P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64)
     _sig(lib, "vra_wna16_unpack_indices", None, P, P, c_i32, c_i32, c_i64)
     _sig(lib, "vra_wna16_dequant", None, P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64)
+    _sig(lib, "vra_wna16_dequant_frag", None, P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64)
+    _sig(lib, "vra_dense_frag_gemm", None, P, P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64)
     _sig(lib, "vra_rms_norm", None, P, P, P, c_i32, c_i32, c_f32, c_i32, c_i64)
     _sig(lib, "vra_qk_rms_norm", None, P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_i64)
     _sig(lib, "vra_add_rms_norm", None, P, P, P, P, P, c_i32, c_i32, c_f32, c_i32, c_i64)
@@ -201,6 +203,8 @@ def load():
     _sig(lib, "vra_engine_copy_logits", c_i32, P, P, c_i32)
     _sig(lib, "vra_engine_debug_tp_snapshots", None, P, c_i32)
     _sig(lib, "vra_engine_norm_deferred", c_i32, P, c_i32, c_i32)
+    _sig(lib, "vra_debug_dense_prefill_min_rows", c_i32)
+    _sig(lib, "vra_debug_set_dense_prefill_min_rows", None, c_i32)
     _sig(lib, "vra_debug_norm_deferred_mask", c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32)
     _sig(lib, "vra_debug_gemv_s_fits", c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32)
     _sig(lib, "vra_engine_debug_read_tp_snapshot", c_i64, P, c_i32, P, c_i64)

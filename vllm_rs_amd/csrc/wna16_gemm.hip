@@ -120,6 +120,7 @@ extern "C" void vra_wna16_dequant(const void* qweight_tiled, const void* scales,
 // launch helpers (shared with the native runtime through gemm_launch.h)
 // ------------------------------------------------------------------------------------------------
 #include "gemm_launch.h"
+#include "gemm_dense_launch.h"
 
 static const int kMaxDynLds = 160 * 1024;
 
@@ -1046,6 +1047,19 @@ extern "C" void vra_wna16_gemm(const void* in, const void* qweight_tiled, const 
   if (gemv_s_direct(1, in, qweight_tiled, scales, qzeros, nullptr, nullptr, nullptr, bias, residual, out, m, k, n, group_size, is_awq, scales_layout,
                     dtype, stream))
     return;
+  // long prefills: the weights dequantised once (Marlin's 16-bit weight, gptq.rs:116-178) + the 256-row dense GEMM (gemm_dense.cuh)
+  if (vra_dense_prefill_fits(m, k, n, group_size)) {
+    if (void* wd = vra_dense_scratch((size_t)k * n * 2, stream)) {
+      vra_launch_dequant_frag(qweight_tiled, scales, qzeros, wd, k, n, group_size, is_awq != 0 && qzeros != nullptr, scales_layout, dtype, 0, 1, stream);
+      GemmXArgs a = {};
+      a.x = in, a.x_ld = k, a.wd = wd, a.residual = residual, a.res_ld = n;
+      a.seg[0] = GemmXSeg{out, bias, n, 0};
+      a.nseg = 1;
+      a.M = m, a.NV = n, a.K = k;
+      vra_launch_gemm_dense(a, false, dtype, vra_gemm_dense_tile(m, n), stream);
+      return;
+    }
+  }
   {
     const void* rs = rowmajor_scales(scales, scales_layout, k, n, group_size, 0, stream);
     if (!rs) return;
@@ -1117,6 +1131,20 @@ extern "C" void vra_wna16_gate_up_silu(const void* in, const void* qw_gate, cons
   if (gemv_s_direct(2, in, qw_gate, sc_gate, qz_gate, qw_up, sc_up, qz_up, nullptr, nullptr, out, m, k, n, group_size, is_awq, scales_layout, dtype,
                     stream))
     return;
+  if (vra_dense_prefill_fits(m, k, 2 * n, group_size)) {
+    if (void* wd = vra_dense_scratch((size_t)k * n * 4, stream)) {
+      const bool awq = is_awq != 0 && qz_gate != nullptr && qz_up != nullptr;
+      vra_launch_dequant_frag(qw_gate, sc_gate, qz_gate, wd, k, n, group_size, awq, scales_layout, dtype, 0, 2, stream);
+      vra_launch_dequant_frag(qw_up, sc_up, qz_up, wd, k, n, group_size, awq, scales_layout, dtype, 1, 2, stream);
+      GemmXArgs a = {};
+      a.x = in, a.x_ld = k, a.wd = wd;
+      a.seg[0] = GemmXSeg{out, nullptr, n, 0};
+      a.nseg = 1;
+      a.M = m, a.NV = 2 * n, a.K = k;
+      vra_launch_gemm_dense(a, true, dtype, vra_gemm_dense_tile(m, 2 * n), stream);
+      return;
+    }
+  }
   {
     int32_t l0 = scales_layout, l1 = scales_layout;
     const void* g0 = rowmajor_scales(sc_gate, l0, k, n, group_size, 0, stream);

@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include "../csrc/attn_launch.h"
+#include "../csrc/gemm_dense_launch.h"
 #include "../csrc/gemm_launch.h"
 #include "../csrc/scratch.h"
 #include "host_utils.h"
@@ -580,6 +581,30 @@ bool Model::linear_fused_norm(const QLinear* ls, int nl, void* const* outs, cons
   }
   bool same = ls[0].quant && nl <= GEMV_MAX_SEG;
   for (int i = 1; i < nl; i++) same = same && ls[i].quant && ls[i].K == K && ls[i].awq == ls[0].awq;
+  // long prefills (gemm_dense.cuh): q/k/v dequantised once into ONE fragment-order tensor (Marlin's 16-bit weights, gptq.rs:116-178),
+  // one launch of the 256-row dense GEMM over the concatenated columns
+  if (same && nl <= GX_MAX_SEG) {
+    int cols = 0;
+    bool seg_ok = true;
+    for (int i = 0; i < nl; i++) seg_ok = seg_ok && ls[i].N % 64 == 0, cols += ls[i].N;
+    void* wd = seg_ok && vra_dense_prefill_fits(M, K, cols, mc_.group_size) ? vra_dense_scratch((size_t)K * cols * es_, stream) : nullptr;
+    if (wd) {
+      vra_rms_norm(x, norm_w, xn_, M, K, mc_.rms_norm_eps, dt_, stream);
+      GemmXArgs a = {};
+      a.x = xn_, a.x_ld = K, a.wd = wd;
+      a.nseg = nl;
+      int c0 = 0;
+      for (int i = 0; i < nl; i++) {
+        vra_launch_dequant_frag(ls[i].w, ls[i].scales, ls[i].qzeros, wd, K, ls[i].N, mc_.group_size, ls[i].awq && ls[i].qzeros != nullptr,
+                                VRA_SCALES_ROWMAJOR, dt_, c0 / 16, 1, stream);
+        a.seg[i] = GemmXSeg{outs[i], ls[i].bias, ls[i].N, c0};
+        c0 += ls[i].N;
+      }
+      a.M = M, a.NV = cols, a.K = K;
+      vra_launch_gemm_dense(a, false, dt_, vra_gemm_dense_tile(M, cols), stream);
+      return !take_err(error, "norm + gemm_dense (segments)");
+    }
+  }
   // prefill: q/k/v in ONE launch of kernel D when the problem fills the chip — decided before the norm launch, which then also
   // leaves kernel D's row-sum table (one launch less per layer)
   GemmDArgs d = {};
@@ -669,8 +694,10 @@ bool Model::gate_up(const LayerWeights& L, const void* x, const void* norm_w, vo
       a.is_awq = L.gate.awq ? 1 : 0;
       vra_launch_gemv(a, true, dt_, stream);
     } else {
+      // long prefills: vra_wna16_gate_up_silu takes the dequant pass + dense GEMM (gemm_dense.cuh); else
       // prefill through kernel D: the norm launch also leaves the GEMM's row-sum table (one launch less per layer)
-      const int mb = M >= 64 && K % 128 == 0 ? vra_gemm_q4_big_fits(true, M, N, K, mc_.group_size, nullptr) : 0;
+      const bool dense = vra_dense_prefill_fits(M, K, 2 * N, mc_.group_size);
+      const int mb = !dense && M >= 64 && K % 128 == 0 ? vra_gemm_q4_big_fits(true, M, N, K, mc_.group_size, nullptr) : 0;
       float* tbl = mb ? vra_gemm_q4_big_xsum_table(M, K) : nullptr;
       if (tbl) {
         vra_rms_norm_xsum(x, norm_w, xn_, tbl, M, K, mc_.rms_norm_eps, dt_, stream);
