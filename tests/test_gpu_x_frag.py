@@ -48,6 +48,14 @@ def test_fragment_order_h_is_bit_identical_to_row_major(name, B):
     lens[0] = 300  # one sequence on the split-KV path of the decode attention
     nblk = sum((n + 8 + 63) // 64 for n in lens) + 2
     eng, oracle = build(cfg, seed=5, max_num_seqs=32, num_gpu_blocks=nblk)
+    # The subject is the DECODE step; the prompts only fill the cache.  From 24 sequences on they add up to > 1024 tokens, where the
+    # prefill would take the dense GEMM on Marlin-rounded weights (csrc/gemm_dense.cuh) — mirrored by the oracle, and within 1 ulp of it
+    # on the prefill logits, but another rounding pattern in the cached K / V: rows 8 and 9 of the B = 31 seed amplify ANY such noise
+    # twenty-fold (the ORACLE's own decode answer moves 21.0 / 21.9 ulp on them when only its prefill switches between the two weight
+    # roundings: profiles/r06_dense_prefill_amplifying_rows.txt, tools/dense_dbg.py).  The prefill stays on the int4 kernels here so
+    # that the decode bounds below keep their meaning; tests/test_gpu_engine.py covers a decode step behind a dense prefill.
+    dense_rows = lib.vra_debug_dense_prefill_min_rows()
+    lib.vra_debug_set_dense_prefill_min_rows(0)
     try:
         prompts = [r.integers(0, cfg["vocab_size"], size=n).tolist() for n in lens]
         bt = simple_tables([len(p) + 8 for p in prompts])
@@ -96,6 +104,7 @@ def test_fragment_order_h_is_bit_identical_to_row_major(name, B):
             tok = orc.argmax_f32(ref)
     finally:
         lib.vra_debug_set_x_frag(1)
+        lib.vra_debug_set_dense_prefill_min_rows(dense_rows)
         eng.close()
 
 

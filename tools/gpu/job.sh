@@ -39,6 +39,11 @@ case "$job" in
     ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_$tag -- python $R/bench.py --steps 32 --warmup 4 --no-graph --no-extras "$@" > $O/prof_$tag.log 2>&1 )
     db=$(find $O/prof_$tag -name "*.db" | head -1); [ -n "$db" ] && python tools/rocpd_stats.py $db 14 > $O/${RN}_trace_$tag.txt 2>&1
     rm -rf $O/prof_$tag ;;
+  trace_prefill)  # trace_prefill <tag> [tokens]: rocprofv3 kernel trace of tools/prefill_once.py (two prompts of `tokens`, default 4096) -> per-kernel summary
+    tag=$1; shift
+    ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_$tag -- python $R/tools/prefill_once.py "$@" > $O/prof_$tag.log 2>&1 )
+    db=$(find $O/prof_$tag -name "*.db" | head -1); [ -n "$db" ] && python tools/rocpd_stats.py $db 20 > $O/${RN}_trace_$tag.txt 2>&1
+    rm -rf $O/prof_$tag ;;
   profiles)   # rocprofv3 traces + counter passes (tools/collect_profiles.sh)
     ROUND=$RN bash tools/collect_profiles.sh > $O/${RN}_collect.log 2>&1 ;;
   final)      # the round's closing evidence: bench line as the driver runs it, full GPU suite, smoke
