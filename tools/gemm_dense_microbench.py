@@ -1,5 +1,5 @@
 """Kernel X (dequant pass + 256-row dense GEMM, csrc/gemm_dense.cuh) against kernel D, at the Llama-3-8B prefill shapes:
-    python tools/gemm_dense_microbench.py [--check] [--tile 0|128|256] [M ...]
+    python tools/gemm_dense_microbench.py [--check] [--tile 0|128|256 (| split-K slices << 16)] [M ...]
 --check: sampled outputs against a float64 product of the dequantised weights (transpose-detecting random data), before timing."""
 import os
 import sys

@@ -19,6 +19,10 @@
 //                 factor and the final 1/l are all lane-local, no cross-lane traffic except the two xor-shuffles of the max.
 // LDS: K tile [64 keys][D] and V tile [D][64 tokens], 16-byte chunks XOR-swizzled so that each ds_read_b128 lane group
 // covers all 64 banks (MI355X_MICROARCH.md §LDS).  One buffer + register prefetch: 2 barriers per tile.
+// (Round 6, measured and rejected: 8 waves = 256 query rows per workgroup with two LDS buffers and ONE barrier per tile — half the
+// staging instructions per wave, parity-green, and slower: 618 against 738 TFLOP/s at 16 384 tokens, 448 against 486 at 8192
+// (profiles/r06_ab_attn_prefill_8_waves.txt).  Two independent 4-wave workgroups per CU drift apart and cover each other's
+// softmax; eight waves behind one barrier do not.)
 // Roofline: MFMA.  FLOPs = 4 * D * (causal query-key pairs) per head.
 #pragma once
 #include "common.cuh"
@@ -128,12 +132,26 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(const Prefi
   // stood in front of every tile's K/V loads.  A half that starts past the context has no block: it reads block 0 (any
   // mapped memory will do — its scores are masked and store_tile zeroes its V tokens); nothing selects on loaded data, so
   // the loads stay in flight over the compute.
+  // (round 6) The ids come out of a lane-held WINDOW of 64 table entries (one coalesced load per 64 blocks, v_readlane with the
+  // wave-uniform index): looked up entry by entry they were two dependent global round trips per tile behind the barrier —
+  // `global_load_dword; s_waitcnt vmcnt(0); v_readfirstlane` twice, 966 of the 5237 cycles of a tile (tools/attn_prefill_ts.py,
+  // profiles/r06_attn_prefill_phases.txt).  Tiles are walked in ascending order, so one window suffices.
   auto block_of = [&](int tok) -> int { return tok >> a.bs_shift; };  // BS is a power of two (launcher)
+  int bt_win = -1;
+  uint32_t bt_lane = 0u;
+  auto table_entry = [&](int idx) -> uint32_t {  // idx wave-uniform
+    const int w = idx >> 6;
+    if (w != bt_win) {
+      bt_win = w;
+      bt_lane = bt[min(w * 64 + lane, a.max_blocks - 1)];
+    }
+    return (uint32_t)__builtin_amdgcn_readlane((int)bt_lane, idx & 63);
+  };
   auto load_blocks = [&](int tile, uint32_t (&blk)[2]) {
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       const int tok = (tile << 6) + 32 * h;
-      blk[h] = tok < ctx ? bt[block_of(tok)] : 0u;
+      blk[h] = tok < ctx ? table_entry(block_of(tok)) : 0u;
     }
   };
   // thread -> chunks of the tile.  K: chunk i = n*256 + tid of [64 keys][KCH chunks]; V: chunk i of [D channels][8 chunks].
@@ -142,13 +160,17 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(const Prefi
   // tile in the phase timers).  next_bases() computes the wave-uniform bases, the loads go out one by one between the MFMA
   // groups of the S and P.V phases.
   size_t kb0 = 0, kb1 = 0, vb0 = 0, vb1 = 0;  // (scalars, not arrays: an array captured by the lambdas below lands in scratch)
+  // (element offsets: block * Hkv*BS*D + head * BS*D is common to a block's K and V panels — one 64-bit product per half instead of
+  // the four nested ones this used to spend ~300 scalar cycles per tile on)
+  const uint32_t blk_elems = (uint32_t)a.Hkv * (uint32_t)a.BS * (uint32_t)D, head_off = (uint32_t)hk * (uint32_t)a.BS * (uint32_t)D;
   auto next_bases = [&](int tile, const uint32_t (&blk)[2]) {
     const int T0 = tile << 6;
-    const int off0 = T0 - block_of(T0) * a.BS, off1 = T0 + 32 - block_of(T0 + 32) * a.BS;
-    kb0 = (((size_t)blk[0] * a.Hkv + hk) * a.BS + off0) * D;
-    kb1 = (((size_t)blk[1] * a.Hkv + hk) * a.BS + off1) * D;
-    vb0 = (((size_t)blk[0] * a.Hkv + hk) * D) * a.BS + off0;
-    vb1 = (((size_t)blk[1] * a.Hkv + hk) * D) * a.BS + off1;
+    const uint32_t off0 = (uint32_t)(T0 & (a.BS - 1)), off1 = (uint32_t)((T0 + 32) & (a.BS - 1));  // BS is a power of two
+    const size_t c0 = (size_t)blk[0] * blk_elems + head_off, c1 = (size_t)blk[1] * blk_elems + head_off;
+    kb0 = c0 + off0 * (uint32_t)D;
+    kb1 = c1 + off1 * (uint32_t)D;
+    vb0 = c0 + off0;
+    vb1 = c1 + off1;
   };
   auto issue_k = [&](int n) {
     const int i = n * PF_THREADS + tid;

@@ -61,6 +61,14 @@ struct GemmXArgs {
   int nseg;
   int M, NV, K;  // NV = virtual columns (multiple of 16)
   int MT, NT;    // tiles along m and n
+  // split-K (mid-size prompts: the output tiles alone leave half the chip idle — M = 2048: o_proj / down_proj are 128 tiles): workgroup
+  // (tile, slice) = id / splitk, id % splitk walks K-steps [KS * slice / splitk, ...); slices 0..splitk-2 hand their f32 accumulators
+  // to the last one through `slabs` (write-through stores, one flag line per slice, fixed summation order: the exchange of kernels
+  // B / C / D).  The whole grid is co-resident (launcher: tiles * splitk <= CUs), so the owner's wait cannot starve its partners.
+  int splitk;
+  float* slabs;
+  uint32_t* counters;
+  uint32_t* err;
 };
 
 static inline size_t gemm_dense_lds_bytes(int bn) { return (size_t)2 * (32 * 1024 + (size_t)(bn / 16) * 2 * 1024); }
@@ -116,13 +124,16 @@ __global__ __launch_bounds__(GX_THREADS, 2) void gemm_dense_kernel(const GemmXAr
   const int r16 = lane & 15, q4 = lane >> 4;
   const int K = a.K, M = a.M;
   const int KS = K >> 6;  // K-steps (even: K % 128 == 0)
+  const int SK = a.splitk > 1 ? a.splitk : 1;
 
   // ---- tile of this workgroup: ids of one XCD (id mod 8) take a contiguous run of the grouped tile order (8 m-tiles per super-row)
-  int mt, nt;
+  int mt, nt, zi;
   {
     const int nwg = (int)gridDim.x, bid = (int)blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int lin_sk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int lin = lin_sk / SK;  // (the slices of a tile are neighbours in the remapped order: same XCD, the slabs stay in its L2)
+    zi = lin_sk - lin * SK;
     constexpr int GM = 8;
     const int per = GM * a.NT;
     const int grp = lin / per, rem = lin - grp * per;
@@ -215,13 +226,15 @@ __global__ __launch_bounds__(GX_THREADS, 2) void gemm_dense_kernel(const GemmXAr
     __builtin_amdgcn_s_barrier();                    \
   } while (0)
 
-  // ---- prologue: K-step 0 entirely, U0 / U3 of K-step 1 (the order the counted waits assume: oldest first)
-  stage_x(0, 0, 0);
-  stage_w(0, 0, 0);
-  stage_w(0, 1, 0);
-  stage_x(0, 1, 0);
-  stage_x(1, 0, 1);
-  stage_w(1, 0, 1);
+  // this workgroup's K-steps (an even count: launcher) — all of them, or slice zi of SK
+  const int ks0 = KS / SK * zi, ks1 = ks0 + KS / SK;
+  // ---- prologue: the first K-step entirely, U0 / U3 of the second (the order the counted waits assume: oldest first)
+  stage_x(0, 0, ks0);
+  stage_w(0, 0, ks0);
+  stage_w(0, 1, ks0);
+  stage_x(0, 1, ks0);
+  stage_x(1, 0, ks0 + 1);
+  stage_w(1, 0, ks0 + 1);
   GX_WAIT_VM();
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();  // the second wave group runs one barrier behind the first
@@ -250,7 +263,7 @@ __global__ __launch_bounds__(GX_THREADS, 2) void gemm_dense_kernel(const GemmXAr
     GX_WAIT_VM();
     GX_COMPUTE(1, 0, w0);
   };
-  for (int ks = 0; ks < KS; ks += 2) {
+  for (int ks = ks0; ks < ks1; ks += 2) {
     kstep(std::integral_constant<int, 0>{}, ks);
     kstep(std::integral_constant<int, 1>{}, ks + 1);
   }
@@ -259,6 +272,54 @@ __global__ __launch_bounds__(GX_THREADS, 2) void gemm_dense_kernel(const GemmXAr
   VRA_MFMA_DRAIN();
 #undef GX_WAIT_VM
 #undef GX_COMPUTE
+
+  // ---- split-K: the slices of a tile meet through memory (gemm_q4_big.cuh): write-through 16-byte stores, one flag line per slice,
+  // the last slice ("owner") polls, adds the slabs to its own partial in slice order and resets the flags
+  if (SK > 1) {
+    const int tile = nt * a.MT + mt, ntiles = a.MT * a.NT;
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a.slabs, 0, 0x7FFFFFF0, RSRC3);
+    auto slab_off = [&](int z, int i, int j) {  // bytes: [slice][tile][m-frag][n-frag][thread] x 16 B
+      return (uint32_t)((((z * ntiles + tile) * 8 + i) * WNF + j) * GX_THREADS + tid) * 16u;
+    };
+    uint32_t* fl = a.counters + (size_t)tile * SK * 16;
+    if (zi != SK - 1) {
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < WNF; j++) {
+          const u32x4 v = {__float_as_uint(acc[i][j][0]), __float_as_uint(acc[i][j][1]), __float_as_uint(acc[i][j][2]), __float_as_uint(acc[i][j][3])};
+          __builtin_amdgcn_raw_buffer_store_b128(v, srs, slab_off(zi, i, j), 0, 16);
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // write-through stores: acknowledged by memory
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(fl + zi * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    if (tid < SK - 1) {
+      const uint64_t t0 = __builtin_readcyclecounter();
+      while (__hip_atomic_load(fl + tid * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        __builtin_amdgcn_s_sleep(1);
+        if (__builtin_readcyclecounter() - t0 > (1ull << 31)) {  // never hang the device on a lost slice
+          __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+      __hip_atomic_store(fl + tid * 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    for (int z = 0; z < SK - 1; z++) {  // fixed order; one m-frag row of accumulators per round trip
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        u32x4 pz[WNF];
+#pragma unroll
+        for (int j = 0; j < WNF; j++) pz[j] = __builtin_amdgcn_raw_buffer_load_b128(srs, slab_off(z, i, j), 0, 16);
+#pragma unroll
+        for (int j = 0; j < WNF; j++)
+#pragma unroll
+          for (int e = 0; e < 4; e++) acc[i][j][e] += __uint_as_float(pz[j][e]);
+      }
+    }
+  }
 
   // ---- epilogue: D[column q4*4 + e][row r16] of accumulator tile (i, j)
   const int vcol0 = nt * BN + wc * (WNF * 16);  // first virtual column of this wave

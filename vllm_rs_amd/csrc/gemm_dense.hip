@@ -6,6 +6,7 @@
 #include <algorithm>
 
 #include "gemm_dense_launch.h"
+#include "scratch.h"
 
 static int gx_cur_dev() {
   int dev = 0;
@@ -21,30 +22,63 @@ static void launch_gemm_dense_t(const GemmXArgs& a, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dense_kernel<DT, BN, DUAL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_devs |= (uint64_t)1 << gx_cur_dev();
   }
-  gemm_dense_kernel<DT, BN, DUAL><<<dim3((unsigned)(a.MT * a.NT)), GX_THREADS, lds, st>>>(a);
+  gemm_dense_kernel<DT, BN, DUAL><<<dim3((unsigned)(a.MT * a.NT * (a.splitk > 1 ? a.splitk : 1))), GX_THREADS, lds, st>>>(a);
 }
 
-int vra_gemm_dense_tile(int M, int nv) {
-  // 256 x 256 tiles unless they leave more than a quarter of the chip without a workgroup in the last round and the narrow tile
-  // fills it (M = 2048: o_proj / down_proj have 8 x 16 = 128 wide tiles for 256 CUs)
-  static const char* env = getenv("VRA_GX_BN");  // tuning aid
-  if (env && (atoi(env) == 128 || atoi(env) == 256)) return atoi(env);
+static int gx_num_cus() {
+  static int n[64] = {0};
+  const int dev = gx_cur_dev();
+  if (!n[dev] && (hipDeviceGetAttribute(&n[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n[dev] <= 0)) n[dev] = 256;
+  return n[dev];
+}
+
+// tile width (256 | 128) and split-K factor (<< 16) for an M x nv x K problem
+int vra_gemm_dense_tile(int M, int nv, int K) {
+  static const char* env = getenv("VRA_GX_BN");  // tuning aid: width | splitk << 16
+  if (env && ((atoi(env) & 0xffff) == 128 || (atoi(env) & 0xffff) == 256)) return atoi(env);
+  const int cus = gx_num_cus();
   const long mt = (M + GX_BM - 1) / GX_BM;
   const long t256 = mt * ((nv + 255) / 256), t128 = mt * ((nv + 127) / 128);
-  // time ~ rounds of 256 workgroups x tile work.  Measured (tools/gemm_dense_microbench.py --tile): a 128-wide tile does half the work
+  // time ~ rounds of `cus` workgroups x tile work.  Measured (tools/gemm_dense_microbench.py --tile): a 128-wide tile does half the work
   // at ~0.8 of the wide tile's rate (o_proj, 4096 rows: 256 wide tiles 107 us, 512 narrow ones 135), and a last round that fills
   // half the chip takes ~0.8 of a full one (q/k/v, 4096 rows: 384 wide tiles 191 us = 1.78 rounds; narrow 202)
-  auto rounds = [](long t) {
-    const long full = t / 256, rem = t % 256;
-    return (double)full + (rem == 0 ? 0.0 : (rem <= 128 ? 0.8 : 1.0));
+  auto rounds = [&](long t) {
+    const long full = t / cus, rem = t % cus;
+    return (double)full + (rem == 0 ? 0.0 : (rem <= cus / 2 ? 0.8 : 1.0));
   };
   const double c256 = rounds(t256) * 1.0, c128 = rounds(t128) * 0.5 / 0.8;
-  return c128 < 0.95 * c256 ? 128 : 256;
+  int best = c128 < 0.95 * c256 ? 128 : 256;
+  double cost = std::min(c128, c256);
+  // split-K on the wide tile: S slices of a tile side by side (all co-resident), one exchange of ~8 + 4 (S - 1) us against a wide tile's
+  // ~105 us per 4096 of K
+  static const char* sk_off = getenv("VRA_GX_NO_SPLITK");
+  if (!(sk_off && atoi(sk_off)) && vra_scratch_slabs() && vra_scratch_counters()) {
+    const int KS = K / 64;
+    const double t_tile = 105.0 * (double)K / 4096.0;
+    for (int S = 2; S <= 4; S *= 2) {
+      if (t256 * S > cus || KS % (2 * S)) continue;
+      if ((size_t)(S - 1) * t256 * 32 * GX_THREADS * 16 > vra_scratch_slab_bytes() / 2 || (size_t)t256 * S * 16 > vra_scratch_counter_count()) continue;
+      const double c = 1.0 / S + (8.0 + 4.0 * (S - 1)) / t_tile;
+      if (c < 0.92 * cost) cost = c, best = 256 | (S << 16);
+    }
+  }
+  return best;
 }
 
-void vra_launch_gemm_dense(GemmXArgs a, bool dual, int dtype, int bn, int64_t stream) {
+void vra_launch_gemm_dense(GemmXArgs a, bool dual, int dtype, int bn_sk, int64_t stream) {
+  const int bn = bn_sk & 0xffff, sk = (bn_sk >> 16) > 1 ? (bn_sk >> 16) : 1;
   a.MT = (a.M + GX_BM - 1) / GX_BM;
   a.NT = (a.NV + bn - 1) / bn;
+  a.splitk = sk;
+  if (sk > 1) {
+    a.slabs = vra_scratch_slabs();
+    a.counters = vra_scratch_counters();
+    a.err = vra_scratch_error_word();
+    if (!a.slabs || !a.counters || bn != 256 || (a.K / 64) % (2 * sk)) {
+      vra_set_error("gemm_dense: split-K scratch unavailable or K not divisible (K=%d, slices=%d)", a.K, sk);
+      return;
+    }
+  }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const bool bf = dtype == VRA_BF16;
 #define VRA_GX(BNV, DU)                                   \
@@ -146,7 +180,8 @@ extern "C" void vra_dense_frag_gemm(const void* x, const void* wd, const void* b
   VRA_CHECK_ARG(m >= 1 && k % 128 == 0 && nv % 16 == 0 && (!dual || nv % 32 == 0), "dense_frag_gemm: bad shape M=%d K=%d NV=%d", m, k, nv);
   VRA_CHECK_ARG(dtype == VRA_BF16 || dtype == VRA_F16, "dense_frag_gemm: dtype must be bf16/f16");
   VRA_CHECK_ARG(!(dual && bias), "dense_frag_gemm: the gate/up form takes no bias");
-  VRA_CHECK_ARG(tile_n == 0 || tile_n == 128 || tile_n == 256, "dense_frag_gemm: tile_n must be 0 (auto), 128 or 256");
+  VRA_CHECK_ARG(tile_n == 0 || (tile_n & 0xffff) == 128 || (tile_n & 0xffff) == 256, "dense_frag_gemm: tile_n must be 0 (auto), 128 or 256 (| split-K slices << 16)");
+  if (tile_n >> 16 > 1) vra_scratch_init();
   GemmXArgs a{};
   a.x = x, a.x_ld = k, a.wd = wd, a.residual = residual;
   const int n_out = dual ? nv / 2 : nv;
@@ -154,5 +189,5 @@ extern "C" void vra_dense_frag_gemm(const void* x, const void* wd, const void* b
   a.seg[0] = GemmXSeg{out, bias, n_out, 0};
   a.nseg = 1;
   a.M = m, a.NV = nv, a.K = k;
-  vra_launch_gemm_dense(a, dual != 0, dtype, tile_n ? tile_n : vra_gemm_dense_tile(m, nv), stream);
+  vra_launch_gemm_dense(a, dual != 0, dtype, tile_n ? tile_n : vra_gemm_dense_tile(m, nv, k), stream);
 }

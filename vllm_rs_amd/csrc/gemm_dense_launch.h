@@ -1,10 +1,10 @@
 // gemm_dense_launch.h — launchers of kernel X (gemm_dense.cuh) shared between the C entry points and the native runtime.
 #pragma once
 #include "gemm_dense.cuh"
-// tile width (256 | 128) for an M x nv (virtual columns) problem
-int vra_gemm_dense_tile(int M, int nv);
-// fills MT / NT; bn from vra_gemm_dense_tile
-void vra_launch_gemm_dense(GemmXArgs a, bool dual, int dtype, int bn, int64_t stream);
+// tile width (256 | 128) | split-K slices << 16 for an M x nv (virtual columns) x K problem
+int vra_gemm_dense_tile(int M, int nv, int K);
+// fills MT / NT / the split-K exchange; bn_sk from vra_gemm_dense_tile
+void vra_launch_gemm_dense(GemmXArgs a, bool dual, int dtype, int bn_sk, int64_t stream);
 // int4 tile layout -> 16-bit fragments w = round_dt((q - z) * s); the tensor's n-block nb lands at virtual n-frag vfrag0 + nb * vstride
 void vra_launch_dequant_frag(const void* tiled, const void* scales, const void* qzeros, void* wd, int K, int N, int group_size, bool awq,
                              int layout, int dtype, int vfrag0, int vstride, int64_t stream);

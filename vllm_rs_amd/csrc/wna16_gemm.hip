@@ -1056,7 +1056,7 @@ extern "C" void vra_wna16_gemm(const void* in, const void* qweight_tiled, const 
       a.seg[0] = GemmXSeg{out, bias, n, 0};
       a.nseg = 1;
       a.M = m, a.NV = n, a.K = k;
-      vra_launch_gemm_dense(a, false, dtype, vra_gemm_dense_tile(m, n), stream);
+      vra_launch_gemm_dense(a, false, dtype, vra_gemm_dense_tile(m, n, k), stream);
       return;
     }
   }
@@ -1141,7 +1141,7 @@ extern "C" void vra_wna16_gate_up_silu(const void* in, const void* qw_gate, cons
       a.seg[0] = GemmXSeg{out, nullptr, n, 0};
       a.nseg = 1;
       a.M = m, a.NV = 2 * n, a.K = k;
-      vra_launch_gemm_dense(a, true, dtype, vra_gemm_dense_tile(m, 2 * n), stream);
+      vra_launch_gemm_dense(a, true, dtype, vra_gemm_dense_tile(m, 2 * n, k), stream);
       return;
     }
   }

@@ -601,7 +601,7 @@ bool Model::linear_fused_norm(const QLinear* ls, int nl, void* const* outs, cons
         c0 += ls[i].N;
       }
       a.M = M, a.NV = cols, a.K = K;
-      vra_launch_gemm_dense(a, false, dt_, vra_gemm_dense_tile(M, cols), stream);
+      vra_launch_gemm_dense(a, false, dt_, vra_gemm_dense_tile(M, cols, K), stream);
       return !take_err(error, "norm + gemm_dense (segments)");
     }
   }
