@@ -225,9 +225,12 @@ def ffi_path(L, cfg, iters=6):
 
 
 def roofline_prefill(eng, L, cfg, rows=4096):
-    """the MFMA roofline of the prefill kernels — the int4 GEMM (kernel D: gemm_q4_big_kernel) at `rows` activation rows,
-    per launch of a layer, timed with HIP events (vra_engine_bench_gemm: rotating layers), and the paged prefill attention
-    (prefill_attn_kernel) on one sequence of `rows` tokens.  FLOPs: 2*M*K*N per GEMM; 4*D*Hq*(T*(T+1)/2) for the causal attention.
+    """the MFMA roofline of the prefill kernels — the int4 GEMMs of a layer at `rows` activation rows, per launch, timed with
+    HIP events (vra_engine_bench_gemm: rotating layers), and the paged prefill attention (prefill_attn_kernel) on one sequence of `rows`
+    tokens.  From 1024 rows on a GEMM is the dequant pass (dequant_frag_kernel: w = rnd((q - z) * s), Marlin's weight, gptq.rs:116-178)
+    plus the 256-row dense GEMM (gemm_dense_kernel, csrc/gemm_dense.cuh): `kernels` times BOTH launches of every GEMM, so `achieved` is
+    the rate a prefill sees; `int4_fused_kernel_d` is the same layer with the path switched off (kernel D: gemm_q4_big_kernel, the exact
+    product with the conversion inside every 64-row tile).  FLOPs: 2*M*K*N per GEMM; 4*D*Hq*(T*(T+1)/2) for the causal attention.
     Peak: 2.5 PFLOP/s dense bf16 (MI355X_MICROARCH.md)."""
     import numpy as np
     from vllm_rs_amd import ops
@@ -235,41 +238,69 @@ def roofline_prefill(eng, L, cfg, rows=4096):
     PEAK = 2500.0
     out = {"bound": "mfma", "peak": PEAK, "unit": "TFLOP/s", "rows": rows, "kernels": {}}
     shapes = {"norm+qkv": (0, H, (Hq + 2 * Hkv) * D), "o_proj+res": (1, Hq * D, H), "gate_up+silu": (2, H, 2 * I), "down+res": (3, I, H)}
-    tot_fl = tot_ms = 0.0
-    for name, (w, K, N) in shapes.items():
-        ms = eng.bench_gemm(w, rows, 6)
-        fl = 2.0 * rows * K * N
-        tot_fl += fl
-        tot_ms += ms
-        out["kernels"][name] = {"ms": ms, "TFLOPs": fl / ms / 1e9, "frac": fl / ms / 1e9 / PEAK}
-    out["kernel"] = "gemm_q4_big_kernel<BF16,*,false,4> (the four int4 GEMMs of a layer; norm+qkv includes its rms_norm launch)"
-    out["achieved"] = tot_fl / tot_ms / 1e9
+
+    def layer(dst):
+        tot_fl = tot_ms = 0.0
+        for name, (w, K, N) in shapes.items():
+            ms = eng.bench_gemm(w, rows, 6)
+            fl = 2.0 * rows * K * N
+            tot_fl += fl
+            tot_ms += ms
+            dst[name] = {"ms": ms, "TFLOPs": fl / ms / 1e9, "frac": fl / ms / 1e9 / PEAK}
+        return tot_fl / tot_ms / 1e9
+
+    dense_rows = L.vra_debug_dense_prefill_min_rows()
+    out["dense_path_from_rows"] = dense_rows
+    out["achieved"] = layer(out["kernels"])
     out["frac"] = out["achieved"] / PEAK
+    if 0 < dense_rows <= rows:
+        out["kernel"] = ("dequant_frag_kernel + gemm_dense_kernel<BF16,256|128,*> (both launches of each of a layer's four GEMMs; norm+qkv and "
+                         "gate_up+silu include their rms_norm launch)")
+        L.vra_debug_set_dense_prefill_min_rows(0)
+        try:
+            d = {}
+            ach = layer(d)
+            out["int4_fused_kernel_d"] = {"kernel": "gemm_q4_big_kernel<BF16,*,false,4>", "kernels": d, "achieved": ach, "frac": ach / PEAK}
+        finally:
+            L.vra_debug_set_dense_prefill_min_rows(dense_rows)
+    else:
+        out["kernel"] = "gemm_q4_big_kernel<BF16,*,false,4> (the four int4 GEMMs of a layer; norm+qkv includes its rms_norm launch)"
     # prefill attention
     BS = 64
     T = rows
     nb = (T + BS - 1) // BS
     r = np.random.default_rng(0)
     att = ops.PagedAttention(Hq, D, D ** -0.5, Hkv, BS, ops.BF16)
-    q = ops.dev((r.standard_normal((T, Hq, D)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16))
-    kc = ops.DevBuf(nb * Hkv * BS * D * 2).fill_bytes(0x3c)
-    vc = ops.DevBuf(nb * Hkv * BS * D * 2).fill_bytes(0x3c)
+    # (random q / K / V: constant data clocks higher and collapses the softmax; ONE output buffer: ops.PagedAttention.forward_prefill
+    # allocates and frees a buffer per call — a device synchronisation per launch that rounds 1-5 of this leg timed along with the kernel)
+    q, kc, vc = ops.DevBuf(T * Hq * D * 2), ops.DevBuf(nb * Hkv * BS * D * 2), ops.DevBuf(nb * Hkv * BS * D * 2)
+    L.vra_fill_normal(q.ptr, T * Hq * D, 31, 0.0, 1.0, 0, 0)
+    L.vra_fill_normal(kc.ptr, nb * Hkv * BS * D, 32, 0.0, 1.0, 0, 0)
+    L.vra_fill_normal(vc.ptr, nb * Hkv * BS * D, 33, 0.0, 1.0, 0, 0)
+    o = ops.DevBuf(T * Hq * D * 2)
     bt, cl, cu = ops.dev(r.permutation(nb).astype(np.uint32)), ops.dev(np.array([T], np.uint32)), ops.dev(np.array([0, T], np.uint32))
     e0, e1 = L.vra_event_create(), L.vra_event_create()
+
+    def launch():
+        L.vra_paged_attention_prefill_sw(o.ptr, q.ptr, None, None, kc.ptr, vc.ptr, bt.ptr, cl.ptr, cu.ptr, None, 1, T, T, Hq, Hkv, D, BS, nb, att.scale,
+                                         0.0, 0, ops.BF16, ops.BF16, 0)
+
     for _ in range(2):
-        att.forward_prefill(q, T, T, cu, 1, k_cache=kc, v_cache=vc, block_tables=bt, context_lens=cl, max_blocks=nb)
+        launch()
+    ops.check_error()
     L.vra_device_sync()
     n = 10
     L.vra_event_record(e0, 0)
     for _ in range(n):
-        att.forward_prefill(q, T, T, cu, 1, k_cache=kc, v_cache=vc, block_tables=bt, context_lens=cl, max_blocks=nb)
+        launch()
     L.vra_event_record(e1, 0)
     ms = L.vra_event_elapsed_ms(e0, e1) / n
     L.vra_event_destroy(e0), L.vra_event_destroy(e1)
     fl = 4.0 * D * Hq * (T * (T + 1) / 2)
     out["prefill_attn"] = {"kernel": "prefill_attn_kernel<BF16,128,false,2>", "tokens": T, "ms": ms, "TFLOPs": fl / ms / 1e9, "frac": fl / ms / 1e9 / PEAK}
     out["note"] = ("why kernel D stops where it does: profiles/r06_kernel_d_probes.txt (the same tiling without the int4 -> bf16 conversion runs "
-                   "1.08 PFLOP/s; the conversion and the per-group scale fix-up are VALU work the wave has no free issue slots for)")
+                   "1.08 PFLOP/s; the conversion and the per-group scale fix-up are VALU work the wave has no free issue slots for) — hence the "
+                   "conversion once per GEMM instead of once per 64-row tile (profiles/r06_gemm_dense_microbench.txt)")
     return out
 
 
@@ -812,7 +843,8 @@ def main():
         line["ttft_p50_ms"] = {"bs1_prompt128": ttft_p50(eng, 128, V, 1), "bs32_prompt128": ttft_p50(eng, 128, V, 32, reps=2),
                                "bs1_prompt2048": ttft_p50(eng, 2048, V, 1, reps=3),
                                # (round 5: the cost-model fix of vra_gemm_q4_big_fits — a 200-token prompt must not be slower than a 256-token one)
-                               "bs1_prompt200": ttft_p50(eng, 200, V, 1, reps=3), "bs1_prompt256": ttft_p50(eng, 256, V, 1, reps=3)}
+                               "bs1_prompt200": ttft_p50(eng, 200, V, 1, reps=3), "bs1_prompt256": ttft_p50(eng, 256, V, 1, reps=3),
+                               "bs1_prompt1024": ttft_p50(eng, 1024, V, 1, reps=3), "bs1_prompt4096": ttft_p50(eng, 4096, V, 1, reps=3)}
         try:  # the MFMA roofline of the prefill kernels (half of the headline metric is TTFT)
             line["roofline_prefill"] = roofline_prefill(eng, L, cfg)
         except Exception as ex:

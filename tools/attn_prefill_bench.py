@@ -24,11 +24,16 @@ for T in [int(a) for a in sys.argv[1:]] or [4096]:
     cl = ops.dev(np.array([T], np.uint32))
     cu = ops.dev(np.array([0, T], np.uint32))
     n = 20
+    o = ops.DevBuf(T * Hq * D * 2)  # (one output buffer: forward_prefill allocates and frees one per call — a device sync per launch)
+    if not fp8:  # random K / V (fp8: the constant fill stays)
+        L.vra_fill_normal(kc.ptr, nb * Hkv * BS * D, 32, 0.0, 1.0, 0, 0)
+        L.vra_fill_normal(vc.ptr, nb * Hkv * BS * D, 33, 0.0, 1.0, 0, 0)
     for it in range(2):
         L.vra_device_sync()
         t0 = time.perf_counter()
         for _ in range(n):
-            o = att.forward_prefill(q, T, T, cu, 1, k_cache=kc, v_cache=vc, block_tables=bt, context_lens=cl, max_blocks=nb)
+            L.vra_paged_attention_prefill_sw(o.ptr, q.ptr, None, None, kc.ptr, vc.ptr, bt.ptr, cl.ptr, cu.ptr, None, 1, T, T, Hq, Hkv, D, BS, nb, att.scale,
+                                             0.0, 0, ops.BF16, att.kv_dtype, 0)
         L.vra_device_sync()
         ms = (time.perf_counter() - t0) / n * 1e3
     fl = 4.0 * D * Hq * (T * (T + 1) / 2)

@@ -1010,8 +1010,9 @@ extern "C" void vra_paged_attention_prefill_sw(void* out, const void* q, const v
 #endif
     const bool kv8 = kv_dtype == VRA_FP8_E4M3;
     const long wgs2 = (long)((max_seqlen_q + 127) / 128) * q_heads * batch;
-    const int mt = wgs2 >= 512 ? 2 : 1;
-    dim3 pg((max_seqlen_q + 64 * mt - 1) / (64 * mt), q_heads, batch);
+    static const char* mt_env = getenv("VRA_PF_MT2_FROM");  // tuning aid: 128-row workgroups from this many of them
+    const int mt = wgs2 >= (mt_env ? atol(mt_env) : 512) ? 2 : 1;
+    dim3 pg(q_heads, (max_seqlen_q + 64 * mt - 1) / (64 * mt), batch);  // x: heads (fastest), y: row blocks, heaviest first
     hipStream_t st = as_stream(stream);
 #define VRA_PF(DT, DD, K8, MM) prefill_attn_kernel<DT, DD, K8, MM><<<pg, PF_THREADS, 0, st>>>(p)
 #define VRA_PF_MT(DT, DD, K8) \

@@ -81,15 +81,21 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(const Prefi
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rq = lane & 15, oct = lane >> 4;
-  const int b = blockIdx.z, qhead = blockIdx.y;
-  const int hk = qhead / (a.Hq / a.Hkv);
+  // (round 6) dispatch order: workgroup ids run over the HEADS first and the row blocks — heaviest first — second, so the 512 co-resident
+  // workgroups are always the heaviest blocks left, of every head.  Ids used to run over a head's row blocks first: the last head's
+  // heaviest block (twice the average work) was dispatched when ~97 % of the grid had been, and the launch ended on that one workgroup —
+  // 4096 tokens: 0.303 -> see profiles/r06_attn_prefill_dispatch_order.txt.  The head of id x is (x mod Hkv) * group + x / Hkv: ids are
+  // dealt round-robin to the 8 XCDs, so with 8 kv heads every XCD's L2 holds the K / V panels of ONE kv head.
+  const int b = blockIdx.z;
+  const int group = a.Hq / a.Hkv;
+  const int hk = (int)blockIdx.x % a.Hkv, qhead = hk * group + (int)blockIdx.x / a.Hkv;
   const int ctx = (int)a.context_lens[b];
   const int q0 = (int)a.cu_q[b];
   const int lq = (int)(a.cu_q[b + 1] - a.cu_q[b]);
   // heavy-first: the last row block of a sequence walks the most tiles and is dispatched first
   const int nxb = (lq + ROWS - 1) / ROWS;
-  if ((int)blockIdx.x >= nxb) return;
-  const int xb = nxb - 1 - (int)blockIdx.x;
+  if ((int)blockIdx.y >= nxb) return;
+  const int xb = nxb - 1 - (int)blockIdx.y;
   const int wg_i0 = xb * ROWS;
   const int wg_last_pos = ctx - lq + min(wg_i0 + ROWS, lq) - 1;
   const int ntiles = (wg_last_pos >> 6) + 1;
