@@ -196,6 +196,35 @@ def test_long_prefill_runs_marlin_rounded_weights_on_the_dense_gemm(variant):
         eng.close()
 
 
+@pytest.mark.parametrize("variant", ["llama3_8b_shape", "qwen2_7b_shape"])
+def test_long_prefill_at_the_real_widths(variant):
+    """one layer at the widths of BASELINE configs 2 and 3, an 1100-token prompt next to a short one, the DEFAULT row rule (dense path from
+    1024 rows): q/k/v as one 256-wide launch over 6144 / 4608 concatenated columns, o_proj / down_proj with split-K (5 row tiles leave most
+    of the chip idle), gate/up interleaved; K = 3584 and 18944 are multiples of neither 1024 nor 256.  Against the oracle's Marlin-rounded
+    variant (oracle/model.py dense_prefill_rows)."""
+    cfg = {
+        "llama3_8b_shape": small_cfg(hidden_size=4096, intermediate_size=14336, num_layers=1, num_heads=32, num_kv_heads=8, head_dim=128,
+                                     vocab_size=2048, rope_theta=500000.0, max_position_embeddings=2048),
+        "qwen2_7b_shape": small_cfg(arch="qwen2", attention_bias=True, hidden_size=3584, intermediate_size=18944, num_layers=1, num_heads=28,
+                                    num_kv_heads=4, head_dim=128, vocab_size=2048, quant_method="awq", rope_theta=1e6, rms_norm_eps=1e-6,
+                                    max_position_embeddings=2048),
+    }[variant]
+    eng, oracle = build(cfg, seed=11, max_model_len=2048)
+    try:
+        assert eng.L.vra_debug_dense_prefill_min_rows() == 1024
+        r = np.random.default_rng(4)
+        prompts = [r.integers(0, cfg["vocab_size"], size=n).tolist() for n in (1100, 37)]
+        bt = simple_tables([len(p) + 8 for p in prompts])
+        ids, pos, slots, ctx, cu = prefill_inputs(prompts, bt)
+        assert om.dense_prefill_rows(cfg, len(ids))
+        got = eng.forward_raw(ids, pos, slots, bt, ctx, cu)
+        ref = oracle.forward(ids, pos, slots, bt, ctx, cu)
+        check_logits(got, ref, f"{variant} 1137-token prefill (dense path)", cfg["dtype"])
+        assert np.array_equal(orc.argmax_f32(got), orc.argmax_f32(ref)) or np.abs(np.sort(ref, axis=-1)[:, -1] - np.sort(ref, axis=-1)[:, -2]).min() < 2 * LOGIT_TOL
+    finally:
+        eng.close()
+
+
 def test_oracle_mirrors_the_engines_deferred_norm_rule():
     """which fused-norm launches of a step apply rstd in their epilogue is a shape rule of the engine (kernel E at 1..4 rows; at 5..32
     rows the kernel-W launches fed ready-made operands by their producer — o_proj, down_proj, the embedding launch for layer 0);
