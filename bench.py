@@ -854,6 +854,21 @@ def main():
         eng.close()
         eng = None
         if a.model == "llama3-8b-gptq":
+            # ---------------- opt-in engine mode: the dequantised weights of the dense prefill path kept RESIDENT (VRA_DENSE_PREFILL_RESIDENT=1:
+            # 14 GB next to the 4.5 GB of int4 tensors, made once at engine creation; bit-identical logits, tests/test_gpu_engine.py) — what a
+            # long prefill costs without its dequant passes.  The default line above keeps int4 as the only resident format.
+            try:
+                os.environ["VRA_DENSE_PREFILL_RESIDENT"] = "1"
+                er = E.Engine(cfg, max_num_seqs=8, max_model_len=8192, num_gpu_blocks=a.blocks, use_graph=not a.no_graph, device=local_rank,
+                              seed=1234, cpu_mem_fold=0.0).init_synthetic()
+                ttft_p50(er, 128, V, 1, reps=2)
+                line["ttft_p50_ms_resident_dense_weights"] = {"bs1_prompt2048": ttft_p50(er, 2048, V, 1, reps=3),
+                                                              "bs1_prompt4096": ttft_p50(er, 4096, V, 1, reps=3), "extra_resident_GB": 13.96}
+                er.close()
+            except Exception as ex:
+                line["ttft_p50_ms_resident_dense_weights"] = {"error": repr(ex)}
+            finally:
+                os.environ.pop("VRA_DENSE_PREFILL_RESIDENT", None)
             # ---------------- config 5: 32 768-token prompt (4 chunks of 8192), then the same prompt again (511-block prefix hit)
             e5 = E.Engine(E.LLAMA31_8B, max_num_seqs=8, max_model_len=40960, num_gpu_blocks=2048, enable_prefix_cache=True,
                           use_graph=not a.no_graph, device=local_rank, seed=1234, cpu_mem_fold=0.0).init_synthetic()

@@ -196,6 +196,36 @@ def test_long_prefill_runs_marlin_rounded_weights_on_the_dense_gemm(variant):
         eng.close()
 
 
+def test_resident_dequantised_weights_change_nothing_but_the_time(monkeypatch):
+    """VRA_DENSE_PREFILL_RESIDENT=1: the dequantised fragments of every layer made once at engine creation instead of in front of every
+    GEMM — the same bits reach the same dense GEMM launches: logits bit-identical to the scratch form, prefill and the decode behind it"""
+    cfg = small_cfg(arch="qwen2", quant_method="awq", attention_bias=True, num_heads=8, num_kv_heads=2, head_dim=64, hidden_size=512)
+    r = np.random.default_rng(8)
+    prompts = [r.integers(0, cfg["vocab_size"], size=n).tolist() for n in (290, 40)]
+    bt = simple_tables([len(p) + 8 for p in prompts])
+    ids, pos, slots, ctx, cu = prefill_inputs(prompts, bt)
+    outs = []
+    from vllm_rs_amd import _lib
+    L = _lib.load()
+    old = L.vra_debug_dense_prefill_min_rows()
+    try:
+        L.vra_debug_set_dense_prefill_min_rows(256)
+        for resident in ("0", "1"):
+            monkeypatch.setenv("VRA_DENSE_PREFILL_RESIDENT", resident)
+            eng, _ = build(cfg, seed=5)
+            got = eng.forward_raw(ids, pos, slots, bt, ctx, cu)
+            seqs = [list(p) + [7] for p in prompts]
+            d_ids = np.array([s[-1] for s in seqs], np.uint32)
+            d_pos = np.array([len(s) - 1 for s in seqs], np.int64)
+            d_slots = np.array([int(bt[b, (len(s) - 1) // 64]) * 64 + (len(s) - 1) % 64 for b, s in enumerate(seqs)], np.int64)
+            dec = eng.forward_raw(d_ids, d_pos, d_slots, bt, np.array([len(s) for s in seqs], np.uint32), None)
+            outs.append((got, dec))
+            eng.close()
+    finally:
+        L.vra_debug_set_dense_prefill_min_rows(old)
+    assert np.array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32)) and np.array_equal(outs[0][1].view(np.uint32), outs[1][1].view(np.uint32))
+
+
 @pytest.mark.parametrize("variant", ["llama3_8b_shape", "qwen2_7b_shape"])
 def test_long_prefill_at_the_real_widths(variant):
     """one layer at the widths of BASELINE configs 2 and 3, an 1100-token prompt next to a short one, the DEFAULT row rule (dense path from

@@ -487,10 +487,79 @@ bool Model::init_buffers(int max_tokens, int max_seqs) {
     const size_t fb = (size_t)(hq_ * mc_.head_dim / 128) * 2 * 4096;
     if (!(afrag_ = dalloc(fb)) || hipMemset(afrag_, 0, fb) != hipSuccess) return false;
   }
+  // resident dequantised weights for long prefills (model.h wd_res_): opt-in, only for engines whose steps can reach the row rule
+  {
+    const char* res = getenv("VRA_DENSE_PREFILL_RESIDENT");
+    if (res && atoi(res) && vra_dense_prefill_min_rows() > 0 && max_tokens >= vra_dense_prefill_min_rows()) {
+      wd_res_.assign(layers_.size() * 4, nullptr);
+      for (size_t l = 0; l < layers_.size(); l++)
+        for (int k = 0; k < 4; k++) {
+          if (!dense_shape_ok((int)l, k)) continue;
+          void* p = dalloc(dense_bytes((int)l, k));
+          if (!p) return false;
+          dense_fill((int)l, k, p, 0);
+          wd_res_[l * 4 + k] = p;
+        }
+      if (vra_last_error()[0]) {
+        error = std::string("resident dequantised weights: ") + vra_last_error();
+        vra_clear_error();
+        return false;
+      }
+    }
+  }
   // (hipMemset of device memory may return before the fill has run: nothing of this may still be pending when the engine's
   // non-blocking stream starts its first forward)
   if (hipDeviceSynchronize() != hipSuccess) return false;
   return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// resident dequantised weights of the dense prefill path (model.h wd_res_; csrc/gemm_dense.cuh)
+// ---------------------------------------------------------------------------------------------
+bool Model::dense_shape_ok(int layer, int kind) const {
+  if (layer < 0 || layer >= (int)layers_.size()) return false;
+  const LayerWeights& L = layers_[layer];
+  auto q4 = [&](const QLinear& l) { return l.quant && l.w && l.K % 128 == 0 && l.N % 16 == 0; };
+  switch (kind) {
+    case 0: return q4(L.q) && q4(L.k) && q4(L.v) && L.k.K == L.q.K && L.v.K == L.q.K && L.q.N % 64 == 0 && L.k.N % 64 == 0 && L.v.N % 64 == 0 &&
+                   L.k.awq == L.q.awq && L.v.awq == L.q.awq;
+    case 1: return q4(L.o);
+    case 2: return q4(L.gate) && q4(L.up) && L.up.K == L.gate.K && L.up.N == L.gate.N && !L.gate.bias && !L.up.bias;
+    case 3: return q4(L.down);
+  }
+  return false;
+}
+size_t Model::dense_bytes(int layer, int kind) const {
+  const LayerWeights& L = layers_[layer];
+  switch (kind) {
+    case 0: return (size_t)L.q.K * (L.q.N + L.k.N + L.v.N) * es_;
+    case 1: return (size_t)L.o.K * L.o.N * es_;
+    case 2: return (size_t)L.gate.K * L.gate.N * 2 * es_;
+    case 3: return (size_t)L.down.K * L.down.N * es_;
+  }
+  return 0;
+}
+void Model::dense_fill(int layer, int kind, void* wd, int64_t stream) {
+  const LayerWeights& L = layers_[layer];
+  auto one = [&](const QLinear& l, int vfrag0, int vstride) {
+    vra_launch_dequant_frag(l.w, l.scales, l.qzeros, wd, l.K, l.N, mc_.group_size, l.awq && l.qzeros != nullptr, VRA_SCALES_ROWMAJOR, dt_, vfrag0, vstride, stream);
+  };
+  switch (kind) {
+    case 0: one(L.q, 0, 1), one(L.k, L.q.N / 16, 1), one(L.v, (L.q.N + L.k.N) / 16, 1); break;
+    case 1: one(L.o, 0, 1); break;
+    case 2: one(L.gate, 0, 2), one(L.up, 1, 2); break;
+    case 3: one(L.down, 0, 1); break;
+  }
+}
+const void* Model::dense_resident(int layer, int kind, int M) const {
+  if (wd_res_.empty() || layer < 0 || (size_t)layer * 4 + kind >= wd_res_.size() || kind < 0) return nullptr;
+  const int mr = vra_dense_prefill_min_rows();
+  return mr > 0 && M >= mr ? wd_res_[(size_t)layer * 4 + kind] : nullptr;
+}
+int Model::dense_kind_of(const QLinear& l) const {
+  if (cur_layer_ < 0 || cur_layer_ >= (int)layers_.size() || !l.w) return -1;
+  const LayerWeights& L = layers_[cur_layer_];
+  return l.w == L.o.w ? 1 : (l.w == L.down.w ? 3 : -1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -527,6 +596,15 @@ bool Model::linear(const QLinear& l0, const void* x, void* out, int M, const voi
     return !take_err(error, "linear (kernel C)");
   }
   if (l.quant) {
+    if (const void* wd = dense_resident(cur_layer_, dense_kind_of(l0), M)) {  // long prefill, resident dequantised weights: no pass
+      GemmXArgs a = {};
+      a.x = x, a.x_ld = l.K, a.wd = wd, a.residual = residual, a.res_ld = l.N;
+      a.seg[0] = GemmXSeg{out, l.bias, l.N, 0};
+      a.nseg = 1;
+      a.M = M, a.NV = l.N, a.K = l.K;
+      vra_launch_gemm_dense(a, false, dt_, vra_gemm_dense_tile(M, l.N, l.K), stream);
+      return !take_err(error, "linear (gemm_dense, resident weights)");
+    }
     vra_wna16_gemm(x, l.w, l.scales, l.qzeros, l.bias, residual, out, M, l.K, l.N, mc_.group_size, l.awq ? 1 : 0,
                    VRA_SCALES_ROWMAJOR, dt_, stream);
   } else if (!residual) {
@@ -587,7 +665,9 @@ bool Model::linear_fused_norm(const QLinear* ls, int nl, void* const* outs, cons
     int cols = 0;
     bool seg_ok = true;
     for (int i = 0; i < nl; i++) seg_ok = seg_ok && ls[i].N % 64 == 0, cols += ls[i].N;
-    void* wd = seg_ok && vra_dense_prefill_fits(M, K, cols, mc_.group_size) ? vra_dense_scratch((size_t)K * cols * es_, stream) : nullptr;
+    const bool fits = seg_ok && vra_dense_prefill_fits(M, K, cols, mc_.group_size);
+    const void* res = fits && nl == 3 && ls[0].w == layers_[cur_layer_].q.w ? dense_resident(cur_layer_, 0, M) : nullptr;
+    const void* wd = res ? res : (fits ? vra_dense_scratch((size_t)K * cols * es_, stream) : nullptr);
     if (wd) {
       vra_rms_norm(x, norm_w, xn_, M, K, mc_.rms_norm_eps, dt_, stream);
       GemmXArgs a = {};
@@ -595,8 +675,9 @@ bool Model::linear_fused_norm(const QLinear* ls, int nl, void* const* outs, cons
       a.nseg = nl;
       int c0 = 0;
       for (int i = 0; i < nl; i++) {
-        vra_launch_dequant_frag(ls[i].w, ls[i].scales, ls[i].qzeros, wd, K, ls[i].N, mc_.group_size, ls[i].awq && ls[i].qzeros != nullptr,
-                                VRA_SCALES_ROWMAJOR, dt_, c0 / 16, 1, stream);
+        if (!res)
+          vra_launch_dequant_frag(ls[i].w, ls[i].scales, ls[i].qzeros, const_cast<void*>(wd), K, ls[i].N, mc_.group_size,
+                                  ls[i].awq && ls[i].qzeros != nullptr, VRA_SCALES_ROWMAJOR, dt_, c0 / 16, 1, stream);
         a.seg[i] = GemmXSeg{outs[i], ls[i].bias, ls[i].N, c0};
         c0 += ls[i].N;
       }
@@ -697,6 +778,16 @@ bool Model::gate_up(const LayerWeights& L, const void* x, const void* norm_w, vo
       // long prefills: vra_wna16_gate_up_silu takes the dequant pass + dense GEMM (gemm_dense.cuh); else
       // prefill through kernel D: the norm launch also leaves the GEMM's row-sum table (one launch less per layer)
       const bool dense = vra_dense_prefill_fits(M, K, 2 * N, mc_.group_size);
+      if (const void* wd = dense && &L == &layers_[cur_layer_] ? dense_resident(cur_layer_, 2, M) : nullptr) {
+        vra_rms_norm(x, norm_w, xn_, M, K, mc_.rms_norm_eps, dt_, stream);
+        GemmXArgs a = {};
+        a.x = xn_, a.x_ld = K, a.wd = wd;
+        a.seg[0] = GemmXSeg{act, nullptr, N, 0};
+        a.nseg = 1;
+        a.M = M, a.NV = 2 * N, a.K = K;
+        vra_launch_gemm_dense(a, true, dt_, vra_gemm_dense_tile(M, 2 * N, K), stream);
+        return !take_err(error, "gate_up (gemm_dense, resident weights)");
+      }
       const int mb = !dense && M >= 64 && K % 128 == 0 ? vra_gemm_q4_big_fits(true, M, N, K, mc_.group_size, nullptr) : 0;
       float* tbl = mb ? vra_gemm_q4_big_xsum_table(M, K) : nullptr;
       if (tbl) {
@@ -938,6 +1029,7 @@ bool Model::forward(const InputMetadata& md, int64_t stream, uint32_t* tokens) {
   pre_o_ok_ = pre_d_ok_ = false;
   for (int l = 0; l < mc_.num_layers; l++) {
     const LayerWeights& L = layers_[l];
+    cur_layer_ = l;
     // ---- attention block (llama.rs:115-126): norm -> q,k,v -> rope -> cache + attention -> o_proj (+ residual)
     const QLinear qkv[3] = {L.q, L.k, L.v};
     void* outs[3] = {q_, k_, v_};
@@ -1086,6 +1178,7 @@ bool Model::launch_gemm(int which, int layer, int M, int64_t stream) {
   if (layer < 0 || layer >= mc_.num_layers || M < 1 || M > max_tokens_) return false;
   if (which == 4) return M <= max_seqs_ && lm_head(h_, M, bench_tokens_, stream);  // final norm + lm_head (+ greedy tokens), the decode form
   const LayerWeights& L = layers_[layer];
+  cur_layer_ = layer;
   // (5..32 rows: x in fragment order where the forward pass reads it that way — the timing does not depend on the values)
   const bool xf = g_x_frag && M > 4 && M <= 32 && world_ == 1;
   const void* x_frag = !xf ? nullptr : (which == 1 ? afrag_ : (which == 3 ? actfrag_ : hfrag_));

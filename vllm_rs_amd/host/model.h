@@ -188,6 +188,18 @@ class Model {
   float *sq_o_ = nullptr, *sq_d_ = nullptr, *sq_e_ = nullptr;
   bool pre_o_ok_ = false, pre_d_ok_ = false;
   void* afrag_ = nullptr;  // the decode attention's output of a 5..32-sequence step in fragment order (o_proj's x on kernel W)
+  // Long prefills (csrc/gemm_dense.cuh) run every int4 GEMM as dequant pass + dense GEMM; by default the pass writes into a scratch tensor
+  // in front of each GEMM (int4 stays the only resident format).  Opt-in (VRA_DENSE_PREFILL_RESIDENT=1 at engine creation): the
+  // dequantised 16-bit fragments of every layer are made ONCE in init_buffers and kept — 2 bytes per weight next to the int4 tensors' 0.5
+  // (Llama-3-8B: 14 GB of the 288) — and the prefill GEMMs skip the pass (3.4 ms per forward of the 8B shape).  kind: 0 q/k/v (one tensor of
+  // concatenated columns), 1 o_proj, 2 gate/up (interleaved fragments), 3 down_proj; [layer * 4 + kind], null = not resident.
+  std::vector<void*> wd_res_;
+  int cur_layer_ = 0;  // the layer whose GEMMs forward() / launch_gemm() is issuing
+  bool dense_shape_ok(int layer, int kind) const;
+  size_t dense_bytes(int layer, int kind) const;
+  void dense_fill(int layer, int kind, void* wd, int64_t stream);
+  const void* dense_resident(int layer, int kind, int M) const;  // the resident tensor when this GEMM of M rows takes the dense path
+  int dense_kind_of(const QLinear& l) const;                      // 1 / 3 for the current layer's o_proj / down_proj, else -1
 };
 
 }  // namespace vra
