@@ -227,7 +227,7 @@ def ffi_path(L, cfg, iters=6):
 def roofline_prefill(eng, L, cfg, rows=4096):
     """the MFMA roofline of the prefill kernels — the int4 GEMMs of a layer at `rows` activation rows, per launch, timed with
     HIP events (vra_engine_bench_gemm: rotating layers), and the paged prefill attention (prefill_attn_kernel) on one sequence of `rows`
-    tokens.  From 1024 rows on a GEMM is the dequant pass (dequant_frag_kernel: w = rnd((q - z) * s), Marlin's weight, gptq.rs:116-178)
+    tokens.  From 768 rows on a GEMM is the dequant pass (dequant_frag_kernel: w = rnd((q - z) * s), Marlin's weight, gptq.rs:116-178)
     plus the 256-row dense GEMM (gemm_dense_kernel, csrc/gemm_dense.cuh): `kernels` times BOTH launches of every GEMM, so `achieved` is
     the rate a prefill sees; `int4_fused_kernel_d` is the same layer with the path switched off (kernel D: gemm_q4_big_kernel, the exact
     product with the conversion inside every 64-row tile).  FLOPs: 2*M*K*N per GEMM; 4*D*Hq*(T*(T+1)/2) for the causal attention.

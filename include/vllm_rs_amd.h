@@ -519,7 +519,7 @@ int32_t vra_debug_norm_deferred_mask(int32_t hidden, int32_t inter_local, int32_
                                      int32_t dtype); /* f16 models defer at 1..4 rows only (no ready-made operands: their range is bf16's) */
 int32_t vra_debug_gemv_s_fits(int32_t ns, int32_t m, int32_t k, int32_t group_size, int32_t n_units, int32_t norm);
 /* parity instrumentation: rows from which the int4 GEMMs of a prefill step run as dequant pass + dense GEMM on Marlin-rounded weights
- * (vra_wna16_dequant_frag / vra_dense_frag_gemm; default 1024, VRA_DENSE_PREFILL_MIN_ROWS; 0 = never).  The oracle restates the
+ * (vra_wna16_dequant_frag / vra_dense_frag_gemm; default 768, VRA_DENSE_PREFILL_MIN_ROWS; 0 = never).  The oracle restates the
  * weight rounding the engine runs (oracle/model.py dense_prefill_rows); tests lower it to reach the path with small models. */
 int32_t vra_debug_dense_prefill_min_rows(void);
 void vra_debug_set_dense_prefill_min_rows(int32_t rows);

@@ -48,7 +48,7 @@ def test_fragment_order_h_is_bit_identical_to_row_major(name, B):
     lens[0] = 300  # one sequence on the split-KV path of the decode attention
     nblk = sum((n + 8 + 63) // 64 for n in lens) + 2
     eng, oracle = build(cfg, seed=5, max_num_seqs=32, num_gpu_blocks=nblk)
-    # The subject is the DECODE step; the prompts only fill the cache.  From 24 sequences on they add up to > 1024 tokens, where the
+    # The subject is the DECODE step; the prompts only fill the cache.  Their tokens add up past the row rule of the dense prefill path for the larger batches, where the
     # prefill would take the dense GEMM on Marlin-rounded weights (csrc/gemm_dense.cuh) — mirrored by the oracle, and within 1 ulp of it
     # on the prefill logits, but another rounding pattern in the cached K / V: rows 8 and 9 of the B = 31 seed amplify ANY such noise
     # twenty-fold (the ORACLE's own decode answer moves 21.0 / 21.9 ulp on them when only its prefill switches between the two weight

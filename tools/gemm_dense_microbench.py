@@ -54,7 +54,7 @@ for M in Ms:
         wd = ops.DevBuf(K * N * 2 * nt)
         nv = N * nt
 
-        def run_d():  # (called with the dense path switched off: vra_wna16_gemm would take it from 1024 rows)
+        def run_d():  # (called with the dense path switched off: vra_wna16_gemm would take it from 768 rows)
             if dual:
                 L.vra_wna16_gate_up_silu(x.ptr, ws[0].ptr, sc[0].ptr, None, ws[1].ptr, sc[1].ptr, None, out_d.ptr, M, K, N, 128, 0, 0, 0, 0)
             else:

@@ -3,7 +3,7 @@
 // Why (round 6): kernel D (gemm_q4_big.cuh) converts int4 -> bf16 inside every 64-row workgroup and pays the exact per-group scale
 // fix-up per accumulator: 3 VALU instructions per MFMA where one is free — 0.30-0.32 of the MFMA peak, and the same skeleton with
 // the conversion removed runs 1.08 PFLOP/s (profiles/r06_kernel_d_probes.txt).  A prompt of M rows repeats that conversion M/64
-// times per weight.  Above ~1000 rows it is cheaper to dequantise a GEMM's weights ONCE into a scratch tensor (a streaming pass:
+// times per weight.  From ~700 rows on it is cheaper to dequantise a GEMM's weights ONCE into a scratch tensor (a streaming pass:
 // 0.5 B read + 2 B written per weight) and run a plain 16-bit GEMM whose inner loop is nothing but LDS reads and MFMAs.  The
 // dequantised weight is  w = round_dt((q - z) * s)  — what the reference's Marlin kernels feed their MMAs (src/utils/gptq.rs:116-178;
 // oracle/vra_oracle.c orc_dequant + orc_gemm_wdense, orc_wna16_gemm_marlin) — so this path is the reference's arithmetic, f32

@@ -115,14 +115,15 @@ void vra_launch_dequant_frag(const void* tiled, const void* scales, const void* 
 }
 
 // ---- when the prefill GEMMs take this path, and the scratch tensor the dequantised weights of ONE GEMM live in
-// Rows from which dequant pass + dense GEMM beats kernel D (tools/gemm_dense_microbench.py, Llama-3-8B shapes: layer of 2048 rows
-// 1341 -> 1012 us, 4096 rows 2590 -> 1634; 500 rows lose).  VRA_DENSE_PREFILL_MIN_ROWS overrides (0 = never); tests lower it through
+// Rows from which dequant pass + dense GEMM beats kernel D (tools/gemm_dense_microbench.py, Llama-3-8B shapes, one layer's four GEMMs,
+// us: 512 rows 376 (D) / 420 (X + pass); 768: 570 / 523; 1024: 661 / 573; 2048: 1179 / 875; 4096: 2290 / 1500; 8192: 4377 / 2845 —
+// profiles/r06_gemm_dense_microbench.txt).  VRA_DENSE_PREFILL_MIN_ROWS overrides (0 = never); tests lower it through
 // vra_debug_set_dense_prefill_min_rows to reach the path with small models.
 static int g_dense_min_rows = -1;
 int vra_dense_prefill_min_rows() {
   if (g_dense_min_rows < 0) {
     const char* e = getenv("VRA_DENSE_PREFILL_MIN_ROWS");
-    g_dense_min_rows = e ? std::max(0, atoi(e)) : 1024;
+    g_dense_min_rows = e ? std::max(0, atoi(e)) : 768;
   }
   return g_dense_min_rows;
 }
