@@ -2,6 +2,7 @@
 #include "model.h"
 
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -486,6 +487,15 @@ bool Model::init_buffers(int max_tokens, int max_seqs) {
   if ((hq_ * mc_.head_dim) % 128 == 0) {
     const size_t fb = (size_t)(hq_ * mc_.head_dim / 128) * 2 * 4096;
     if (!(afrag_ = dalloc(fb)) || hipMemset(afrag_, 0, fb) != hipSuccess) return false;
+  }
+  // the scratch tensor of the dense prefill path (the dequantised weights of ONE GEMM; process-wide, csrc/gemm_dense.hip) is sized for
+  // this model's largest GEMM now, before the KV cache is planned from what is left of the device memory
+  if (vra_dense_prefill_min_rows() > 0 && max_tokens >= vra_dense_prefill_min_rows()) {
+    size_t need = 0;
+    for (size_t l = 0; l < layers_.size(); l++)
+      for (int k = 0; k < 4; k++)
+        if (dense_shape_ok((int)l, k)) need = std::max(need, dense_bytes((int)l, k));
+    if (need) (void)vra_dense_scratch(need, 0);  // (unavailable: the GEMMs keep to the int4 kernels)
   }
   // resident dequantised weights for long prefills (model.h wd_res_): opt-in, only for engines whose steps can reach the row rule
   {
