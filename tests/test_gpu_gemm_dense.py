@@ -93,6 +93,28 @@ def test_dense_frag_gemm(M, K, N, dt, tile):
     assert_close_dt(out.numpy(np.uint16, (M, N)), ref2, dt, max_ulp=3.0, name="kernel X bias+residual", mag=mag)
 
 
+@pytest.mark.parametrize("slices", [2, 4])
+def test_dense_frag_gemm_tail_split(slices):
+    """more tiles than CUs with a part-filled last round (2 x 136 = 272 tiles on the MI355X's 256 CUs): the first 256 tiles over the full K,
+    the 16 of the last round split `slices` ways and summed through memory — same result as the unsplit launch up to the f32 order"""
+    M, K, N = 512, 512, 136 * 256
+    r = rng(91 + slices)
+    q = make_quant(r, K, N, 128, BF16, False)
+    x = rand_dt(r, (M, K), BF16)
+    wd = dequant_frag(q, K, N, 128, BF16, False)
+    out = ops.DevBuf(M * N * 2).fill_bytes(0xEE)
+    d_x = ops.dev(x)
+    ops.lib().vra_dense_frag_gemm(d_x.ptr, wd.ptr, None, None, out.ptr, M, K, N, 0, BF16, 256 | slices << 24, 0)
+    msg = ops.lib().vra_last_error().decode()
+    if "tail split does not fit" in msg:  # (a part with another CU count)
+        ops.lib().vra_clear_error()
+        pytest.skip(msg)
+    ops.check_error()
+    ref = orc.gemm_wdense(x, orc.dequant(q["idx"], None, q["scales"], 128, BF16), None, None, BF16)
+    assert_close_dt(out.numpy(np.uint16, (M, N)), ref, BF16, name=f"kernel X, tail split {slices}", abs_floor=2e-3)
+    assert ops.lib().vra_take_device_error() == 0
+
+
 @pytest.mark.parametrize("tile", [128, 256])
 @pytest.mark.parametrize("awq", [False, True])
 def test_dense_frag_gemm_gate_up(awq, tile):

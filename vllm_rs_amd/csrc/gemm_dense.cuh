@@ -66,6 +66,11 @@ struct GemmXArgs {
   // to the last one through `slabs` (write-through stores, one flag line per slice, fixed summation order: the exchange of kernels
   // B / C / D).  The whole grid is co-resident (launcher: tiles * splitk <= CUs), so the owner's wait cannot starve its partners.
   int splitk;
+  // tail split (large M whose tile count is 1.x rounds of the chip — q/k/v at 4096 rows: 384 tiles on 256 CUs): the first `tail_first`
+  // tiles (whole rounds) run over the full K, only the tiles of the last, part-filled round are split `tail_sk` ways — it then takes
+  // 1 / tail_sk of a round instead of ~0.8.  Every XCD gets its share of both kinds; a tile's slices are dispatched side by side, the
+  // owner last (non-owners never wait, so the owner's wait cannot starve them).
+  int tail_first, tail_sk;
   float* slabs;
   uint32_t* counters;
   uint32_t* err;
@@ -124,16 +129,31 @@ __global__ __launch_bounds__(GX_THREADS, 2) void gemm_dense_kernel(const GemmXAr
   const int r16 = lane & 15, q4 = lane >> 4;
   const int K = a.K, M = a.M;
   const int KS = K >> 6;  // K-steps (even: K % 128 == 0)
-  const int SK = a.splitk > 1 ? a.splitk : 1;
+  int SK = a.splitk > 1 ? a.splitk : 1;  // (wave-uniform; per workgroup with a tail split)
 
   // ---- tile of this workgroup: ids of one XCD (id mod 8) take a contiguous run of the grouped tile order (8 m-tiles per super-row)
-  int mt, nt, zi;
+  int mt, nt, zi, xtile, xtiles;  // xtile of xtiles: the tile's index among the tiles that exchange partial sums
   {
     const int nwg = (int)gridDim.x, bid = (int)blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    const int lin_sk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int lin = lin_sk / SK;  // (the slices of a tile are neighbours in the remapped order: same XCD, the slabs stay in its L2)
-    zi = lin_sk - lin * SK;
+    int lin;
+    if (a.tail_sk > 1) {
+      const int pos = bid >> 3, fq = a.tail_first >> 3, tq = (nwg - a.tail_first) >> 3;  // per XCD: full-K tiles, then tail workgroups
+      if (pos < fq) {
+        lin = xcd * fq + pos, SK = 1, zi = 0;
+      } else {
+        const int rr = xcd * tq + (pos - fq);
+        SK = a.tail_sk;
+        lin = a.tail_first + rr / SK;
+        zi = rr - (rr / SK) * SK;
+      }
+      xtile = lin - a.tail_first, xtiles = a.MT * a.NT - a.tail_first;
+    } else {
+      const int lin_sk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+      lin = lin_sk / SK;  // (the slices of a tile are neighbours in the remapped order: same XCD, the slabs stay in its L2)
+      zi = lin_sk - lin * SK;
+      xtile = lin, xtiles = a.MT * a.NT;
+    }
     constexpr int GM = 8;
     const int per = GM * a.NT;
     const int grp = lin / per, rem = lin - grp * per;
@@ -276,7 +296,7 @@ __global__ __launch_bounds__(GX_THREADS, 2) void gemm_dense_kernel(const GemmXAr
   // ---- split-K: the slices of a tile meet through memory (gemm_q4_big.cuh): write-through 16-byte stores, one flag line per slice,
   // the last slice ("owner") polls, adds the slabs to its own partial in slice order and resets the flags
   if (SK > 1) {
-    const int tile = nt * a.MT + mt, ntiles = a.MT * a.NT;
+    const int tile = xtile, ntiles = xtiles;
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a.slabs, 0, 0x7FFFFFF0, RSRC3);
     auto slab_off = [&](int z, int i, int j) {  // bytes: [slice][tile][m-frag][n-frag][thread] x 16 B
       return (uint32_t)((((z * ntiles + tile) * 8 + i) * WNF + j) * GX_THREADS + tid) * 16u;

@@ -22,7 +22,9 @@ static void launch_gemm_dense_t(const GemmXArgs& a, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dense_kernel<DT, BN, DUAL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_devs |= (uint64_t)1 << gx_cur_dev();
   }
-  gemm_dense_kernel<DT, BN, DUAL><<<dim3((unsigned)(a.MT * a.NT * (a.splitk > 1 ? a.splitk : 1))), GX_THREADS, lds, st>>>(a);
+  const int tiles = a.MT * a.NT;
+  const unsigned grid = a.tail_sk > 1 ? (unsigned)(a.tail_first + (tiles - a.tail_first) * a.tail_sk) : (unsigned)(tiles * (a.splitk > 1 ? a.splitk : 1));
+  gemm_dense_kernel<DT, BN, DUAL><<<dim3(grid), GX_THREADS, lds, st>>>(a);
 }
 
 static int gx_num_cus() {
@@ -61,20 +63,45 @@ int vra_gemm_dense_tile(int M, int nv, int K) {
       const double c = 1.0 / S + (8.0 + 4.0 * (S - 1)) / t_tile;
       if (c < 0.92 * cost) cost = c, best = 256 | (S << 16);
     }
+    // tail split: whole rounds over the full K, the tiles of a last round that fills at most half the chip split S ways (<< 24)
+    static const char* tail_off = getenv("VRA_GX_NO_TAIL_SPLIT");
+    const long rem = t256 % cus, full = t256 - rem;
+    // (measured, tools/gemm_dense_microbench.py: q/k/v of 3072 rows, 288 tiles, 182 -> 148 us; of 4096 rows, 384 tiles, 189 -> 173;
+    // gate/up of 2048 rows — 3.5 rounds — gains nothing: only problems of ONE whole round + a tail take it)
+    if (!(tail_off && atoi(tail_off)) && full == cus && rem > 0 && rem <= cus / 2 && cus % 8 == 0) {
+      for (int S = 4; S >= 2; S /= 2) {
+        if (rem * S > cus || (rem * S) % 8 || KS % (2 * S)) continue;
+        if ((size_t)(S - 1) * rem * 32 * GX_THREADS * 16 > vra_scratch_slab_bytes() / 2 || (size_t)rem * S * 16 > vra_scratch_counter_count()) continue;
+        const double c = (double)(full / cus) + 1.0 / S + (8.0 + 4.0 * (S - 1)) / t_tile;
+        if (c < 0.95 * cost) cost = c, best = 256 | (S << 24);
+        break;
+      }
+    }
   }
   return best;
 }
 
 void vra_launch_gemm_dense(GemmXArgs a, bool dual, int dtype, int bn_sk, int64_t stream) {
-  const int bn = bn_sk & 0xffff, sk = (bn_sk >> 16) > 1 ? (bn_sk >> 16) : 1;
+  const int bn = bn_sk & 0xffff, sk = ((bn_sk >> 16) & 0xff) > 1 ? ((bn_sk >> 16) & 0xff) : 1, tsk = (bn_sk >> 24) > 1 ? (bn_sk >> 24) : 1;
   a.MT = (a.M + GX_BM - 1) / GX_BM;
   a.NT = (a.NV + bn - 1) / bn;
   a.splitk = sk;
-  if (sk > 1) {
+  a.tail_sk = 0, a.tail_first = 0;
+  if (tsk > 1) {  // (encoded only by vra_gemm_dense_tile, which checked the shape)
+    const int cus = gx_num_cus(), tiles = a.MT * a.NT;
+    a.tail_first = tiles / cus * cus;
+    a.tail_sk = tsk;
+    a.splitk = 1;
+    if (bn != 256 || a.tail_first <= 0 || a.tail_first >= tiles || (a.tail_first & 7) || ((tiles - a.tail_first) * tsk) % 8 || (a.K / 64) % (2 * tsk)) {
+      vra_set_error("gemm_dense: tail split does not fit the shape (tiles=%d, slices=%d)", tiles, tsk);
+      return;
+    }
+  }
+  if (sk > 1 || tsk > 1) {
     a.slabs = vra_scratch_slabs();
     a.counters = vra_scratch_counters();
     a.err = vra_scratch_error_word();
-    if (!a.slabs || !a.counters || bn != 256 || (a.K / 64) % (2 * sk)) {
+    if (!a.slabs || !a.counters || bn != 256 || (a.K / 64) % (2 * std::max(sk, tsk))) {
       vra_set_error("gemm_dense: split-K scratch unavailable or K not divisible (K=%d, slices=%d)", a.K, sk);
       return;
     }
@@ -181,7 +208,7 @@ extern "C" void vra_dense_frag_gemm(const void* x, const void* wd, const void* b
   VRA_CHECK_ARG(m >= 1 && k % 128 == 0 && nv % 16 == 0 && (!dual || nv % 32 == 0), "dense_frag_gemm: bad shape M=%d K=%d NV=%d", m, k, nv);
   VRA_CHECK_ARG(dtype == VRA_BF16 || dtype == VRA_F16, "dense_frag_gemm: dtype must be bf16/f16");
   VRA_CHECK_ARG(!(dual && bias), "dense_frag_gemm: the gate/up form takes no bias");
-  VRA_CHECK_ARG(tile_n == 0 || (tile_n & 0xffff) == 128 || (tile_n & 0xffff) == 256, "dense_frag_gemm: tile_n must be 0 (auto), 128 or 256 (| split-K slices << 16)");
+  VRA_CHECK_ARG(tile_n == 0 || (tile_n & 0xffff) == 128 || (tile_n & 0xffff) == 256, "dense_frag_gemm: tile_n must be 0 (auto), 128 or 256 (| split-K slices << 16 | tail slices << 24)");
   if (tile_n >> 16 > 1) vra_scratch_init();
   GemmXArgs a{};
   a.x = x, a.x_ld = k, a.wd = wd, a.residual = residual;
