@@ -5,6 +5,7 @@
 //     context bucket); padded lanes use slot -1 / context 0 (fix of Appendix A6)
 //   LLMEngine three-phase step src/core/engine.rs:812-1128, TTFT per :1004-1012
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <string.h>
 
 #include <algorithm>
@@ -24,6 +25,44 @@ static std::string comm_timeout_detail(void* comm) {
   return " [slice " + std::to_string(d[0]) + ", waiting for rank " + std::to_string(d[1]) + ": expected epoch " + std::to_string(d[2]) +
          ", its flag read " + std::to_string(d[3]) + "]";
 }
+
+// Optional profiler ranges (SURVEY §5 aux: the reference marks its prefill / decode steps for nsys; here roctx, shown by
+// `rocprofv3 --marker-trace`): VRA_ROCTX=1 loads the roctx library at run time — no link-time dependency, nothing on the hot path otherwise.
+#include <dlfcn.h>
+namespace {
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    const char* on = getenv("VRA_ROCTX");
+    if (!on || !atoi(on)) return;
+    // (the rocprofiler-sdk library is the one rocprofv3 intercepts; roctracer's libroctx64 for older tools)
+    void* h = nullptr;
+    for (const char* name : {"librocprofiler-sdk-roctx.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so", "libroctx64.so", "/opt/rocm/lib/libroctx64.so"})
+      if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) return;
+    push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+    pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+    if (!push || !pop) push = nullptr, pop = nullptr;
+  }
+};
+struct RoctxRange {
+  static Roctx& api() {
+    static Roctx r;
+    return r;
+  }
+  bool on;
+  RoctxRange(const char* what, int tokens, int seqs) : on(api().push != nullptr) {
+    if (!on) return;
+    char buf[96];
+    snprintf(buf, sizeof buf, "vra %s tokens=%d seqs=%d", what, tokens, seqs);
+    api().push(buf);
+  }
+  ~RoctxRange() {
+    if (on) api().pop();
+  }
+};
+}  // namespace
 
 namespace vra {
 
@@ -437,11 +476,13 @@ class Engine {
       if (md.n_tokens < 0) return fail("prefill step exceeds max_step_tokens / max_num_seqs");
       if (!upload_meta(md)) return fail("metadata upload failed");
       last_graph_ = nullptr;  // (vra_engine_bench_replay replays the decode graph of the MOST RECENT step only: ADVICE r4)
+      RoctxRange range("prefill", md.n_tokens, B);
       if (!model_.forward(md, (int64_t)stream_, d_tokens_)) return fail(model_.error);
     } else {
       const int bucket = std::min(batch_bucket(B), max_seqs_);
       InputMetadata md = prepare_decode(ids, std::max(bucket, B));
       if (!upload_meta(md)) return fail("metadata upload failed");
+      RoctxRange range("decode", md.n_tokens, B);
       bool launched = false;
       if (ec_.use_graph) {
         const int cb = ctx_bucket(md.max_context_len);
