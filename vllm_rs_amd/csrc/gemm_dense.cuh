@@ -76,7 +76,10 @@ struct GemmXArgs {
   uint32_t* err;
 };
 
-static inline size_t gemm_dense_lds_bytes(int bn) { return (size_t)2 * (32 * 1024 + (size_t)(bn / 16) * 2 * 1024); }
+static inline size_t gemm_dense_lds_bytes(int bn) {  // the K loop's two buffers, or the epilogue's [256][bn (+ 8)] tile of outputs
+  const size_t loop = (size_t)2 * (32 * 1024 + (size_t)(bn / 16) * 2 * 1024), epi = (size_t)GX_BM * ((size_t)bn * 2 + 16);
+  return loop > epi ? loop : epi;
+}
 
 // ---- the dequant pass: int4 tile layout -> 16-bit fragments.  One thread = one 16-byte lane word of the int4 layout (8 codes of one
 // column for each of 4 k-chunks of 32) -> four 16-byte lane words of four consecutive k-chunk fragments.
@@ -341,51 +344,77 @@ __global__ __launch_bounds__(GX_THREADS, 2) void gemm_dense_kernel(const GemmXAr
     }
   }
 
-  // ---- epilogue: D[column q4*4 + e][row r16] of accumulator tile (i, j)
-  const int vcol0 = nt * BN + wc * (WNF * 16);  // first virtual column of this wave
-  if (vcol0 >= a.NV) return;
-  const bool s1 = a.nseg > 1 && vcol0 >= a.seg[1].vcol_start, s2 = a.nseg > 2 && vcol0 >= a.seg[2].vcol_start;
-  uint16_t* const outp = static_cast<uint16_t*>(s2 ? a.seg[2].out : (s1 ? a.seg[1].out : a.seg[0].out));
-  const uint16_t* const biasp = static_cast<const uint16_t*>(s2 ? a.seg[2].bias : (s1 ? a.seg[1].bias : a.seg[0].bias));
-  const int out_ld = s2 ? a.seg[2].out_ld : (s1 ? a.seg[1].out_ld : a.seg[0].out_ld);
-  const int vrel = vcol0 - (s2 ? a.seg[2].vcol_start : (s1 ? a.seg[1].vcol_start : a.seg[0].vcol_start));
+  // ---- epilogue, through LDS (round 6): a lane holds 4 columns x 1 row of each accumulator tile — stored from there, every store
+  // instruction touches 16 rows in 32-byte pieces (and the residual is read the same way): a residual cost 13-20 us per tile round
+  // that way (tools/gemm_dense_overhead.py: 2 K-steps 22.6 -> 35.8 us; now 21.4 -> 26.8; K = 4096 with residual 132-138 -> 121-126 us).  The rounded outputs (bias / SiLU*mul applied) go to LDS as a [256 rows][columns] tile
+  // instead (row stride + 16 bytes: the 64 lanes of a ds_write_b64 cover all banks), and the workgroup stores WHOLE ROWS, 16 bytes per lane,
+  // adding the residual from equally contiguous loads.  Same roundings at the same points: rnd(acc) [+ bias, rnd] [SiLU*mul] are what LDS
+  // holds, rnd(that + residual) is what leaves.
   constexpr int NOUT = DUAL ? WNF / 2 : WNF;  // output n-frags of the wave
+  constexpr int OUTC = NOUT * 16 * 4;         // output columns of the tile
+  constexpr int ROWB = OUTC * 2 + 16;         // bytes of a row of the LDS tile
+  __builtin_amdgcn_s_barrier();  // every wave has drained its LDS-DMA (vmcnt(0) above) and finished its LDS reads: the buffers are free
+  {
+    const int vcol0 = nt * BN + wc * (WNF * 16);  // first virtual column of this wave (one segment: starts are multiples of 64)
+    const bool s1 = a.nseg > 1 && vcol0 >= a.seg[1].vcol_start, s2 = a.nseg > 2 && vcol0 >= a.seg[2].vcol_start;
+    const uint16_t* const biasp = static_cast<const uint16_t*>(s2 ? a.seg[2].bias : (s1 ? a.seg[1].bias : a.seg[0].bias));
+    const int vrel = vcol0 - (s2 ? a.seg[2].vcol_start : (s1 ? a.seg[1].vcol_start : a.seg[0].vcol_start));
 #pragma unroll
-  for (int jo = 0; jo < NOUT; jo++) {
-    const int j = DUAL ? 2 * jo : jo;  // DUAL: fragments (j, j + 1) = (gate, up) of the same 16 output columns
-    if (vcol0 + j * 16 >= a.NV) continue;
-    const int n = (DUAL ? vrel / 2 : vrel) + jo * 16 + q4 * 4;
-    float bs[4] = {0.f, 0.f, 0.f, 0.f};
-    if (biasp) {
-      const u32x2 bw = *reinterpret_cast<const u32x2*>(biasp + n);
-      bs[0] = DT::to_f32((uint16_t)(bw[0] & 0xffffu)), bs[1] = DT::to_f32((uint16_t)(bw[0] >> 16));
-      bs[2] = DT::to_f32((uint16_t)(bw[1] & 0xffffu)), bs[3] = DT::to_f32((uint16_t)(bw[1] >> 16));
-    }
+    for (int jo = 0; jo < NOUT; jo++) {
+      const int j = DUAL ? 2 * jo : jo;  // DUAL: fragments (j, j + 1) = (gate, up) of the same 16 output columns
+      const bool live = vcol0 + j * 16 < a.NV;
+      float bs[4] = {0.f, 0.f, 0.f, 0.f};
+      if (biasp && live) {
+        const int n = (DUAL ? vrel / 2 : vrel) + jo * 16 + q4 * 4;
+        const u32x2 bw = *reinterpret_cast<const u32x2*>(biasp + n);
+        bs[0] = DT::to_f32((uint16_t)(bw[0] & 0xffffu)), bs[1] = DT::to_f32((uint16_t)(bw[0] >> 16));
+        bs[2] = DT::to_f32((uint16_t)(bw[1] & 0xffffu)), bs[3] = DT::to_f32((uint16_t)(bw[1] >> 16));
+      }
+      unsigned char* const lp = smem + (size_t)(wr * 128 + r16) * ROWB + (wc * (NOUT * 16) + jo * 16 + q4 * 4) * 2;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const int m = m0 + wr * 128 + i * 16 + r16;
-      if (m >= M) continue;
-      float v[4];
+      for (int i = 0; i < 8; i++) {
+        float v[4];
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
-        float t = rnd_dt<DT>(acc[i][j][e]);
-        if (biasp) t = rnd_dt<DT>(t + bs[e]);
-        if (DUAL) {
-          const float u = rnd_dt<DT>(acc[i][j + 1][e]);
-          const float sl = rnd_dt<DT>(t / (1.0f + expf(-t)));
-          t = sl * u;
+        for (int e = 0; e < 4; e++) {
+          float t = rnd_dt<DT>(acc[i][j][e]);
+          if (biasp) t = rnd_dt<DT>(t + bs[e]);
+          if (DUAL) {
+            const float u = rnd_dt<DT>(acc[i][j + 1][e]);
+            const float sl = rnd_dt<DT>(t / (1.0f + expf(-t)));
+            t = sl * u;
+          }
+          v[e] = t;
         }
-        v[e] = t;
+        *reinterpret_cast<u32x2*>(lp + (size_t)(i * 16) * ROWB) = u32x2{DT::pack2(v[0], v[1]), DT::pack2(v[2], v[3])};
       }
-      if (a.residual) {
-        const u32x2 rw2 = *reinterpret_cast<const u32x2*>(static_cast<const uint16_t*>(a.residual) + (size_t)m * a.res_ld + n);
-        v[0] = rnd_dt<DT>(v[0]) + DT::to_f32((uint16_t)(rw2[0] & 0xffffu));
-        v[1] = rnd_dt<DT>(v[1]) + DT::to_f32((uint16_t)(rw2[0] >> 16));
-        v[2] = rnd_dt<DT>(v[2]) + DT::to_f32((uint16_t)(rw2[1] & 0xffffu));
-        v[3] = rnd_dt<DT>(v[3]) + DT::to_f32((uint16_t)(rw2[1] >> 16));
-      }
-      const u32x2 o = {DT::pack2(v[0], v[1]), DT::pack2(v[2], v[3])};
-      *reinterpret_cast<u32x2*>(outp + (size_t)m * out_ld + n) = o;
     }
+  }
+  __syncthreads();
+  // whole rows out: thread -> (row, 16-byte chunk of 8 columns)
+  constexpr int CPR = OUTC / 8;            // chunks per row
+  constexpr int RPP = GX_THREADS / CPR;    // rows per pass of the workgroup
+  const int crow = tid / CPR, cch = tid % CPR;
+  const int ocol = (DUAL ? nt * (BN / 2) : nt * BN) + cch * 8;  // output column of the chunk (DUAL: of the half-width output)
+  const int vcol = DUAL ? 2 * ocol : ocol;                      // its virtual column (segments, the NV bound)
+  if (vcol >= a.NV) return;
+  const bool c1 = a.nseg > 1 && vcol >= a.seg[1].vcol_start, c2 = a.nseg > 2 && vcol >= a.seg[2].vcol_start;
+  uint16_t* const outp = static_cast<uint16_t*>(c2 ? a.seg[2].out : (c1 ? a.seg[1].out : a.seg[0].out));
+  const int out_ld = c2 ? a.seg[2].out_ld : (c1 ? a.seg[1].out_ld : a.seg[0].out_ld);
+  const int n = ocol - (c2 ? a.seg[2].vcol_start : (c1 ? a.seg[1].vcol_start : a.seg[0].vcol_start)) / (DUAL ? 2 : 1);
+#pragma unroll 4
+  for (int p = 0; p < GX_BM / RPP; p++) {
+    const int row = p * RPP + crow, m = m0 + row;
+    if (m >= M) break;
+    u32x4 o = *reinterpret_cast<const u32x4*>(smem + (size_t)row * ROWB + cch * 16);
+    if (a.residual) {
+      const u32x4 rv = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(a.residual) + (size_t)m * a.res_ld + n);
+      float f[8], g[8];
+      unpack8<DT>(o, f);
+      unpack8<DT>(rv, g);
+#pragma unroll
+      for (int e = 0; e < 8; e++) f[e] += g[e];
+      o = pack8<DT>(f);
+    }
+    *reinterpret_cast<u32x4*>(outp + (size_t)m * out_ld + n) = o;  // (nt stores measured: no gain, profiles/r06_ab_gemm_dense_epilogue.txt)
   }
 }
