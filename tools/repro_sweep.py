@@ -33,7 +33,8 @@ CFGS = {
     "small_channelwise": small_cfg(group_size=-1),
     "small_f16": small_cfg(dtype=F16),
 }
-PREFILL = [(1,), (3,), (7,), (20,), (33,), (64,), (100,), (128,), (200, 57), (512,), (1000, 24), (2048,), (5,) * 8, (17,) * 32, (300, 1, 64, 129)]
+# (768+ tokens: the dense prefill path — kernel X with its split-K / tail-split exchanges through memory, csrc/gemm_dense.cuh)
+PREFILL = [(1,), (3,), (7,), (20,), (33,), (64,), (100,), (128,), (200, 57), (512,), (1000, 24), (2048,), (3072,), (4096,), (5,) * 8, (17,) * 32, (300, 1, 64, 129)]
 DECODE = [1, 2, 3, 4, 5, 8, 9, 15, 16, 17, 24, 32]
 REPS = 6
 
