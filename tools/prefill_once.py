@@ -7,7 +7,8 @@ import numpy as np
 
 from vllm_rs_amd import engine as E
 
-eng = E.Engine(dict(E.LLAMA3_8B), max_num_seqs=8, max_model_len=8192, num_gpu_blocks=512, use_graph=False).init_synthetic()
+MODEL = {"llama3-8b": E.LLAMA3_8B, "qwen2-7b-awq": E.QWEN2_7B}[os.environ.get("VRA_PREFILL_MODEL", "llama3-8b")]  # (profiling aid)
+eng = E.Engine(dict(MODEL), max_num_seqs=8, max_model_len=8192, num_gpu_blocks=512, use_graph=False).init_synthetic()
 r = np.random.default_rng(0)
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 for _ in range(2):

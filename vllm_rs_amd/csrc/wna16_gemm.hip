@@ -772,7 +772,14 @@ int vra_gemm_q4_big_fits(bool dual, int M, int cols, int K, int group_size, cons
     return 15.0 + ((double)(q / 2) * pair + (double)(q % 2) * lone) * kf;
   };
   const double flops = 2.0 * (double)M * (double)cols * (dual ? 2.0 : 1.0) * (double)K;
-  const double est_b = 17.0 + flops / ((dual ? 420.0 : 490.0) * 1e6);
+  // (round 6: the rates above were fitted at K = 4096 / 14336.  Where K is not a multiple of 1024 — Qwen2-7B: 3584, 18944 — kernel B measures
+  // 195..350 TFLOP/s, tools/gemm_shape_probe.py, profiles/r06_qwen2_gemm_shapes.txt: priced at 490 it took the q/k/v GEMM of a 512-row prefill,
+  // 76 us against kernel D's 59, and o_proj at 640 rows, 75 against 58)
+  // ... and at the Llama shapes kernel B runs 240..400 TFLOP/s between 257 and 767 rows (profiles/r06_llama_midm_gemm_shapes.txt): priced at 490
+  // it took q/k/v at 384 rows (81 us against kernel D's 60), o_proj at 576 / 640 rows (79 against 58) and down_proj at 576 (218 against ~145);
+  // at 400 those go to kernel D and the launches where B does win (down_proj at 288 / 320 rows: 120 against 140) stay
+  const bool k_odd = (K % 1024) != 0;
+  const double est_b = 17.0 + flops / ((dual ? (k_odd ? 215.0 : 345.0) : (k_odd ? 250.0 : 400.0)) * 1e6);
   double best = est_b;
   int pick = 0;
   const double d4 = est_d(4), d2 = est_d(2);
