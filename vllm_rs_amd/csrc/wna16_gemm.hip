@@ -769,7 +769,10 @@ int vra_gemm_q4_big_fits(bool dual, int M, int cols, int K, int group_size, cons
     const long w = (long)gx * ((M + 16 * mb - 1) / (16 * mb));
     const long q = (w + cus - 1) / cus;
     const double pair = mb == 4 ? 82.0 : 46.0, lone = mb == 4 ? 47.0 : 28.0;
-    return 15.0 + ((double)(q / 2) * pair + (double)(q % 2) * lone) * kf;
+    // (round 6: the gate/up pair on 32-row tiles runs ~15 % behind this model above 256 rows — 320 rows: 152 us against the 64-row tiles' 142,
+    // profiles/r06_llama_midm_gemm_shapes.txt)
+    const double pen = dual && mb == 2 && M > 256 ? 1.15 : 1.0;
+    return 15.0 + ((double)(q / 2) * pair + (double)(q % 2) * lone) * kf * pen;
   };
   const double flops = 2.0 * (double)M * (double)cols * (dual ? 2.0 : 1.0) * (double)K;
   // (round 6: the rates above were fitted at K = 4096 / 14336.  Where K is not a multiple of 1024 — Qwen2-7B: 3584, 18944 — kernel B measures
