@@ -84,10 +84,20 @@ static inline size_t gemm_dense_lds_bytes(int bn) {  // the K loop's two buffers
 // ---- the dequant pass: int4 tile layout -> 16-bit fragments.  One thread = one 16-byte lane word of the int4 layout (8 codes of one
 // column for each of 4 k-chunks of 32) -> four 16-byte lane words of four consecutive k-chunk fragments.
 //   virtual n-frag of the tensor's n-block nb:  vfrag0 + nb * vstride   (q/k/v: the segment's first fragment, stride 1; gate / up: 0 / 1, stride 2)
+// up to three tensors of one GEMM per launch (blockIdx.y: q | k | v, gate | up): same K, group size, layout and format
+struct DequantFragBatch {
+  const u32x4* tiled[3];
+  const uint16_t* scales[3];
+  const uint32_t* qzeros[3];
+  int N[3], vfrag0[3], vstride[3];
+};
 template <class DT, bool AWQ>
-__global__ __launch_bounds__(256) void dequant_frag_kernel(const u32x4* __restrict__ tiled, const uint16_t* __restrict__ scales,
-                                                           const uint32_t* __restrict__ qzeros, u32x4* __restrict__ wd, int K, int N,
-                                                           int group_size, int layout, int vfrag0, int vstride) {
+__global__ __launch_bounds__(256) void dequant_frag_kernel(const DequantFragBatch b, u32x4* __restrict__ wd, int K, int group_size, int layout) {
+  const int ti = (int)blockIdx.y;
+  const u32x4* __restrict__ tiled = b.tiled[ti];
+  const uint16_t* __restrict__ scales = b.scales[ti];
+  const uint32_t* __restrict__ qzeros = b.qzeros[ti];
+  const int N = b.N[ti], vfrag0 = b.vfrag0[ti], vstride = b.vstride[ti];
   const int KT = K >> 7;
   const int g = group_size > 0 ? group_size : K;
   const bool grouped = group_size > 0 && group_size < K;

@@ -123,22 +123,34 @@ void vra_launch_gemm_dense(GemmXArgs a, bool dual, int dtype, int bn_sk, int64_t
 #undef VRA_GX
 }
 
-void vra_launch_dequant_frag(const void* tiled, const void* scales, const void* qzeros, void* wd, int K, int N, int group_size, bool awq,
-                             int layout, int dtype, int vfrag0, int vstride, int64_t stream) {
+void vra_launch_dequant_frag_batch(int n, const void* const* tiled, const void* const* scales, const void* const* qzeros, const int* N, const int* vfrag0,
+                                   const int* vstride, void* wd, int K, int group_size, bool awq, int layout, int dtype, int64_t stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const size_t total = (size_t)(N >> 4) * (K >> 7) * 64;
-  const unsigned grid = (unsigned)((total + 255) / 256);
+  DequantFragBatch b = {};
+  size_t most = 0;
+  bool zeros = awq;
+  for (int i = 0; i < n && i < 3; i++) {
+    b.tiled[i] = static_cast<const u32x4*>(tiled[i]), b.scales[i] = static_cast<const uint16_t*>(scales[i]);
+    b.qzeros[i] = static_cast<const uint32_t*>(qzeros ? qzeros[i] : nullptr);
+    b.N[i] = N[i], b.vfrag0[i] = vfrag0[i], b.vstride[i] = vstride[i];
+    most = std::max(most, (size_t)(N[i] >> 4) * (K >> 7) * 64);
+    zeros = zeros && b.qzeros[i] != nullptr;
+  }
+  const dim3 grid((unsigned)((most + 255) / 256), (unsigned)std::min(n, 3));
   const bool bf = dtype == VRA_BF16;
-#define VRA_DQ(DT, AW) \
-  dequant_frag_kernel<DT, AW><<<grid, 256, 0, st>>>((const u32x4*)tiled, (const uint16_t*)scales, (const uint32_t*)qzeros, (u32x4*)wd, K, N, group_size, layout, vfrag0, vstride)
+#define VRA_DQ(DT, AW) dequant_frag_kernel<DT, AW><<<grid, 256, 0, st>>>(b, (u32x4*)wd, K, group_size, layout)
   if (bf) {
-    if (awq && qzeros) VRA_DQ(BF16, true);
+    if (zeros) VRA_DQ(BF16, true);
     else VRA_DQ(BF16, false);
   } else {
-    if (awq && qzeros) VRA_DQ(F16, true);
+    if (zeros) VRA_DQ(F16, true);
     else VRA_DQ(F16, false);
   }
 #undef VRA_DQ
+}
+void vra_launch_dequant_frag(const void* tiled, const void* scales, const void* qzeros, void* wd, int K, int N, int group_size, bool awq,
+                             int layout, int dtype, int vfrag0, int vstride, int64_t stream) {
+  vra_launch_dequant_frag_batch(1, &tiled, &scales, &qzeros, &N, &vfrag0, &vstride, wd, K, group_size, awq, layout, dtype, stream);
 }
 
 // ---- when the prefill GEMMs take this path, and the scratch tensor the dequantised weights of ONE GEMM live in

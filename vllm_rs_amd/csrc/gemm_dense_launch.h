@@ -8,6 +8,9 @@ void vra_launch_gemm_dense(GemmXArgs a, bool dual, int dtype, int bn_sk, int64_t
 // int4 tile layout -> 16-bit fragments w = round_dt((q - z) * s); the tensor's n-block nb lands at virtual n-frag vfrag0 + nb * vstride
 void vra_launch_dequant_frag(const void* tiled, const void* scales, const void* qzeros, void* wd, int K, int N, int group_size, bool awq,
                              int layout, int dtype, int vfrag0, int vstride, int64_t stream);
+// the same for up to three tensors of one GEMM (q | k | v, gate | up: same K, group size, layout, format) in ONE launch
+void vra_launch_dequant_frag_batch(int n, const void* const* tiled, const void* const* scales, const void* const* qzeros, const int* N, const int* vfrag0,
+                                   const int* vstride, void* wd, int K, int group_size, bool awq, int layout, int dtype, int64_t stream);
 // the dispatch rule: rows from which a prefill GEMM of M rows x K x nv virtual columns runs as dequant pass + kernel X
 int vra_dense_prefill_min_rows();
 bool vra_dense_prefill_fits(int M, int K, int nv, int group_size);

@@ -1144,8 +1144,11 @@ extern "C" void vra_wna16_gate_up_silu(const void* in, const void* qw_gate, cons
   if (vra_dense_prefill_fits(m, k, 2 * n, group_size)) {
     if (void* wd = vra_dense_scratch((size_t)k * n * 4, stream)) {
       const bool awq = is_awq != 0 && qz_gate != nullptr && qz_up != nullptr;
-      vra_launch_dequant_frag(qw_gate, sc_gate, qz_gate, wd, k, n, group_size, awq, scales_layout, dtype, 0, 2, stream);
-      vra_launch_dequant_frag(qw_up, sc_up, qz_up, wd, k, n, group_size, awq, scales_layout, dtype, 1, 2, stream);
+      const void* tw[2] = {qw_gate, qw_up};
+      const void* ts[2] = {sc_gate, sc_up};
+      const void* tz[2] = {qz_gate, qz_up};
+      const int tn[2] = {n, n}, tf[2] = {0, 1}, tst[2] = {2, 2};
+      vra_launch_dequant_frag_batch(2, tw, ts, tz, tn, tf, tst, wd, k, group_size, awq, scales_layout, dtype, stream);  // gate | up interleaved, one launch
       GemmXArgs a = {};
       a.x = in, a.x_ld = k, a.wd = wd;
       a.seg[0] = GemmXSeg{out, nullptr, n, 0};

@@ -684,13 +684,17 @@ bool Model::linear_fused_norm(const QLinear* ls, int nl, void* const* outs, cons
       a.x = xn_, a.x_ld = K, a.wd = wd;
       a.nseg = nl;
       int c0 = 0;
+      const void *tw[3] = {}, *ts[3] = {}, *tz[3] = {};
+      int tn[3] = {}, tf[3] = {}, tst[3] = {1, 1, 1};
+      bool zeros = ls[0].awq;
       for (int i = 0; i < nl; i++) {
-        if (!res)
-          vra_launch_dequant_frag(ls[i].w, ls[i].scales, ls[i].qzeros, const_cast<void*>(wd), K, ls[i].N, mc_.group_size,
-                                  ls[i].awq && ls[i].qzeros != nullptr, VRA_SCALES_ROWMAJOR, dt_, c0 / 16, 1, stream);
+        tw[i] = ls[i].w, ts[i] = ls[i].scales, tz[i] = ls[i].qzeros, tn[i] = ls[i].N, tf[i] = c0 / 16;
+        zeros = zeros && ls[i].qzeros != nullptr;
         a.seg[i] = GemmXSeg{outs[i], ls[i].bias, ls[i].N, c0};
         c0 += ls[i].N;
       }
+      if (!res)  // q | k | v dequantised by ONE launch
+        vra_launch_dequant_frag_batch(nl, tw, ts, tz, tn, tf, tst, const_cast<void*>(wd), K, mc_.group_size, zeros, VRA_SCALES_ROWMAJOR, dt_, stream);
       a.M = M, a.NV = cols, a.K = K;
       vra_launch_gemm_dense(a, false, dt_, vra_gemm_dense_tile(M, cols, K), stream);
       return !take_err(error, "norm + gemm_dense (segments)");
